@@ -1,0 +1,90 @@
+"""ctypes binding of libblsgpu.so (the C ABI in include/bls12_381_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or cannot be loaded, importing a
+compute entry point raises.  (`oracle/` is test infrastructure and is never imported from here.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libblsgpu.so")
+
+c_u64p = ctypes.POINTER(ctypes.c_uint64)
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+c_vp = ctypes.c_void_p
+c_sz = ctypes.c_size_t
+c_int = ctypes.c_int
+
+# name -> (restype, argtypes); must list every symbol declared in include/bls12_381_hip.h
+SIGNATURES = {
+    "blsgpu_create": (c_int, [c_int, ctypes.POINTER(c_vp)]),
+    "blsgpu_destroy": (None, [c_vp]),
+    "blsgpu_last_error": (ctypes.c_char_p, []),
+    "blsgpu_device_count": (c_int, []),
+    "blsgpu_set_stream": (c_int, [c_vp, c_vp]),
+    "blsgpu_synchronize": (c_int, [c_vp]),
+    "blsgpu_g1_bases_upload": (c_int, [c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
+    "blsgpu_g2_bases_upload": (c_int, [c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
+    "blsgpu_g1_bases_from_device": (c_int, [c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
+    "blsgpu_g2_bases_from_device": (c_int, [c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
+    "blsgpu_bases_from_scalars": (c_int, [c_vp, c_int, c_vp, c_sz, ctypes.POINTER(c_vp)]),
+    "blsgpu_bases_len": (c_sz, [c_vp]),
+    "blsgpu_bases_download": (c_int, [c_vp, c_vp, c_sz, c_sz, c_vp, c_vp]),
+    "blsgpu_bases_free": (None, [c_vp]),
+    "blsgpu_g1_msm": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
+    "blsgpu_g2_msm": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
+    "blsgpu_g1_msm_device": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
+    "blsgpu_g2_msm_device": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
+    "blsgpu_g1_msm_host": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_g2_msm_host": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_set_msm_window": (c_int, [c_vp, c_int]),
+    "blsgpu_g1_sum": (c_int, [c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_g2_sum": (c_int, [c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_g1_batch_normalize": (c_int, [c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "blsgpu_g2_batch_normalize": (c_int, [c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "blsgpu_pairing_batch": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_miller_loop_batch": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_multi_miller_loop": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_final_exponentiation_batch": (c_int, [c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_fp12_product": (c_int, [c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_pairing_batch_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_multi_miller_loop_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_fp_op": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_fp2_op": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_fp12_op": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_point_op": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_fp_mul_throughput": (c_int, [c_vp, c_int, ctypes.POINTER(ctypes.c_double)]),
+    "blsgpu_mad_throughput": (c_int, [c_vp, c_int, ctypes.POINTER(ctypes.c_double)]),
+    "blsgpu_last_msm_phase_ms": (c_int, [c_vp, c_int, ctypes.POINTER(ctypes.c_float)]),
+    "blsgpu_set_profiling": (c_int, [c_vp, c_int]),
+}
+
+_lib = None
+
+
+class BlsGpuError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libblsgpu.so (once) and bind every declared symbol.  Raises if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BlsGpuError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "There is no CPU fallback for the bls12_381_amd compute path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI drifted from the header
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().blsgpu_last_error()
+        raise BlsGpuError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

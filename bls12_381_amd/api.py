@@ -1,0 +1,655 @@
+"""Host-side mirror of the zkcrypto/bls12_381 surface for the accelerated hot path.
+
+Same names, argument meaning and error behaviour as the reference's operator / trait API
+(/root/reference/src/lib.rs:49-83): `Scalar`, `G1Affine`, `G1Projective`, `G2Affine`, `G2Projective`, `Gt`,
+`MillerLoopResult`, `G2Prepared`, `pairing`, `multi_miller_loop`, `Bls12` -- every group / pairing
+operation below is executed by the HIP kernels through the C ABI (include/bls12_381_hip.h).  Values are
+carried in the reference's own in-memory format (canonical Montgomery limbs, R = 2^384), as numpy uint64
+arrays, so they can be handed to / taken from a Rust caller unchanged.
+
+Only (de)serialisation (big-endian byte encodings, src/notes/serialization.rs) and `Scalar` bookkeeping
+run on the host in Python integers; they are format conversion, not part of the compute path.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import BlsGpuError, check
+
+# ---- curve constants (src/fp.rs:70-77, src/scalar.rs:76-81, src/g1.rs:197-217, src/g2.rs:210-250) ----
+P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+R_ORDER = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+_MONT_R = (1 << 384) % P
+_MONT_RINV = pow(_MONT_R, -1, P)
+_G1X = 0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB
+_G1Y = 0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1
+_G2X = (0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8,
+        0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E)
+_G2Y = (0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
+        0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE)
+
+
+def fp_to_limbs(x):
+    """integer in [0,p) -> 6 Montgomery limbs (np.uint64), the reference's `Fp([u64; 6])`"""
+    v = (int(x) * _MONT_R) % P
+    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(6)], dtype=np.uint64)
+
+
+def limbs_to_fp(l):
+    v = 0
+    for i, w in enumerate(np.asarray(l, dtype=np.uint64).reshape(-1)[:6]):
+        v |= int(w) << (64 * i)
+    return (v * _MONT_RINV) % P
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _u64(a, shape):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a.reshape(shape)
+
+
+def _flags(f, n):
+    if f is None:
+        return None
+    f = np.ascontiguousarray(f, dtype=np.uint8).reshape(-1)
+    if f.shape[0] != n:
+        raise ValueError("infinity flag array has the wrong length")
+    return f
+
+
+def scalars_to_bytes(scalars):
+    """iterable of ints / Scalars / (n,32) uint8 array -> (n,32) uint8 little-endian canonical (Scalar::to_bytes)"""
+    if isinstance(scalars, np.ndarray) and scalars.dtype == np.uint8:
+        return np.ascontiguousarray(scalars).reshape(-1, 32)
+    out = np.zeros((len(scalars), 32), dtype=np.uint8)
+    for i, s in enumerate(scalars):
+        v = s.value if isinstance(s, Scalar) else int(s) % R_ORDER
+        out[i] = np.frombuffer(v.to_bytes(32, "little"), dtype=np.uint8)
+    return out
+
+
+class ResidentBases:
+    """Device-resident base points in the library's internal form (`blsgpu_bases`)."""
+
+    def __init__(self, ctx, handle, group):
+        self.ctx, self.handle, self.group = ctx, handle, group
+
+    def __len__(self):
+        return int(_lib.load().blsgpu_bases_len(self.handle))
+
+    def download(self, first=0, count=None):
+        n = len(self) - first if count is None else count
+        w = 12 if self.group == 1 else 24
+        xy = np.zeros((n, w), dtype=np.uint64)
+        inf = np.zeros(n, dtype=np.uint8)
+        check(_lib.load().blsgpu_bases_download(self.ctx.h, self.handle, first, n, _ptr(xy), _ptr(inf)), "bases_download")
+        return xy, inf
+
+    def free(self):
+        if self.handle:
+            _lib.load().blsgpu_bases_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One device + one HIP stream + scratch memory (`blsgpu_ctx`).  Not re-entrant."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        h = ctypes.c_void_p()
+        check(self.lib.blsgpu_create(device, ctypes.byref(h)), "blsgpu_create")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.blsgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plumbing ------------------------------------------------------------------------------------
+    def set_stream(self, stream_ptr):
+        check(self.lib.blsgpu_set_stream(self.h, ctypes.c_void_p(stream_ptr) if stream_ptr else None), "set_stream")
+
+    def synchronize(self):
+        check(self.lib.blsgpu_synchronize(self.h), "synchronize")
+
+    def set_msm_window(self, c):
+        check(self.lib.blsgpu_set_msm_window(self.h, c), "set_msm_window")
+
+    def set_profiling(self, on):
+        check(self.lib.blsgpu_set_profiling(self.h, 1 if on else 0), "set_profiling")
+
+    def last_msm_phase_ms(self):
+        names = ["digits", "scan", "scatter", "order", "accumulate", "reduce", "combine", "total"]
+        out = {}
+        for i, nm in enumerate(names):
+            v = ctypes.c_float()
+            check(self.lib.blsgpu_last_msm_phase_ms(self.h, i, ctypes.byref(v)), "last_msm_phase_ms")
+            out[nm] = v.value
+        return out
+
+    # -- bases -----------------------------------------------------------------------------------------
+    def upload_bases(self, group, xy, infinity=None):
+        w = 12 if group == 1 else 24
+        xy = _u64(xy, (-1, w))
+        n = xy.shape[0]
+        inf = _flags(infinity, n)
+        h = ctypes.c_void_p()
+        fn = self.lib.blsgpu_g1_bases_upload if group == 1 else self.lib.blsgpu_g2_bases_upload
+        check(fn(self.h, _ptr(xy), _ptr(inf), n, ctypes.byref(h)), "bases_upload")
+        return ResidentBases(self, h, group)
+
+    def bases_from_device(self, group, d_xy, d_inf, n):
+        h = ctypes.c_void_p()
+        fn = self.lib.blsgpu_g1_bases_from_device if group == 1 else self.lib.blsgpu_g2_bases_from_device
+        check(fn(self.h, ctypes.c_void_p(d_xy), ctypes.c_void_p(d_inf) if d_inf else None, n, ctypes.byref(h)), "bases_from_device")
+        return ResidentBases(self, h, group)
+
+    def bases_from_scalars(self, group, scalars):
+        s = scalars_to_bytes(scalars)
+        h = ctypes.c_void_p()
+        check(self.lib.blsgpu_bases_from_scalars(self.h, group, _ptr(s), s.shape[0], ctypes.byref(h)), "bases_from_scalars")
+        return ResidentBases(self, h, group)
+
+    # -- MSM -------------------------------------------------------------------------------------------
+    def msm(self, bases, scalars, first=0):
+        """sum_i scalars[i] * bases[first+i] -> projective wire limbs (18 or 36 uint64)."""
+        s = scalars_to_bytes(scalars)
+        n = s.shape[0]
+        out = np.zeros(18 if bases.group == 1 else 36, dtype=np.uint64)
+        fn = self.lib.blsgpu_g1_msm if bases.group == 1 else self.lib.blsgpu_g2_msm
+        check(fn(self.h, bases.handle, first, _ptr(s), n, _ptr(out)), "msm")
+        return out
+
+    def msm_device(self, bases, d_scalars, n, d_out, first=0):
+        fn = self.lib.blsgpu_g1_msm_device if bases.group == 1 else self.lib.blsgpu_g2_msm_device
+        check(fn(self.h, bases.handle, first, ctypes.c_void_p(d_scalars), n, ctypes.c_void_p(d_out)), "msm_device")
+
+    def msm_host(self, group, xy, infinity, scalars):
+        w = 12 if group == 1 else 24
+        xy = _u64(xy, (-1, w))
+        s = scalars_to_bytes(scalars)
+        if s.shape[0] != xy.shape[0]:
+            raise ValueError("bases and scalars differ in length")
+        inf = _flags(infinity, xy.shape[0])
+        out = np.zeros(18 if group == 1 else 36, dtype=np.uint64)
+        fn = self.lib.blsgpu_g1_msm_host if group == 1 else self.lib.blsgpu_g2_msm_host
+        check(fn(self.h, _ptr(xy), _ptr(inf), _ptr(s), xy.shape[0], _ptr(out)), "msm_host")
+        return out
+
+    # -- group helpers -----------------------------------------------------------------------------------
+    def point_sum(self, group, xyz):
+        w = 18 if group == 1 else 36
+        xyz = _u64(xyz, (-1, w))
+        out = np.zeros(w, dtype=np.uint64)
+        fn = self.lib.blsgpu_g1_sum if group == 1 else self.lib.blsgpu_g2_sum
+        check(fn(self.h, _ptr(xyz), xyz.shape[0], _ptr(out)), "sum")
+        return out
+
+    def batch_normalize(self, group, xyz):
+        w = 18 if group == 1 else 36
+        xyz = _u64(xyz, (-1, w))
+        n = xyz.shape[0]
+        xy = np.zeros((n, w * 2 // 3), dtype=np.uint64)
+        inf = np.zeros(n, dtype=np.uint8)
+        fn = self.lib.blsgpu_g1_batch_normalize if group == 1 else self.lib.blsgpu_g2_batch_normalize
+        check(fn(self.h, _ptr(xyz), n, _ptr(xy), _ptr(inf)), "batch_normalize")
+        return xy, inf
+
+    def point_op(self, group, op, a, b=None, b_inf=None):
+        w = 18 if group == 1 else 36
+        a = _u64(a, (-1, w))
+        n = a.shape[0]
+        if b is not None:
+            b = _u64(b, (n, -1))
+        out = np.zeros((n, w), dtype=np.uint64)
+        check(self.lib.blsgpu_point_op(self.h, group, op, _ptr(a), _ptr(b), _ptr(_flags(b_inf, n)), n, _ptr(out)), "point_op")
+        return out
+
+    # -- field self-test hooks ---------------------------------------------------------------------------
+    def _elem_op(self, fn, words, op, a, b):
+        a = _u64(a, (-1, words))
+        if b is not None:
+            b = _u64(b, (a.shape[0], words))
+        out = np.zeros_like(a)
+        check(fn(self.h, op, _ptr(a), _ptr(b), a.shape[0], _ptr(out)), "field op")
+        return out
+
+    def fp_op(self, op, a, b=None):
+        return self._elem_op(self.lib.blsgpu_fp_op, 6, op, a, b)
+
+    def fp2_op(self, op, a, b=None):
+        return self._elem_op(self.lib.blsgpu_fp2_op, 12, op, a, b)
+
+    def fp12_op(self, op, a, b=None):
+        return self._elem_op(self.lib.blsgpu_fp12_op, 72, op, a, b)
+
+    def fp_mul_throughput(self, iters=2000):
+        v = ctypes.c_double()
+        check(self.lib.blsgpu_fp_mul_throughput(self.h, iters, ctypes.byref(v)), "fp_mul_throughput")
+        return v.value
+
+    def mad_throughput(self, iters=2000):
+        v = ctypes.c_double()
+        check(self.lib.blsgpu_mad_throughput(self.h, iters, ctypes.byref(v)), "mad_throughput")
+        return v.value
+
+    # -- pairings ------------------------------------------------------------------------------------------
+    def _pair_args(self, g1_xy, g1_inf, g2_xy, g2_inf):
+        g1 = _u64(g1_xy, (-1, 12))
+        g2 = _u64(g2_xy, (-1, 24))
+        if g1.shape[0] != g2.shape[0]:
+            raise ValueError("G1 and G2 inputs differ in length")
+        n = g1.shape[0]
+        return g1, _flags(g1_inf, n), g2, _flags(g2_inf, n), n
+
+    def pairing_batch(self, g1_xy, g1_inf, g2_xy, g2_inf):
+        g1, f1, g2, f2, n = self._pair_args(g1_xy, g1_inf, g2_xy, g2_inf)
+        out = np.zeros((n, 72), dtype=np.uint64)
+        check(self.lib.blsgpu_pairing_batch(self.h, _ptr(g1), _ptr(f1), _ptr(g2), _ptr(f2), n, _ptr(out)), "pairing_batch")
+        return out
+
+    def miller_loop_batch(self, g1_xy, g1_inf, g2_xy, g2_inf):
+        g1, f1, g2, f2, n = self._pair_args(g1_xy, g1_inf, g2_xy, g2_inf)
+        out = np.zeros((n, 72), dtype=np.uint64)
+        check(self.lib.blsgpu_miller_loop_batch(self.h, _ptr(g1), _ptr(f1), _ptr(g2), _ptr(f2), n, _ptr(out)), "miller_loop_batch")
+        return out
+
+    def multi_miller_loop(self, g1_xy, g1_inf, g2_xy, g2_inf):
+        g1, f1, g2, f2, n = self._pair_args(g1_xy, g1_inf, g2_xy, g2_inf)
+        out = np.zeros(72, dtype=np.uint64)
+        check(self.lib.blsgpu_multi_miller_loop(self.h, _ptr(g1), _ptr(f1), _ptr(g2), _ptr(f2), n, _ptr(out)), "multi_miller_loop")
+        return out
+
+    def final_exponentiation_batch(self, f):
+        f = _u64(f, (-1, 72))
+        out = np.zeros_like(f)
+        check(self.lib.blsgpu_final_exponentiation_batch(self.h, _ptr(f), f.shape[0], _ptr(out)), "final_exponentiation")
+        return out
+
+    def fp12_product(self, f):
+        f = _u64(f, (-1, 72))
+        out = np.zeros(72, dtype=np.uint64)
+        check(self.lib.blsgpu_fp12_product(self.h, _ptr(f), f.shape[0], _ptr(out)), "fp12_product")
+        return out
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+# ======================================================================================================
+# value types mirroring the reference
+# ======================================================================================================
+class Scalar:
+    """Element of Fr (src/scalar.rs).  Only `to_bytes`/`from_bytes` are on the hot path (the bit source
+    of scalar multiplication, scalar.rs:284-296); arithmetic is plain Python integers mod r."""
+
+    __slots__ = ("value",)
+
+    def __init__(self, value=0):
+        self.value = int(value) % R_ORDER
+
+    @staticmethod
+    def zero(): return Scalar(0)
+    @staticmethod
+    def one(): return Scalar(1)
+
+    @staticmethod
+    def from_bytes(b):
+        """scalar.rs:256-280: 32 little-endian bytes, None (CtOption none) if not canonical."""
+        v = int.from_bytes(bytes(b), "little")
+        return Scalar(v) if v < R_ORDER else None
+
+    @staticmethod
+    def from_bytes_wide(b):
+        """scalar.rs:300-331: 64 little-endian bytes reduced mod r."""
+        return Scalar(int.from_bytes(bytes(b), "little"))
+
+    def to_bytes(self): return self.value.to_bytes(32, "little")
+    def __add__(self, o): return Scalar(self.value + o.value)
+    def __sub__(self, o): return Scalar(self.value - o.value)
+    def __neg__(self): return Scalar(-self.value)
+    def __mul__(self, o):
+        if isinstance(o, Scalar):
+            return Scalar(self.value * o.value)
+        return NotImplemented
+    def invert(self): return None if self.value == 0 else Scalar(pow(self.value, -1, R_ORDER))
+    def __eq__(self, o): return isinstance(o, Scalar) and self.value == o.value
+    def __hash__(self): return hash(self.value)
+    def __repr__(self): return f"Scalar(0x{self.value:064x})"
+
+
+def _fp_bytes(l):
+    return limbs_to_fp(l).to_bytes(48, "big")
+
+
+def _lex_largest(v):
+    return v > (P - 1) // 2
+
+
+class _Group:
+    """shared plumbing of the four point types; G = 1 or 2, W = u64 words per coordinate"""
+    G = 1
+    W = 6
+
+
+class G1Affine(_Group):
+    """src/g1.rs:28-32.  `xy` = 12 uint64 Montgomery limbs (x | y), `infinity` bool."""
+    G, W = 1, 6
+
+    def __init__(self, xy, infinity=False):
+        self.xy = _u64(xy, (2 * self.W,)).copy()
+        self.infinity = bool(infinity)
+
+    @classmethod
+    def identity(cls):
+        one = fp_to_limbs(1)
+        z = np.zeros(cls.W, dtype=np.uint64)
+        if cls.G == 1:
+            return cls(np.concatenate([z, one]), True)
+        return cls(np.concatenate([z, z, one, z]), True)
+
+    @classmethod
+    def generator(cls):
+        if cls.G == 1:
+            return cls(np.concatenate([fp_to_limbs(_G1X), fp_to_limbs(_G1Y)]))
+        return cls(np.concatenate([fp_to_limbs(_G2X[0]), fp_to_limbs(_G2X[1]), fp_to_limbs(_G2Y[0]), fp_to_limbs(_G2Y[1])]))
+
+    def is_identity(self): return self.infinity
+
+    def __neg__(self):
+        xy = self.xy.copy()
+        for k in range(self.W // 6):
+            off = self.W + 6 * k
+            xy[off:off + 6] = fp_to_limbs((-limbs_to_fp(xy[off:off + 6])) % P)
+        return type(self)(xy, self.infinity)
+
+    def __eq__(self, o):
+        return type(o) is type(self) and ((self.infinity and o.infinity) or
+                                          (self.infinity == o.infinity and bool(np.array_equal(self.xy, o.xy))))
+
+    def to_projective(self):
+        one = fp_to_limbs(1)
+        z = np.zeros(self.W, dtype=np.uint64)
+        if not self.infinity:
+            z[:6] = one
+        return self._PROJ(np.concatenate([self.xy, z]))
+
+    def __mul__(self, s):
+        """`&G1Affine * &Scalar` (g1.rs:573-579): a 1-term MSM on the GPU."""
+        ctx = default_context()
+        out = ctx.msm_host(self.G, self.xy[None, :], np.array([self.infinity], dtype=np.uint8), [s])
+        return self._PROJ(out)
+
+    # -- encodings (src/notes/serialization.rs; g1.rs:221-260, g2.rs:254-299) --
+    def to_uncompressed(self):
+        if self.G == 1:
+            res = bytearray((b"\0" * 96) if self.infinity else _fp_bytes(self.xy[0:6]) + _fp_bytes(self.xy[6:12]))
+        else:
+            res = bytearray((b"\0" * 192) if self.infinity else
+                            _fp_bytes(self.xy[6:12]) + _fp_bytes(self.xy[0:6]) + _fp_bytes(self.xy[18:24]) + _fp_bytes(self.xy[12:18]))
+        if self.infinity:
+            res[0] |= 1 << 6
+        return bytes(res)
+
+    def to_compressed(self):
+        if self.G == 1:
+            res = bytearray((b"\0" * 48) if self.infinity else _fp_bytes(self.xy[0:6]))
+            big = (not self.infinity) and _lex_largest(limbs_to_fp(self.xy[6:12]))
+        else:
+            res = bytearray((b"\0" * 96) if self.infinity else _fp_bytes(self.xy[6:12]) + _fp_bytes(self.xy[0:6]))
+            y0, y1 = limbs_to_fp(self.xy[12:18]), limbs_to_fp(self.xy[18:24])
+            big = (not self.infinity) and (_lex_largest(y1) or (y1 == 0 and _lex_largest(y0)))
+        res[0] |= 1 << 7
+        if self.infinity:
+            res[0] |= 1 << 6
+        if big:
+            res[0] |= 1 << 5
+        return bytes(res)
+
+    @classmethod
+    def from_uncompressed_unchecked(cls, b):
+        """g1.rs:273-322 / g2.rs:311-380; None where the reference returns CtOption::none."""
+        b = bytes(b)
+        n = 2 * cls.W // 6
+        if len(b) != 48 * n:
+            return None
+        c, i, s = (b[0] >> 7) & 1, (b[0] >> 6) & 1, (b[0] >> 5) & 1
+        vals = [int.from_bytes((bytes([b[0] & 0x1F]) + b[1:48]) if k == 0 else b[48 * k:48 * k + 48], "big") for k in range(n)]
+        if any(v >= P for v in vals) or c or s or (i and any(vals)):
+            return None
+        if i:
+            return cls.identity()
+        if cls.G == 1:
+            return cls(np.concatenate([fp_to_limbs(vals[0]), fp_to_limbs(vals[1])]))
+        return cls(np.concatenate([fp_to_limbs(vals[1]), fp_to_limbs(vals[0]), fp_to_limbs(vals[3]), fp_to_limbs(vals[2])]))
+
+    def __repr__(self):
+        return f"{type(self).__name__}({'identity' if self.infinity else self.to_compressed().hex()})"
+
+
+class G1Projective(_Group):
+    """src/g1.rs:442-446.  `xyz` = 18 uint64 Montgomery limbs (X | Y | Z), x = X/Z; identity (0:1:0)."""
+    G, W = 1, 6
+    _AFF = G1Affine
+
+    def __init__(self, xyz):
+        self.xyz = _u64(xyz, (3 * self.W,)).copy()
+
+    @classmethod
+    def identity(cls): return cls._AFF.identity().to_projective()
+    @classmethod
+    def generator(cls): return cls._AFF.generator().to_projective()
+
+    def is_identity(self):
+        return not self.xyz[2 * self.W:].any()
+
+    def to_affine(self):
+        """`G1Affine::from(&G1Projective)` (g1.rs:49-63)."""
+        xy, inf = default_context().batch_normalize(self.G, self.xyz[None, :])
+        return self._AFF(xy[0], bool(inf[0]))
+
+    @classmethod
+    def batch_normalize(cls, points):
+        """`G1Projective::batch_normalize` (g1.rs:806-839)."""
+        if not points:
+            return []
+        xy, inf = default_context().batch_normalize(cls.G, np.stack([p.xyz for p in points]))
+        return [cls._AFF(xy[i], bool(inf[i])) for i in range(len(points))]
+
+    def __add__(self, o):
+        ctx = default_context()
+        if isinstance(o, self._AFF):
+            return type(self)(ctx.point_op(self.G, 2, self.xyz[None, :], o.xy[None, :], np.array([o.infinity], dtype=np.uint8))[0])
+        return type(self)(ctx.point_op(self.G, 0, self.xyz[None, :], o.xyz[None, :])[0])
+
+    def __neg__(self):
+        a = self.xyz.copy()
+        for k in range(self.W // 6):
+            off = self.W + 6 * k
+            a[off:off + 6] = fp_to_limbs((-limbs_to_fp(a[off:off + 6])) % P)
+        return type(self)(a)
+
+    def __sub__(self, o): return self + (-o)
+    def double(self): return type(self)(default_context().point_op(self.G, 1, self.xyz[None, :])[0])
+
+    def __mul__(self, s):
+        """`&G1Projective * &Scalar` (g1.rs:556-562)."""
+        return self.to_affine() * s
+
+    @classmethod
+    def sum(cls, points):
+        """`Sum for G1Projective` (g1.rs:161-171)."""
+        pts = list(points)
+        if not pts:
+            return cls.identity()
+        return cls(default_context().point_sum(cls.G, np.stack([p.xyz for p in pts])))
+
+    def __eq__(self, o):
+        """projective equality (g1.rs:479-496) decided on canonical affine forms"""
+        return type(o) is type(self) and self.to_affine() == o.to_affine()
+
+    def __repr__(self): return f"{type(self).__name__}({self.to_affine()!r})"
+
+
+class G2Affine(G1Affine):
+    """src/g2.rs.  `xy` = 24 uint64 limbs (x.c0 x.c1 y.c0 y.c1)."""
+    G, W = 2, 12
+
+
+class G2Projective(G1Projective):
+    G, W = 2, 12
+    _AFF = G2Affine
+
+
+G1Affine._PROJ = G1Projective
+G2Affine._PROJ = G2Projective
+
+
+class Gt:
+    """Target group element (src/pairings.rs:204-337), written additively like the reference: `+` is the
+    Fp12 product, `-x` the conjugate.  `f` = 72 uint64 limbs in struct order."""
+
+    def __init__(self, f):
+        self.f = _u64(f, (72,)).copy()
+
+    @staticmethod
+    def identity():
+        f = np.zeros(72, dtype=np.uint64)
+        f[:6] = fp_to_limbs(1)
+        return Gt(f)
+
+    @staticmethod
+    def generator():
+        """pairings.rs:359-475: e(G1::generator, G2::generator)."""
+        return pairing(G1Affine.generator(), G2Affine.generator())
+
+    def __add__(self, o): return Gt(default_context().fp12_op(0, self.f[None, :], o.f[None, :])[0])
+    def __neg__(self): return Gt(default_context().fp12_op(8, self.f[None, :])[0])
+    def __sub__(self, o): return self + (-o)
+    def double(self): return Gt(default_context().fp12_op(3, self.f[None, :])[0])
+
+    def __mul__(self, s):
+        """`&Gt * &Scalar` (pairings.rs:297-322): double-and-add over the 255 low bits."""
+        v = s.value if isinstance(s, Scalar) else int(s) % R_ORDER
+        ctx = default_context()
+        acc = Gt.identity().f
+        for bit in range(254, -1, -1):
+            acc = ctx.fp12_op(3, acc[None, :])[0]
+            if (v >> bit) & 1:
+                acc = ctx.fp12_op(0, acc[None, :], self.f[None, :])[0]
+        return Gt(acc)
+
+    @staticmethod
+    def sum(items):
+        items = list(items)
+        if not items:
+            return Gt.identity()
+        return Gt(default_context().fp12_product(np.stack([g.f for g in items])))
+
+    def __eq__(self, o): return isinstance(o, Gt) and bool(np.array_equal(self.f, o.f))
+    def __repr__(self): return f"Gt({self.f[:2]}...)"
+
+
+class MillerLoopResult:
+    """src/pairings.rs:26.  Deliberately has no equality, like the reference (:21-26)."""
+
+    def __init__(self, f):
+        self.f = _u64(f, (72,)).copy()
+
+    @staticmethod
+    def default(): return MillerLoopResult(Gt.identity().f)
+
+    def final_exponentiation(self):
+        """pairings.rs:48-176."""
+        return Gt(default_context().final_exponentiation_batch(self.f[None, :])[0])
+
+    def __add__(self, o):
+        """pairings.rs:179-186: product of the underlying Fp12 values."""
+        return MillerLoopResult(default_context().fp12_op(0, self.f[None, :], o.f[None, :])[0])
+
+
+class G2Prepared:
+    """src/pairings.rs:498-546.  Opaque in the reference (private fields); here it keeps the affine point --
+    the GPU recomputes the 68 line coefficients on the fly instead of storing 19 584 B per point."""
+
+    def __init__(self, q):
+        if not isinstance(q, G2Affine):
+            raise TypeError("G2Prepared::from expects a G2Affine")
+        self.q = q
+
+
+def pairing(p, q):
+    """`pairing(&G1Affine, &G2Affine) -> Gt` (src/pairings.rs:607-653)."""
+    out = default_context().pairing_batch(p.xy[None, :], np.array([p.infinity], dtype=np.uint8), q.xy[None, :],
+                                          np.array([q.infinity], dtype=np.uint8))
+    return Gt(out[0])
+
+
+def multi_miller_loop(terms):
+    """`multi_miller_loop(&[(&G1Affine, &G2Prepared)]) -> MillerLoopResult` (src/pairings.rs:554-603)."""
+    terms = list(terms)
+    n = len(terms)
+    g1 = np.zeros((n, 12), dtype=np.uint64)
+    g2 = np.zeros((n, 24), dtype=np.uint64)
+    f1 = np.zeros(n, dtype=np.uint8)
+    f2 = np.zeros(n, dtype=np.uint8)
+    for i, (p, prep) in enumerate(terms):
+        g1[i], f1[i], g2[i], f2[i] = p.xy, p.infinity, prep.q.xy, prep.q.infinity
+    return MillerLoopResult(default_context().multi_miller_loop(g1, f1, g2, f2))
+
+
+def _msm(group, bases, scalars):
+    ctx = default_context()
+    proj = G1Projective if group == 1 else G2Projective
+    if isinstance(bases, ResidentBases):
+        return proj(ctx.msm(bases, scalars))
+    bases = list(bases)
+    if len(bases) != len(scalars):
+        raise ValueError("bases and scalars differ in length")
+    w = 12 if group == 1 else 24
+    xy = np.stack([b.xy for b in bases]) if bases else np.zeros((0, w), dtype=np.uint64)
+    inf = np.array([b.infinity for b in bases], dtype=np.uint8)
+    return proj(ctx.msm_host(group, xy, inf, scalars))
+
+
+def msm_g1(bases, scalars):
+    """bases.iter().zip(scalars).map(|(p, s)| p * s).sum::<G1Projective>()"""
+    return _msm(1, bases, scalars)
+
+
+def msm_g2(bases, scalars):
+    return _msm(2, bases, scalars)
+
+
+class Bls12:
+    """`pairing::Engine` + `MultiMillerLoop` for BLS12-381 (src/pairings.rs:790-824)."""
+    Fr, G1, G1Affine, G2, G2Affine, Gt, G2Prepared, Result = Scalar, G1Projective, G1Affine, G2Projective, G2Affine, Gt, G2Prepared, MillerLoopResult
+
+    @staticmethod
+    def pairing(p, q): return pairing(p, q)
+    @staticmethod
+    def multi_miller_loop(terms): return multi_miller_loop(terms)

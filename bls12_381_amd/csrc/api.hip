@@ -1,0 +1,799 @@
+// api.hip -- host side of libblsgpu.so: the C ABI declared in include/bls12_381_hip.h.
+// One context = one device + one stream + grow-only scratch.  All heavy lifting is in the kernels of
+// msm.cuh / pairing.cuh; this file only sequences launches and moves bytes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/bls12_381_hip.h"
+#include "msm.cuh"
+#include "pairing.cuh"
+
+using namespace bls;
+
+static thread_local std::string g_err;
+static int fail(const char* what, hipError_t e, int line) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "%s: %s (api.hip:%d)", what, hipGetErrorString(e), line);
+  g_err = buf;
+  return BLSGPU_ERR_HIP;
+}
+static int bad(const char* what) { g_err = what; return BLSGPU_ERR_ARG; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(#x, e_, __LINE__); } while (0)
+#define LAUNCHCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail("kernel launch", e_, __LINE__); } while (0)
+
+struct DevBuf {
+  void* p = nullptr; size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) { if (hipFree(p) != hipSuccess) return -1; p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    if (hipMalloc(&p, want) != hipSuccess) return -1;
+    cap = want; return 0;
+  }
+  void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+struct blsgpu_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  int msm_c = 0;
+  bool profiling = false;
+  hipEvent_t ev[9];
+  float phase_ms[8] = {0};
+  // scratch
+  DevBuf ent, sorted, hist, offs, cursor, bsum, order, lhist, buckets, lvlR[2], lvlT, tsum[2], wacc[2], wsums, result, io_a, io_b, io_c, io_d, io_out, flags_a, flags_b;
+};
+
+struct blsgpu_bases {
+  int group = 1; size_t n = 0; int device = 0; u32* rec = nullptr;   // AFF_WORDS per point
+};
+
+template <class F> struct GroupTag;
+template <> struct GroupTag<FpPolicy> { static constexpr int id = 1; };
+template <> struct GroupTag<Fp2Policy> { static constexpr int id = 2; };
+
+// ---------------------------------------------------------------------------------------------------
+// small kernels living at the ABI level
+// ---------------------------------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(256) k_bases_import(const u32* __restrict__ xy, const uint8_t* __restrict__ inf, u32* __restrict__ rec, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int WW = Wire<F>::WORDS, EL = Store<F>::EL;
+  u32* r = rec + i * Store<F>::AFF_WORDS;
+  auto x = Wire<F>::load(xy + i * 2 * WW);
+  auto y = Wire<F>::load(xy + i * 2 * WW + WW);
+  Store<F>::st(r, x); Store<F>::st(r + EL, y);
+  r[2 * EL] = inf ? (inf[i] != 0) : 0;
+  for (int j = 2 * EL + 1; j < Store<F>::AFF_WORDS; j++) r[j] = 0;
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_bases_export(const u32* __restrict__ rec, u32* __restrict__ xy, uint8_t* __restrict__ inf, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int WW = Wire<F>::WORDS;
+  Aff<F> q; bool f;
+  load_aff<F>(rec + i * Store<F>::AFF_WORDS, q, f);
+  Wire<F>::save(q.x, xy + i * 2 * WW);
+  Wire<F>::save(q.y, xy + i * 2 * WW + WW);
+  inf[i] = f ? 1 : 0;
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_proj_import(const u32* __restrict__ xyz, u32* __restrict__ rec, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int WW = Wire<F>::WORDS, EL = Store<F>::EL;
+  u32* r = rec + i * Store<F>::PROJ_WORDS;
+  Store<F>::st(r, Wire<F>::load(xyz + i * 3 * WW));
+  Store<F>::st(r + EL, Wire<F>::load(xyz + i * 3 * WW + WW));
+  Store<F>::st(r + 2 * EL, Wire<F>::load(xyz + i * 3 * WW + 2 * WW));
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_proj_export(const u32* __restrict__ rec, u32* __restrict__ xyz, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int WW = Wire<F>::WORDS;
+  Proj<F> p; load_proj<F>(rec + i * Store<F>::PROJ_WORDS, p);
+  Wire<F>::save(p.x, xyz + i * 3 * WW);
+  Wire<F>::save(p.y, xyz + i * 3 * WW + WW);
+  Wire<F>::save(p.z, xyz + i * 3 * WW + 2 * WW);
+}
+// projective record -> affine wire (one inversion per point; identity -> (0, 1, inf))   g1.rs:49-63
+template <class F>
+__global__ void __launch_bounds__(256) k_proj_to_affine(const u32* __restrict__ rec, u32* __restrict__ xy, uint8_t* __restrict__ inf, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int WW = Wire<F>::WORDS;
+  Proj<F> p; load_proj<F>(rec + i * Store<F>::PROJ_WORDS, p);
+  bool zz = is_zero(p.z);
+  auto zi = inv(p.z);
+  auto x = mul(p.x, zi);
+  auto y = mul(p.y, zi);
+  auto one = F::one(); auto zero = F::zero();
+  if (zz) {
+    Wire<F>::save(zero, xy + i * 2 * WW);
+    Wire<F>::save(one, xy + i * 2 * WW + WW);
+  } else {
+    Wire<F>::save(x, xy + i * 2 * WW);
+    Wire<F>::save(y, xy + i * 2 * WW + WW);
+  }
+  inf[i] = zz ? 1 : 0;
+}
+// fixed-base scalar multiplication of the generator: rec[i] = affine([k_i] G)     (synthetic inputs)
+template <class F> DEV Aff<F> generator();
+template <> DEV Aff<FpPolicy> generator<FpPolicy>() {
+  constexpr PLimbs gx = {BLS_G1_GEN_X}, gy = {BLS_G1_GEN_Y};
+  Aff<FpPolicy> g; g.x = fe1_const(gx); g.y = fe1_const(gy); return g;
+}
+template <> DEV Aff<Fp2Policy> generator<Fp2Policy>() {
+  constexpr PLimbs x0 = {BLS_G2_GEN_X0}, x1 = {BLS_G2_GEN_X1}, y0 = {BLS_G2_GEN_Y0}, y1 = {BLS_G2_GEN_Y1};
+  Aff<Fp2Policy> g; g.x.c0 = fe1_const(x0); g.x.c1 = fe1_const(x1); g.y.c0 = fe1_const(y0); g.y.c1 = fe1_const(y1); return g;
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_bases_from_scalars(const u32* __restrict__ scalars, u32* __restrict__ rec, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int EL = Store<F>::EL;
+  Aff<F> g = generator<F>();
+  Proj<F> acc = pt_identity<F>();
+  for (int w = 7; w >= 0; w--) {
+    u32 word = scalars[i * 8 + w];
+    for (int b = 31; b >= 0; b--) {
+      acc = pt_double<F>(acc);
+      Proj<F> t = pt_add_mixed<F>(acc, g, false);
+      acc = pt_select(((word >> b) & 1) != 0, t, acc);
+    }
+  }
+  bool zz = is_zero(acc.z);
+  auto zi = inv(acc.z);
+  auto x = canon_any(mul(acc.x, zi));
+  auto y = canon_any(mul(acc.y, zi));
+  if (zz) { x = canon_any(F::zero()); y = canon_any(F::one()); }   // G1Affine::identity() = (0, 1, inf)
+  u32* r = rec + i * Store<F>::AFF_WORDS;
+  Store<F>::st(r, x); Store<F>::st(r + EL, y);
+  r[2 * EL] = zz ? 1 : 0;
+  for (int j = 2 * EL + 1; j < Store<F>::AFF_WORDS; j++) r[j] = 0;
+}
+
+// n projective records -> their sum (single block; n is tiny: per-rank partials)
+template <class F>
+__global__ void __launch_bounds__(64) k_proj_sum(const u32* __restrict__ rec, u32* __restrict__ out, size_t n) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Proj<F> acc = pt_identity<F>();
+  for (size_t i = 0; i < n; i++) { Proj<F> p; load_proj<F>(rec + i * Store<F>::PROJ_WORDS, p); acc = pt_add<F>(acc, p); }
+  store_proj<F>(out, acc);
+}
+template <class F>
+__global__ void k_store_identity(u32* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) store_proj<F>(out, pt_identity<F>());
+}
+
+// ---- field / point self-test kernels ------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_fp_op(int op, const u32* __restrict__ a, const u32* __restrict__ b, u32* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe1 x = fe_from_ref(a + i * 12);
+  fe1 y = b ? fe_from_ref(b + i * 12) : x;
+  switch (op) {
+    case 0: fe_to_ref(mul(x, y), out + i * 12); break;
+    case 1: fe_to_ref(add(x, y), out + i * 12); break;
+    case 2: fe_to_ref(sub(x, y), out + i * 12); break;
+    case 3: fe_to_ref(sqr(x), out + i * 12); break;
+    case 4: fe_to_ref(inv(x), out + i * 12); break;
+    default: fe_to_ref(neg(x), out + i * 12); break;
+  }
+}
+__global__ void __launch_bounds__(256) k_fp2_op(int op, const u32* __restrict__ a, const u32* __restrict__ b, u32* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe2_1 x = fe2_from_ref(a + i * 24);
+  fe2_1 y = b ? fe2_from_ref(b + i * 24) : x;
+  switch (op) {
+    case 0: fe2_to_ref(mul(x, y), out + i * 24); break;
+    case 1: fe2_to_ref(add(x, y), out + i * 24); break;
+    case 2: fe2_to_ref(sub(x, y), out + i * 24); break;
+    case 3: fe2_to_ref(sqr(x), out + i * 24); break;
+    case 4: fe2_to_ref(inv(x), out + i * 24); break;
+    case 5: fe2_to_ref(neg(x), out + i * 24); break;
+    default: fe2_to_ref(mul_by_nonresidue(x), out + i * 24); break;
+  }
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_point_op(int op, const u32* __restrict__ a, const u32* __restrict__ b, const uint8_t* __restrict__ binf,
+                                                  u32* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int WW = Wire<F>::WORDS;
+  Proj<F> p;
+  p.x = F::st(Wire<F>::load(a + i * 3 * WW)); p.y = F::st(Wire<F>::load(a + i * 3 * WW + WW)); p.z = F::st(Wire<F>::load(a + i * 3 * WW + 2 * WW));
+  Proj<F> r;
+  if (op == 0) {
+    Proj<F> q;
+    q.x = F::st(Wire<F>::load(b + i * 3 * WW)); q.y = F::st(Wire<F>::load(b + i * 3 * WW + WW)); q.z = F::st(Wire<F>::load(b + i * 3 * WW + 2 * WW));
+    r = pt_add<F>(p, q);
+  } else if (op == 1) {
+    r = pt_double<F>(p);
+  } else {
+    Aff<F> q; q.x = Wire<F>::load(b + i * 2 * WW); q.y = Wire<F>::load(b + i * 2 * WW + WW);
+    r = pt_add_mixed<F>(p, q, binf ? binf[i] != 0 : false);
+  }
+  Wire<F>::save(r.x, out + i * 3 * WW); Wire<F>::save(r.y, out + i * 3 * WW + WW); Wire<F>::save(r.z, out + i * 3 * WW + 2 * WW);
+}
+__global__ void __launch_bounds__(256) k_fp_mul_chain(u32* __restrict__ out, const u32* __restrict__ in, int iters) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  fe a, b;
+  for (int j = 0; j < NL; j++) { a.l[j] = in[(tid & 255) * 28 + j] & LMASK; b.l[j] = in[(tid & 255) * 28 + 14 + j] & LMASK; }
+  a.l[NL - 1] &= 0xffff; b.l[NL - 1] &= 0xffff;
+  for (int it = 0; it < iters; it++) { fe r = (fe)mul(a, b); a = b; b = r; }
+  for (int j = 0; j < NL; j++) out[(size_t)tid * NL + j] = b.l[j];
+}
+__global__ void __launch_bounds__(256) k_mad_chain(u32* __restrict__ out, const u32* __restrict__ in, int iters) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 x = in[tid & 1023], y = in[(tid + 7) & 1023] | 1;
+  u64 a0 = x, a1 = x + 1, a2 = x + 2, a3 = x + 3, a4 = x + 4, a5 = x + 5, a6 = x + 6, a7 = x + 7;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      a0 = (u64)x * y + a0; a1 = (u64)x * y + a1; a2 = (u64)x * y + a2; a3 = (u64)x * y + a3;
+      a4 = (u64)x * y + a4; a5 = (u64)x * y + a5; a6 = (u64)x * y + a6; a7 = (u64)x * y + a7;
+      asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+    }
+  }
+  u64 s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+  out[tid] = (u32)s ^ (u32)(s >> 32);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------------
+static inline unsigned nblk(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+extern "C" const char* blsgpu_last_error(void) { return g_err.c_str(); }
+extern "C" int blsgpu_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
+  if (!out) return bad("blsgpu_create: out is NULL");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_err = "no HIP device"; return BLSGPU_ERR_NODEV; }
+  if (device < 0 || device >= n) return bad("blsgpu_create: device index out of range");
+  HIPCHK(hipSetDevice(device));
+  blsgpu_ctx* c = new blsgpu_ctx();
+  c->device = device;
+  HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+  for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
+  *out = c;
+  return BLSGPU_OK;
+}
+extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  DevBuf* bufs[] = {&c->ent, &c->sorted, &c->hist, &c->offs, &c->cursor, &c->bsum, &c->order, &c->lhist, &c->buckets, &c->lvlR[0], &c->lvlR[1],
+                    &c->lvlT, &c->tsum[0], &c->tsum[1], &c->wacc[0], &c->wacc[1], &c->wsums, &c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d,
+                    &c->io_out, &c->flags_a, &c->flags_b};
+  for (auto b : bufs) b->release();
+  for (auto& e : c->ev) hipEventDestroy(e);
+  hipStreamDestroy(c->own_stream);
+  delete c;
+}
+extern "C" int blsgpu_set_stream(blsgpu_ctx* c, void* s) {
+  if (!c) return bad("ctx is NULL");
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_synchronize(blsgpu_ctx* c) {
+  if (!c) return bad("ctx is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_set_msm_window(blsgpu_ctx* c, int w) {
+  if (!c) return bad("ctx is NULL");
+  if (w != 0 && (w < 4 || w > 20)) return bad("msm window must be 0 or in [4,20]");
+  c->msm_c = w; return BLSGPU_OK;
+}
+extern "C" int blsgpu_set_profiling(blsgpu_ctx* c, int on) { if (!c) return bad("ctx is NULL"); c->profiling = on != 0; return BLSGPU_OK; }
+extern "C" int blsgpu_last_msm_phase_ms(blsgpu_ctx* c, int phase, float* ms) {
+  if (!c || !ms || phase < 0 || phase > 7) return bad("bad phase query");
+  *ms = c->phase_ms[phase]; return BLSGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bases
+// ---------------------------------------------------------------------------------------------------
+template <class F>
+static int bases_import(blsgpu_ctx* c, const void* d_xy, const void* d_inf, size_t n, blsgpu_bases** out) {
+  blsgpu_bases* b = new blsgpu_bases();
+  b->group = GroupTag<F>::id; b->n = n; b->device = c->device;
+  size_t bytes = (n ? n : 1) * Store<F>::AFF_WORDS * 4;
+  if (hipMalloc((void**)&b->rec, bytes) != hipSuccess) { delete b; g_err = "hipMalloc(bases) failed"; return BLSGPU_ERR_HIP; }
+  if (n) {
+    hipLaunchKernelGGL(k_bases_import<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (const u32*)d_xy, (const uint8_t*)d_inf, b->rec, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { hipFree(b->rec); delete b; return fail("k_bases_import", e, __LINE__); }
+  }
+  *out = b;
+  return BLSGPU_OK;
+}
+template <class F>
+static int bases_upload(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, blsgpu_bases** out) {
+  if (!c || !out || (n && !xy)) return bad("bases_upload: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  size_t xb = n * 2 * Wire<F>::WORDS * 4;
+  if (c->io_a.reserve(xb ? xb : 16) || c->flags_a.reserve(n ? n : 16)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  if (n) HIPCHK(hipMemcpyAsync(c->io_a.p, xy, xb, hipMemcpyHostToDevice, c->stream));
+  if (n && inf) HIPCHK(hipMemcpyAsync(c->flags_a.p, inf, n, hipMemcpyHostToDevice, c->stream));
+  int rc = bases_import<F>(c, c->io_a.p, inf ? c->flags_a.p : nullptr, n, out);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_g1_bases_upload(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, blsgpu_bases** out) { return bases_upload<FpPolicy>(c, xy, inf, n, out); }
+extern "C" int blsgpu_g2_bases_upload(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, blsgpu_bases** out) { return bases_upload<Fp2Policy>(c, xy, inf, n, out); }
+extern "C" int blsgpu_g1_bases_from_device(blsgpu_ctx* c, const void* xy, const void* inf, size_t n, blsgpu_bases** out) {
+  if (!c || !out || (n && !xy)) return bad("bases_from_device: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  return bases_import<FpPolicy>(c, xy, inf, n, out);
+}
+extern "C" int blsgpu_g2_bases_from_device(blsgpu_ctx* c, const void* xy, const void* inf, size_t n, blsgpu_bases** out) {
+  if (!c || !out || (n && !xy)) return bad("bases_from_device: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  return bases_import<Fp2Policy>(c, xy, inf, n, out);
+}
+extern "C" int blsgpu_bases_from_scalars(blsgpu_ctx* c, int group, const uint8_t* scalars, size_t n, blsgpu_bases** out) {
+  if (!c || !out || (n && !scalars) || (group != 1 && group != 2)) return bad("bases_from_scalars: bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->io_a.reserve(n ? n * 32 : 16)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  if (n) HIPCHK(hipMemcpyAsync(c->io_a.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+  blsgpu_bases* b = new blsgpu_bases();
+  b->group = group; b->n = n; b->device = c->device;
+  size_t words = group == 1 ? Store<FpPolicy>::AFF_WORDS : Store<Fp2Policy>::AFF_WORDS;
+  if (hipMalloc((void**)&b->rec, (n ? n : 1) * words * 4) != hipSuccess) { delete b; g_err = "hipMalloc(bases) failed"; return BLSGPU_ERR_HIP; }
+  if (n) {
+    if (group == 1) hipLaunchKernelGGL(k_bases_from_scalars<FpPolicy>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), b->rec, n);
+    else hipLaunchKernelGGL(k_bases_from_scalars<Fp2Policy>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), b->rec, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { hipFree(b->rec); delete b; return fail("k_bases_from_scalars", e, __LINE__); }
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *out = b;
+  return BLSGPU_OK;
+}
+extern "C" size_t blsgpu_bases_len(const blsgpu_bases* b) { return b ? b->n : 0; }
+extern "C" void blsgpu_bases_free(blsgpu_bases* b) {
+  if (!b) return;
+  hipSetDevice(b->device);
+  if (b->rec) hipFree(b->rec);
+  delete b;
+}
+template <class F>
+static int bases_download(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, size_t count, uint64_t* xy, uint8_t* inf) {
+  size_t xb = count * 2 * Wire<F>::WORDS * 4;
+  if (c->io_out.reserve(xb ? xb : 16) || c->flags_b.reserve(count ? count : 16)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  if (!count) return BLSGPU_OK;
+  hipLaunchKernelGGL(k_bases_export<F>, dim3(nblk(count, 256)), dim3(256), 0, c->stream, b->rec + first * Store<F>::AFF_WORDS, c->io_out.as<u32>(),
+                     c->flags_b.as<uint8_t>(), count);
+  LAUNCHCHK();
+  HIPCHK(hipMemcpyAsync(xy, c->io_out.p, xb, hipMemcpyDeviceToHost, c->stream));
+  if (inf) HIPCHK(hipMemcpyAsync(inf, c->flags_b.p, count, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_bases_download(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, size_t count, uint64_t* xy, uint8_t* inf) {
+  if (!c || !b || (count && !xy) || first + count > b->n) return bad("bases_download: bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  return b->group == 1 ? bases_download<FpPolicy>(c, b, first, count, xy, inf) : bases_download<Fp2Policy>(c, b, first, count, xy, inf);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// MSM
+// ---------------------------------------------------------------------------------------------------
+static int pick_window(size_t n) {
+  // minimise  n*W (mixed adds) + 2*W*2^(c-1)*1.2 (bucket reduction), W = ceil(256/c)
+  int best = 8; double bc = 1e300;
+  for (int c = 6; c <= 16; c++) {
+    int W = (256 + c - 1) / c;
+    double cost = (double)n * W + 2.4 * W * (double)(1u << (c - 1));
+    if (cost < bc) { bc = cost; best = c; }
+  }
+  return best;
+}
+
+template <class F>
+static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, const void* d_scalars, size_t n, void* d_out_wire) {
+  if (!c || !bases || !d_out_wire || (n && !d_scalars)) return bad("msm: NULL argument");
+  if (bases->group != GroupTag<F>::id) return bad("msm: bases belong to the other group");
+  if (first + n > bases->n) return bad("msm: range exceeds the resident bases");
+  if (n > ((size_t)1 << 27)) return bad("msm: n too large for one call (shard the input)");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  constexpr int PW = Store<F>::PROJ_WORDS;
+  if (c->result.reserve(PW * 4)) { g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP; }
+  if (n == 0) {
+    hipLaunchKernelGGL(k_store_identity<F>, dim3(1), dim3(64), 0, st, c->result.as<u32>());
+    LAUNCHCHK();
+    hipLaunchKernelGGL(k_proj_export<F>, dim3(1), dim3(256), 0, st, c->result.as<u32>(), (u32*)d_out_wire, (size_t)1);
+    LAUNCHCHK();
+    return BLSGPU_OK;
+  }
+  const int cw = c->msm_c ? c->msm_c : pick_window(n);
+  const int nwin = (256 + cw - 1) / cw;
+  const u32 nbw = 1u << (cw - 1);
+  const size_t nb = (size_t)nwin * nbw;
+  const size_t total = (size_t)nwin * n;
+  if (total > 0xfffffff0ull) return bad("msm: n * windows exceeds 2^32 entries");
+  int bad_alloc = 0;
+  bad_alloc |= c->ent.reserve(total * 4);
+  bad_alloc |= c->sorted.reserve(total * 4);
+  bad_alloc |= c->hist.reserve(nb * 4);
+  bad_alloc |= c->cursor.reserve(nb * 4);
+  bad_alloc |= c->offs.reserve((nb + 1) * 4);
+  bad_alloc |= c->bsum.reserve(4096 * 4);
+  bad_alloc |= c->order.reserve(nb * 4);
+  bad_alloc |= c->lhist.reserve(2 * LOAD_BINS * 4);
+  bad_alloc |= c->buckets.reserve(nb * PW * 4);
+  size_t lvl = (nb / 2 + 1) * PW * 4;
+  bad_alloc |= c->lvlR[0].reserve(lvl); bad_alloc |= c->lvlR[1].reserve(lvl); bad_alloc |= c->lvlT.reserve(lvl);
+  bad_alloc |= c->tsum[0].reserve(lvl); bad_alloc |= c->tsum[1].reserve(lvl);
+  bad_alloc |= c->wacc[0].reserve((size_t)nwin * 32 * PW * 4); bad_alloc |= c->wacc[1].reserve((size_t)nwin * 32 * PW * 4);
+  bad_alloc |= c->wsums.reserve((size_t)nwin * PW * 4);
+  if (bad_alloc) { g_err = "hipMalloc(msm scratch) failed"; return BLSGPU_ERR_HIP; }
+  const bool prof = c->profiling;
+  auto mark = [&](int i) { if (prof) hipEventRecord(c->ev[i], st); };
+
+  mark(0);
+  // 1. digits + histogram
+  HIPCHK(hipMemsetAsync(c->hist.p, 0, nb * 4, st));
+  HIPCHK(hipMemsetAsync(c->cursor.p, 0, nb * 4, st));
+  HIPCHK(hipMemsetAsync(c->lhist.p, 0, 2 * LOAD_BINS * 4, st));
+  hipLaunchKernelGGL(k_msm_digits, dim3(nblk(n, 256)), dim3(256), 0, st, (const u32*)d_scalars, c->ent.as<u32>(), c->hist.as<u32>(), (int)n, cw, nwin);
+  LAUNCHCHK();
+  mark(1);
+  // 2. scan
+  unsigned sb = nblk(nb, 1024);
+  if (sb > 4096) return bad("msm: too many buckets");
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(sb), dim3(256), 0, st, c->hist.as<u32>(), c->bsum.as<u32>(), (int)nb);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, c->bsum.as<u32>(), (int)sb);
+  hipLaunchKernelGGL(k_scan_apply, dim3(sb), dim3(256), 0, st, c->hist.as<u32>(), c->bsum.as<u32>(), c->offs.as<u32>(), (int)nb);
+  LAUNCHCHK();
+  mark(2);
+  // 3. scatter
+  hipLaunchKernelGGL(k_msm_scatter, dim3(nblk(total, 256)), dim3(256), 0, st, c->ent.as<u32>(), c->offs.as<u32>(), c->cursor.as<u32>(), c->sorted.as<u32>(),
+                     (int)n, total);
+  LAUNCHCHK();
+  mark(3);
+  // 4. bucket order by load
+  u32* lh = c->lhist.as<u32>();
+  hipLaunchKernelGGL(k_load_hist, dim3(nblk(nb, 256)), dim3(256), 0, st, c->hist.as<u32>(), lh, (int)nb);
+  hipLaunchKernelGGL(k_load_scan, dim3(1), dim3(1024), 0, st, lh);
+  hipLaunchKernelGGL(k_load_scatter, dim3(nblk(nb, 256)), dim3(256), 0, st, c->hist.as<u32>(), lh, c->order.as<u32>(), (int)nb);
+  LAUNCHCHK();
+  mark(4);
+  // 5. accumulate
+  hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(nb, 256)), dim3(256), 0, st, bases->rec + first * Store<F>::AFF_WORDS, c->sorted.as<u32>(),
+                     c->offs.as<u32>(), c->order.as<u32>(), c->buckets.as<u32>(), (int)nb);
+  LAUNCHCHK();
+  mark(5);
+  // 6. per-window weighted sums:  wsum = sum_g T_g + M * wsum0(R)
+  {
+    std::vector<int> Ms;
+    const u32* E = c->buckets.as<u32>();
+    int nn = (int)nbw, off = 1, cur = 0, level = 0;
+    // level T sums are stored consecutively in wacc[0]: level l at offset l * nwin
+    u32* tstore = c->wacc[0].as<u32>();
+    while (nn > 1) {
+      int M = nn >= 8 ? 8 : nn;
+      int G = nn / M;
+      u32* Rout = c->lvlR[cur].as<u32>();
+      u32* Tout = c->lvlT.as<u32>();
+      hipLaunchKernelGGL(k_wsum_level<F>, dim3(nblk((size_t)nwin * G, 256)), dim3(256), 0, st, E, Rout, Tout, nwin, nn, M, off);
+      LAUNCHCHK();
+      // sum the G T-records of each window down to one
+      const u32* Tin = Tout; int tn = G, tc = 0;
+      while (tn > 1) {
+        int TM = tn >= 8 ? 8 : tn; int TG = (tn + TM - 1) / TM;
+        u32* o = c->tsum[tc].as<u32>();
+        hipLaunchKernelGGL(k_tree_sum<F>, dim3(nblk((size_t)nwin * TG, 256)), dim3(256), 0, st, Tin, o, nwin, tn, TM);
+        LAUNCHCHK();
+        Tin = o; tn = TG; tc ^= 1;
+      }
+      HIPCHK(hipMemcpyAsync(tstore + (size_t)level * nwin * PW, Tin, (size_t)nwin * PW * 4, hipMemcpyDeviceToDevice, st));
+      Ms.push_back(M);
+      E = Rout; nn = G; off = 0; cur ^= 1; level++;
+      if (level >= 31) return bad("msm: reduction depth");
+    }
+    if (level == 0) {
+      // a single bucket per window (c = 1): the bucket itself is the window sum
+      HIPCHK(hipMemcpyAsync(c->wsums.p, c->buckets.p, (size_t)nwin * PW * 4, hipMemcpyDeviceToDevice, st));
+    } else {
+      // Horner over the levels: acc_L = T_L ; acc_l = T_l + M_l * acc_{l+1}
+      u32* accbuf = c->wacc[1].as<u32>();
+      HIPCHK(hipMemcpyAsync(accbuf, tstore + (size_t)(level - 1) * nwin * PW, (size_t)nwin * PW * 4, hipMemcpyDeviceToDevice, st));
+      for (int l = level - 2; l >= 0; l--) {
+        int k = 0; while ((1 << k) < Ms[l]) k++;
+        hipLaunchKernelGGL(k_shift_add<F>, dim3(nblk(nwin, 64)), dim3(64), 0, st, accbuf, tstore + (size_t)l * nwin * PW, accbuf, nwin, k);
+        LAUNCHCHK();
+      }
+      HIPCHK(hipMemcpyAsync(c->wsums.p, accbuf, (size_t)nwin * PW * 4, hipMemcpyDeviceToDevice, st));
+    }
+  }
+  mark(6);
+  // 7. combine windows
+  hipLaunchKernelGGL(k_msm_combine<F>, dim3(1), dim3(64), 0, st, c->wsums.as<u32>(), c->result.as<u32>(), nwin, cw);
+  LAUNCHCHK();
+  hipLaunchKernelGGL(k_proj_export<F>, dim3(1), dim3(256), 0, st, c->result.as<u32>(), (u32*)d_out_wire, (size_t)1);
+  LAUNCHCHK();
+  mark(7);
+  if (prof) {
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < 7; i++) hipEventElapsedTime(&c->phase_ms[i], c->ev[i], c->ev[i + 1]);
+    hipEventElapsedTime(&c->phase_ms[7], c->ev[0], c->ev[7]);
+  }
+  return BLSGPU_OK;
+}
+
+template <class F>
+static int msm_host(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, const uint8_t* scalars, size_t n, uint64_t* out) {
+  if (!c || !out || (n && !scalars)) return bad("msm: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->io_b.reserve(n ? n * 32 : 16) || c->io_out.reserve(3 * Wire<F>::WORDS * 4)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  if (n) HIPCHK(hipMemcpyAsync(c->io_b.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+  int rc = msm_device<F>(c, bases, first, c->io_b.p, n, c->io_out.p);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(out, c->io_out.p, 3 * Wire<F>::WORDS * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_g1_msm(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, uint64_t* out) { return msm_host<FpPolicy>(c, b, first, s, n, out); }
+extern "C" int blsgpu_g2_msm(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, uint64_t* out) { return msm_host<Fp2Policy>(c, b, first, s, n, out); }
+extern "C" int blsgpu_g1_msm_device(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const void* s, size_t n, void* out) { return msm_device<FpPolicy>(c, b, first, s, n, out); }
+extern "C" int blsgpu_g2_msm_device(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const void* s, size_t n, void* out) { return msm_device<Fp2Policy>(c, b, first, s, n, out); }
+template <class F>
+static int msm_oneshot(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) {
+  blsgpu_bases* b = nullptr;
+  int rc = bases_upload<F>(c, xy, inf, n, &b);
+  if (rc) return rc;
+  rc = msm_host<F>(c, b, 0, s, n, out);
+  blsgpu_bases_free(b);
+  return rc;
+}
+extern "C" int blsgpu_g1_msm_host(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) { return msm_oneshot<FpPolicy>(c, xy, inf, s, n, out); }
+extern "C" int blsgpu_g2_msm_host(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) { return msm_oneshot<Fp2Policy>(c, xy, inf, s, n, out); }
+
+// ---------------------------------------------------------------------------------------------------
+// group helpers
+// ---------------------------------------------------------------------------------------------------
+template <class F>
+static int proj_sum(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* out) {
+  if (!c || !out || (n && !xyz)) return bad("sum: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  constexpr int WW = Wire<F>::WORDS, PW = Store<F>::PROJ_WORDS;
+  if (c->io_a.reserve(n ? n * 3 * WW * 4 : 16) || c->io_c.reserve((n ? n : 1) * PW * 4) || c->result.reserve(PW * 4) || c->io_out.reserve(3 * WW * 4)) {
+    g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP;
+  }
+  if (n) {
+    HIPCHK(hipMemcpyAsync(c->io_a.p, xyz, n * 3 * WW * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_proj_import<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), c->io_c.as<u32>(), n);
+  }
+  hipLaunchKernelGGL(k_proj_sum<F>, dim3(1), dim3(64), 0, c->stream, c->io_c.as<u32>(), c->result.as<u32>(), n);
+  hipLaunchKernelGGL(k_proj_export<F>, dim3(1), dim3(256), 0, c->stream, c->result.as<u32>(), c->io_out.as<u32>(), (size_t)1);
+  LAUNCHCHK();
+  HIPCHK(hipMemcpyAsync(out, c->io_out.p, 3 * WW * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_g1_sum(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* out) { return proj_sum<FpPolicy>(c, xyz, n, out); }
+extern "C" int blsgpu_g2_sum(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* out) { return proj_sum<Fp2Policy>(c, xyz, n, out); }
+
+template <class F>
+static int batch_normalize(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* xy, uint8_t* inf) {
+  if (!c || (n && (!xyz || !xy))) return bad("batch_normalize: NULL argument");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  constexpr int WW = Wire<F>::WORDS, PW = Store<F>::PROJ_WORDS;
+  if (c->io_a.reserve(n * 3 * WW * 4) || c->io_c.reserve(n * PW * 4) || c->io_out.reserve(n * 2 * WW * 4) || c->flags_b.reserve(n)) {
+    g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP;
+  }
+  HIPCHK(hipMemcpyAsync(c->io_a.p, xyz, n * 3 * WW * 4, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_proj_import<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), c->io_c.as<u32>(), n);
+  hipLaunchKernelGGL(k_proj_to_affine<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_c.as<u32>(), c->io_out.as<u32>(), c->flags_b.as<uint8_t>(), n);
+  LAUNCHCHK();
+  HIPCHK(hipMemcpyAsync(xy, c->io_out.p, n * 2 * WW * 4, hipMemcpyDeviceToHost, c->stream));
+  if (inf) HIPCHK(hipMemcpyAsync(inf, c->flags_b.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_g1_batch_normalize(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* xy, uint8_t* inf) { return batch_normalize<FpPolicy>(c, xyz, n, xy, inf); }
+extern "C" int blsgpu_g2_batch_normalize(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* xy, uint8_t* inf) { return batch_normalize<Fp2Policy>(c, xyz, n, xy, inf); }
+
+// ---------------------------------------------------------------------------------------------------
+// self-test hooks
+// ---------------------------------------------------------------------------------------------------
+static int elem_op(blsgpu_ctx* c, int words, int kind, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+  if (!c || (n && (!a || !out))) return bad("op: NULL argument");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  size_t bytes = n * words * 4;
+  if (c->io_a.reserve(bytes) || c->io_b.reserve(bytes) || c->io_out.reserve(bytes)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  HIPCHK(hipMemcpyAsync(c->io_a.p, a, bytes, hipMemcpyHostToDevice, c->stream));
+  if (b) HIPCHK(hipMemcpyAsync(c->io_b.p, b, bytes, hipMemcpyHostToDevice, c->stream));
+  const u32* bp = b ? c->io_b.as<u32>() : nullptr;
+  if (kind == 1) hipLaunchKernelGGL(k_fp_op, dim3(nblk(n, 256)), dim3(256), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
+  else if (kind == 2) hipLaunchKernelGGL(k_fp2_op, dim3(nblk(n, 256)), dim3(256), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
+  else hipLaunchKernelGGL(k_fp12_op, dim3(nblk(n, 64)), dim3(64), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
+  LAUNCHCHK();
+  HIPCHK(hipMemcpyAsync(out, c->io_out.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_fp_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+  if (op < 0 || op > 5) return bad("fp_op: unknown op");
+  return elem_op(c, 12, 1, op, a, b, n, out);
+}
+extern "C" int blsgpu_fp2_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+  if (op < 0 || op > 6) return bad("fp2_op: unknown op");
+  return elem_op(c, 24, 2, op, a, b, n, out);
+}
+extern "C" int blsgpu_fp12_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+  if (!(op == 0 || op == 3 || op == 4 || op == 7 || op == 8 || op == 9)) return bad("fp12_op: unknown op");
+  return elem_op(c, 144, 12, op, a, b, n, out);
+}
+template <class F>
+static int point_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, const uint8_t* binf, size_t n, uint64_t* out) {
+  constexpr int WW = Wire<F>::WORDS;
+  size_t ab = n * 3 * WW * 4, bb = n * (op == 2 ? 2 : 3) * WW * 4;
+  if (c->io_a.reserve(ab) || c->io_b.reserve(bb) || c->io_out.reserve(ab) || c->flags_a.reserve(n)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  HIPCHK(hipMemcpyAsync(c->io_a.p, a, ab, hipMemcpyHostToDevice, c->stream));
+  if (op != 1) HIPCHK(hipMemcpyAsync(c->io_b.p, b, bb, hipMemcpyHostToDevice, c->stream));
+  if (op == 2 && binf) HIPCHK(hipMemcpyAsync(c->flags_a.p, binf, n, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_point_op<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, op, c->io_a.as<u32>(), c->io_b.as<u32>(),
+                     (op == 2 && binf) ? c->flags_a.as<uint8_t>() : nullptr, c->io_out.as<u32>(), n);
+  LAUNCHCHK();
+  HIPCHK(hipMemcpyAsync(out, c->io_out.p, ab, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_point_op(blsgpu_ctx* c, int group, int op, const uint64_t* a, const uint64_t* b, const uint8_t* binf, size_t n, uint64_t* out) {
+  if (!c || (n && (!a || !out || (op != 1 && !b))) || op < 0 || op > 2 || (group != 1 && group != 2)) return bad("point_op: bad argument");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  return group == 1 ? point_op<FpPolicy>(c, op, a, b, binf, n, out) : point_op<Fp2Policy>(c, op, a, b, binf, n, out);
+}
+
+static int chain_probe(blsgpu_ctx* c, int iters, double* rate, bool fp) {
+  if (!c || !rate || iters <= 0) return bad("throughput: bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, c->device));
+  int blocks = prop.multiProcessorCount * 8;   // 8 blocks x 4 waves = 8 waves per SIMD
+  if (c->io_a.reserve(256 * 28 * 4 + 4096) || c->io_out.reserve((size_t)blocks * 256 * NL * 4)) { g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP; }
+  HIPCHK(hipMemsetAsync(c->io_a.p, 0x11, 256 * 28 * 4 + 4096, c->stream));
+  auto launch = [&](int it) {
+    if (fp) hipLaunchKernelGGL(k_fp_mul_chain, dim3(blocks), dim3(256), 0, c->stream, c->io_out.as<u32>(), c->io_a.as<u32>(), it);
+    else hipLaunchKernelGGL(k_mad_chain, dim3(blocks), dim3(256), 0, c->stream, c->io_out.as<u32>(), c->io_a.as<u32>(), it);
+  };
+  launch(4);
+  HIPCHK(hipEventRecord(c->ev[0], c->stream));
+  launch(iters);
+  HIPCHK(hipEventRecord(c->ev[1], c->stream));
+  HIPCHK(hipEventSynchronize(c->ev[1]));
+  float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+  double ops = (double)blocks * 256.0 * iters * (fp ? 1.0 : 64.0);
+  *rate = ops / (ms * 1e-3);
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_fp_mul_throughput(blsgpu_ctx* c, int iters, double* r) { return chain_probe(c, iters, r, true); }
+extern "C" int blsgpu_mad_throughput(blsgpu_ctx* c, int iters, double* r) { return chain_probe(c, iters, r, false); }
+
+// ---------------------------------------------------------------------------------------------------
+// pairings
+// ---------------------------------------------------------------------------------------------------
+static int pairing_launch(blsgpu_ctx* c, int mode, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) {
+  // mode 0: full pairing, 1: Miller loop only
+  hipLaunchKernelGGL(k_pairing, dim3(nblk(n, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, mode, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2,
+                     (const uint8_t*)g2inf, (u32*)out, n);
+  LAUNCHCHK();
+  return BLSGPU_OK;
+}
+static int pairing_host(blsgpu_ctx* c, int mode, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, size_t n, uint64_t* out) {
+  if (!c || (n && (!g1 || !g2 || !out))) return bad("pairing: NULL argument");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  if (c->io_a.reserve(n * 96) || c->io_b.reserve(n * 192) || c->flags_a.reserve(n) || c->flags_b.reserve(n) || c->io_out.reserve(n * 576)) {
+    g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP;
+  }
+  HIPCHK(hipMemcpyAsync(c->io_a.p, g1, n * 96, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->io_b.p, g2, n * 192, hipMemcpyHostToDevice, c->stream));
+  if (g1inf) HIPCHK(hipMemcpyAsync(c->flags_a.p, g1inf, n, hipMemcpyHostToDevice, c->stream));
+  if (g2inf) HIPCHK(hipMemcpyAsync(c->flags_b.p, g2inf, n, hipMemcpyHostToDevice, c->stream));
+  int rc = pairing_launch(c, mode, c->io_a.p, g1inf ? c->flags_a.p : nullptr, c->io_b.p, g2inf ? c->flags_b.p : nullptr, n, c->io_out.p);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(out, c->io_out.p, n * 576, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_pairing_batch(blsgpu_ctx* c, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, size_t n, uint64_t* out) {
+  return pairing_host(c, 0, g1, g1inf, g2, g2inf, n, out);
+}
+extern "C" int blsgpu_miller_loop_batch(blsgpu_ctx* c, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, size_t n, uint64_t* out) {
+  return pairing_host(c, 1, g1, g1inf, g2, g2inf, n, out);
+}
+extern "C" int blsgpu_pairing_batch_device(blsgpu_ctx* c, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) {
+  if (!c || (n && (!g1 || !g2 || !out))) return bad("pairing: NULL argument");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  return pairing_launch(c, 0, g1, g1inf, g2, g2inf, n, out);
+}
+
+// product of n Fp12 wire values already in device memory (d_in) -> one wire value (d_out); tree of k_fp12_prod
+static int fp12_product_device(blsgpu_ctx* c, const u32* d_in, size_t n, u32* d_out) {
+  if (c->io_c.reserve((n / 2 + 1) * 576) || c->io_d.reserve((n / 4 + 1) * 576)) { g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP; }
+  if (n == 0) {
+    hipLaunchKernelGGL(k_fp12_one, dim3(1), dim3(64), 0, c->stream, d_out);
+    LAUNCHCHK();
+    return BLSGPU_OK;
+  }
+  const u32* in = d_in; int flip = 0;
+  while (n > 1) {
+    size_t m = (n + FP12_PROD_FAN - 1) / FP12_PROD_FAN;
+    u32* o = (m == 1) ? d_out : (flip ? c->io_d.as<u32>() : c->io_c.as<u32>());
+    hipLaunchKernelGGL(k_fp12_prod, dim3(nblk(m, 64)), dim3(64), 0, c->stream, in, o, n, m);
+    LAUNCHCHK();
+    in = o; n = m; flip ^= 1;
+  }
+  if (in != d_out) HIPCHK(hipMemcpyAsync(d_out, in, 576, hipMemcpyDeviceToDevice, c->stream));
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_multi_miller_loop_device(blsgpu_ctx* c, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) {
+  if (!c || !out || (n && (!g1 || !g2))) return bad("multi_miller_loop: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->io_out.reserve((n ? n : 1) * 576)) { g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP; }
+  if (n) { int rc = pairing_launch(c, 1, g1, g1inf, g2, g2inf, n, c->io_out.p); if (rc) return rc; }
+  return fp12_product_device(c, c->io_out.as<u32>(), n, (u32*)out);
+}
+extern "C" int blsgpu_multi_miller_loop(blsgpu_ctx* c, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, size_t n, uint64_t* out) {
+  if (!c || !out || (n && (!g1 || !g2))) return bad("multi_miller_loop: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->io_a.reserve(n ? n * 96 : 16) || c->io_b.reserve(n ? n * 192 : 16) || c->flags_a.reserve(n ? n : 16) || c->flags_b.reserve(n ? n : 16) || c->result.reserve(576)) {
+    g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP;
+  }
+  if (n) {
+    HIPCHK(hipMemcpyAsync(c->io_a.p, g1, n * 96, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->io_b.p, g2, n * 192, hipMemcpyHostToDevice, c->stream));
+    if (g1inf) HIPCHK(hipMemcpyAsync(c->flags_a.p, g1inf, n, hipMemcpyHostToDevice, c->stream));
+    if (g2inf) HIPCHK(hipMemcpyAsync(c->flags_b.p, g2inf, n, hipMemcpyHostToDevice, c->stream));
+  }
+  int rc = blsgpu_multi_miller_loop_device(c, c->io_a.p, g1inf ? c->flags_a.p : nullptr, c->io_b.p, g2inf ? c->flags_b.p : nullptr, n, c->result.p);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(out, c->result.p, 576, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_final_exponentiation_batch(blsgpu_ctx* c, const uint64_t* in, size_t n, uint64_t* out) {
+  if (!c || (n && (!in || !out))) return bad("final_exponentiation: NULL argument");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  if (c->io_a.reserve(n * 576) || c->io_out.reserve(n * 576)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  HIPCHK(hipMemcpyAsync(c->io_a.p, in, n * 576, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_final_exp, dim3(nblk(n, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, c->io_a.as<u32>(), c->io_out.as<u32>(), n);
+  LAUNCHCHK();
+  HIPCHK(hipMemcpyAsync(out, c->io_out.p, n * 576, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_fp12_product(blsgpu_ctx* c, const uint64_t* in, size_t n, uint64_t* out) {
+  if (!c || !out || (n && !in)) return bad("fp12_product: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->io_a.reserve(n ? n * 576 : 16) || c->result.reserve(576)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  if (n) HIPCHK(hipMemcpyAsync(c->io_a.p, in, n * 576, hipMemcpyHostToDevice, c->stream));
+  int rc = fp12_product_device(c, c->io_a.as<u32>(), n, c->result.as<u32>());
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(out, c->result.p, 576, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}

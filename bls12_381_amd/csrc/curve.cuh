@@ -1,0 +1,145 @@
+// curve.cuh -- G1 / G2 point arithmetic: the reference's complete RCB15 formulas (a = 0) written once
+// over a field policy (Fp for G1, Fp2 for G2).
+//
+// Reference: /root/reference/src/g1.rs  double :638-667 (Alg. 9), add :670-712 (Alg. 7),
+// add_mixed :715-752 (Alg. 8), mul_by_3b :597-601, identity (0:1:0) :605-611;  src/g2.rs the same
+// code over Fp2 (:709-738, :741-783, :786-823) with mul_by_3b = multiplication by 3b' = 12 + 12u
+// (:196, :650-652).  Homogeneous projective (X:Y:Z), x = X/Z; the formulas have no exceptional cases
+// (P+P, P-P, identity operands), which is what keeps Pippenger's bucket accumulation free of
+// divergence on a 64-wide wavefront.  Bounds of the lazy field arithmetic are proven by the types.
+#pragma once
+#include "fp2.cuh"
+
+namespace bls {
+
+// ---- field policies ------------------------------------------------------------------------------
+struct FpPolicy {
+  typedef fe elem;          // working storage (value < 8p)
+  typedef fe1 aff_elem;     // canonical affine coordinate
+  template <class T> static DEV elem st(const T& a) { return store(a); }
+  static DEV elem zero() { return fe_zero(); }
+  static DEV elem one() { return fe_one(); }
+  // 3b * a = 12 a     (g1.rs:597-601)
+  template <int A, int V> static DEV auto mul_by_3b(const Fe<A, V>& a) {
+    if constexpr (12 * A <= 15) return norm(mul_small<12>(a));
+    else return norm(mul_small<12>(norm(a)));
+  }
+};
+struct Fp2Policy {
+  typedef fe2 elem;
+  typedef fe2_1 aff_elem;
+  template <class T> static DEV elem st(const T& a) { return store2(a); }
+  static DEV elem zero() { return fe2_zero(); }
+  static DEV elem one() { return fe2_one(); }
+  // 3b' * a = (12 + 12u)(a0 + a1 u) = 12(a0 - a1) + 12(a0 + a1) u     (g2.rs:196,650-652)
+  template <int A, int V> static DEV auto mul_by_3b(const Fe2<A, V>& a) {
+    auto n = norm(a);
+    auto t = norm(mul_by_nonresidue(n));       // <1, 2V+1>
+    return reduce_v(norm(mul_small<12>(t)));  // back below 2p: keeps every Fp2 product input small
+  }
+};
+
+template <class F> struct Aff { typename F::aff_elem x, y; };
+template <class F> struct Proj { typename F::elem x, y, z; };
+
+template <class F> DEV Proj<F> pt_identity() {
+  Proj<F> r; r.x = F::zero(); r.y = F::one(); r.z = F::zero(); return r;
+}
+
+// RCB15 Algorithm 8 (mixed addition).  q_inf mirrors conditional_select(&tmp, self, rhs.is_identity()).
+template <class F>
+DEV Proj<F> pt_add_mixed(const Proj<F>& p, const Aff<F>& q, bool q_inf) {
+  auto t0 = mul(p.x, q.x);
+  auto t1 = mul(p.y, q.y);
+  auto t3 = mul(add(q.x, q.y), add(p.x, p.y));
+  auto t4 = add(t0, t1);
+  auto t3b = norm(sub(t3, t4));
+  auto t4b = norm(add(mul(q.y, p.z), p.y));
+  auto y3 = norm(add(mul(q.x, p.z), p.x));
+  auto t0b = norm(add(dbl(t0), t0));          // 3 t0
+  auto t2 = F::mul_by_3b(p.z);
+  auto z3 = norm(add(t1, t2));
+  auto t1b = norm(sub(t1, t2));
+  auto y3b = F::mul_by_3b(y3);
+  auto x3 = mul(t4b, y3b);
+  auto t2b = mul(t3b, t1b);
+  auto x3b = sub(t2b, x3);
+  auto y3c = mul(y3b, t0b);
+  auto t1c = mul(t1b, z3);
+  auto y3d = add(t1c, y3c);
+  auto t0c = mul(t0b, t3b);
+  auto z3b = mul(z3, t4b);
+  auto z3c = add(z3b, t0c);
+  Proj<F> r;
+  r.x = F::st(x3b); r.y = F::st(y3d); r.z = F::st(z3c);
+  if (q_inf) r = p;
+  return r;
+}
+
+// RCB15 Algorithm 7 (projective + projective)
+template <class F>
+DEV Proj<F> pt_add(const Proj<F>& p, const Proj<F>& q) {
+  auto t0 = mul(p.x, q.x);
+  auto t1 = mul(p.y, q.y);
+  auto t2 = mul(p.z, q.z);
+  auto t3 = mul(add(p.x, p.y), add(q.x, q.y));
+  auto t3b = norm(sub(t3, add(t0, t1)));
+  auto t4 = mul(add(p.y, p.z), add(q.y, q.z));
+  auto t4b = norm(sub(t4, add(t1, t2)));
+  auto x3 = mul(add(p.x, p.z), add(q.x, q.z));
+  auto y3 = norm(sub(x3, add(t0, t2)));
+  auto t0b = norm(add(dbl(t0), t0));
+  auto t2b = F::mul_by_3b(t2);
+  auto z3 = norm(add(t1, t2b));
+  auto t1b = norm(sub(t1, t2b));
+  auto y3b = F::mul_by_3b(y3);
+  auto x3b = mul(t4b, y3b);
+  auto t2c = mul(t3b, t1b);
+  auto x3c = sub(t2c, x3b);
+  auto y3c = mul(y3b, t0b);
+  auto t1c = mul(t1b, z3);
+  auto y3d = add(t1c, y3c);
+  auto t0c = mul(t0b, t3b);
+  auto z3b = mul(z3, t4b);
+  auto z3c = add(z3b, t0c);
+  Proj<F> r;
+  r.x = F::st(x3c); r.y = F::st(y3d); r.z = F::st(z3c);
+  return r;
+}
+
+// RCB15 Algorithm 9 (doubling).  The reference's final select-to-identity for Z = 0 is implied:
+// with Z = 0 the formula yields (0 : Y^3-ish : 0), the same point (X:Y:0 is the identity for any Y != 0).
+template <class F>
+DEV Proj<F> pt_double(const Proj<F>& p) {
+  auto t0 = sqr(p.y);
+  auto z3 = norm(mul_small<8>(t0));
+  auto t1 = mul(p.y, p.z);
+  auto t2 = F::mul_by_3b(sqr(p.z));
+  auto x3 = mul(t2, z3);
+  auto y3 = norm(add(t0, t2));
+  auto z3b = mul(t1, z3);
+  auto t2b = norm(mul_small<3>(t2));
+  auto t0b = norm(sub(t0, t2b));
+  auto y3b = mul(t0b, y3);
+  auto y3c = add(x3, y3b);
+  auto t1b = mul(p.x, p.y);
+  auto x3b = mul(t0b, t1b);
+  auto x3c = dbl(x3b);
+  Proj<F> r;
+  r.x = F::st(x3c); r.y = F::st(y3c); r.z = F::st(z3b);
+  return r;
+}
+
+template <class F> DEV Proj<F> pt_neg(const Proj<F>& p) {
+  Proj<F> r; r.x = p.x; r.y = F::st(neg(p.y)); r.z = p.z; return r;
+}
+template <class F> DEV Proj<F> pt_select(bool c, const Proj<F>& a, const Proj<F>& b) {
+  Proj<F> r; r.x = select(c, a.x, b.x); r.y = select(c, a.y, b.y); r.z = select(c, a.z, b.z); return r;
+}
+
+typedef Aff<FpPolicy> G1Aff;
+typedef Proj<FpPolicy> G1Proj;
+typedef Aff<Fp2Policy> G2Aff;
+typedef Proj<Fp2Policy> G2Proj;
+
+}  // namespace bls

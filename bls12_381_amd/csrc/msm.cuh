@@ -1,0 +1,350 @@
+// msm.cuh -- Pippenger multi-scalar multiplication  sum_i s_i * P_i  for G1 and G2 (templated on the
+// field policy).
+//
+// The reference has no MSM routine; it defines the result as  points.zip(scalars).map(|(p,s)| p*s).sum()
+// i.e. 255-step double-and-add per point (src/g1.rs:754-774, src/g2.rs:825-845) folded with `Sum`
+// (src/g1.rs:161-171).  The same group element is produced here with the bucket method:
+//
+//   1. digits      scalars (32 B LE canonical integers, the output format of Scalar::to_bytes,
+//                  src/scalar.rs:284-296) -> W signed c-bit digits each; histogram of bucket loads
+//   2. scan        exclusive prefix sum of the histogram -> bucket offsets
+//   3. scatter     counting sort of (sign, point index) by (window, |digit|)
+//   4. order       buckets sorted by load (descending) so that the 64 lanes of a wavefront walk
+//                  buckets of equal length (no tail divergence)
+//   5. accumulate  one lane per bucket: gathers its points (128 B / 256 B records) and adds them with the
+//                  exception-free mixed addition of curve.cuh -- this is >90% of the arithmetic
+//   6. reduce      sum_k k * B_k per window by chunked running sums (log-depth recursion)
+//   7. combine     Horner over the windows (c doublings + 1 addition each)
+//
+// Data layout in HBM: bases are converted once at upload to the internal field form and stored as
+// 128-byte (G1) / 256-byte (G2) records, so a gather is 8 / 16 aligned 16-byte loads per lane; scalars
+// are read coalesced exactly once; the sorted index array and the bucket array are the only large
+// temporaries (4 B per (point, window) and 176 / 336 B per bucket).
+#pragma once
+#include "convert.cuh"
+
+namespace bls {
+
+// ---- resident storage records ---------------------------------------------------------------------
+template <class F> struct Store;
+template <> struct Store<FpPolicy> {
+  static constexpr int AFF_WORDS = 32;    // x[14] y[14] inf pad[3]          (128 B)
+  static constexpr int PROJ_WORDS = 44;   // x[14] y[14] z[14] pad[2]        (176 B)
+  static constexpr int EL = NL;
+  static DEV void ld(const u32* w, fe1& a) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) a.l[i] = w[i];
+  }
+  template <class T> static DEV void st(u32* w, const T& a) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) w[i] = a.l[i];
+  }
+  static DEV void ldw(const u32* w, fe& a) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) a.l[i] = w[i];
+  }
+};
+template <> struct Store<Fp2Policy> {
+  static constexpr int AFF_WORDS = 64;    // x0 x1 y0 y1 (14 each) inf pad[7]  (256 B)
+  static constexpr int PROJ_WORDS = 84;   // 6 x 14                            (336 B)
+  static constexpr int EL = 2 * NL;
+  static DEV void ld(const u32* w, fe2_1& a) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) { a.c0.l[i] = w[i]; a.c1.l[i] = w[NL + i]; }
+  }
+  template <class T> static DEV void st(u32* w, const T& a) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) { w[i] = a.c0.l[i]; w[NL + i] = a.c1.l[i]; }
+  }
+  static DEV void ldw(const u32* w, fe2& a) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) { a.c0.l[i] = w[i]; a.c1.l[i] = w[NL + i]; }
+  }
+};
+
+template <class F> DEV void load_aff(const u32* rec, Aff<F>& q, bool& inf) {
+  constexpr int EL = Store<F>::EL;
+  // 16-byte vector loads of the whole record
+  u32 w[2 * EL + 4];
+  const uint4* v = reinterpret_cast<const uint4*>(rec);
+#pragma unroll
+  for (int i = 0; i < (2 * EL + 4) / 4; i++) {
+    uint4 t = v[i];
+    w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w;
+  }
+  Store<F>::ld(w, q.x);
+  Store<F>::ld(w + EL, q.y);
+  inf = w[2 * EL] != 0;
+}
+template <class F> DEV void load_proj(const u32* rec, Proj<F>& p) {
+  constexpr int EL = Store<F>::EL;
+  Store<F>::ldw(rec, p.x); Store<F>::ldw(rec + EL, p.y); Store<F>::ldw(rec + 2 * EL, p.z);
+}
+template <class F> DEV void store_proj(u32* rec, const Proj<F>& p) {
+  constexpr int EL = Store<F>::EL;
+  Store<F>::st(rec, p.x); Store<F>::st(rec + EL, p.y); Store<F>::st(rec + 2 * EL, p.z);
+}
+
+// negate an affine point's y lazily, keeping one static type for both signs
+DEV Fe<2, 2> cond_neg(const fe1& y, bool n) { return select(n, neg(y), (Fe<2, 2>)y); }
+DEV Fe2<2, 2> cond_neg(const fe2_1& y, bool n) { return select(n, neg(y), (Fe2<2, 2>)y); }
+
+// mixed addition with a sign-adjusted affine operand (same formula as pt_add_mixed; y has bound <2,2>)
+template <class F, class YT>
+DEV Proj<F> pt_add_mixed_y(const Proj<F>& p, const typename F::aff_elem& qx, const YT& qy) {
+  auto t0 = mul(p.x, qx);
+  auto t1 = mul(p.y, qy);
+  auto t3 = mul(norm(add(qx, qy)), add(p.x, p.y));
+  auto t4 = add(t0, t1);
+  auto t3b = norm(sub(t3, t4));
+  auto t4b = norm(add(mul(qy, p.z), p.y));
+  auto y3 = norm(add(mul(qx, p.z), p.x));
+  auto t0b = norm(add(dbl(t0), t0));
+  auto t2 = F::mul_by_3b(p.z);
+  auto z3 = norm(add(t1, t2));
+  auto t1b = norm(sub(t1, t2));
+  auto y3b = F::mul_by_3b(y3);
+  auto x3 = mul(t4b, y3b);
+  auto t2b = mul(t3b, t1b);
+  auto x3b = sub(t2b, x3);
+  auto y3c = mul(y3b, t0b);
+  auto t1c = mul(t1b, z3);
+  auto y3d = add(t1c, y3c);
+  auto t0c = mul(t0b, t3b);
+  auto z3b = mul(z3, t4b);
+  auto z3c = add(z3b, t0c);
+  Proj<F> r;
+  r.x = F::st(x3b); r.y = F::st(y3d); r.z = F::st(z3c);
+  return r;
+}
+
+// ---- 1. digits + histogram -------------------------------------------------------------------------
+// ent[w * n + i] = global bucket (w * nbw + |d| - 1) | sign << 31, or 0xffffffff for a zero digit.
+__global__ void __launch_bounds__(256) k_msm_digits(const u32* __restrict__ scalars, u32* __restrict__ ent,
+                                                    u32* __restrict__ hist, int n, int c, int nwin) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 s[9];
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+  uint4 a = sp[0], b = sp[1];
+  s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w; s[8] = 0;
+  const u32 nbw = 1u << (c - 1);
+  const u32 mask = (1u << c) - 1;
+  u32 carry = 0;
+  for (int w = 0; w < nwin; w++) {
+    int bit = w * c, lo = bit >> 5, sh = bit & 31;
+    u32 raw = 0;
+    if (lo < 8) {
+      u64 t = ((u64)s[lo + 1] << 32 | s[lo]) >> sh;
+      raw = (u32)t & mask;
+    }
+    raw += carry;
+    u32 neg = raw > nbw;
+    u32 mag = neg ? ((1u << c) - raw) : raw;
+    carry = neg;
+    u32 e = 0xffffffffu;
+    if (mag) {
+      u32 gb = (u32)w * nbw + (mag - 1);
+      e = gb | (neg << 31);
+      atomicAdd(&hist[gb], 1u);
+    }
+    ent[(size_t)w * n + i] = e;
+  }
+}
+
+// ---- 2. exclusive scan (three small kernels; <= 2^22 elements) --------------------------------------
+__global__ void __launch_bounds__(256) k_scan_block_sums(const u32* __restrict__ in, u32* __restrict__ bsum, int n) {
+  __shared__ u32 sh[256];
+  int base = blockIdx.x * 1024;
+  u32 t = 0;
+  for (int j = 0; j < 4; j++) {
+    int idx = base + threadIdx.x * 4 + j;
+    if (idx < n) t += in[idx];
+  }
+  sh[threadIdx.x] = t;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) bsum[blockIdx.x] = sh[0];
+}
+__global__ void __launch_bounds__(1024) k_scan_top(u32* __restrict__ bsum, int nb) {
+  // single block: exclusive scan of up to 4096 block sums
+  __shared__ u32 sh[4096];
+  for (int i = threadIdx.x; i < 4096; i += 1024) sh[i] = i < nb ? bsum[i] : 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 run = 0;
+    for (int i = 0; i < nb; i++) { u32 v = sh[i]; sh[i] = run; run += v; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nb; i += 1024) bsum[i] = sh[i];
+}
+__global__ void __launch_bounds__(256) k_scan_apply(const u32* __restrict__ in, const u32* __restrict__ bsum,
+                                                    u32* __restrict__ out, int n) {
+  __shared__ u32 sh[256];
+  int base = blockIdx.x * 1024;
+  u32 v[4]; u32 t = 0;
+  for (int j = 0; j < 4; j++) {
+    int idx = base + threadIdx.x * 4 + j;
+    v[j] = idx < n ? in[idx] : 0;
+    t += v[j];
+  }
+  sh[threadIdx.x] = t;
+  __syncthreads();
+  // Hillis-Steele inclusive scan over 256 partials
+  for (int s = 1; s < 256; s <<= 1) {
+    u32 x = (int)threadIdx.x >= s ? sh[threadIdx.x - s] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += x;
+    __syncthreads();
+  }
+  u32 run = bsum[blockIdx.x] + sh[threadIdx.x] - t;
+  for (int j = 0; j < 4; j++) {
+    int idx = base + threadIdx.x * 4 + j;
+    if (idx < n) out[idx] = run;
+    run += v[j];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[n] = run;   // total in out[n]
+}
+
+// ---- 3. scatter ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_msm_scatter(const u32* __restrict__ ent, const u32* __restrict__ offs,
+                                                     u32* __restrict__ cursor, u32* __restrict__ sorted,
+                                                     int n, size_t total) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  u32 e = ent[t];
+  if (e == 0xffffffffu) return;
+  u32 gb = e & 0x7fffffffu;
+  u32 i = (u32)(t % (size_t)n);
+  u32 pos = offs[gb] + atomicAdd(&cursor[gb], 1u);
+  sorted[pos] = i | (e & 0x80000000u);
+}
+
+// ---- 4. bucket order by load (descending) -----------------------------------------------------------
+constexpr int LOAD_BINS = 1024;
+__global__ void __launch_bounds__(256) k_load_hist(const u32* __restrict__ hist, u32* __restrict__ lhist, int nb) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  u32 l = hist[b]; if (l >= LOAD_BINS) l = LOAD_BINS - 1;
+  atomicAdd(&lhist[LOAD_BINS - 1 - l], 1u);      // descending: bin 0 = heaviest
+}
+__global__ void __launch_bounds__(1024) k_load_scan(u32* __restrict__ lhist) {
+  __shared__ u32 sh[LOAD_BINS];
+  sh[threadIdx.x] = lhist[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 run = 0;
+    for (int i = 0; i < LOAD_BINS; i++) { u32 v = sh[i]; sh[i] = run; run += v; }
+  }
+  __syncthreads();
+  lhist[threadIdx.x] = sh[threadIdx.x];
+}
+__global__ void __launch_bounds__(256) k_load_scatter(const u32* __restrict__ hist, u32* __restrict__ lcur,
+                                                      u32* __restrict__ order, int nb) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  u32 l = hist[b]; if (l >= LOAD_BINS) l = LOAD_BINS - 1;
+  u32 pos = atomicAdd(&lcur[LOAD_BINS - 1 - l], 1u);
+  order[pos] = (u32)b;
+}
+
+// ---- 5. bucket accumulation ---------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(256) k_msm_accumulate(const u32* __restrict__ bases, const u32* __restrict__ sorted,
+                                                        const u32* __restrict__ offs, const u32* __restrict__ order,
+                                                        u32* __restrict__ buckets, int nb) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nb) return;
+  u32 b = order[t];
+  u32 beg = offs[b], end = offs[b + 1];
+  Proj<F> acc = pt_identity<F>();
+  for (u32 j = beg; j < end; j++) {
+    u32 e = sorted[j];
+    Aff<F> q; bool inf;
+    load_aff<F>(bases + (size_t)(e & 0x7fffffffu) * Store<F>::AFF_WORDS, q, inf);
+    auto qy = cond_neg(q.y, (e >> 31) != 0);
+    Proj<F> r = pt_add_mixed_y<F>(acc, q.x, qy);
+    acc = pt_select(inf, acc, r);
+  }
+  store_proj<F>(buckets + (size_t)b * Store<F>::PROJ_WORDS, acc);
+}
+
+// ---- 6. weighted bucket reduction -----------------------------------------------------------------------
+// One level:  elements E[seg][0..n) (PROJ records), weight(j) = j + off.  Thread (seg, g) handles chunk
+// j in [g*M, (g+1)*M):  R = sum E_j,  T = sum (j - g*M + off) * E_j   (running sums, high index first).
+// Then  wsum(seg) = sum_g T_g + M * sum_g g * R_g.
+template <class F>
+__global__ void __launch_bounds__(256) k_wsum_level(const u32* __restrict__ E, u32* __restrict__ Rout, u32* __restrict__ Tout,
+                                                    int nseg, int n, int M, int off) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int G = n / M;
+  if (t >= nseg * G) return;
+  int seg = t / G, g = t - seg * G;
+  const u32* base = E + ((size_t)seg * n + (size_t)g * M) * Store<F>::PROJ_WORDS;
+  Proj<F> run = pt_identity<F>(), tot = pt_identity<F>();
+  for (int i = M - 1; i >= 0; i--) {
+    Proj<F> e; load_proj<F>(base + (size_t)i * Store<F>::PROJ_WORDS, e);
+    run = pt_add<F>(run, e);
+    if (i > 0 || off) tot = pt_add<F>(tot, run);
+  }
+  store_proj<F>(Rout + (size_t)t * Store<F>::PROJ_WORDS, run);
+  store_proj<F>(Tout + (size_t)t * Store<F>::PROJ_WORDS, tot);
+}
+// plain sum of n records per segment into one record (single thread per segment; n is small)
+template <class F>
+__global__ void __launch_bounds__(64) k_seg_sum(const u32* __restrict__ E, u32* __restrict__ out, int nseg, int n) {
+  int seg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seg >= nseg) return;
+  Proj<F> acc = pt_identity<F>();
+  for (int i = 0; i < n; i++) {
+    Proj<F> e; load_proj<F>(E + ((size_t)seg * n + i) * Store<F>::PROJ_WORDS, e);
+    acc = pt_add<F>(acc, e);
+  }
+  store_proj<F>(out + (size_t)seg * Store<F>::PROJ_WORDS, acc);
+}
+// tree sum: out[seg][g] = sum of M consecutive records
+template <class F>
+__global__ void __launch_bounds__(256) k_tree_sum(const u32* __restrict__ E, u32* __restrict__ out, int nseg, int n, int M) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int G = (n + M - 1) / M;
+  if (t >= nseg * G) return;
+  int seg = t / G, g = t - seg * G;
+  Proj<F> acc = pt_identity<F>();
+  for (int i = g * M; i < (g + 1) * M && i < n; i++) {
+    Proj<F> e; load_proj<F>(E + ((size_t)seg * n + i) * Store<F>::PROJ_WORDS, e);
+    acc = pt_add<F>(acc, e);
+  }
+  store_proj<F>(out + (size_t)t * Store<F>::PROJ_WORDS, acc);
+}
+// acc[seg] = 2^k * x[seg] + y[seg]   (k doublings)
+template <class F>
+__global__ void __launch_bounds__(64) k_shift_add(const u32* __restrict__ x, const u32* __restrict__ y, u32* __restrict__ out,
+                                                  int nseg, int k) {
+  int seg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seg >= nseg) return;
+  Proj<F> a, b;
+  load_proj<F>(x + (size_t)seg * Store<F>::PROJ_WORDS, a);
+  load_proj<F>(y + (size_t)seg * Store<F>::PROJ_WORDS, b);
+  for (int i = 0; i < k; i++) a = pt_double<F>(a);
+  a = pt_add<F>(a, b);
+  store_proj<F>(out + (size_t)seg * Store<F>::PROJ_WORDS, a);
+}
+
+// ---- 7. window combine (Horner) ------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(64) k_msm_combine(const u32* __restrict__ wsums, u32* __restrict__ out, int nwin, int c) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  Proj<F> acc;
+  load_proj<F>(wsums + (size_t)(nwin - 1) * Store<F>::PROJ_WORDS, acc);
+  for (int w = nwin - 2; w >= 0; w--) {
+    for (int i = 0; i < c; i++) acc = pt_double<F>(acc);
+    Proj<F> s; load_proj<F>(wsums + (size_t)w * Store<F>::PROJ_WORDS, s);
+    acc = pt_add<F>(acc, s);
+  }
+  store_proj<F>(out, acc);
+}
+
+}  // namespace bls

@@ -1,0 +1,407 @@
+// pairing.cuh -- Fp6 / Fp12 towers, Miller loop and final exponentiation, one pairing per lane.
+//
+// Reference: /root/reference/src/fp6.rs (mul :200-274, square :277-291, mul_by_1 :113-119, mul_by_01
+// :121-136, mul_by_nonresidue :139-150, frobenius_map :154-188, invert :294-312), src/fp12.rs (mul
+// :197-214, square :174-185, mul_by_014 :116-128, conjugate :136-141, frobenius_map :145-171, invert
+// :187-194) and src/pairings.rs (miller_loop :668-694, ell :696-707, doubling_step :709-738,
+// addition_step :740-770, final_exponentiation :48-176 with fp4_square / cyclotomic_square /
+// cycolotomic_exp, pairing :607-653).
+//
+// The Miller loop uses the reference's own line formulas and schedule (bits of BLS_X >> 1, 63 doubling
+// and 5 addition steps, conjugate at the end), so the raw Miller value is the same Fp12 element the
+// reference's `multi_miller_loop` produces; the final exponentiation follows the reference's chain and
+// therefore raises to 3 (p^4 - p^2 + 1) / r exactly as it does.  Field products are computed with
+// different (Karatsuba / sum-of-products) groupings than the reference's, which changes nothing: every
+// value is an exact field element and is serialised only after full reduction.
+//
+// The loop schedule is a compile-time constant, so all 64 lanes of a wavefront stay converged.  Tower
+// elements live in the storage form fe2 (limbs normalised, value < 32p); the out-of-line helpers take
+// them by reference, i.e. operands are staged in per-lane scratch and streamed through the VGPRs.
+#pragma once
+#include "convert.cuh"
+
+namespace bls {
+
+struct Fp6 { fe2 c0, c1, c2; };
+struct Fp12 { Fp6 c0, c1; };
+
+constexpr int PAIRING_BLOCK = 64;
+constexpr int FP12_PROD_FAN = 8;
+
+#define S2(x) store2(x)
+
+DEV Fp6 fp6_zero() { Fp6 r; r.c0 = fe2_zero(); r.c1 = fe2_zero(); r.c2 = fe2_zero(); return r; }
+DEV Fp6 fp6_one() { Fp6 r; r.c0 = fe2_one(); r.c1 = fe2_zero(); r.c2 = fe2_zero(); return r; }
+DEV Fp12 fp12_one() { Fp12 r; r.c0 = fp6_one(); r.c1 = fp6_zero(); return r; }
+
+DEV Fp6 fp6_add(const Fp6& a, const Fp6& b) {
+  Fp6 r; r.c0 = S2(add(a.c0, b.c0)); r.c1 = S2(add(a.c1, b.c1)); r.c2 = S2(add(a.c2, b.c2)); return r;
+}
+DEV Fp6 fp6_sub(const Fp6& a, const Fp6& b) {
+  Fp6 r; r.c0 = S2(sub(a.c0, b.c0)); r.c1 = S2(sub(a.c1, b.c1)); r.c2 = S2(sub(a.c2, b.c2)); return r;
+}
+DEV Fp6 fp6_neg(const Fp6& a) { Fp6 r; r.c0 = S2(neg(a.c0)); r.c1 = S2(neg(a.c1)); r.c2 = S2(neg(a.c2)); return r; }
+// multiply by v  (fp6.rs:139-150)
+DEV Fp6 fp6_mul_by_nonresidue(const Fp6& a) {
+  Fp6 r; r.c0 = S2(mul_by_nonresidue(a.c2)); r.c1 = a.c0; r.c2 = a.c1; return r;
+}
+
+// Karatsuba over Fp2 (6 Fp2 products); same element as fp6.rs:200-274
+DEVNI void fp6_mul(Fp6& r, const Fp6& a, const Fp6& b) {
+  auto v0 = mul(a.c0, b.c0);
+  auto v1 = mul(a.c1, b.c1);
+  auto v2 = mul(a.c2, b.c2);
+  auto t12 = mul(add(a.c1, a.c2), add(b.c1, b.c2));
+  auto t01 = mul(add(a.c0, a.c1), add(b.c0, b.c1));
+  auto t02 = mul(add(a.c0, a.c2), add(b.c0, b.c2));
+  auto x12 = norm(sub(sub(t12, v1), v2));                 // a1 b2 + a2 b1
+  auto c0 = add(v0, mul_by_nonresidue(x12));
+  auto x01 = norm(sub(sub(t01, v0), v1));                 // a0 b1 + a1 b0
+  auto c1 = add(x01, mul_by_nonresidue(v2));
+  auto x02 = norm(sub(sub(t02, v0), v2));                 // a0 b2 + a2 b0
+  auto c2 = add(x02, v1);
+  r.c0 = S2(c0); r.c1 = S2(c1); r.c2 = S2(c2);
+}
+// fp6.rs:277-291
+DEVNI void fp6_sqr(Fp6& r, const Fp6& a) {
+  auto s0 = sqr(a.c0);
+  auto ab = mul(a.c0, a.c1);
+  auto s1 = dbl(ab);
+  auto s2 = sqr(norm(add(sub(a.c0, a.c1), a.c2)));
+  auto bc = mul(a.c1, a.c2);
+  auto s3 = dbl(bc);
+  auto s4 = sqr(a.c2);
+  auto c0 = add(mul_by_nonresidue(norm(s3)), s0);
+  auto c1 = add(mul_by_nonresidue(s4), s1);
+  auto c2 = sub(sub(norm(add(add(s1, s2), s3)), s0), s4);
+  r.c0 = S2(c0); r.c1 = S2(c1); r.c2 = S2(c2);
+}
+// fp6.rs:113-119
+DEVNI void fp6_mul_by_1(Fp6& r, const Fp6& a, const fe2& c1) {
+  auto t0 = mul(a.c2, c1);
+  auto t1 = mul(a.c0, c1);
+  auto t2 = mul(a.c1, c1);
+  r.c0 = S2(mul_by_nonresidue(t0)); r.c1 = S2(t1); r.c2 = S2(t2);
+}
+// fp6.rs:121-136
+DEVNI void fp6_mul_by_01(Fp6& r, const Fp6& a, const fe2& c0, const fe2& c1) {
+  auto a_a = mul(a.c0, c0);
+  auto b_b = mul(a.c1, c1);
+  auto t1 = add(mul_by_nonresidue(mul(a.c2, c1)), a_a);
+  auto t2 = sub(sub(mul(add(c0, c1), add(a.c0, a.c1)), a_a), b_b);
+  auto t3 = add(mul(a.c2, c0), b_b);
+  r.c0 = S2(t1); r.c1 = S2(t2); r.c2 = S2(t3);
+}
+// fp6.rs:154-188
+DEVNI void fp6_frobenius(Fp6& r, const Fp6& a) {
+  constexpr PLimbs k1 = {BLS_FROB6_C1_1}, k2 = {BLS_FROB6_C2_0};
+  auto c0 = conj(a.c0);
+  auto c1 = norm(conj(a.c1));
+  auto c2 = norm(conj(a.c2));
+  // c1 * (0 + k1 u) = (-c1.c1 k1) + (c1.c0 k1) u
+  fe1 K1 = fe1_const(k1), K2 = fe1_const(k2);
+  Fe2<1, 2> m1; m1.c0 = (Fe<1, 2>)mul(norm(neg(c1.c1)), K1); m1.c1 = (Fe<1, 2>)mul(c1.c0, K1);
+  auto m2 = mul_fp(c2, K2);
+  r.c0 = S2(c0); r.c1 = S2(m1); r.c2 = S2(m2);
+}
+// fp6.rs:294-312
+DEVNI void fp6_inv(Fp6& r, const Fp6& a) {
+  auto c0 = norm(sub(sqr(a.c0), mul_by_nonresidue(mul(a.c1, a.c2))));
+  auto c1 = norm(sub(mul_by_nonresidue(sqr(a.c2)), mul(a.c0, a.c1)));
+  auto c2 = norm(sub(sqr(a.c1), mul(a.c0, a.c2)));
+  auto t = norm(add(mul_by_nonresidue(norm(add(mul(a.c1, c2), mul(a.c2, c1)))), mul(a.c0, c0)));
+  auto ti = inv(t);
+  r.c0 = S2(mul(ti, c0)); r.c1 = S2(mul(ti, c1)); r.c2 = S2(mul(ti, c2));
+}
+
+// ---- Fp12 --------------------------------------------------------------------------------------------
+// fp12.rs:197-214
+DEVNI void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) {
+  Fp6 aa, bb, t;
+  fp6_mul(aa, a.c0, b.c0);
+  fp6_mul(bb, a.c1, b.c1);
+  Fp6 o = fp6_add(b.c0, b.c1);
+  Fp6 s = fp6_add(a.c1, a.c0);
+  fp6_mul(t, s, o);
+  r.c1 = fp6_sub(fp6_sub(t, aa), bb);
+  r.c0 = fp6_add(fp6_mul_by_nonresidue(bb), aa);
+}
+// fp12.rs:174-185
+DEVNI void fp12_sqr(Fp12& r, const Fp12& a) {
+  Fp6 ab, t;
+  fp6_mul(ab, a.c0, a.c1);
+  Fp6 c0c1 = fp6_add(a.c0, a.c1);
+  Fp6 c0 = fp6_add(fp6_mul_by_nonresidue(a.c1), a.c0);
+  fp6_mul(t, c0, c0c1);
+  t = fp6_sub(t, ab);
+  r.c1 = fp6_add(ab, ab);
+  r.c0 = fp6_sub(t, fp6_mul_by_nonresidue(ab));
+}
+// fp12.rs:116-128
+DEVNI void fp12_mul_by_014(Fp12& r, const Fp12& a, const fe2& c0, const fe2& c1, const fe2& c4) {
+  Fp6 aa, bb, t;
+  fp6_mul_by_01(aa, a.c0, c0, c1);
+  fp6_mul_by_1(bb, a.c1, c4);
+  fe2 o = S2(add(c1, c4));
+  Fp6 s = fp6_add(a.c1, a.c0);
+  fp6_mul_by_01(t, s, c0, o);
+  r.c1 = fp6_sub(fp6_sub(t, aa), bb);
+  r.c0 = fp6_add(fp6_mul_by_nonresidue(bb), aa);
+}
+DEV void fp12_conj(Fp12& r, const Fp12& a) { r.c0 = a.c0; r.c1 = fp6_neg(a.c1); }
+// fp12.rs:145-171
+DEVNI void fp12_frobenius(Fp12& r, const Fp12& a) {
+  constexpr PLimbs k0 = {BLS_FROB12_C1_0}, k1 = {BLS_FROB12_C1_1};
+  Fp6 c0, c1;
+  fp6_frobenius(c0, a.c0);
+  fp6_frobenius(c1, a.c1);
+  fe2 K; K.c0 = (Fe<1, VS2>)fe1_const(k0); K.c1 = (Fe<1, VS2>)fe1_const(k1);
+  r.c0 = c0;
+  r.c1.c0 = S2(mul(c1.c0, K)); r.c1.c1 = S2(mul(c1.c1, K)); r.c1.c2 = S2(mul(c1.c2, K));
+}
+// fp12.rs:187-194
+DEVNI void fp12_inv(Fp12& r, const Fp12& a) {
+  Fp6 s0, s1, t, ti;
+  fp6_sqr(s0, a.c0);
+  fp6_sqr(s1, a.c1);
+  t = fp6_sub(s0, fp6_mul_by_nonresidue(s1));
+  fp6_inv(ti, t);
+  fp6_mul(r.c0, a.c0, ti);
+  Fp6 nt = fp6_neg(ti);
+  fp6_mul(r.c1, a.c1, nt);
+}
+
+// ---- wire I/O ------------------------------------------------------------------------------------------
+DEV void fp12_load(Fp12& f, const u32* w) {
+  fe2* e[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+#pragma unroll
+  for (int i = 0; i < 6; i++) { fe2_1 t = fe2_from_ref(w + 24 * i); *e[i] = (fe2)t; }
+}
+DEV void fp12_save(const Fp12& f, u32* w) {
+  const fe2* e[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+#pragma unroll
+  for (int i = 0; i < 6; i++) fe2_to_ref(*e[i], w + 24 * i);
+}
+
+// ---- Miller loop -------------------------------------------------------------------------------------
+struct G2Jac { fe2 x, y, z; };       // the pairing's running point R (pairings.rs:709-770 operate on G2Projective fields)
+struct Line { fe2 a, b, c; };        // the (Fp2, Fp2, Fp2) coefficient triple
+
+// pairings.rs:709-738 (CLN Algorithm 26)
+DEVNI void doubling_step(G2Jac& r, Line& l) {
+  auto tmp0 = sqr(r.x);
+  auto tmp1 = sqr(r.y);
+  auto tmp2 = sqr(tmp1);
+  auto tmp3 = norm(sub(sub(sqr(add(tmp1, r.x)), tmp0), tmp2));
+  auto tmp3d = norm(dbl(tmp3));
+  auto tmp4 = norm(add(dbl(tmp0), tmp0));
+  auto tmp6 = add(r.x, tmp4);
+  auto tmp5 = sqr(tmp4);
+  auto zsq = sqr(r.z);
+  auto rx = norm(sub(sub(tmp5, tmp3d), tmp3d));
+  auto rz = sub(sub(sqr(add(r.z, r.y)), tmp1), zsq);
+  auto ry = mul(norm(sub(tmp3d, rx)), tmp4);
+  auto tmp2o = norm(mul_small<8>(tmp2));
+  auto ryo = sub(ry, tmp2o);
+  auto t3 = mul(tmp4, zsq);
+  auto t3n = neg(norm(dbl(t3)));
+  auto t6 = sub(sub(sqr(norm(tmp6)), tmp0), tmp5);
+  auto t1q = norm(mul_small<4>(tmp1));
+  auto t6o = sub(norm(t6), t1q);
+  fe2 rzs = S2(rz);
+  auto t0 = mul(rzs, zsq);
+  r.x = S2(rx); r.y = S2(ryo); r.z = rzs;
+  l.a = S2(dbl(t0)); l.b = S2(t3n); l.c = S2(t6o);
+}
+// pairings.rs:740-770 (CLN Algorithm 27)
+DEVNI void addition_step(G2Jac& r, const fe2& qx, const fe2& qy, Line& l) {
+  auto zsq = sqr(r.z);
+  auto ysq = sqr(qy);
+  auto t0 = mul(zsq, qx);
+  auto t1 = mul(norm(sub(sub(sqr(add(qy, r.z)), ysq), zsq)), zsq);
+  auto t2 = norm(sub(t0, r.x));
+  auto t3 = sqr(t2);
+  auto t4 = norm(mul_small<4>(t3));
+  auto t5 = mul(t4, t2);
+  auto t6 = norm(sub(sub(t1, r.y), r.y));
+  auto t9 = mul(t6, qx);
+  auto t7 = mul(t4, r.x);
+  auto rx = norm(sub(sub(sub(sqr(t6), t5), t7), t7));
+  auto rz = sub(sub(sqr(add(r.z, t2)), zsq), t3);
+  fe2 rzs = S2(rz);
+  auto t10 = add(qy, rzs);
+  auto t8 = mul(norm(sub(t7, rx)), t6);
+  auto t0b = mul(r.y, t5);
+  auto ry = sub(t8, norm(dbl(t0b)));
+  auto t10b = sub(sqr(t10), ysq);
+  auto ztsq = sqr(rzs);
+  auto t10c = sub(norm(t10b), ztsq);
+  auto t9b = sub(norm(dbl(t9)), norm(t10c));
+  auto t10d = dbl(rzs);
+  auto t6n = neg(t6);
+  auto t1b = dbl(norm(t6n));
+  r.x = S2(rx); r.y = S2(ry); r.z = rzs;
+  l.a = S2(t10d); l.b = S2(t1b); l.c = S2(t9b);
+}
+// pairings.rs:696-707
+DEVNI void ell(Fp12& f, const Line& l, const fe1& px, const fe1& py) {
+  fe2 c0 = S2(mul_fp(l.a, py));
+  fe2 c1 = S2(mul_fp(l.b, px));
+  Fp12 t;
+  fp12_mul_by_014(t, f, l.c, c1, c0);
+  f = t;
+}
+
+// bits of BLS_X >> 1 below the leading one, MSB first (pairings.rs:671-685): 62 iterations, 5 set bits
+constexpr unsigned long long X_HALF = 0xd201000000010000ull >> 1;
+
+DEVNI void miller_loop(Fp12& f, const fe1& px, const fe1& py, const fe2& qx, const fe2& qy) {
+  G2Jac r; r.x = qx; r.y = qy; r.z = fe2_one();
+  f = fp12_one();
+  Line l;
+  for (int b = 61; b >= 0; b--) {           // bit 62 is the leading one
+    doubling_step(r, l);
+    ell(f, l, px, py);
+    if ((X_HALF >> b) & 1) {
+      addition_step(r, qx, qy, l);
+      ell(f, l, px, py);
+    }
+    Fp12 t; fp12_sqr(t, f); f = t;
+  }
+  doubling_step(r, l);
+  ell(f, l, px, py);
+  Fp12 t; fp12_conj(t, f); f = t;           // BLS_X_IS_NEGATIVE
+}
+
+// ---- final exponentiation ------------------------------------------------------------------------------
+// pairings.rs:50-62
+DEV void fp4_square(fe2& c0, fe2& c1, const fe2& a, const fe2& b) {
+  auto t0 = sqr(a);
+  auto t1 = sqr(b);
+  auto t2 = mul_by_nonresidue(t1);
+  c0 = S2(add(t2, t0));
+  auto t3 = sqr(add(a, b));
+  c1 = S2(sub(sub(t3, t0), t1));
+}
+// pairings.rs:66-112
+DEVNI void cyclotomic_square(Fp12& r, const Fp12& f) {
+  fe2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
+  fe2 t0, t1, t2, t3;
+  fp4_square(t0, t1, z0, z1);
+  fe2 nz0 = S2(add(dbl(norm(sub(t0, z0))), t0));
+  fe2 nz1 = S2(add(dbl(norm(add(t1, z1))), t1));
+  fp4_square(t0, t1, z2, z3);
+  fp4_square(t2, t3, z4, z5);
+  fe2 nz4 = S2(add(dbl(norm(sub(t0, z4))), t0));
+  fe2 nz5 = S2(add(dbl(norm(add(t1, z5))), t1));
+  fe2 t0b = S2(mul_by_nonresidue(t3));
+  fe2 nz2 = S2(add(dbl(norm(add(t0b, z2))), t0b));
+  fe2 nz3 = S2(add(dbl(norm(sub(t2, z3))), t2));
+  r.c0.c0 = nz0; r.c0.c1 = nz4; r.c0.c2 = nz3;
+  r.c1.c0 = nz2; r.c1.c1 = nz1; r.c1.c2 = nz5;
+}
+// pairings.rs:114-132 (`cycolotomic_exp`): f^|x| then conjugate
+DEVNI void cyclotomic_exp(Fp12& r, const Fp12& f) {
+  constexpr unsigned long long X = 0xd201000000010000ull;
+  Fp12 tmp = f;                       // the leading one: tmp = one * f
+  for (int b = 62; b >= 0; b--) {
+    Fp12 t; cyclotomic_square(t, tmp); tmp = t;
+    if ((X >> b) & 1) { fp12_mul(t, tmp, f); tmp = t; }
+  }
+  fp12_conj(r, tmp);
+}
+// pairings.rs:134-173
+DEVNI void final_exponentiation(Fp12& out, const Fp12& fin) {
+  Fp12 f = fin, t0, t1, t2, t3, t4, t5, t6, x;
+  fp12_frobenius(t0, f);
+  for (int i = 0; i < 5; i++) { fp12_frobenius(x, t0); t0 = x; }
+  fp12_inv(t1, f);
+  fp12_mul(t2, t0, t1);
+  t1 = t2;
+  fp12_frobenius(x, t2); fp12_frobenius(t2, x);
+  fp12_mul(x, t2, t1); t2 = x;
+  cyclotomic_square(x, t2); fp12_conj(t1, x);
+  cyclotomic_exp(t3, t2);
+  cyclotomic_square(t4, t3);
+  fp12_mul(t5, t1, t3);
+  cyclotomic_exp(t1, t5);
+  cyclotomic_exp(t0, t1);
+  cyclotomic_exp(t6, t0);
+  fp12_mul(x, t6, t4); t6 = x;
+  cyclotomic_exp(t4, t6);
+  fp12_conj(x, t5); t5 = x;
+  fp12_mul(x, t5, t2);
+  Fp12 y; fp12_mul(y, t4, x); t4 = y;
+  fp12_conj(t5, t2);
+  fp12_mul(x, t1, t2); t1 = x;
+  fp12_frobenius(x, t1); fp12_frobenius(t1, x); fp12_frobenius(x, t1); t1 = x;
+  fp12_mul(x, t6, t5); t6 = x;
+  fp12_frobenius(x, t6); t6 = x;
+  fp12_mul(x, t3, t0); t3 = x;
+  fp12_frobenius(x, t3); fp12_frobenius(t3, x);
+  fp12_mul(x, t3, t1); t3 = x;
+  fp12_mul(x, t3, t6); t3 = x;
+  fp12_mul(out, t3, t4);
+}
+
+// ---- kernels ---------------------------------------------------------------------------------------------
+// mode 0: out[i] = pairing(g1[i], g2[i]);  mode 1: out[i] = raw Miller loop value.
+// Identity on either side -> Fp12::one() (pairings.rs:636-651; multi_miller_loop skips such terms :566-569).
+__global__ void __launch_bounds__(PAIRING_BLOCK) k_pairing(int mode, const u32* __restrict__ g1, const uint8_t* __restrict__ g1inf,
+                                                          const u32* __restrict__ g2, const uint8_t* __restrict__ g2inf,
+                                                          u32* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool ident = (g1inf && g1inf[i]) || (g2inf && g2inf[i]);
+  Fp12 f;
+  if (ident) {
+    f = fp12_one();
+  } else {
+    fe1 px = fe_from_ref(g1 + i * 24), py = fe_from_ref(g1 + i * 24 + 12);
+    fe2 qx = (fe2)fe2_from_ref(g2 + i * 48), qy = (fe2)fe2_from_ref(g2 + i * 48 + 24);
+    miller_loop(f, px, py, qx, qy);
+    if (mode == 0) { Fp12 g; final_exponentiation(g, f); f = g; }
+  }
+  fp12_save(f, out + i * 144);
+}
+__global__ void __launch_bounds__(PAIRING_BLOCK) k_final_exp(const u32* __restrict__ in, u32* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fp12 f, g;
+  fp12_load(f, in + i * 144);
+  final_exponentiation(g, f);
+  fp12_save(g, out + i * 144);
+}
+// out[j] = product of in[j*FAN .. min(n, (j+1)*FAN))
+__global__ void __launch_bounds__(64) k_fp12_prod(const u32* __restrict__ in, u32* __restrict__ out, size_t n, size_t m) {
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  size_t beg = j * FP12_PROD_FAN, end = beg + FP12_PROD_FAN < n ? beg + FP12_PROD_FAN : n;
+  Fp12 acc; fp12_load(acc, in + beg * 144);
+  for (size_t i = beg + 1; i < end; i++) {
+    Fp12 x, t; fp12_load(x, in + i * 144);
+    fp12_mul(t, acc, x); acc = t;
+  }
+  fp12_save(acc, out + j * 144);
+}
+__global__ void k_fp12_one(u32* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { Fp12 f = fp12_one(); fp12_save(f, out); }
+}
+__global__ void __launch_bounds__(64) k_fp12_op(int op, const u32* __restrict__ a, const u32* __restrict__ b, u32* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fp12 x, y, r;
+  fp12_load(x, a + i * 144);
+  if (b) fp12_load(y, b + i * 144); else y = x;
+  switch (op) {
+    case 0: fp12_mul(r, x, y); break;
+    case 3: fp12_sqr(r, x); break;
+    case 4: fp12_inv(r, x); break;
+    case 7: fp12_frobenius(r, x); break;
+    case 8: fp12_conj(r, x); break;
+    default: cyclotomic_square(r, x); break;
+  }
+  fp12_save(r, out + i * 144);
+}
+
+}  // namespace bls

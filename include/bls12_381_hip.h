@@ -1,0 +1,136 @@
+/* bls12_381_hip.h -- C ABI of the MI355X-native BLS12-381 hot path (libblsgpu.so).
+ *
+ * This is the drop-in boundary for the data-parallel path of zkcrypto/bls12_381 v0.8.0: multi-scalar
+ * multiplication over G1/G2 and batched Miller-loop / final-exponentiation pairings.  The reference has
+ * no FFI (it is `#![deny(unsafe_code)]`, src/lib.rs:17); each entry point below names the Rust
+ * operator / trait method it replaces.  INTEGRATION.md shows the `extern "C"` block and the wrapper a
+ * maintainer would add on the Rust side.
+ *
+ * Wire formats (all little-endian, plain memory, caller-owned):
+ *   Fp      6 x u64   canonical Montgomery limbs, R = 2^384       (`Fp([u64;6])`, src/fp.rs:11-15)
+ *   Fp2     c0 | c1                                               (src/fp2.rs:11-14)
+ *   Fp12    c0.c0.c0 c0.c0.c1 c0.c1.c0 ... c1.c2.c1 (72 u64)      (src/fp12.rs:13-16, src/fp6.rs:12-16)
+ *   Scalar  32 bytes, little-endian canonical integer in [0, r)   (`Scalar::to_bytes`, src/scalar.rs:284-296)
+ *   G1 affine      x | y          (12 u64)  + out-of-band infinity byte   (src/g1.rs:28-32)
+ *   G1 projective  X | Y | Z      (18 u64), x = X/Z, identity (0:1:0)     (src/g1.rs:442-446,605-611)
+ *   G2 affine      x.c0 x.c1 y.c0 y.c1 (24 u64) + infinity byte           (src/g2.rs)
+ *   G2 projective  36 u64
+ * Results are exact group / field elements in canonical limbs: after affine conversion (G1/G2) or as they
+ * are (Gt) they are bit-identical to what the reference computes on the same inputs.
+ *
+ * Every function returns BLSGPU_OK (0) or a negative error code; nothing is retained from caller buffers
+ * after return.  A context owns one device, one HIP stream and its scratch memory; it is not re-entrant
+ * (use one context per host thread).
+ */
+#ifndef BLS12_381_HIP_H
+#define BLS12_381_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLSGPU_OK 0
+#define BLSGPU_ERR_HIP (-1)      /* a HIP runtime call failed (blsgpu_last_error gives the text) */
+#define BLSGPU_ERR_ARG (-2)      /* bad argument (NULL pointer, length mismatch, unsupported size) */
+#define BLSGPU_ERR_NODEV (-3)    /* no usable gfx950 device */
+
+typedef struct blsgpu_ctx blsgpu_ctx;
+typedef struct blsgpu_bases blsgpu_bases;   /* device-resident base points in the library's internal form */
+
+/* ---- context ------------------------------------------------------------------------------------ */
+int blsgpu_create(int device, blsgpu_ctx** out);
+void blsgpu_destroy(blsgpu_ctx* ctx);
+const char* blsgpu_last_error(void);
+int blsgpu_device_count(void);
+/* Use an existing HIP stream (e.g. torch's current stream) for all work of this context; NULL restores
+ * the context's own stream. */
+int blsgpu_set_stream(blsgpu_ctx* ctx, void* hip_stream);
+int blsgpu_synchronize(blsgpu_ctx* ctx);
+
+/* ---- resident bases ------------------------------------------------------------------------------- */
+/* Upload n affine points (host memory).  `infinity` may be NULL (no identities).
+ * Replaces holding a `&[G1Affine]` / `&[G2Affine]` on the Rust side. */
+int blsgpu_g1_bases_upload(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, size_t n, blsgpu_bases** out);
+int blsgpu_g2_bases_upload(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, size_t n, blsgpu_bases** out);
+/* Same, but `xy` / `infinity` are device pointers (e.g. torch tensors' data_ptr). */
+int blsgpu_g1_bases_from_device(blsgpu_ctx* ctx, const void* d_xy, const void* d_infinity, size_t n, blsgpu_bases** out);
+int blsgpu_g2_bases_from_device(blsgpu_ctx* ctx, const void* d_xy, const void* d_infinity, size_t n, blsgpu_bases** out);
+/* bases[i] = [k_i] * generator for n 32-byte LE scalars (device-side fixed-base multiplication; used to
+ * build synthetic inputs and SRS-style tables).  `group` is 1 or 2. */
+int blsgpu_bases_from_scalars(blsgpu_ctx* ctx, int group, const uint8_t* scalars, size_t n, blsgpu_bases** out);
+size_t blsgpu_bases_len(const blsgpu_bases* b);
+/* Read points [first, first+count) back in wire format (xy: count*12 or count*24 u64; infinity: count bytes). */
+int blsgpu_bases_download(blsgpu_ctx* ctx, const blsgpu_bases* b, size_t first, size_t count, uint64_t* xy, uint8_t* infinity);
+void blsgpu_bases_free(blsgpu_bases* b);
+
+/* ---- multi-scalar multiplication ------------------------------------------------------------------- */
+/* out = sum_{i<n} scalars[i] * bases[first + i]   as a projective point (18 / 36 u64).
+ * Replaces  bases.iter().zip(scalars).map(|(p, s)| p * s).sum::<G1Projective>()
+ * (`Mul<&Scalar> for &G1Affine` src/g1.rs:573-579 -> `multiply` :754-774, `Sum` :161-171; G2: src/g2.rs:626-632,
+ * 825-845, 162-172).  n = 0 yields the identity (0:1:0). */
+int blsgpu_g1_msm(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const uint8_t* scalars, size_t n, uint64_t out_xyz[18]);
+int blsgpu_g2_msm(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const uint8_t* scalars, size_t n, uint64_t out_xyz[36]);
+/* Asynchronous variants: scalars and the result live in device memory, work is enqueued on the
+ * context's stream and the call returns without synchronising. */
+int blsgpu_g1_msm_device(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const void* d_scalars, size_t n, void* d_out_xyz);
+int blsgpu_g2_msm_device(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const void* d_scalars, size_t n, void* d_out_xyz);
+/* One-shot convenience: upload, multiply, free. */
+int blsgpu_g1_msm_host(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, const uint8_t* scalars, size_t n, uint64_t out_xyz[18]);
+int blsgpu_g2_msm_host(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, const uint8_t* scalars, size_t n, uint64_t out_xyz[36]);
+/* Window width c (bits) used by Pippenger; 0 = automatic. */
+int blsgpu_set_msm_window(blsgpu_ctx* ctx, int c);
+
+/* ---- group helpers ----------------------------------------------------------------------------------- */
+/* out = sum of n projective points (`Sum for G1Projective`, src/g1.rs:161-171) -- the fold used after the
+ * cross-GPU all-gather of per-rank partial results. */
+int blsgpu_g1_sum(blsgpu_ctx* ctx, const uint64_t* xyz, size_t n, uint64_t out_xyz[18]);
+int blsgpu_g2_sum(blsgpu_ctx* ctx, const uint64_t* xyz, size_t n, uint64_t out_xyz[36]);
+/* Projective -> affine for n points (`G1Projective::batch_normalize`, src/g1.rs:806-839; `G1Affine::from`,
+ * :49-63).  Identity maps to x = 0, y = 1 (Montgomery one), infinity = 1. */
+int blsgpu_g1_batch_normalize(blsgpu_ctx* ctx, const uint64_t* xyz, size_t n, uint64_t* xy, uint8_t* infinity);
+int blsgpu_g2_batch_normalize(blsgpu_ctx* ctx, const uint64_t* xyz, size_t n, uint64_t* xy, uint8_t* infinity);
+
+/* ---- pairings ------------------------------------------------------------------------------------------ */
+/* out[i] = pairing(g1[i], g2[i]) for n independent pairs (`pairing`, src/pairings.rs:607-653; 72 u64 each).
+ * An identity on either side yields Gt::identity() = Fp12::one(), as the reference does. */
+int blsgpu_pairing_batch(blsgpu_ctx* ctx, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy, const uint8_t* g2_inf, size_t n, uint64_t* out_gt);
+/* out[i] = raw Miller-loop value of pair i (a `MillerLoopResult`, src/pairings.rs:26) -- bit-identical to the
+ * reference's because the same line formulas are used (src/pairings.rs:696-770). */
+int blsgpu_miller_loop_batch(blsgpu_ctx* ctx, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy, const uint8_t* g2_inf, size_t n, uint64_t* out_f);
+/* out = prod_i ML(g1[i], g2[i])  (`multi_miller_loop`, src/pairings.rs:554-603; pairs with an identity are
+ * skipped).  n = 0 yields Fp12::one() (`MillerLoopResult::default`, :28-32). */
+int blsgpu_multi_miller_loop(blsgpu_ctx* ctx, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy, const uint8_t* g2_inf, size_t n, uint64_t out_f[72]);
+/* out[i] = final_exponentiation(in[i])  (`MillerLoopResult::final_exponentiation`, src/pairings.rs:48-176). */
+int blsgpu_final_exponentiation_batch(blsgpu_ctx* ctx, const uint64_t* in_f, size_t n, uint64_t* out_gt);
+/* out = prod of n Fp12 values (`MillerLoopResult + MillerLoopResult`, src/pairings.rs:179-186; `Gt + Gt`). */
+int blsgpu_fp12_product(blsgpu_ctx* ctx, const uint64_t* in_f, size_t n, uint64_t out_f[72]);
+/* Device-pointer variants (inputs/outputs in device memory, asynchronous on the context's stream). */
+int blsgpu_pairing_batch_device(blsgpu_ctx* ctx, const void* d_g1_xy, const void* d_g1_inf, const void* d_g2_xy, const void* d_g2_inf, size_t n, void* d_out_gt);
+int blsgpu_multi_miller_loop_device(blsgpu_ctx* ctx, const void* d_g1_xy, const void* d_g1_inf, const void* d_g2_xy, const void* d_g2_inf, size_t n, void* d_out_f);
+
+/* ---- field self-test hooks (parity tests of the arithmetic core against the oracle) ---------------------- */
+/* out[i] = a[i] op b[i] over n Fp elements in wire format; op: 0 mul, 1 add, 2 sub, 3 square(a), 4 invert(a), 5 neg(a). */
+int blsgpu_fp_op(blsgpu_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
+/* Same over Fp2 (12 u64 per element); op: 0 mul, 1 add, 2 sub, 3 square, 4 invert, 5 neg, 6 mul_by_nonresidue. */
+int blsgpu_fp2_op(blsgpu_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
+/* Same over Fp12 (72 u64 per element); op: 0 mul, 3 square, 4 invert, 7 frobenius_map, 8 conjugate, 9 cyclotomic_square. */
+int blsgpu_fp12_op(blsgpu_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
+/* Point ops over n pairs in wire format; op: 0 add (proj+proj), 1 double (a), 2 add_mixed (proj + affine b). group 1|2. */
+int blsgpu_point_op(blsgpu_ctx* ctx, int group, int op, const uint64_t* a, const uint64_t* b, const uint8_t* b_inf, size_t n, uint64_t* out);
+/* Throughput probe: `iters` dependent Fp multiplications in every lane of a full-chip launch; returns
+ * multiplications per second (the arithmetic roofline evidence quoted by bench.py). */
+int blsgpu_fp_mul_throughput(blsgpu_ctx* ctx, int iters, double* muls_per_second);
+/* Same for a stream of independent v_mad_u64_u32 (the peak MAC32 rate used as roofline denominator). */
+int blsgpu_mad_throughput(blsgpu_ctx* ctx, int iters, double* mads_per_second);
+/* Duration (ms) of the most recent launch of the named phase inside the last MSM (HIP events on the
+ * context's stream): 0 digits+hist, 1 scan, 2 scatter, 3 order, 4 accumulate, 5 reduce, 6 combine, 7 total. */
+int blsgpu_last_msm_phase_ms(blsgpu_ctx* ctx, int phase, float* ms);
+int blsgpu_set_profiling(blsgpu_ctx* ctx, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLS12_381_HIP_H */

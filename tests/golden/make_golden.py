@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Extract the reference's own known-answer material into committed fixtures.
+
+Run in the build container (needs /root/reference, which does not exist on the GPU box):
+
+    python3 tests/golden/make_golden.py
+
+Outputs (all under tests/golden/):
+  ref_kats.json     every 6-limb (Fp) / 4-limb (Scalar) hex literal of the reference's #[test] functions,
+                    grouped per test in source order, plus the named module constants and the RELIC
+                    pairing constant (Gt::generator) -- /root/reference/src/{fp,fp2,fp6,fp12,g1,g2,scalar,
+                    pairings}.rs.  Only numbers are extracted; no reference code is copied.
+  g1_uncompressed_valid_test_vectors.dat, g1_compressed_..., g2_uncompressed_..., g2_compressed_...
+                    byte copies of /root/reference/src/tests/*.dat (k*generator, k = 0..999;
+                    src/tests/mod.rs:3-76) -- binary golden vectors, not source.
+"""
+import json, os, re, shutil
+
+REF = "/root/reference/src"
+OUT = os.path.dirname(os.path.abspath(__file__))
+HEX6 = re.compile(r"\[\s*((?:0x[0-9a-f_]+\s*,\s*){5}0x[0-9a-f_]+)\s*,?\s*\]")
+HEX4 = re.compile(r"\[\s*((?:0x[0-9a-f_]+\s*,\s*){3}0x[0-9a-f_]+)\s*,?\s*\]")
+
+
+def limbs(m):
+    return [int(x.strip().replace("_", ""), 16) for x in m.split(",") if x.strip()]
+
+
+def arrays(text, rx):
+    return [limbs(m) for m in rx.findall(text)]
+
+
+def lines(path, a, b):
+    with open(path) as fh:
+        return "".join(fh.readlines()[a - 1:b])
+
+
+kats = {"tests": {}, "consts": {}}
+for mod in ["fp", "fp2", "fp6", "fp12", "g1", "g2", "scalar", "pairings"]:
+    src = open(f"{REF}/{mod}.rs").read()
+    for part in src.split("#[test]")[1:]:
+        name = re.search(r"fn (\w+)\(", part).group(1)
+        a6, a4 = arrays(part, HEX6), arrays(part, HEX4)
+        if a6 or a4:
+            kats["tests"][f"{mod}.{name}"] = {"fp": a6, "scalar": a4}
+
+C = kats["consts"]
+C["fp.MODULUS"] = arrays(lines(f"{REF}/fp.rs", 70, 77), HEX6)[0]
+C["fp.INV"] = int(re.search(r"const INV: u64 = (0x[0-9a-f_]+);", open(f"{REF}/fp.rs").read()).group(1).replace("_", ""), 16)
+C["fp.R"] = arrays(lines(f"{REF}/fp.rs", 83, 90), HEX6)[0]
+C["fp.R2"] = arrays(lines(f"{REF}/fp.rs", 93, 100), HEX6)[0]
+C["fp.R3"] = arrays(lines(f"{REF}/fp.rs", 103, 110), HEX6)[0]
+C["g1.B"] = arrays(lines(f"{REF}/g1.rs", 176, 183), HEX6)[0]
+C["g1.GENERATOR"] = arrays(lines(f"{REF}/g1.rs", 197, 217), HEX6)
+C["g1.BETA"] = arrays(lines(f"{REF}/g1.rs", 421, 428), HEX6)[0]
+C["g2.B"] = arrays(lines(f"{REF}/g2.rs", 177, 194), HEX6)
+C["g2.GENERATOR"] = arrays(lines(f"{REF}/g2.rs", 210, 250), HEX6)
+C["fp6.FROBENIUS_C1"] = arrays(lines(f"{REF}/fp6.rs", 159, 171), HEX6)
+C["fp6.FROBENIUS_C2"] = arrays(lines(f"{REF}/fp6.rs", 173, 186), HEX6)
+C["fp12.FROBENIUS_C1"] = arrays(lines(f"{REF}/fp12.rs", 149, 168), HEX6)
+C["scalar.MODULUS"] = arrays(lines(f"{REF}/scalar.rs", 76, 81), HEX4)[0]
+gt = arrays(lines(f"{REF}/pairings.rs", 359, 475), HEX6)
+assert len(gt) == 12, len(gt)
+C["pairings.GT_GENERATOR"] = gt
+relic = arrays(lines(f"{REF}/tests/mod.rs", 78, 231), HEX6)
+assert len(relic) == 12 and relic == gt, "RELIC constant in src/tests/mod.rs must equal Gt::generator"
+C["lib.BLS_X"] = int(re.search(r"const BLS_X: u64 = (0x[0-9a-f_]+);", open(f"{REF}/lib.rs").read()).group(1).replace("_", ""), 16)
+
+with open(os.path.join(OUT, "ref_kats.json"), "w") as fh:
+    json.dump(kats, fh, indent=0, separators=(",", ":"))
+for g in ["g1_uncompressed", "g1_compressed", "g2_uncompressed", "g2_compressed"]:
+    shutil.copyfile(f"{REF}/tests/{g}_valid_test_vectors.dat", os.path.join(OUT, f"{g}_valid_test_vectors.dat"))
+print("tests:", len(kats["tests"]), "consts:", len(C))

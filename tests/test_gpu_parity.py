@@ -1,0 +1,383 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the reference's golden vectors.
+
+All tests need a real MI355X (`-m gpu`).  Comparison points: field elements and Gt / raw
+Miller values as canonical Montgomery limbs (bit-exact), group elements as uncompressed affine bytes;
+point-formula outputs additionally as exact projective triples, because the kernels use the reference's
+own complete formulas.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bls12_381_ref as o
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import bls12_381_amd as b
+    return b.default_context()
+
+
+# ---- oracle <-> wire helpers ---------------------------------------------------------------------------
+def fpw(x):
+    return np.array(o.fp_to_mont_limbs(x), dtype=np.uint64)
+
+
+def fp2w(a):
+    return np.concatenate([fpw(a[0]), fpw(a[1])])
+
+
+def fp12w(f):
+    return np.concatenate([fpw(c) for c in o.fp12_flatten(f)])
+
+
+def wfp(w):
+    return o.fp_from_mont_limbs([int(x) for x in w])
+
+
+def wfp2(w):
+    return (wfp(w[0:6]), wfp(w[6:12]))
+
+
+def wfp12(w):
+    return o.fp12_unflatten([wfp(w[6 * i:6 * i + 6]) for i in range(12)])
+
+
+def g1aff_w(a):
+    return np.concatenate([fpw(a[0]), fpw(a[1])]), np.uint8(1 if a[2] else 0)
+
+
+def g2aff_w(a):
+    return np.concatenate([fp2w(a[0]), fp2w(a[1])]), np.uint8(1 if a[2] else 0)
+
+
+def g1proj_w(p):
+    return np.concatenate([fpw(p[0]), fpw(p[1]), fpw(p[2])])
+
+
+def g2proj_w(p):
+    return np.concatenate([fp2w(p[0]), fp2w(p[1]), fp2w(p[2])])
+
+
+def w_g1proj(w):
+    return (wfp(w[0:6]), wfp(w[6:12]), wfp(w[12:18]))
+
+
+def w_g2proj(w):
+    return (wfp2(w[0:12]), wfp2(w[12:24]), wfp2(w[24:36]))
+
+
+def rng_fp(r):
+    v = 0
+    for i in range(6):
+        v |= r.next() << (64 * i)
+    return v % o.P
+
+
+EDGE_FP = [0, 1, 2, o.P - 1, o.P - 2, (o.P - 1) // 2, (o.P + 1) // 2, (1 << 380), (1 << 381) - 1 - ((1 << 381) - 1) // o.P * 0,
+           o.MONT_R, pow(o.MONT_R, -1, o.P), 0xFFFFFFFF, (1 << 364) - 1, (1 << 364), o.P - (1 << 28), (1 << 28) - 1]
+EDGE_FP = [v % o.P for v in EDGE_FP]
+
+
+# ---- field arithmetic ------------------------------------------------------------------------------------
+def test_fp_ops(ctx, kats):
+    r = o.SplitMix64(0xB1512381)
+    a = EDGE_FP + [rng_fp(r) for _ in range(3000)]
+    b = list(reversed(EDGE_FP)) + [rng_fp(r) for _ in range(3000)]
+    # the reference's own multiplication / squaring KAT operands (src/fp.rs:700-749)
+    t = kats["tests"]
+    ka, kb, _ = [o.fp_from_mont_limbs(v) for v in t["fp.test_multiplication"]["fp"]]
+    a += [ka, o.fp_from_mont_limbs(t["fp.test_squaring"]["fp"][0])]
+    b += [kb, o.fp_from_mont_limbs(t["fp.test_squaring"]["fp"][0])]
+    A, B = np.stack([fpw(x) for x in a]), np.stack([fpw(x) for x in b])
+    for op, fn in [(0, o.fp_mul), (1, o.fp_add), (2, o.fp_sub)]:
+        got = ctx.fp_op(op, A, B)
+        want = np.stack([fpw(fn(x, y)) for x, y in zip(a, b)])
+        assert np.array_equal(got, want), f"fp op {op}"
+    assert np.array_equal(ctx.fp_op(3, A), np.stack([fpw(o.fp_sqr(x)) for x in a]))
+    assert np.array_equal(ctx.fp_op(5, A), np.stack([fpw(o.fp_neg(x)) for x in a]))
+    inv = ctx.fp_op(4, A[:200])
+    assert np.array_equal(inv, np.stack([fpw(o.fp_inv(x) or 0) for x in a[:200]]))
+    # KAT results verbatim
+    assert np.array_equal(ctx.fp_op(0, np.array([t["fp.test_multiplication"]["fp"][0]], dtype=np.uint64),
+                                    np.array([t["fp.test_multiplication"]["fp"][1]], dtype=np.uint64))[0],
+                          np.array(t["fp.test_multiplication"]["fp"][2], dtype=np.uint64))
+
+
+def test_fp2_ops(ctx, kats):
+    r = o.SplitMix64(7)
+    a = [(x, y) for x in EDGE_FP[:6] for y in EDGE_FP[:6]] + [(rng_fp(r), rng_fp(r)) for _ in range(1500)]
+    b = [(rng_fp(r), rng_fp(r)) for _ in range(len(a))]
+    A, B = np.stack([fp2w(x) for x in a]), np.stack([fp2w(x) for x in b])
+    for op, fn in [(0, o.fp2_mul), (1, o.fp2_add), (2, o.fp2_sub)]:
+        assert np.array_equal(ctx.fp2_op(op, A, B), np.stack([fp2w(fn(x, y)) for x, y in zip(a, b)])), f"fp2 op {op}"
+    assert np.array_equal(ctx.fp2_op(3, A), np.stack([fp2w(o.fp2_sqr(x)) for x in a]))
+    assert np.array_equal(ctx.fp2_op(5, A), np.stack([fp2w(o.fp2_neg(x)) for x in a]))
+    assert np.array_equal(ctx.fp2_op(6, A), np.stack([fp2w(o.fp2_mul_by_nonresidue(x)) for x in a]))
+    assert np.array_equal(ctx.fp2_op(4, A[:100]), np.stack([fp2w(o.fp2_inv(x) or (0, 0)) for x in a[:100]]))
+    t = kats["tests"]["fp2.test_multiplication"]["fp"]
+    got = ctx.fp2_op(0, np.array([t[0] + t[1]], dtype=np.uint64), np.array([t[2] + t[3]], dtype=np.uint64))[0]
+    assert np.array_equal(got, np.array(t[4] + t[5], dtype=np.uint64))
+
+
+def test_fp12_ops(ctx):
+    r = o.SplitMix64(99)
+    def rnd12(): return o.fp12_unflatten([rng_fp(r) for _ in range(12)])
+    a = [rnd12() for _ in range(40)] + [o.FP12_ONE]
+    b = [rnd12() for _ in range(41)]
+    A, B = np.stack([fp12w(x) for x in a]), np.stack([fp12w(x) for x in b])
+    assert np.array_equal(ctx.fp12_op(0, A, B), np.stack([fp12w(o.fp12_mul(x, y)) for x, y in zip(a, b)]))
+    assert np.array_equal(ctx.fp12_op(3, A), np.stack([fp12w(o.fp12_sqr(x)) for x in a]))
+    assert np.array_equal(ctx.fp12_op(4, A), np.stack([fp12w(o.fp12_inv(x)) for x in a]))
+    assert np.array_equal(ctx.fp12_op(7, A), np.stack([fp12w(o.fp12_frobenius(x)) for x in a]))
+    assert np.array_equal(ctx.fp12_op(8, A), np.stack([fp12w(o.fp12_conj(x)) for x in a]))
+    # cyclotomic_square is only meaningful on the cyclotomic subgroup: x^((p^6-1)(p^2+1))
+    def to_cyc(f):
+        t = f
+        for _ in range(6):
+            t = o.fp12_frobenius(t)
+        t = o.fp12_mul(t, o.fp12_inv(f))
+        return o.fp12_mul(o.fp12_frobenius(o.fp12_frobenius(t)), t)
+    cyc = [to_cyc(x) for x in a[:8]]
+    C = np.stack([fp12w(x) for x in cyc])
+    want = np.stack([fp12w(o.cyclotomic_square(x)) for x in cyc])
+    assert np.array_equal(ctx.fp12_op(9, C), want)
+    assert np.array_equal(want, np.stack([fp12w(o.fp12_sqr(x)) for x in cyc]))
+    # product tree
+    assert np.array_equal(ctx.fp12_product(A[:19]), fp12w(__import__("functools").reduce(o.fp12_mul, a[:19])))
+    assert np.array_equal(ctx.fp12_product(A[:0]), fp12w(o.FP12_ONE))
+
+
+# ---- point formulas: exact projective triples --------------------------------------------------------------
+def _points(group, n, seed):
+    r = o.SplitMix64(seed)
+    gen = o.G1_GEN if group == 1 else o.G2_GEN
+    mul = o.g1_affine_mul if group == 1 else o.g2_affine_mul
+    ident = o.g1_identity() if group == 1 else o.g2_identity()
+    pts = [mul(gen, r.scalar()) for _ in range(n)]
+    return pts, ident
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_point_ops(ctx, group):
+    pts, ident = _points(group, 12, 5 + group)
+    pw, wp = (g1proj_w, w_g1proj) if group == 1 else (g2proj_w, w_g2proj)
+    add, dbl, madd, toaff = (o.g1_add, o.g1_double, o.g1_add_mixed, o.g1_to_affine) if group == 1 else \
+        (o.g2_add, o.g2_double, o.g2_add_mixed, o.g2_to_affine)
+    affw = g1aff_w if group == 1 else g2aff_w
+    neg = o.g1_neg if group == 1 else o.g2_neg
+    a = pts[:6] + [ident, pts[0], pts[1], ident, pts[2], pts[3]]
+    b = pts[6:] + [pts[3], ident, pts[1], ident, neg(pts[2]), dbl(pts[3])]
+    A, B = np.stack([pw(x) for x in a]), np.stack([pw(x) for x in b])
+    got = ctx.point_op(group, 0, A, B)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert wp(got[i]) == add(x, y), f"add {i}"
+    got = ctx.point_op(group, 1, A)
+    for i, x in enumerate(a):
+        assert toaff(wp(got[i])) == toaff(dbl(x)), f"double {i}"
+        if not toaff(x)[2]:
+            assert wp(got[i]) == dbl(x)
+    baff = [toaff(y) for y in b]
+    Bx = np.stack([affw(y)[0] for y in baff])
+    Bi = np.array([affw(y)[1] for y in baff], dtype=np.uint8)
+    got = ctx.point_op(group, 2, A, Bx, Bi)
+    for i, (x, y) in enumerate(zip(a, baff)):
+        assert wp(got[i]) == madd(x, y), f"mixed {i}"
+    # Sum + batch_normalize (incl. identities)
+    s = ctx.point_sum(group, A)
+    acc = ident
+    for x in a:
+        acc = add(acc, x)
+    assert toaff(wp(s)) == toaff(acc)
+    xy, inf = ctx.batch_normalize(group, A)
+    for i, x in enumerate(a):
+        ex, ei = affw(toaff(x))
+        assert np.array_equal(xy[i], ex) and inf[i] == ei
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_fixed_base_multiples_match_golden(ctx, group, golden_dir):
+    """k * generator for k = 0..999 computed on the GPU == src/tests/*_uncompressed_valid_test_vectors.dat."""
+    import bls12_381_amd as b
+    ks = list(range(1000))
+    bases = ctx.bases_from_scalars(group, ks)
+    xy, inf = bases.download()
+    name = "g1" if group == 1 else "g2"
+    usz = 96 if group == 1 else 192
+    raw = open(os.path.join(golden_dir, f"{name}_uncompressed_valid_test_vectors.dat"), "rb").read()
+    craw = open(os.path.join(golden_dir, f"{name}_compressed_valid_test_vectors.dat"), "rb").read()
+    cls = b.G1Affine if group == 1 else b.G2Affine
+    for k in ks:
+        pt = cls(xy[k], bool(inf[k]))
+        assert pt.to_uncompressed() == raw[usz * k:usz * (k + 1)], k
+        assert pt.to_compressed() == craw[usz // 2 * k:usz // 2 * (k + 1)], k
+        if k % 100 == 0:
+            assert cls.from_uncompressed_unchecked(raw[usz * k:usz * (k + 1)]) == pt
+
+
+# ---- MSM ---------------------------------------------------------------------------------------------------
+def _msm_case(ctx, group, ks, scalars, window=0):
+    """bases = [k_i] G built on the device; expected = [sum k_i s_i] G from the oracle (discrete-log identity),
+    compared on uncompressed affine bytes."""
+    ctx.set_msm_window(window)
+    bases = ctx.bases_from_scalars(group, ks)
+    out = ctx.msm(bases, scalars)
+    xy, inf = ctx.batch_normalize(group, out[None, :])
+    tot = sum(k * s for k, s in zip(ks, scalars)) % o.R_ORDER
+    if group == 1:
+        want = o.g1_to_uncompressed(o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, tot)))
+        import bls12_381_amd as b
+        got = b.G1Affine(xy[0], bool(inf[0])).to_uncompressed()
+    else:
+        want = o.g2_to_uncompressed(o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, tot)))
+        import bls12_381_amd as b
+        got = b.G2Affine(xy[0], bool(inf[0])).to_uncompressed()
+    ctx.set_msm_window(0)
+    assert got == want
+
+
+@pytest.mark.parametrize("group", [1, 2])
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 17, 256, 1024])
+def test_msm_small_vs_reference_definition(ctx, group, n):
+    """sum_i (P_i * s_i) exactly as the reference defines it (double-and-add + Sum), n <= 2^10 (config 1)."""
+    r = o.SplitMix64(0xB1512381 + n)
+    ks = [r.scalar() for _ in range(n)]
+    ss = [r.scalar() for _ in range(n)]
+    if n <= 17:
+        gen, amul, msm, toaff, enc = (o.G1_GEN, o.g1_affine_mul, o.g1_msm, o.g1_to_affine, o.g1_to_uncompressed) if group == 1 else \
+            (o.G2_GEN, o.g2_affine_mul, o.g2_msm, o.g2_to_affine, o.g2_to_uncompressed)
+        pts = [toaff(amul(gen, k)) for k in ks]
+        want = enc(toaff(msm(pts, ss)))
+        import bls12_381_amd as b
+        if group == 1:
+            got = b.msm_g1([b.G1Affine(*g1aff_w(p)) for p in pts], ss).to_affine().to_uncompressed()
+        else:
+            got = b.msm_g2([b.G2Affine(*g2aff_w(p)) for p in pts], ss).to_affine().to_uncompressed()
+        assert got == want
+    _msm_case(ctx, group, ks, ss)
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_msm_edge_cases(ctx, group):
+    r = o.SplitMix64(4242)
+    rr = o.R_ORDER
+    # scalars 0, 1, r-1, 2^k boundaries; identity bases (k = 0); duplicates; P and -P with equal digits
+    ks = [1, 2, 3, 0, 5, 5, 5, rr - 5, 7, rr - 7, 0, 11] + [r.scalar() for _ in range(20)]
+    ss = [0, 1, rr - 1, 12345, 9, 9, rr - 9, 9, (1 << 254), (1 << 254), 0, (1 << 16) - 1] + \
+         [(1 << (16 * i)) - 1 for i in range(1, 11)] + [(1 << 15) + (1 << (16 * i + 15)) for i in range(10)]
+    for w in (0, 4, 7, 13, 16):
+        _msm_case(ctx, group, ks, ss, window=w)
+    _msm_case(ctx, group, [3] * 300, [1] * 300)                 # one bucket takes everything
+    _msm_case(ctx, group, [r.scalar() for _ in range(64)], [0] * 64)     # all-zero scalars -> identity
+    _msm_case(ctx, group, [4, rr - 4], [77, 77])                          # P + (-P) inside one bucket
+
+
+@pytest.mark.parametrize("group,logn", [(1, 14), (1, 16), (2, 14)])
+def test_msm_medium(ctx, group, logn):
+    n = 1 << logn
+    r = o.SplitMix64(logn * 1000 + group)
+    ks = [r.scalar() for _ in range(n)]
+    ss = [r.scalar() for _ in range(n)]
+    _msm_case(ctx, group, ks, ss)
+
+
+def test_msm_full_size_2_20(ctx):
+    """BASELINE config 2: 2^20-point G1 MSM, checked through the discrete-log identity."""
+    n = 1 << 20
+    rs = np.random.RandomState(20)
+    kb = rs.randint(0, 256, size=(n, 32), dtype=np.uint8); kb[:, 31] &= 0x3F
+    sb = rs.randint(0, 256, size=(n, 32), dtype=np.uint8); sb[:, 31] &= 0x3F
+    ks = [int.from_bytes(kb[i].tobytes(), "little") for i in range(n)]
+    ss = [int.from_bytes(sb[i].tobytes(), "little") for i in range(n)]
+    bases = ctx.bases_from_scalars(1, kb)
+    out = ctx.msm(bases, sb)
+    xy, inf = ctx.batch_normalize(1, out[None, :])
+    tot = sum(k * s for k, s in zip(ks, ss)) % o.R_ORDER
+    import bls12_381_amd as b
+    assert b.G1Affine(xy[0], bool(inf[0])).to_uncompressed() == o.g1_to_uncompressed(o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, tot)))
+    # linearity (size-independent property): MSM(2s) == 2 * MSM(s)
+    s2 = [(2 * s) % o.R_ORDER for s in ss[:4096]]
+    a = ctx.msm(bases, ss[:4096]); b2 = ctx.msm(bases, s2)
+    d = ctx.point_op(1, 1, a[None, :])
+    assert np.array_equal(ctx.batch_normalize(1, d)[0], ctx.batch_normalize(1, b2[None, :])[0])
+
+
+# ---- pairings --------------------------------------------------------------------------------------------------
+def _pair_inputs(n, seed):
+    r = o.SplitMix64(seed)
+    ps = [o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, r.scalar())) for _ in range(n)]
+    qs = [o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, r.scalar())) for _ in range(n)]
+    return ps, qs
+
+
+def test_pairing_generator_kat(ctx, kats):
+    """src/tests/mod.rs:78-231: e(G1gen, G2gen) == the RELIC constant, bit for bit."""
+    import bls12_381_amd as b
+    want = np.array(kats["consts"]["pairings.GT_GENERATOR"], dtype=np.uint64).reshape(72)
+    got = b.pairing(b.G1Affine.generator(), b.G2Affine.generator())
+    assert np.array_equal(got.f, want)
+    ml = b.multi_miller_loop([(b.G1Affine.generator(), b.G2Prepared(b.G2Affine.generator()))])
+    assert np.array_equal(ml.final_exponentiation().f, want)
+    assert b.Gt.generator() == got and b.Bls12.pairing(b.G1Affine.generator(), b.G2Affine.generator()) == got
+
+
+def test_pairing_batch_vs_oracle(ctx):
+    ps, qs = _pair_inputs(6, 31337)
+    ps += [o.G1_IDENTITY_AFF, ps[0]]
+    qs += [qs[0], o.G2_IDENTITY_AFF]
+    G1 = np.stack([g1aff_w(p)[0] for p in ps]); F1 = np.array([g1aff_w(p)[1] for p in ps], dtype=np.uint8)
+    G2 = np.stack([g2aff_w(q)[0] for q in qs]); F2 = np.array([g2aff_w(q)[1] for q in qs], dtype=np.uint8)
+    ml = ctx.miller_loop_batch(G1, F1, G2, F2)
+    want_ml = [o.miller_loop(p, q) for p, q in zip(ps, qs)]
+    for i in range(len(ps)):
+        assert np.array_equal(ml[i], fp12w(want_ml[i])), f"miller {i}"
+    gt = ctx.pairing_batch(G1, F1, G2, F2)
+    for i in range(len(ps)):
+        assert np.array_equal(gt[i], fp12w(o.final_exponentiation(want_ml[i]))), f"pairing {i}"
+    assert np.array_equal(ctx.final_exponentiation_batch(ml), gt)
+    # multi_miller_loop: same Fp12 value as the reference's shared-accumulator loop (identities skipped)
+    mm = ctx.multi_miller_loop(G1, F1, G2, F2)
+    want_mm = o.multi_miller_loop([(p, o.g2_prepare(q)) for p, q in zip(ps, qs)])
+    assert np.array_equal(mm, fp12w(want_mm))
+    assert np.array_equal(ctx.multi_miller_loop(G1[:0], F1[:0], G2[:0], F2[:0]), fp12w(o.FP12_ONE))
+
+
+def test_pairing_bilinearity_and_api(ctx):
+    """pairings.rs:835-921 through the mirrored API."""
+    import bls12_381_amd as b
+    a, c = b.Scalar(0x1234567890ABCDEF), b.Scalar(0xFEDCBA0987654321)
+    g = (b.G1Affine.generator() * a).to_affine()
+    h = (b.G2Affine.generator() * c).to_affine()
+    p = b.pairing(g, h)
+    assert p == b.pairing((b.G1Affine.generator() * (a * c)).to_affine(), b.G2Affine.generator())
+    assert p == b.Gt.generator() * (a * c)
+    assert p != b.Gt.identity()
+    assert b.pairing(b.G1Affine.identity(), h) == b.Gt.identity()
+    assert -p == b.pairing(g, -h) and (p + (-p)) == b.Gt.identity()
+    terms = [(g, b.G2Prepared(h)), (b.G1Affine.identity(), b.G2Prepared(h)), (b.G1Affine.generator(), b.G2Prepared(b.G2Affine.generator()))]
+    assert b.multi_miller_loop(terms).final_exponentiation() == p + b.Gt.generator()
+    assert b.MillerLoopResult.default().final_exponentiation() == b.Gt.identity()
+    # group API: (g*a)*b == g*(a*b), Sum, batch_normalize
+    gp = b.G1Projective.generator()
+    assert (gp * a) * c == gp * (a * c)
+    assert b.G1Projective.sum([gp, gp.double(), b.G1Projective.identity()]) == gp * b.Scalar(3)
+    assert b.G1Projective.batch_normalize([gp, b.G1Projective.identity()])[1].is_identity()
+
+
+def test_pairing_batch_large(ctx):
+    """2^10 pairings: e([a_i]G1, [b_i]G2) all equal e(G1,G2)^(a_i b_i); checked via a product identity."""
+    n = 1 << 10
+    r = o.SplitMix64(777)
+    a = [r.scalar() for _ in range(n)]
+    bb = [r.scalar() for _ in range(n)]
+    b1 = ctx.bases_from_scalars(1, a); b2 = ctx.bases_from_scalars(2, bb)
+    g1, f1 = b1.download(); g2, f2 = b2.download()
+    gt = ctx.pairing_batch(g1, f1, g2, f2)
+    prod = ctx.fp12_product(gt)
+    e = sum(x * y for x, y in zip(a, bb)) % o.R_ORDER
+    assert np.array_equal(prod, fp12w(o.gt_mul_scalar(o.pairing(o.G1_GEN, o.G2_GEN), e)))
+    for i in (0, 1, n - 1):
+        assert np.array_equal(gt[i], fp12w(o.gt_mul_scalar(o.pairing(o.G1_GEN, o.G2_GEN), a[i] * bb[i] % o.R_ORDER)))

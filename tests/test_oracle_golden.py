@@ -1,0 +1,209 @@
+"""Pin the oracle (oracle/bls12_381_ref.py) to the reference's own known-answer material.
+
+Fixtures were extracted from /root/reference by tests/golden/make_golden.py (committed with the data):
+field KATs of src/fp.rs / src/fp2.rs, group KATs of src/g1.rs / src/g2.rs, the module constants, the
+four k*G golden files (src/tests/mod.rs:3-76) and the RELIC pairing constant (src/pairings.rs:359-475).
+All literals are Montgomery limbs (R = 2^384); `fp_from_mont_limbs` decodes them.
+"""
+import os
+
+import pytest
+
+from oracle import bls12_381_ref as o
+
+F = o.fp_from_mont_limbs
+
+
+def fp2s(arrs):
+    """consecutive limb arrays -> list of Fp2 (c0, c1)"""
+    return [(F(arrs[i]), F(arrs[i + 1])) for i in range(0, len(arrs), 2)]
+
+
+def test_constants(kats):
+    c = kats["consts"]
+    assert sum(l << (64 * i) for i, l in enumerate(c["fp.MODULUS"])) == o.P
+    assert c["fp.INV"] == (-pow(o.P, -1, 1 << 64)) % (1 << 64)
+    assert F(c["fp.R"]) == 1
+    assert F(c["fp.R2"]) == o.MONT_R and F(c["fp.R3"]) == (o.MONT_R * o.MONT_R) % o.P
+    assert F(c["g1.B"]) == 4
+    assert [F(x) for x in c["g1.GENERATOR"][:2]] == [o.G1_GEN[0], o.G1_GEN[1]]
+    assert fp2s(c["g2.B"]) == [(4, 4)]
+    g2 = fp2s(c["g2.GENERATOR"])
+    assert g2[0] == o.G2_GEN[0] and g2[1] == o.G2_GEN[1]
+    assert sum(l << (64 * i) for i, l in enumerate(c["scalar.MODULUS"])) == o.R_ORDER
+    assert c["lib.BLS_X"] == o.BLS_X
+    # Frobenius coefficients are recomputed from their definition in the oracle
+    assert o.FROB6_C1 == (0, F(c["fp6.FROBENIUS_C1"][0]))
+    assert o.FROB6_C2 == (F(c["fp6.FROBENIUS_C2"][0]), 0)
+    assert o.FROB12_C1 == (F(c["fp12.FROBENIUS_C1"][0]), F(c["fp12.FROBENIUS_C1"][1]))
+    beta = F(c["g1.BETA"])
+    assert beta != 1 and pow(beta, 3, o.P) == 1
+    assert o.g1_is_on_curve(o.G1_GEN) and o.g2_is_on_curve(o.G2_GEN)
+
+
+def test_fp_kats(kats):
+    t = kats["tests"]
+    a, b = map(F, t["fp.test_squaring"]["fp"]);               assert o.fp_sqr(a) == b
+    a, b, c = map(F, t["fp.test_multiplication"]["fp"]);      assert o.fp_mul(a, b) == c
+    a, b, c = map(F, t["fp.test_addition"]["fp"]);            assert o.fp_add(a, b) == c
+    a, b, c = map(F, t["fp.test_subtraction"]["fp"]);         assert o.fp_sub(a, b) == c
+    a, b = map(F, t["fp.test_negation"]["fp"]);               assert o.fp_neg(a) == b
+    a, b = map(F, t["fp.test_inversion"]["fp"]);              assert o.fp_inv(a) == b
+    assert o.fp_inv(0) is None
+    a, b = map(F, t["fp.test_sqrt"]["fp"])                    # a = 4, sqrt is +-2
+    assert o.fp_sqrt(a) in (b, o.fp_neg(b)) and o.fp_sqr(o.fp_sqrt(a)) == a
+    x, y, z = map(F, t["fp.test_lexicographic_largest"]["fp"])
+    assert not o.fp_lex_largest(x) and o.fp_lex_largest(y) and o.fp_lex_largest(z)
+    assert not o.fp_lex_largest(0) and not o.fp_lex_largest(1)
+
+
+def test_fp2_kats(kats):
+    t = kats["tests"]
+    a, b = fp2s(t["fp2.test_squaring"]["fp"]);                assert o.fp2_sqr(a) == b
+    a, b, c = fp2s(t["fp2.test_multiplication"]["fp"]);       assert o.fp2_mul(a, b) == c
+    a, b, c = fp2s(t["fp2.test_addition"]["fp"]);             assert o.fp2_add(a, b) == c
+    a, b, c = fp2s(t["fp2.test_subtraction"]["fp"]);          assert o.fp2_sub(a, b) == c
+    a, b = fp2s(t["fp2.test_negation"]["fp"]);                assert o.fp2_neg(a) == b
+    a, b = fp2s(t["fp2.test_inversion"]["fp"]);               assert o.fp2_inv(a) == b
+    assert o.fp2_inv((0, 0)) is None
+    s = fp2s(t["fp2.test_sqrt"]["fp"])                        # (a, b, c): a.sqrt()^2 == a, b.sqrt()^2 == b, c has no root
+    for v in s[:2]:
+        assert o.fp2_sqr(o.fp2_sqrt(v)) == v
+    assert o.fp2_sqrt(s[2]) is None
+
+
+def test_tower_identities(kats):
+    """src/fp6.rs:376-561 / src/fp12.rs:265-649 check algebraic identities on fixed elements; same here."""
+    vals = kats["tests"]["fp6.test_arithmetic"]["fp"]
+    a, b, c = [tuple(fp2s(vals[6 * i:6 * i + 6])) for i in range(3)]
+    assert o.fp6_sqr(a) == o.fp6_mul(a, a) and o.fp6_sqr(b) == o.fp6_mul(b, b)
+    assert o.fp6_mul(o.fp6_add(a, b), o.fp6_sqr(c)) == o.fp6_add(o.fp6_mul(o.fp6_mul(c, c), a), o.fp6_mul(o.fp6_mul(c, c), b))
+    assert o.fp6_mul(o.fp6_inv(a), o.fp6_inv(b)) == o.fp6_inv(o.fp6_mul(a, b))
+    assert o.fp6_mul(o.fp6_inv(a), a) == o.FP6_ONE
+    assert o.fp6_mul_by_1(a, b[1]) == o.fp6_mul(a, (o.FP2_ZERO, b[1], o.FP2_ZERO))
+    assert o.fp6_mul_by_01(a, b[0], b[1]) == o.fp6_mul(a, (b[0], b[1], o.FP2_ZERO))
+    f = a
+    for _ in range(6):
+        f = o.fp6_frobenius(f)
+    assert f == a
+    vals = kats["tests"]["fp12.test_arithmetic"]["fp"]
+    x, y, z = [o.fp12_unflatten([F(v) for v in vals[12 * i:12 * i + 12]]) for i in range(3)]
+    assert o.fp12_sqr(x) == o.fp12_mul(x, x)
+    assert o.fp12_mul(o.fp12_inv(x), x) == o.FP12_ONE
+    assert o.fp12_mul(o.fp12_mul(x, y), z) == o.fp12_mul(x, o.fp12_mul(y, z))
+    f = x
+    for _ in range(12):
+        f = o.fp12_frobenius(f)
+    assert f == x
+    assert o.fp12_frobenius(x) != x
+    sparse = (y[0][0], y[0][1], y[1][1])
+    full = ((sparse[0], sparse[1], o.FP2_ZERO), (o.FP2_ZERO, sparse[2], o.FP2_ZERO))
+    assert o.fp12_mul_by_014(x, *sparse) == o.fp12_mul(x, full)
+
+
+def test_g1_kats(kats):
+    t = kats["tests"]
+    gen = o.g1_from_affine(o.G1_GEN)
+    d = [F(v) for v in t["g1.test_doubling"]["fp"]]           # affine 2G
+    assert o.g1_to_affine(o.g1_double(gen)) == (d[0], d[1], False)
+    assert o.g1_to_affine(o.g1_double(o.g1_identity()))[2]
+    # degenerate-case KATs of test_projective_addition / test_mixed_addition: beta * (x,y) + (x,y)
+    # degenerate case (g1.rs:1372-1417 / :1493-1539): a = 4G, b = (beta^2 * a.x, -a.y) has the same x^3
+    for name in ("g1.test_projective_addition", "g1.test_mixed_addition"):
+        v = [F(x) for x in t[name]["fp"]]
+        beta, cx, cy = (v[-3] * v[-3]) % o.P, v[-2], v[-1]
+        a = o.g1_double(o.g1_double(gen))
+        b = ((a[0] * beta) % o.P, (-a[1]) % o.P, a[2])
+        assert o.g1_to_affine(o.g1_add(a, b)) == (cx, cy, False)
+        assert o.g1_to_affine(o.g1_add_mixed(a, o.g1_to_affine(b))) == (cx, cy, False)
+    # group laws
+    g2_, g3 = o.g1_double(gen), o.g1_add(o.g1_double(gen), gen)
+    assert o.g1_eq(o.g1_add(gen, gen), g2_) and o.g1_eq(o.g1_add_mixed(g2_, o.G1_GEN), g3)
+    assert o.g1_eq(o.g1_add(g3, o.g1_neg(g3)), o.g1_identity())
+    assert o.g1_eq(o.g1_add_mixed(o.g1_identity(), o.G1_GEN), gen)
+    assert o.g1_eq(o.g1_add_mixed(gen, o.G1_IDENTITY_AFF), gen)
+    # (g * a) * b == g * (a * b)   (g1.rs:1558-1595)
+    sa, sb = [sum(l << (64 * i) for i, l in enumerate(x)) for x in t["g1.test_projective_scalar_multiplication"]["scalar"]]
+    sa, sb = (sa * pow(o.FR_MONT_R, -1, o.R_ORDER)) % o.R_ORDER, (sb * pow(o.FR_MONT_R, -1, o.R_ORDER)) % o.R_ORDER
+    assert o.g1_eq(o.g1_mul(o.g1_mul(gen, sa), sb), o.g1_mul(gen, (sa * sb) % o.R_ORDER))
+    # batch_normalize over identity patterns (g1.rs:1691-1727)
+    pts = [gen, o.g1_identity(), o.g1_double(gen), o.g1_identity()]
+    assert o.g1_batch_normalize(pts) == [o.g1_to_affine(p) for p in pts]
+    assert o.g1_eq(o.g1_mul(gen, o.R_ORDER - 1), o.g1_neg(gen))
+
+
+def test_g2_kats(kats):
+    t = kats["tests"]
+    gen = o.g2_from_affine(o.G2_GEN)
+    d = fp2s(t["g2.test_doubling"]["fp"])
+    assert o.g2_to_affine(o.g2_double(gen)) == (d[0], d[1], False)
+    g2_, g3 = o.g2_double(gen), o.g2_add(o.g2_double(gen), gen)
+    assert o.g2_eq(o.g2_add(gen, gen), g2_) and o.g2_eq(o.g2_add_mixed(g2_, o.G2_GEN), g3)
+    assert o.g2_eq(o.g2_add(g3, o.g2_neg(g3)), o.g2_identity())
+    sa, sb = [sum(l << (64 * i) for i, l in enumerate(x)) for x in t["g2.test_projective_scalar_multiplication"]["scalar"]]
+    sa, sb = (sa * pow(o.FR_MONT_R, -1, o.R_ORDER)) % o.R_ORDER, (sb * pow(o.FR_MONT_R, -1, o.R_ORDER)) % o.R_ORDER
+    assert o.g2_eq(o.g2_mul(o.g2_mul(gen, sa), sb), o.g2_mul(gen, (sa * sb) % o.R_ORDER))
+    pts = [gen, o.g2_identity(), o.g2_double(gen)]
+    assert o.g2_batch_normalize(pts) == [o.g2_to_affine(p) for p in pts]
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_golden_multiples(group, golden_dir):
+    """src/tests/mod.rs:3-76: record k of each file is k * generator (k = 0..999) -- all four encodings."""
+    usz, csz = (96, 48) if group == "g1" else (192, 96)
+    unc = open(os.path.join(golden_dir, f"{group}_uncompressed_valid_test_vectors.dat"), "rb").read()
+    cmp_ = open(os.path.join(golden_dir, f"{group}_compressed_valid_test_vectors.dat"), "rb").read()
+    assert len(unc) == 1000 * usz and len(cmp_) == 1000 * csz
+    if group == "g1":
+        e, gen_aff, add_mixed, to_aff = o.g1_identity(), o.G1_GEN, o.g1_add_mixed, o.g1_to_affine
+        enc_u, enc_c, dec_u, dec_c = o.g1_to_uncompressed, o.g1_to_compressed, o.g1_from_uncompressed_unchecked, o.g1_from_compressed_unchecked
+    else:
+        e, gen_aff, add_mixed, to_aff = o.g2_identity(), o.G2_GEN, o.g2_add_mixed, o.g2_to_affine
+        enc_u, enc_c, dec_u, dec_c = o.g2_to_uncompressed, o.g2_to_compressed, o.g2_from_uncompressed_unchecked, o.g2_from_compressed_unchecked
+    for k in range(1000):
+        a = to_aff(e)
+        ub, cb = unc[k * usz:(k + 1) * usz], cmp_[k * csz:(k + 1) * csz]
+        assert enc_u(a) == ub, k
+        assert enc_c(a) == cb, k
+        if k % 50 == 0 or k < 4:
+            assert dec_u(ub) == a and dec_c(cb) == a
+        e = add_mixed(e, gen_aff)
+
+
+def test_scalar_mul_matches_golden(golden_dir):
+    """`multiply` (255-step double-and-add) against the golden k*G records for a few k."""
+    unc = open(os.path.join(golden_dir, "g1_uncompressed_valid_test_vectors.dat"), "rb").read()
+    for k in (0, 1, 2, 3, 77, 999):
+        assert o.g1_to_uncompressed(o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, k))) == unc[96 * k:96 * k + 96]
+    unc2 = open(os.path.join(golden_dir, "g2_uncompressed_valid_test_vectors.dat"), "rb").read()
+    for k in (0, 1, 5, 998):
+        assert o.g2_to_uncompressed(o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, k))) == unc2[192 * k:192 * k + 192]
+
+
+def test_pairing_relic_kat(kats):
+    """src/tests/mod.rs:78-231: e(G1, G2) equals the RELIC constant, and pairing == multi_miller_loop + final exp."""
+    expect = o.fp12_unflatten([F(v) for v in kats["consts"]["pairings.GT_GENERATOR"]])
+    got = o.pairing(o.G1_GEN, o.G2_GEN)
+    assert got == expect
+    ml = o.multi_miller_loop([(o.G1_GEN, o.g2_prepare(o.G2_GEN))])
+    assert ml == o.miller_loop(o.G1_GEN, o.G2_GEN)
+    assert o.final_exponentiation(ml) == expect
+
+
+def test_pairing_properties():
+    """pairings.rs:835-970: bilinearity, unitarity, multi_miller_loop with identities."""
+    a, b = 0x1234567, 0x7654321
+    g, h = o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, a)), o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, b))
+    p = o.pairing(g, h)
+    gt = o.pairing(o.G1_GEN, o.G2_GEN)
+    assert p == o.gt_mul_scalar(gt, (a * b) % o.R_ORDER)
+    assert p == o.pairing(o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, a * b)), o.G2_GEN)
+    assert o.pairing(o.G1_IDENTITY_AFF, h) == o.FP12_ONE and o.pairing(g, o.G2_IDENTITY_AFF) == o.FP12_ONE
+    # unitary: e(P, -Q) * e(P, Q) = 1, and conjugate is the inverse
+    nh = (h[0], o.fp2_neg(h[1]), False)
+    assert o.fp12_mul(o.pairing(g, nh), p) == o.FP12_ONE and o.fp12_conj(p) == o.pairing(g, nh)
+    # multi miller loop of 3 terms incl. identities == product of pairings
+    terms = [(g, h), (o.G1_IDENTITY_AFF, h), (o.G1_GEN, o.G2_GEN), (g, o.G2_IDENTITY_AFF)]
+    ml = o.multi_miller_loop([(x, o.g2_prepare(y)) for x, y in terms])
+    assert o.final_exponentiation(ml) == o.fp12_mul(p, gt)
+    assert o.multi_miller_loop([]) == o.FP12_ONE
