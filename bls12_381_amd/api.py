@@ -367,7 +367,7 @@ class G1Affine(_Group):
     @classmethod
     def identity(cls):
         one = fp_to_limbs(1)
-        z = np.zeros(cls.W, dtype=np.uint64)
+        z = np.zeros(6, dtype=np.uint64)
         if cls.G == 1:
             return cls(np.concatenate([z, one]), True)
         return cls(np.concatenate([z, z, one, z]), True)

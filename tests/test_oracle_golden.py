@@ -207,3 +207,60 @@ def test_pairing_properties():
     ml = o.multi_miller_loop([(x, o.g2_prepare(y)) for x, y in terms])
     assert o.final_exponentiation(ml) == o.fp12_mul(p, gt)
     assert o.multi_miller_loop([]) == o.FP12_ONE
+
+
+# ---- tier-1 C oracle (oracle/bls_oracle.c) against tier 0 and the golden vectors -----------------------------
+def _fpw(x):
+    import numpy as np
+    return np.array(o.fp_to_mont_limbs(x), dtype=np.uint64)
+
+
+def test_c_oracle_field(kats):
+    import numpy as np
+    from oracle import c_oracle as c
+    r = o.SplitMix64(1)
+    def rnd():
+        v = 0
+        for i in range(6):
+            v |= r.next() << (64 * i)
+        return v % o.P
+    a = [0, 1, o.P - 1] + [rnd() for _ in range(300)]
+    b = [o.P - 1, 0, o.P - 1] + [rnd() for _ in range(300)]
+    A, B = np.stack([_fpw(x) for x in a]), np.stack([_fpw(x) for x in b])
+    for op, fn in [(0, o.fp_mul), (1, o.fp_add), (2, o.fp_sub)]:
+        assert np.array_equal(c.fp_op(op, A, B), np.stack([_fpw(fn(x, y)) for x, y in zip(a, b)]))
+    assert np.array_equal(c.fp_op(3, A), np.stack([_fpw(o.fp_sqr(x)) for x in a]))
+    assert np.array_equal(c.fp_op(5, A), np.stack([_fpw(o.fp_neg(x)) for x in a]))
+    assert np.array_equal(c.fp_op(4, A[:20]), np.stack([_fpw(o.fp_inv(x) or 0) for x in a[:20]]))
+    t = kats["tests"]["fp.test_multiplication"]["fp"]
+    assert np.array_equal(c.fp_op(0, np.array([t[0]], dtype=np.uint64), np.array([t[1]], dtype=np.uint64))[0], np.array(t[2], dtype=np.uint64))
+
+
+def test_c_oracle_g1(golden_dir):
+    import numpy as np
+    from oracle import c_oracle as c
+    gen = np.concatenate([_fpw(o.G1_GEN[0]), _fpw(o.G1_GEN[1])])
+    unc = open(os.path.join(golden_dir, "g1_uncompressed_valid_test_vectors.dat"), "rb").read()
+    for k in (0, 1, 2, 3, 500, 999, o.R_ORDER - 1, 0x1234567890ABCDEF1234567890ABCDEF):
+        s = np.frombuffer((k % o.R_ORDER).to_bytes(32, "little"), dtype=np.uint8)
+        proj = c.g1_affine_mul(gen, False, s)
+        # exact projective triple == tier 0 (same formulas, same order)
+        want = o.g1_affine_mul(o.G1_GEN, k)
+        assert [o.fp_from_mont_limbs(proj[6 * i:6 * i + 6]) for i in range(3)] == list(want)
+        xy, inf = c.g1_to_affine(proj)
+        aff = (o.fp_from_mont_limbs(xy[:6]), o.fp_from_mont_limbs(xy[6:]), inf)
+        if k < 1000:
+            assert o.g1_to_uncompressed(aff) == unc[96 * k:96 * k + 96]
+    # reference-definition MSM, 1 thread and all threads, vs tier 0
+    r = o.SplitMix64(9)
+    ks = [r.scalar() for _ in range(24)]
+    ss = [r.scalar() for _ in range(24)]
+    pts = [o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, k)) for k in ks]
+    xy = np.stack([np.concatenate([_fpw(p[0]), _fpw(p[1])]) for p in pts])
+    sb = np.stack([np.frombuffer(s.to_bytes(32, "little"), dtype=np.uint8) for s in ss])
+    want = o.g1_to_affine(o.g1_msm(pts, ss))
+    for th in (1, 0):
+        out, used = c.g1_msm(xy, None, sb, th)
+        got = c.g1_to_affine(out)
+        assert (o.fp_from_mont_limbs(got[0][:6]), o.fp_from_mont_limbs(got[0][6:]), got[1]) == want
+        assert used >= 1
