@@ -74,16 +74,29 @@ def main():
     kb, sb = synth_inputs(n, 0xB1512381 + rank)
     bases = ctx.bases_from_scalars(1, kb)                       # resident bases: [k_i] G1 built on the device
     d_scalars = torch.from_numpy(sb).to(dev)
-    d_out = torch.zeros(18, dtype=torch.int64, device=dev)
+    d_out = [torch.zeros(18, dtype=torch.int64, device=dev) for _ in range(4)]      # up to four calls may be in flight
     gathered = [torch.zeros(18, dtype=torch.int64, device=dev) for _ in range(world)] if world > 1 else None
+    ctx.set_pipelining(True)         # the latency-bound tail of MSM i overlaps the chip-filling phases of MSM i+1
+    state = {"i": 0}
+
+    def exchange(buf):
+        """the path's single exchange step: all-gather the per-rank partial sums, fold on every rank"""
+        dist.all_gather(gathered, buf)
+        parts = torch.stack(gathered).cpu().numpy().view(np.uint64)
+        return ctx.point_sum(1, parts)
 
     def step():
-        ctx.msm_device(bases, d_scalars.data_ptr(), n, d_out.data_ptr())
-        if world > 1:
-            dist.all_gather(gathered, d_out)
-            parts = torch.stack(gathered).cpu().numpy().view(np.uint64)
-            return ctx.point_sum(1, parts)
-        return None
+        i = state["i"]; state["i"] = i + 1
+        ctx.msm_device(bases, d_scalars.data_ptr(), n, d_out[i & 3].data_ptr())
+        if world > 1 and i > 0:
+            ctx.join(1)              # result i-1 is complete (stream-level wait); MSM i stays in flight
+            exchange(d_out[(i - 1) & 3])
+
+    def drain():
+        ctx.join(0)
+        if world > 1 and state["i"] > 0:
+            exchange(d_out[(state["i"] - 1) & 3])
+        state["i"] = 0
 
     def fence():
         torch.cuda.synchronize()
@@ -93,16 +106,20 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    ctx.set_pipelining(False)
+    d_out = d_out[0]
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the library's stream ----------
     roof = None

@@ -23,6 +23,9 @@ SIGNATURES = {
     "blsgpu_device_count": (c_int, []),
     "blsgpu_set_stream": (c_int, [c_vp, c_vp]),
     "blsgpu_synchronize": (c_int, [c_vp]),
+    "blsgpu_set_pipelining": (c_int, [c_vp, c_int]),
+    "blsgpu_join": (c_int, [c_vp]),
+    "blsgpu_join_lag": (c_int, [c_vp, c_int]),
     "blsgpu_g1_bases_upload": (c_int, [c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
     "blsgpu_g2_bases_upload": (c_int, [c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
     "blsgpu_g1_bases_from_device": (c_int, [c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),

@@ -129,6 +129,12 @@ class Context:
     def synchronize(self):
         check(self.lib.blsgpu_synchronize(self.h), "synchronize")
 
+    def set_pipelining(self, on):
+        check(self.lib.blsgpu_set_pipelining(self.h, 1 if on else 0), "set_pipelining")
+
+    def join(self, lag=0):
+        check(self.lib.blsgpu_join_lag(self.h, lag), "join")
+
     def set_msm_window(self, c):
         check(self.lib.blsgpu_set_msm_window(self.h, c), "set_msm_window")
 

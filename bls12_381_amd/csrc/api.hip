@@ -38,15 +38,29 @@ struct DevBuf {
   template <class T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
+constexpr int NSLOT = 4;       // MSM calls whose tails may be in flight at once
 struct blsgpu_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
   int msm_c = 0;
   bool profiling = false;
+  bool pipelining = false;
   hipEvent_t ev[9];
   float phase_ms[8] = {0};
-  // scratch
-  DevBuf ent, sorted, hist, offs, cursor, bsum, order, lhist, buckets, lvlR[2], lvlT, tsum[2], wacc[2], wsums, result, io_a, io_b, io_c, io_d, io_out, flags_a, flags_b;
+  // MSM: the chip-filling phases run on `stream`; the latency-bound tail (bucket reduction + window
+  // combine, a few wavefronts) of call i runs on tail_stream[i & 1] and overlaps the next call's heavy
+  // phases.  Everything the tail touches is double-buffered per slot.
+  struct Slot {
+    hipStream_t tail = nullptr;
+    hipEvent_t ev_acc = nullptr, ev_tail = nullptr;
+    bool tail_pending = false;
+    unsigned long long seq = 0;
+    DevBuf buckets, lvlR[2], lvlT, tsum[2], wacc[2], wsums, result;
+  } slot[NSLOT];
+  int next_slot = 0;
+  unsigned long long msm_calls = 0;
+  // scratch of the heavy phases (serialised on `stream`)
+  DevBuf ent, sorted, hist, offs, cursor, bsum, items, heavy, ctrl, result, io_a, io_b, io_c, io_d, io_out, flags_a, flags_b;
 };
 
 struct blsgpu_bases {
@@ -267,6 +281,14 @@ extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
   HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
   for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
+  int prio_lo = 0, prio_hi = 0;
+  HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+  for (auto& sl : c->slot) {
+    // the tail is a handful of wavefronts racing a chip-filling kernel: give its queue the highest priority
+    HIPCHK(hipStreamCreateWithPriority(&sl.tail, hipStreamNonBlocking, prio_hi));
+    HIPCHK(hipEventCreateWithFlags(&sl.ev_acc, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&sl.ev_tail, hipEventDisableTiming));
+  }
   *out = c;
   return BLSGPU_OK;
 }
@@ -274,10 +296,15 @@ extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
-  DevBuf* bufs[] = {&c->ent, &c->sorted, &c->hist, &c->offs, &c->cursor, &c->bsum, &c->order, &c->lhist, &c->buckets, &c->lvlR[0], &c->lvlR[1],
-                    &c->lvlT, &c->tsum[0], &c->tsum[1], &c->wacc[0], &c->wacc[1], &c->wsums, &c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d,
+  DevBuf* bufs[] = {&c->ent, &c->sorted, &c->hist, &c->offs, &c->cursor, &c->bsum, &c->items, &c->heavy, &c->ctrl, &c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d,
                     &c->io_out, &c->flags_a, &c->flags_b};
   for (auto b : bufs) b->release();
+  for (auto& sl : c->slot) {
+    hipStreamSynchronize(sl.tail);
+    DevBuf* sb[] = {&sl.buckets, &sl.lvlR[0], &sl.lvlR[1], &sl.lvlT, &sl.tsum[0], &sl.tsum[1], &sl.wacc[0], &sl.wacc[1], &sl.wsums, &sl.result};
+    for (auto b : sb) b->release();
+    hipEventDestroy(sl.ev_acc); hipEventDestroy(sl.ev_tail); hipStreamDestroy(sl.tail);
+  }
   for (auto& e : c->ev) hipEventDestroy(e);
   hipStreamDestroy(c->own_stream);
   delete c;
@@ -291,8 +318,18 @@ extern "C" int blsgpu_synchronize(blsgpu_ctx* c) {
   if (!c) return bad("ctx is NULL");
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
+  for (auto& sl : c->slot) { HIPCHK(hipStreamSynchronize(sl.tail)); sl.tail_pending = false; }
   return BLSGPU_OK;
 }
+extern "C" int blsgpu_set_pipelining(blsgpu_ctx* c, int on) { if (!c) return bad("ctx is NULL"); c->pipelining = on != 0; return BLSGPU_OK; }
+extern "C" int blsgpu_join_lag(blsgpu_ctx* c, int lag) {
+  if (!c || lag < 0) return bad("join: bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  for (auto& sl : c->slot)
+    if (sl.tail_pending && sl.seq + (unsigned long long)lag <= c->msm_calls) HIPCHK(hipStreamWaitEvent(c->stream, sl.ev_tail, 0));
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_join(blsgpu_ctx* c) { return blsgpu_join_lag(c, 0); }
 extern "C" int blsgpu_set_msm_window(blsgpu_ctx* c, int w) {
   if (!c) return bad("ctx is NULL");
   if (w != 0 && (w < 4 || w > 20)) return bad("msm window must be 0 or in [4,20]");
@@ -416,6 +453,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   constexpr int PW = Store<F>::PROJ_WORDS;
   if (c->result.reserve(PW * 4)) { g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP; }
   if (n == 0) {
+    if (blsgpu_join(c) != BLSGPU_OK) return BLSGPU_ERR_HIP;
     hipLaunchKernelGGL(k_store_identity<F>, dim3(1), dim3(64), 0, st, c->result.as<u32>());
     LAUNCHCHK();
     hipLaunchKernelGGL(k_proj_export<F>, dim3(1), dim3(256), 0, st, c->result.as<u32>(), (u32*)d_out_wire, (size_t)1);
@@ -435,15 +473,32 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   bad_alloc |= c->cursor.reserve(nb * 4);
   bad_alloc |= c->offs.reserve((nb + 1) * 4);
   bad_alloc |= c->bsum.reserve(4096 * 4);
-  bad_alloc |= c->order.reserve(nb * 4);
-  bad_alloc |= c->lhist.reserve(2 * LOAD_BINS * 4);
-  bad_alloc |= c->buckets.reserve(nb * PW * 4);
-  size_t lvl = (nb / 2 + 1) * PW * 4;
-  bad_alloc |= c->lvlR[0].reserve(lvl); bad_alloc |= c->lvlR[1].reserve(lvl); bad_alloc |= c->lvlT.reserve(lvl);
-  bad_alloc |= c->tsum[0].reserve(lvl); bad_alloc |= c->tsum[1].reserve(lvl);
-  bad_alloc |= c->wacc[0].reserve((size_t)nwin * 32 * PW * 4); bad_alloc |= c->wacc[1].reserve((size_t)nwin * 32 * PW * 4);
-  bad_alloc |= c->wsums.reserve((size_t)nwin * PW * 4);
+  // item cap: ~4x the mean bucket load, so that with uniform scalars (almost) no bucket is cut
+  u32 cap = 128;
+  while (cap < ITEM_CAP_MAX && (size_t)cap * nbw < 4 * n) cap *= 2;
+  const size_t max_items = total / cap + nb + 1;                // every bucket has >= 1 item
+  const size_t max_records = nb + max_items;                    // bucket sums + partial sums of heavy buckets
+  bad_alloc |= c->items.reserve(max_items * sizeof(ItemDesc));
+  bad_alloc |= c->heavy.reserve(nb * sizeof(uint4));
+  bad_alloc |= c->ctrl.reserve((4 + 2 * ITEM_BINS) * 4);
+  blsgpu_ctx::Slot& sl = c->slot[c->next_slot];
+  c->next_slot = (c->next_slot + 1) % NSLOT;
+  // the slot's buffers may still be read by the tail of the call before last
+  if (sl.tail_pending) HIPCHK(hipStreamWaitEvent(st, sl.ev_tail, 0));
+  {
+    // (re)allocation frees memory: make sure nothing of this slot is in flight
+    size_t lvl = (nb / 2 + 1) * PW * 4;
+    bool grow = sl.buckets.cap < max_records * PW * 4 || sl.lvlR[0].cap < lvl || sl.wacc[0].cap < (size_t)nwin * 32 * PW * 4 || sl.wsums.cap < (size_t)nwin * PW * 4;
+    if (grow) { HIPCHK(hipStreamSynchronize(sl.tail)); HIPCHK(hipStreamSynchronize(st)); }
+    bad_alloc |= sl.buckets.reserve(max_records * PW * 4);
+    bad_alloc |= sl.lvlR[0].reserve(lvl); bad_alloc |= sl.lvlR[1].reserve(lvl); bad_alloc |= sl.lvlT.reserve(lvl);
+    bad_alloc |= sl.tsum[0].reserve(lvl); bad_alloc |= sl.tsum[1].reserve(lvl);
+    bad_alloc |= sl.wacc[0].reserve((size_t)nwin * 32 * PW * 4); bad_alloc |= sl.wacc[1].reserve((size_t)nwin * 32 * PW * 4);
+    bad_alloc |= sl.wsums.reserve((size_t)nwin * PW * 4);
+    bad_alloc |= sl.result.reserve(PW * 4);
+  }
   if (bad_alloc) { g_err = "hipMalloc(msm scratch) failed"; return BLSGPU_ERR_HIP; }
+  hipStream_t tt = sl.tail;
   const bool prof = c->profiling;
   auto mark = [&](int i) { if (prof) hipEventRecord(c->ev[i], st); };
 
@@ -451,7 +506,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   // 1. digits + histogram
   HIPCHK(hipMemsetAsync(c->hist.p, 0, nb * 4, st));
   HIPCHK(hipMemsetAsync(c->cursor.p, 0, nb * 4, st));
-  HIPCHK(hipMemsetAsync(c->lhist.p, 0, 2 * LOAD_BINS * 4, st));
+  HIPCHK(hipMemsetAsync(c->ctrl.p, 0, (4 + 2 * ITEM_BINS) * 4, st));
   hipLaunchKernelGGL(k_msm_digits, dim3(nblk(n, 256)), dim3(256), 0, st, (const u32*)d_scalars, c->ent.as<u32>(), c->hist.as<u32>(), (int)n, cw, nwin);
   LAUNCHCHK();
   mark(1);
@@ -468,69 +523,83 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
                      (int)n, total);
   LAUNCHCHK();
   mark(3);
-  // 4. bucket order by load
-  u32* lh = c->lhist.as<u32>();
-  hipLaunchKernelGGL(k_load_hist, dim3(nblk(nb, 256)), dim3(256), 0, st, c->hist.as<u32>(), lh, (int)nb);
-  hipLaunchKernelGGL(k_load_scan, dim3(1), dim3(1024), 0, st, lh);
-  hipLaunchKernelGGL(k_load_scatter, dim3(nblk(nb, 256)), dim3(256), 0, st, c->hist.as<u32>(), lh, c->order.as<u32>(), (int)nb);
+  // 4. work items
+  u32* ctrl = c->ctrl.as<u32>();
+  u32* bins = ctrl + 4;
+  u32* bcur = ctrl + 4 + ITEM_BINS;
+  hipLaunchKernelGGL(k_item_count, dim3(nblk(nb, 256)), dim3(256), 0, st, c->offs.as<u32>(), bins, ctrl, (int)nb, cap);
+  hipLaunchKernelGGL(k_item_scan, dim3(1), dim3(256), 0, st, bins, ctrl, cap);
+  hipLaunchKernelGGL(k_item_fill, dim3(nblk(nb, 256)), dim3(256), 0, st, c->offs.as<u32>(), bins, bcur, ctrl, c->items.as<ItemDesc>(),
+                     c->heavy.as<uint4>(), (int)nb, cap);
   LAUNCHCHK();
   mark(4);
-  // 5. accumulate
-  hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(nb, 256)), dim3(256), 0, st, bases->rec + first * Store<F>::AFF_WORDS, c->sorted.as<u32>(),
-                     c->offs.as<u32>(), c->order.as<u32>(), c->buckets.as<u32>(), (int)nb);
+  // 5. accumulate (grid covers the worst-case item count; surplus lanes exit on ctrl[2])
+  u32* records = sl.buckets.as<u32>();
+  hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(max_items, 256)), dim3(256), 0, st, bases->rec + first * Store<F>::AFF_WORDS, c->sorted.as<u32>(),
+                     c->items.as<ItemDesc>(), ctrl, records);
+  hipLaunchKernelGGL(k_msm_heavy_small<F>, dim3(256), dim3(256), 0, st, c->heavy.as<uint4>(), ctrl, records);
+  hipLaunchKernelGGL(k_msm_heavy_big<F>, dim3(512), dim3(256), 0, st, c->heavy.as<uint4>(), ctrl, records);
   LAUNCHCHK();
   mark(5);
+  // ---- tail on the slot's own stream ---------------------------------------------------------------
+  HIPCHK(hipEventRecord(sl.ev_acc, st));
+  HIPCHK(hipStreamWaitEvent(tt, sl.ev_acc, 0));
   // 6. per-window weighted sums:  wsum = sum_g T_g + M * wsum0(R)
   {
     std::vector<int> Ms;
-    const u32* E = c->buckets.as<u32>();
+    const u32* E = records;
     int nn = (int)nbw, off = 1, cur = 0, level = 0;
     // level T sums are stored consecutively in wacc[0]: level l at offset l * nwin
-    u32* tstore = c->wacc[0].as<u32>();
+    u32* tstore = sl.wacc[0].as<u32>();
     while (nn > 1) {
       int M = nn >= 8 ? 8 : nn;
       int G = nn / M;
-      u32* Rout = c->lvlR[cur].as<u32>();
-      u32* Tout = c->lvlT.as<u32>();
-      hipLaunchKernelGGL(k_wsum_level<F>, dim3(nblk((size_t)nwin * G, 256)), dim3(256), 0, st, E, Rout, Tout, nwin, nn, M, off);
+      u32* Rout = sl.lvlR[cur].as<u32>();
+      u32* Tout = sl.lvlT.as<u32>();
+      hipLaunchKernelGGL(k_wsum_level<F>, dim3(nblk((size_t)nwin * G, 256)), dim3(256), 0, tt, E, Rout, Tout, nwin, nn, M, off);
       LAUNCHCHK();
       // sum the G T-records of each window down to one
       const u32* Tin = Tout; int tn = G, tc = 0;
       while (tn > 1) {
         int TM = tn >= 8 ? 8 : tn; int TG = (tn + TM - 1) / TM;
-        u32* o = c->tsum[tc].as<u32>();
-        hipLaunchKernelGGL(k_tree_sum<F>, dim3(nblk((size_t)nwin * TG, 256)), dim3(256), 0, st, Tin, o, nwin, tn, TM);
+        u32* o = sl.tsum[tc].as<u32>();
+        hipLaunchKernelGGL(k_tree_sum<F>, dim3(nblk((size_t)nwin * TG, 256)), dim3(256), 0, tt, Tin, o, nwin, tn, TM);
         LAUNCHCHK();
         Tin = o; tn = TG; tc ^= 1;
       }
-      HIPCHK(hipMemcpyAsync(tstore + (size_t)level * nwin * PW, Tin, (size_t)nwin * PW * 4, hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(tstore + (size_t)level * nwin * PW, Tin, (size_t)nwin * PW * 4, hipMemcpyDeviceToDevice, tt));
       Ms.push_back(M);
       E = Rout; nn = G; off = 0; cur ^= 1; level++;
       if (level >= 31) return bad("msm: reduction depth");
     }
     if (level == 0) {
       // a single bucket per window (c = 1): the bucket itself is the window sum
-      HIPCHK(hipMemcpyAsync(c->wsums.p, c->buckets.p, (size_t)nwin * PW * 4, hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(sl.wsums.p, records, (size_t)nwin * PW * 4, hipMemcpyDeviceToDevice, tt));
     } else {
       // Horner over the levels: acc_L = T_L ; acc_l = T_l + M_l * acc_{l+1}
-      u32* accbuf = c->wacc[1].as<u32>();
-      HIPCHK(hipMemcpyAsync(accbuf, tstore + (size_t)(level - 1) * nwin * PW, (size_t)nwin * PW * 4, hipMemcpyDeviceToDevice, st));
+      u32* accbuf = sl.wacc[1].as<u32>();
+      HIPCHK(hipMemcpyAsync(accbuf, tstore + (size_t)(level - 1) * nwin * PW, (size_t)nwin * PW * 4, hipMemcpyDeviceToDevice, tt));
       for (int l = level - 2; l >= 0; l--) {
         int k = 0; while ((1 << k) < Ms[l]) k++;
-        hipLaunchKernelGGL(k_shift_add<F>, dim3(nblk(nwin, 64)), dim3(64), 0, st, accbuf, tstore + (size_t)l * nwin * PW, accbuf, nwin, k);
+        hipLaunchKernelGGL(k_shift_add<F>, dim3(nblk(nwin, 64)), dim3(64), 0, tt, accbuf, tstore + (size_t)l * nwin * PW, accbuf, nwin, k);
         LAUNCHCHK();
       }
-      HIPCHK(hipMemcpyAsync(c->wsums.p, accbuf, (size_t)nwin * PW * 4, hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(sl.wsums.p, accbuf, (size_t)nwin * PW * 4, hipMemcpyDeviceToDevice, tt));
     }
   }
-  mark(6);
+  if (prof) hipEventRecord(c->ev[6], tt);
   // 7. combine windows
-  hipLaunchKernelGGL(k_msm_combine<F>, dim3(1), dim3(64), 0, st, c->wsums.as<u32>(), c->result.as<u32>(), nwin, cw);
+  hipLaunchKernelGGL(k_msm_combine<F>, dim3(1), dim3(64), 0, tt, sl.wsums.as<u32>(), sl.result.as<u32>(), nwin, cw);
   LAUNCHCHK();
-  hipLaunchKernelGGL(k_proj_export<F>, dim3(1), dim3(256), 0, st, c->result.as<u32>(), (u32*)d_out_wire, (size_t)1);
+  hipLaunchKernelGGL(k_proj_export<F>, dim3(1), dim3(256), 0, tt, sl.result.as<u32>(), (u32*)d_out_wire, (size_t)1);
   LAUNCHCHK();
-  mark(7);
+  if (prof) hipEventRecord(c->ev[7], tt);
+  HIPCHK(hipEventRecord(sl.ev_tail, tt));
+  sl.tail_pending = true;
+  sl.seq = ++c->msm_calls;
+  if (!c->pipelining) HIPCHK(hipStreamWaitEvent(st, sl.ev_tail, 0));    // in-order semantics on the caller's stream
   if (prof) {
+    HIPCHK(hipStreamSynchronize(tt));
     HIPCHK(hipStreamSynchronize(st));
     for (int i = 0; i < 7; i++) hipEventElapsedTime(&c->phase_ms[i], c->ev[i], c->ev[i + 1]);
     hipEventElapsedTime(&c->phase_ms[7], c->ev[0], c->ev[7]);
@@ -545,6 +614,8 @@ static int msm_host(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, cons
   if (c->io_b.reserve(n ? n * 32 : 16) || c->io_out.reserve(3 * Wire<F>::WORDS * 4)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
   if (n) HIPCHK(hipMemcpyAsync(c->io_b.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
   int rc = msm_device<F>(c, bases, first, c->io_b.p, n, c->io_out.p);
+  if (rc) return rc;
+  rc = blsgpu_join(c);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, 3 * Wire<F>::WORDS * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));

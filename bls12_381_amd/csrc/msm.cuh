@@ -9,10 +9,11 @@
 //                  src/scalar.rs:284-296) -> W signed c-bit digits each; histogram of bucket loads
 //   2. scan        exclusive prefix sum of the histogram -> bucket offsets
 //   3. scatter     counting sort of (sign, point index) by (window, |digit|)
-//   4. order       buckets sorted by load (descending) so that the 64 lanes of a wavefront walk
-//                  buckets of equal length (no tail divergence)
-//   5. accumulate  one lane per bucket: gathers its points (128 B / 256 B records) and adds them with the
-//                  exception-free mixed addition of curve.cuh -- this is >90% of the arithmetic
+//   4. items       buckets cut into work items of <= 128 entries, sorted by length (descending) so that
+//                  the 64 lanes of a wavefront walk items of equal length and no lane walks a long bucket
+//   5. accumulate  one lane per item: gathers its points (128 B / 256 B records) and adds them with the
+//                  exception-free mixed addition of curve.cuh -- this is >90% of the arithmetic; partial
+//                  sums of buckets that were cut are folded by a block-level tree
 //   6. reduce      sum_k k * B_k per window by chunked running sums (log-depth recursion)
 //   7. combine     Horner over the windows (c doublings + 1 addition each)
 //
@@ -223,45 +224,91 @@ __global__ void __launch_bounds__(256) k_msm_scatter(const u32* __restrict__ ent
   sorted[pos] = i | (e & 0x80000000u);
 }
 
-// ---- 4. bucket order by load (descending) -----------------------------------------------------------
-constexpr int LOAD_BINS = 1024;
-__global__ void __launch_bounds__(256) k_load_hist(const u32* __restrict__ hist, u32* __restrict__ lhist, int nb) {
+// ---- 4. work items: buckets cut into chunks of <= ITEM_CAP entries, sorted by length (descending) ----------
+// A lane of the accumulation kernel walks ONE item.  Cutting bounds the walk (a single digit value shared
+// by many scalars -- or the narrow top window -- would otherwise serialise a whole bucket on one lane) and
+// sorting by length makes the 64 lanes of a wavefront finish together.  Buckets with one item write their
+// sum straight into the bucket array; the others ("heavy") write partial sums that k_msm_heavy folds.
+constexpr int ITEM_CAP_MAX = 4096;                // the cap is chosen per call: max(128, ~4 x mean bucket load)
+constexpr int ITEM_BINS = ITEM_CAP_MAX + 1;       // bin = cap - len  (bin 0 = longest)
+constexpr int HEAVY_SMALL = 16;                   // heavy buckets with <= this many partials are folded by one lane
+struct ItemDesc { u32 start, len, dest; };        // entries [start, start+len) of `sorted`; dest = record index
+// ctrl[0] = #partial records handed out, ctrl[1] = #heavy buckets, ctrl[2] = #items
+__global__ void __launch_bounds__(256) k_item_count(const u32* __restrict__ offs, u32* __restrict__ bins, u32* __restrict__ ctrl, int nb, u32 cap) {
+  __shared__ u32 cnt[ITEM_BINS];
+  for (u32 i = threadIdx.x; i <= cap; i += 256) cnt[i] = 0;
+  __syncthreads();
   int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nb) return;
-  u32 l = hist[b]; if (l >= LOAD_BINS) l = LOAD_BINS - 1;
-  atomicAdd(&lhist[LOAD_BINS - 1 - l], 1u);      // descending: bin 0 = heaviest
+  if (b < nb) {
+    u32 load = offs[b + 1] - offs[b];
+    u32 full = load / cap, rem = load - full * cap;
+    if (full) atomicAdd(&cnt[0], full);
+    if (rem || !full) atomicAdd(&cnt[cap - rem], 1u);
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i <= cap; i += 256) if (cnt[i]) atomicAdd(&bins[i], cnt[i]);
 }
-__global__ void __launch_bounds__(1024) k_load_scan(u32* __restrict__ lhist) {
-  __shared__ u32 sh[LOAD_BINS];
-  sh[threadIdx.x] = lhist[threadIdx.x];
+__global__ void __launch_bounds__(256) k_item_scan(u32* __restrict__ bins, u32* __restrict__ ctrl, u32 cap) {
+  __shared__ u32 sh[ITEM_BINS];
+  for (u32 i = threadIdx.x; i <= cap; i += 256) sh[i] = bins[i];
   __syncthreads();
   if (threadIdx.x == 0) {
     u32 run = 0;
-    for (int i = 0; i < LOAD_BINS; i++) { u32 v = sh[i]; sh[i] = run; run += v; }
+    for (u32 i = 0; i <= cap; i++) { u32 v = sh[i]; sh[i] = run; run += v; }
+    ctrl[2] = run;
   }
   __syncthreads();
-  lhist[threadIdx.x] = sh[threadIdx.x];
+  for (u32 i = threadIdx.x; i <= cap; i += 256) bins[i] = sh[i];      // exclusive bin bases
 }
-__global__ void __launch_bounds__(256) k_load_scatter(const u32* __restrict__ hist, u32* __restrict__ lcur,
-                                                      u32* __restrict__ order, int nb) {
+__global__ void __launch_bounds__(256) k_item_fill(const u32* __restrict__ offs, const u32* __restrict__ bins, u32* __restrict__ bcur,
+                                                   u32* __restrict__ ctrl, ItemDesc* __restrict__ items, uint4* __restrict__ heavy, int nb, u32 cap) {
+  __shared__ u32 cnt[ITEM_BINS];
+  __shared__ u32 base[ITEM_BINS];
+  const u32 ITEM_CAP = cap;
+  for (u32 i = threadIdx.x; i <= cap; i += 256) cnt[i] = 0;
+  __syncthreads();
   int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nb) return;
-  u32 l = hist[b]; if (l >= LOAD_BINS) l = LOAD_BINS - 1;
-  u32 pos = atomicAdd(&lcur[LOAD_BINS - 1 - l], 1u);
-  order[pos] = (u32)b;
+  u32 beg = 0, load = 0, full = 0, rem = 0, r_full = 0, r_rem = 0;
+  bool has_rem = false;
+  if (b < nb) {
+    beg = offs[b]; load = offs[b + 1] - beg;
+    full = load / ITEM_CAP; rem = load - full * ITEM_CAP;
+    has_rem = rem || !full;
+    if (full) r_full = atomicAdd(&cnt[0], full);
+    if (has_rem) r_rem = atomicAdd(&cnt[ITEM_CAP - rem], 1u);
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i <= cap; i += 256) base[i] = cnt[i] ? bins[i] + atomicAdd(&bcur[i], cnt[i]) : 0;
+  __syncthreads();
+  if (b < nb) {
+    u32 nitems = full + (has_rem ? 1u : 0u);
+    u32 dest0 = (u32)b;
+    if (nitems > 1) {
+      dest0 = (u32)nb + atomicAdd(&ctrl[0], nitems);
+      u32 h = atomicAdd(&ctrl[1], 1u);
+      heavy[h] = make_uint4((u32)b, dest0, nitems, 0);
+    }
+    for (u32 j = 0; j < full; j++) {
+      ItemDesc d; d.start = beg + j * ITEM_CAP; d.len = ITEM_CAP; d.dest = dest0 + j;
+      items[base[0] + r_full + j] = d;
+    }
+    if (has_rem) {
+      ItemDesc d; d.start = beg + full * ITEM_CAP; d.len = rem; d.dest = dest0 + full;
+      items[base[ITEM_CAP - rem] + r_rem] = d;
+    }
+  }
 }
 
 // ---- 5. bucket accumulation ---------------------------------------------------------------------------
 template <class F>
 __global__ void __launch_bounds__(256) k_msm_accumulate(const u32* __restrict__ bases, const u32* __restrict__ sorted,
-                                                        const u32* __restrict__ offs, const u32* __restrict__ order,
-                                                        u32* __restrict__ buckets, int nb) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nb) return;
-  u32 b = order[t];
-  u32 beg = offs[b], end = offs[b + 1];
+                                                        const ItemDesc* __restrict__ items, const u32* __restrict__ ctrl,
+                                                        u32* __restrict__ records) {
+  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ctrl[2]) return;
+  ItemDesc d = items[t];
   Proj<F> acc = pt_identity<F>();
-  for (u32 j = beg; j < end; j++) {
+  for (u32 j = d.start; j < d.start + d.len; j++) {
     u32 e = sorted[j];
     Aff<F> q; bool inf;
     load_aff<F>(bases + (size_t)(e & 0x7fffffffu) * Store<F>::AFF_WORDS, q, inf);
@@ -269,7 +316,52 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const u32* __restrict__ 
     Proj<F> r = pt_add_mixed_y<F>(acc, q.x, qy);
     acc = pt_select(inf, acc, r);
   }
-  store_proj<F>(buckets + (size_t)b * Store<F>::PROJ_WORDS, acc);
+  store_proj<F>(records + (size_t)d.dest * Store<F>::PROJ_WORDS, acc);
+}
+// fold the partial sums of the heavy buckets: one lane per bucket when it has few partials ...
+template <class F>
+__global__ void __launch_bounds__(256) k_msm_heavy_small(const uint4* __restrict__ heavy, const u32* __restrict__ ctrl, u32* __restrict__ records) {
+  constexpr int PW = Store<F>::PROJ_WORDS;
+  u32 nh = ctrl[1];
+  for (u32 h = blockIdx.x * blockDim.x + threadIdx.x; h < nh; h += gridDim.x * blockDim.x) {
+    uint4 d = heavy[h];
+    if (d.z > HEAVY_SMALL) continue;
+    const u32* part = records + (size_t)d.y * PW;
+    Proj<F> acc; load_proj<F>(part, acc);
+    for (u32 k = 1; k < d.z; k++) { Proj<F> e; load_proj<F>(part + (size_t)k * PW, e); acc = pt_add<F>(acc, e); }
+    store_proj<F>(records + (size_t)d.x * PW, acc);
+  }
+}
+// ... and one block per bucket (in-place tree, fan 8) when it has many
+template <class F>
+__global__ void __launch_bounds__(256) k_msm_heavy_big(const uint4* __restrict__ heavy, const u32* __restrict__ ctrl, u32* __restrict__ records) {
+  constexpr int PW = Store<F>::PROJ_WORDS;
+  u32 nh = ctrl[1];
+  for (u32 h = blockIdx.x; h < nh; h += gridDim.x) {
+    uint4 d = heavy[h];
+    if (d.z <= HEAVY_SMALL) continue;                      // uniform across the block
+    u32* part = records + (size_t)d.y * PW;
+    u32 n = d.z;
+    for (u32 stride = 1; stride < n; stride *= 8) {
+      u32 groups = (n + stride * 8 - 1) / (stride * 8);
+      for (u32 g = threadIdx.x; g < groups; g += blockDim.x) {
+        size_t i0 = (size_t)g * stride * 8;
+        Proj<F> acc; load_proj<F>(part + i0 * PW, acc);
+        for (int k = 1; k < 8; k++) {
+          size_t i = i0 + (size_t)k * stride;
+          if (i < n) { Proj<F> e; load_proj<F>(part + i * PW, e); acc = pt_add<F>(acc, e); }
+        }
+        store_proj<F>(part + i0 * PW, acc);
+      }
+      __threadfence();      // partials written by other waves of this block must be visible (L1 is not coherent)
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      Proj<F> acc; load_proj<F>(part, acc);
+      store_proj<F>(records + (size_t)d.x * PW, acc);
+    }
+    __syncthreads();
+  }
 }
 
 // ---- 6. weighted bucket reduction -----------------------------------------------------------------------
@@ -279,6 +371,7 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const u32* __restrict__ 
 template <class F>
 __global__ void __launch_bounds__(256) k_wsum_level(const u32* __restrict__ E, u32* __restrict__ Rout, u32* __restrict__ Tout,
                                                     int nseg, int n, int M, int off) {
+  __builtin_amdgcn_s_setprio(3);      // latency-bound tail: win VALU arbitration against co-resident bulk waves
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   int G = n / M;
   if (t >= nseg * G) return;
@@ -308,6 +401,7 @@ __global__ void __launch_bounds__(64) k_seg_sum(const u32* __restrict__ E, u32* 
 // tree sum: out[seg][g] = sum of M consecutive records
 template <class F>
 __global__ void __launch_bounds__(256) k_tree_sum(const u32* __restrict__ E, u32* __restrict__ out, int nseg, int n, int M) {
+  __builtin_amdgcn_s_setprio(3);      // latency-bound tail: win VALU arbitration against co-resident bulk waves
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   int G = (n + M - 1) / M;
   if (t >= nseg * G) return;
@@ -323,6 +417,7 @@ __global__ void __launch_bounds__(256) k_tree_sum(const u32* __restrict__ E, u32
 template <class F>
 __global__ void __launch_bounds__(64) k_shift_add(const u32* __restrict__ x, const u32* __restrict__ y, u32* __restrict__ out,
                                                   int nseg, int k) {
+  __builtin_amdgcn_s_setprio(3);      // latency-bound tail: win VALU arbitration against co-resident bulk waves
   int seg = blockIdx.x * blockDim.x + threadIdx.x;
   if (seg >= nseg) return;
   Proj<F> a, b;
@@ -336,6 +431,7 @@ __global__ void __launch_bounds__(64) k_shift_add(const u32* __restrict__ x, con
 // ---- 7. window combine (Horner) ------------------------------------------------------------------------
 template <class F>
 __global__ void __launch_bounds__(64) k_msm_combine(const u32* __restrict__ wsums, u32* __restrict__ out, int nwin, int c) {
+  __builtin_amdgcn_s_setprio(3);      // latency-bound tail: win VALU arbitration against co-resident bulk waves
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   Proj<F> acc;
   load_proj<F>(wsums + (size_t)(nwin - 1) * Store<F>::PROJ_WORDS, acc);
