@@ -470,7 +470,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   bad_alloc |= c->ent.reserve(total * 4);
   bad_alloc |= c->sorted.reserve(total * 4);
   bad_alloc |= c->hist.reserve(nb * 4);
-  bad_alloc |= c->cursor.reserve(nb * 4);
+  bad_alloc |= c->cursor.reserve(total * 4);      // per-entry rank inside its bucket
   bad_alloc |= c->offs.reserve((nb + 1) * 4);
   bad_alloc |= c->bsum.reserve(4096 * 4);
   // item cap: ~4x the mean bucket load, so that with uniform scalars (almost) no bucket is cut
@@ -505,9 +505,8 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   mark(0);
   // 1. digits + histogram
   HIPCHK(hipMemsetAsync(c->hist.p, 0, nb * 4, st));
-  HIPCHK(hipMemsetAsync(c->cursor.p, 0, nb * 4, st));
   HIPCHK(hipMemsetAsync(c->ctrl.p, 0, (4 + 2 * ITEM_BINS) * 4, st));
-  hipLaunchKernelGGL(k_msm_digits, dim3(nblk(n, 256)), dim3(256), 0, st, (const u32*)d_scalars, c->ent.as<u32>(), c->hist.as<u32>(), (int)n, cw, nwin);
+  hipLaunchKernelGGL(k_msm_digits, dim3(nblk(n, 256)), dim3(256), 0, st, (const u32*)d_scalars, c->ent.as<u32>(), c->cursor.as<u32>(), c->hist.as<u32>(), (int)n, cw, nwin);
   LAUNCHCHK();
   mark(1);
   // 2. scan
@@ -519,7 +518,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   LAUNCHCHK();
   mark(2);
   // 3. scatter
-  hipLaunchKernelGGL(k_msm_scatter, dim3(nblk(total, 256)), dim3(256), 0, st, c->ent.as<u32>(), c->offs.as<u32>(), c->cursor.as<u32>(), c->sorted.as<u32>(),
+  hipLaunchKernelGGL(k_msm_scatter, dim3(nblk(total, 256)), dim3(256), 0, st, c->ent.as<u32>(), c->cursor.as<u32>(), c->offs.as<u32>(), c->sorted.as<u32>(),
                      (int)n, total);
   LAUNCHCHK();
   mark(3);

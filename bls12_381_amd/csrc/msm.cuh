@@ -120,8 +120,10 @@ DEV Proj<F> pt_add_mixed_y(const Proj<F>& p, const typename F::aff_elem& qx, con
 }
 
 // ---- 1. digits + histogram -------------------------------------------------------------------------
-// ent[w * n + i] = global bucket (w * nbw + |d| - 1) | sign << 31, or 0xffffffff for a zero digit.
-__global__ void __launch_bounds__(256) k_msm_digits(const u32* __restrict__ scalars, u32* __restrict__ ent,
+// ent[w * n + i] = global bucket (w * nbw + |d| - 1) | sign << 31, or 0xffffffff for a zero digit;
+// rank[w * n + i] = arrival order of the entry inside its bucket (the value returned by the histogram
+// atomic), which makes the later scatter a plain permutation with no second round of atomics.
+__global__ void __launch_bounds__(256) k_msm_digits(const u32* __restrict__ scalars, u32* __restrict__ ent, u32* __restrict__ rank,
                                                     u32* __restrict__ hist, int n, int c, int nwin) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -143,13 +145,14 @@ __global__ void __launch_bounds__(256) k_msm_digits(const u32* __restrict__ scal
     u32 neg = raw > nbw;
     u32 mag = neg ? ((1u << c) - raw) : raw;
     carry = neg;
-    u32 e = 0xffffffffu;
+    u32 e = 0xffffffffu, rk = 0;
     if (mag) {
       u32 gb = (u32)w * nbw + (mag - 1);
       e = gb | (neg << 31);
-      atomicAdd(&hist[gb], 1u);
+      rk = atomicAdd(&hist[gb], 1u);
     }
     ent[(size_t)w * n + i] = e;
+    rank[(size_t)w * n + i] = rk;
   }
 }
 
@@ -211,17 +214,15 @@ __global__ void __launch_bounds__(256) k_scan_apply(const u32* __restrict__ in, 
 }
 
 // ---- 3. scatter ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_msm_scatter(const u32* __restrict__ ent, const u32* __restrict__ offs,
-                                                     u32* __restrict__ cursor, u32* __restrict__ sorted,
-                                                     int n, size_t total) {
+__global__ void __launch_bounds__(256) k_msm_scatter(const u32* __restrict__ ent, const u32* __restrict__ rank, const u32* __restrict__ offs,
+                                                     u32* __restrict__ sorted, int n, size_t total) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   u32 e = ent[t];
   if (e == 0xffffffffu) return;
   u32 gb = e & 0x7fffffffu;
   u32 i = (u32)(t % (size_t)n);
-  u32 pos = offs[gb] + atomicAdd(&cursor[gb], 1u);
-  sorted[pos] = i | (e & 0x80000000u);
+  sorted[offs[gb] + rank[t]] = i | (e & 0x80000000u);
 }
 
 // ---- 4. work items: buckets cut into chunks of <= ITEM_CAP entries, sorted by length (descending) ----------
