@@ -79,9 +79,10 @@ struct Fe {
 };
 
 // Storage forms used in structs/arrays (limbs normalised):
-//   fe1  canonical inputs (value < p);   fe  working values (value < 8p; every point formula in
-//   curve.cuh maps coordinates < 8p to coordinates < 8p);   fe2p  output of a mul with small inputs.
-constexpr int VS = 8;
+//   fe1  canonical inputs (value < p);   fe  working values (value < 12p; every point formula in
+//   curve.cuh maps coordinates < 12p to coordinates < 12p without a value reduction -- build with
+//   -DBLS_STRICT_STORE to have the compiler prove it);   fe2p  output of a mul with small inputs.
+constexpr int VS = 12;
 typedef Fe<1, VS> fe;
 typedef Fe<1, 1> fe1;
 typedef Fe<1, 2> fe2p;
@@ -354,6 +355,9 @@ DEV fe store(const Fe<A, V>& a) {
     if constexpr (A == 1) return (fe)a;
     else return (fe)norm(a);
   } else {
+#ifdef BLS_STRICT_STORE
+    static_assert(V <= VS, "store: value bound exceeds the storage bound (strict build)");
+#endif
     return (fe)reduce_v(norm(a));
   }
 }
@@ -433,6 +437,20 @@ DEV bool is_zero(const Fe<A, V>& a) {
   for (int i = 0; i < NL; i++) t |= c.l[i];
   return t == 0;
 }
+
+// cheap filter for "is this value a multiple of p": its low 28 bits must equal those of k*p for some k < V.
+// False positives have probability ~V/2^28; a hit is confirmed with the exact (slow) is_zero.
+template <int A, int V>
+DEV bool maybe_zero(const Fe<A, V>& a) {
+  constexpr PLimbs p = P_L;
+  u32 l0 = a.l[0] & LMASK;
+  bool hit = false;
+#pragma unroll
+  for (int k = 0; k < V; k++) hit |= (l0 == (((u32)k * p.l[0]) & LMASK));
+  return hit;
+}
+template <int A, int V>
+DEV bool is_zero_fast(const Fe<A, V>& a) { return maybe_zero(a) && is_zero(a); }
 
 template <int A1, int V1, int A2, int V2>
 DEV bool fe_eq(const Fe<A1, V1>& a, const Fe<A2, V2>& b) {

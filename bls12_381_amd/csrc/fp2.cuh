@@ -88,6 +88,8 @@ DEV auto select(bool c, const Fe2<A, V>& a, const Fe2<A, V>& b) {
 }
 template <int A, int V>
 DEV bool is_zero(const Fe2<A, V>& a) { return is_zero(a.c0) & is_zero(a.c1); }
+template <int A, int V>
+DEV bool is_zero_fast(const Fe2<A, V>& a) { return maybe_zero(a.c0) && maybe_zero(a.c1) && is_zero(a); }
 
 // 1/(a0 + a1 u) = (a0 - a1 u)/(a0^2 + a1^2)        (fp2.rs:300-319)
 template <int A, int V>

@@ -308,16 +308,18 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const u32* __restrict__ 
   u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ctrl[2]) return;
   ItemDesc d = items[t];
-  Proj<F> acc = pt_identity<F>();
+  Xyzz<F> acc;
+  acc.x = F::zero(); acc.y = F::zero(); acc.zz = F::zero(); acc.zzz = F::zero();
+  bool acc_inf = true;
   for (u32 j = d.start; j < d.start + d.len; j++) {
     u32 e = sorted[j];
     Aff<F> q; bool inf;
     load_aff<F>(bases + (size_t)(e & 0x7fffffffu) * Store<F>::AFF_WORDS, q, inf);
+    if (inf) continue;                                    // identity base: contributes nothing
     auto qy = cond_neg(q.y, (e >> 31) != 0);
-    Proj<F> r = pt_add_mixed_y<F>(acc, q.x, qy);
-    acc = pt_select(inf, acc, r);
+    acc = xyzz_add_mixed<F>(acc, acc_inf, q.x, qy);
   }
-  store_proj<F>(records + (size_t)d.dest * Store<F>::PROJ_WORDS, acc);
+  store_proj<F>(records + (size_t)d.dest * Store<F>::PROJ_WORDS, xyzz_to_proj<F>(acc, acc_inf));
 }
 // fold the partial sums of the heavy buckets: one lane per bucket when it has few partials ...
 template <class F>
