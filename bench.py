@@ -48,7 +48,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=LOG_N, help="log2 of points per GPU (default 20 = BASELINE configs[1])")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for single-GPU plumbing tests)")
+    ap.add_argument("--same-device", action="store_true", help="testing aid: all ranks use GPU 0 (needs --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (batched pairings, G2 MSM)")
     args = ap.parse_args()
 
     import torch
@@ -60,11 +63,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import bls12_381_amd as bls
 
@@ -75,15 +83,18 @@ def main():
     bases = ctx.bases_from_scalars(1, kb)                       # resident bases: [k_i] G1 built on the device
     d_scalars = torch.from_numpy(sb).to(dev)
     d_out = [torch.zeros(18, dtype=torch.int64, device=dev) for _ in range(4)]      # up to four calls may be in flight
-    gathered = [torch.zeros(18, dtype=torch.int64, device=dev) for _ in range(world)] if world > 1 else None
+    xdev = dev if args.backend == "nccl" else torch.device("cpu")       # where the exchanged partials live
+    gathered = torch.zeros((world, 18), dtype=torch.int64, device=xdev) if world > 1 else None
+    d_fold = torch.zeros(18, dtype=torch.int64, device=dev)
     ctx.set_pipelining(True)         # the latency-bound tail of MSM i overlaps the chip-filling phases of MSM i+1
     state = {"i": 0}
 
     def exchange(buf):
         """the path's single exchange step: all-gather the per-rank partial sums, fold on every rank"""
-        dist.all_gather(gathered, buf)
-        parts = torch.stack(gathered).cpu().numpy().view(np.uint64)
-        return ctx.point_sum(1, parts)
+        dist.all_gather(list(gathered.unbind(0)), buf.to(xdev))     # rows of one (world, 18) tensor
+        g = gathered if gathered.device == dev else gathered.to(dev)
+        ctx.point_sum_device(1, g.data_ptr(), world, d_fold.data_ptr())     # asynchronous fold on this rank's GPU
+        state["g"] = g
 
     def step():
         i = state["i"]; state["i"] = i + 1
@@ -115,9 +126,16 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        # every rank must hold the same folded result: compare canonical affine limbs through a max/min all-reduce
+        last = d_fold.cpu().numpy().view(np.uint64)
+        aff = torch.from_numpy(ctx.batch_normalize(1, last[None, :])[0][0].view(np.int64).copy()).to(xdev)
+        hi, lo = aff.clone(), aff.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX); dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        if not bool(torch.equal(hi, lo)):
+            raise SystemExit("bench: ranks disagree on the folded MSM result")
     ctx.set_pipelining(False)
     d_out = d_out[0]
 
@@ -169,6 +187,47 @@ def main():
         if not same:
             raise SystemExit("bench: GPU MSM over the CPU sample differs from the oracle")
 
+    # ---- secondary measurements of the same path (BASELINE configs[2]); never part of `value` ---------------
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = {}
+        np_ = 1 << 16
+        rs = np.random.RandomState(99)
+        ka = rs.randint(0, 256, size=(np_, 32), dtype=np.uint8); ka[:, 31] &= 0x3F
+        kq = rs.randint(0, 256, size=(np_, 32), dtype=np.uint8); kq[:, 31] &= 0x3F
+        g1xy, g1f = ctx.bases_from_scalars(1, ka).download()
+        g2xy, g2f = ctx.bases_from_scalars(2, kq).download()
+        d_g1 = torch.from_numpy(g1xy.view(np.int64)).to(dev); d_g2 = torch.from_numpy(g2xy.view(np.int64)).to(dev)
+        d_gt = torch.zeros((np_, 72), dtype=torch.int64, device=dev)
+        def pair():
+            bls._lib.check(ctx.lib.blsgpu_pairing_batch_device(ctx.h, d_g1.data_ptr(), None, d_g2.data_ptr(), None, np_, d_gt.data_ptr()), "pairing_batch_device")
+        pair(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            pair()
+        torch.cuda.synchronize()
+        pdt = (time.perf_counter() - t1) / 3
+        extras["pairings_per_s"] = np_ / pdt
+        extras["pairing_batch"] = {"n": np_, "ms": 1e3 * pdt, "note": "2^16 independent pairing(P_i, Q_i), inputs and outputs in HBM",
+                                   "frac_of_fp_mul_chain_rate": (np_ * 16000 / pdt) / fp_rate}
+        n2 = 1 << 18
+        k2 = rs.randint(0, 256, size=(n2, 32), dtype=np.uint8); k2[:, 31] &= 0x3F
+        b2 = ctx.bases_from_scalars(2, k2)
+        d_s2 = torch.from_numpy(sb[:n2].copy()).to(dev)
+        d_o2 = [torch.zeros(36, dtype=torch.int64, device=dev) for _ in range(4)]
+        ctx.set_pipelining(True)
+        for i in range(2):
+            ctx.msm_device(b2, d_s2.data_ptr(), n2, d_o2[i].data_ptr())
+        ctx.join(0); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(8):
+            ctx.msm_device(b2, d_s2.data_ptr(), n2, d_o2[i & 3].data_ptr())
+        ctx.join(0); torch.cuda.synchronize()
+        g2dt = (time.perf_counter() - t1) / 8
+        ctx.set_pipelining(False)
+        extras["g2_msm_scalar_muls_per_s"] = n2 / g2dt
+        extras["g2_msm"] = {"n": n2, "ms": 1e3 * g2dt}
+
     if rank == 0:
         total = float(n) * world * args.steps
         line = {
@@ -179,7 +238,7 @@ def main():
             "config": {"workload": "2^%d-point G1 MSM per MI355X, bases resident in HBM, scalars in HBM; one result per step "
                                    "(N>1: RCCL all-gather of N partial sums + fold)" % args.log_n,
                        "points_per_gpu": n, "total_points": n * world, "parallelism": "shard%d" % world},
-            "roofline": roof, "cpu_baseline": cpu, "msm_phase_ms": phases,
+            "roofline": roof, "cpu_baseline": cpu, "msm_phase_ms": phases, "extras": extras,
         }
         print(json.dumps(line))
     if world > 1:

@@ -43,6 +43,8 @@ SIGNATURES = {
     "blsgpu_set_msm_window": (c_int, [c_vp, c_int]),
     "blsgpu_g1_sum": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g2_sum": (c_int, [c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_g1_sum_device": (c_int, [c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_g2_sum_device": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g1_batch_normalize": (c_int, [c_vp, c_vp, c_sz, c_vp, c_vp]),
     "blsgpu_g2_batch_normalize": (c_int, [c_vp, c_vp, c_sz, c_vp, c_vp]),
     "blsgpu_pairing_batch": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),

@@ -208,6 +208,10 @@ class Context:
         check(fn(self.h, _ptr(xyz), xyz.shape[0], _ptr(out)), "sum")
         return out
 
+    def point_sum_device(self, group, d_xyz, n, d_out):
+        fn = self.lib.blsgpu_g1_sum_device if group == 1 else self.lib.blsgpu_g2_sum_device
+        check(fn(self.h, ctypes.c_void_p(d_xyz), n, ctypes.c_void_p(d_out)), "sum_device")
+
     def batch_normalize(self, group, xyz):
         w = 18 if group == 1 else 36
         xyz = _u64(xyz, (-1, w))

@@ -658,6 +658,21 @@ static int proj_sum(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* out)
   HIPCHK(hipStreamSynchronize(c->stream));
   return BLSGPU_OK;
 }
+// device-pointer variant: wire-format partials in device memory -> wire-format sum in device memory, asynchronous
+template <class F>
+static int proj_sum_device(blsgpu_ctx* c, const void* d_xyz, size_t n, void* d_out) {
+  if (!c || !d_out || (n && !d_xyz)) return bad("sum_device: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  constexpr int PW = Store<F>::PROJ_WORDS;
+  if (c->io_c.reserve((n ? n : 1) * PW * 4) || c->result.reserve(PW * 4)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  if (n) hipLaunchKernelGGL(k_proj_import<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (const u32*)d_xyz, c->io_c.as<u32>(), n);
+  hipLaunchKernelGGL(k_proj_sum<F>, dim3(1), dim3(64), 0, c->stream, c->io_c.as<u32>(), c->result.as<u32>(), n);
+  hipLaunchKernelGGL(k_proj_export<F>, dim3(1), dim3(256), 0, c->stream, c->result.as<u32>(), (u32*)d_out, (size_t)1);
+  LAUNCHCHK();
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_g1_sum_device(blsgpu_ctx* c, const void* xyz, size_t n, void* out) { return proj_sum_device<FpPolicy>(c, xyz, n, out); }
+extern "C" int blsgpu_g2_sum_device(blsgpu_ctx* c, const void* xyz, size_t n, void* out) { return proj_sum_device<Fp2Policy>(c, xyz, n, out); }
 extern "C" int blsgpu_g1_sum(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* out) { return proj_sum<FpPolicy>(c, xyz, n, out); }
 extern "C" int blsgpu_g2_sum(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* out) { return proj_sum<Fp2Policy>(c, xyz, n, out); }
 

@@ -99,6 +99,9 @@ int blsgpu_set_msm_window(blsgpu_ctx* ctx, int c);
  * cross-GPU all-gather of per-rank partial results. */
 int blsgpu_g1_sum(blsgpu_ctx* ctx, const uint64_t* xyz, size_t n, uint64_t out_xyz[18]);
 int blsgpu_g2_sum(blsgpu_ctx* ctx, const uint64_t* xyz, size_t n, uint64_t out_xyz[36]);
+/* Same with device pointers, asynchronous on the context's stream (no host round trip after the all-gather). */
+int blsgpu_g1_sum_device(blsgpu_ctx* ctx, const void* d_xyz, size_t n, void* d_out_xyz);
+int blsgpu_g2_sum_device(blsgpu_ctx* ctx, const void* d_xyz, size_t n, void* d_out_xyz);
 /* Projective -> affine for n points (`G1Projective::batch_normalize`, src/g1.rs:806-839; `G1Affine::from`,
  * :49-63).  Identity maps to x = 0, y = 1 (Montgomery one), infinity = 1. */
 int blsgpu_g1_batch_normalize(blsgpu_ctx* ctx, const uint64_t* xyz, size_t n, uint64_t* xy, uint8_t* infinity);
