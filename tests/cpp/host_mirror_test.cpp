@@ -1,0 +1,33 @@
+// Exercises include/bls12_381.hpp (the C++ mirror of the reference API) against properties the reference's own
+// tests use (src/pairings.rs:835-921, src/g1.rs:1558-1595).  Argument 1: 576-byte file with the RELIC Gt constant.
+#include <cstdio>
+#include <cstdlib>
+#include "bls12_381.hpp"
+using namespace bls;
+#define REQUIRE(c) do { if (!(c)) { std::printf("FAILED: %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
+int main(int argc, char** argv) {
+  Gt want;
+  if (argc > 1) { FILE* f = std::fopen(argv[1], "rb"); REQUIRE(f && std::fread(want.f.data(), 1, 576, f) == 576); std::fclose(f); }
+  Gt g = pairing(G1Affine::generator(), G2Affine::generator());
+  if (argc > 1) REQUIRE(g == want);                                  // RELIC KAT, src/tests/mod.rs:78-231
+  REQUIRE(Gt::generator() == g);
+  Scalar a = Scalar::from_u64(0x1234567), b = Scalar::from_u64(0x7654321), ab = Scalar::from_u64(0x1234567ull * 0x7654321ull);
+  G1Affine ga = (G1Affine::generator() * a).to_affine();
+  G2Affine hb = (G2Affine::generator() * b).to_affine();
+  Gt p = pairing(ga, hb);
+  REQUIRE(p == pairing((G1Affine::generator() * ab).to_affine(), G2Affine::generator()));   // bilinearity
+  REQUIRE(pairing(G1Affine::identity(), hb) == Gt::identity());
+  REQUIRE((p + (-p)) == Gt::identity());
+  auto ml = multi_miller_loop({{ga, G2Prepared(hb)}, {G1Affine::identity(), G2Prepared(hb)}, {G1Affine::generator(), G2Prepared(G2Affine::generator())}});
+  REQUIRE(ml.final_exponentiation() == p + g);
+  REQUIRE(MillerLoopResult::default_value().final_exponentiation() == Gt::identity());
+  G1Projective gp = G1Projective::generator();
+  REQUIRE((gp * a) * b == gp * ab);
+  REQUIRE(G1Projective::sum({gp, gp.dbl(), G1Projective::identity()}) == gp * Scalar::from_u64(3));
+  REQUIRE(G1Projective::batch_normalize({gp, G1Projective::identity()})[1].is_identity());
+  REQUIRE((gp + G1Affine::generator()) == gp.dbl());
+  auto m = msm<1>({G1Affine::generator(), ga}, {b, Scalar::from_u64(1)});
+  REQUIRE(m == gp * b + G1Projective{(G1Affine::generator() * a).xyz});
+  std::printf("host mirror ok\n");
+  return 0;
+}

@@ -381,3 +381,18 @@ def test_pairing_batch_large(ctx):
     assert np.array_equal(prod, fp12w(o.gt_mul_scalar(o.pairing(o.G1_GEN, o.G2_GEN), e)))
     for i in (0, 1, n - 1):
         assert np.array_equal(gt[i], fp12w(o.gt_mul_scalar(o.pairing(o.G1_GEN, o.G2_GEN), a[i] * bb[i] % o.R_ORDER)))
+
+
+def test_cpp_host_mirror(ctx, kats, tmp_path):
+    """include/bls12_381.hpp (C++ mirror of the reference API) compiled with g++ against libblsgpu.so and run."""
+    import subprocess
+    import bls12_381_amd as b
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_mirror_test")
+    libdir = os.path.dirname(b.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "host_mirror_test.cpp"),
+                           "-L" + libdir, "-lblsgpu", "-Wl,-rpath," + libdir, "-o", exe])
+    kat = tmp_path / "gt.bin"
+    kat.write_bytes(np.array(kats["consts"]["pairings.GT_GENERATOR"], dtype=np.uint64).tobytes())
+    out = subprocess.run([exe, str(kat)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "host mirror ok" in out.stdout, out.stdout + out.stderr
