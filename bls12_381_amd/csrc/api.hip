@@ -469,7 +469,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   int bad_alloc = 0;
   bad_alloc |= c->ent.reserve(total * 4);
   bad_alloc |= c->sorted.reserve(total * 4);
-  bad_alloc |= c->hist.reserve(nb * 4);
+  bad_alloc |= c->hist.reserve((nb > 3 * (size_t)SORT_MAX_COUNTERS + 4 ? nb : 3 * (size_t)SORT_MAX_COUNTERS + 4) * 4);
   bad_alloc |= c->cursor.reserve(total * 4);      // per-entry rank inside its bucket
   bad_alloc |= c->offs.reserve((nb + 1) * 4);
   bad_alloc |= c->bsum.reserve(4096 * 4);
@@ -503,25 +503,53 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   auto mark = [&](int i) { if (prof) hipEventRecord(c->ev[i], st); };
 
   mark(0);
-  // 1. digits + histogram
-  HIPCHK(hipMemsetAsync(c->hist.p, 0, nb * 4, st));
-  HIPCHK(hipMemsetAsync(c->ctrl.p, 0, (4 + 2 * ITEM_BINS) * 4, st));
-  hipLaunchKernelGGL(k_msm_digits, dim3(nblk(n, 256)), dim3(256), 0, st, (const u32*)d_scalars, c->ent.as<u32>(), c->cursor.as<u32>(), c->hist.as<u32>(), (int)n, cw, nwin);
-  LAUNCHCHK();
-  mark(1);
-  // 2. scan
-  unsigned sb = nblk(nb, 1024);
-  if (sb > 4096) return bad("msm: too many buckets");
-  hipLaunchKernelGGL(k_scan_block_sums, dim3(sb), dim3(256), 0, st, c->hist.as<u32>(), c->bsum.as<u32>(), (int)nb);
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, c->bsum.as<u32>(), (int)sb);
-  hipLaunchKernelGGL(k_scan_apply, dim3(sb), dim3(256), 0, st, c->hist.as<u32>(), c->bsum.as<u32>(), c->offs.as<u32>(), (int)nb);
-  LAUNCHCHK();
-  mark(2);
-  // 3. scatter
-  hipLaunchKernelGGL(k_msm_scatter, dim3(nblk(total, 256)), dim3(256), 0, st, c->ent.as<u32>(), c->cursor.as<u32>(), c->offs.as<u32>(), c->sorted.as<u32>(),
-                     (int)n, total);
-  LAUNCHCHK();
-  mark(3);
+  const bool fast_sort = (n <= ((size_t)1 << 24)) && cw <= 16 && cw >= 2;
+  if (fast_sort) {
+    // 1'-3'. two-level counting sort (LDS atomics; see msm.cuh)
+    const int key_bits = cw - 1;
+    const int coarse_bits = key_bits < 8 ? key_bits : 8;
+    const int fine_bits = key_bits - coarse_bits;           // <= 7
+    const int ncoarse = 1 << coarse_bits;
+    const int nc = nwin * ncoarse;
+    if (nc > SORT_MAX_COUNTERS) return bad("msm: window configuration exceeds the sort's counter table");
+    u32* ghist = c->hist.as<u32>();                          // [nc] counts | [nc+1] bases | [nc] cursors
+    u32* gbase = ghist + nc;
+    u32* gcur = gbase + nc + 1;
+    HIPCHK(hipMemsetAsync(ghist, 0, (size_t)nc * 4, st));
+    HIPCHK(hipMemsetAsync(c->ctrl.p, 0, (4 + 2 * ITEM_BINS) * 4, st));
+    const unsigned tiles = nblk(n, SORT_TILE);
+    hipLaunchKernelGGL(k_sort_hist, dim3(tiles), dim3(256), (size_t)nc * 4, st, (const u32*)d_scalars, ghist, (int)n, cw, nwin, fine_bits, ncoarse);
+    LAUNCHCHK();
+    mark(1);
+    hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, st, ghist, gbase, gcur, nc);
+    LAUNCHCHK();
+    mark(2);
+    hipLaunchKernelGGL(k_sort_scatter, dim3(tiles), dim3(256), (size_t)nc * 8, st, (const u32*)d_scalars, gbase, gcur, c->ent.as<u32>(), (int)n, cw, nwin,
+                       fine_bits, ncoarse);
+    hipLaunchKernelGGL(k_sort_fine, dim3(nc), dim3(256), 0, st, c->ent.as<u32>(), gbase, c->sorted.as<u32>(), c->offs.as<u32>(), fine_bits, nc);
+    LAUNCHCHK();
+    mark(3);
+  } else {
+    // 1. digits + histogram
+    HIPCHK(hipMemsetAsync(c->hist.p, 0, nb * 4, st));
+    HIPCHK(hipMemsetAsync(c->ctrl.p, 0, (4 + 2 * ITEM_BINS) * 4, st));
+    hipLaunchKernelGGL(k_msm_digits, dim3(nblk(n, 256)), dim3(256), 0, st, (const u32*)d_scalars, c->ent.as<u32>(), c->cursor.as<u32>(), c->hist.as<u32>(), (int)n, cw, nwin);
+    LAUNCHCHK();
+    mark(1);
+    // 2. scan
+    unsigned sb = nblk(nb, 1024);
+    if (sb > 4096) return bad("msm: too many buckets");
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(sb), dim3(256), 0, st, c->hist.as<u32>(), c->bsum.as<u32>(), (int)nb);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, c->bsum.as<u32>(), (int)sb);
+    hipLaunchKernelGGL(k_scan_apply, dim3(sb), dim3(256), 0, st, c->hist.as<u32>(), c->bsum.as<u32>(), c->offs.as<u32>(), (int)nb);
+    LAUNCHCHK();
+    mark(2);
+    // 3. scatter
+    hipLaunchKernelGGL(k_msm_scatter, dim3(nblk(total, 256)), dim3(256), 0, st, c->ent.as<u32>(), c->cursor.as<u32>(), c->offs.as<u32>(), c->sorted.as<u32>(),
+                       (int)n, total);
+    LAUNCHCHK();
+    mark(3);
+  }
   // 4. work items
   u32* ctrl = c->ctrl.as<u32>();
   u32* bins = ctrl + 4;

@@ -156,6 +156,146 @@ __global__ void __launch_bounds__(256) k_msm_digits(const u32* __restrict__ scal
   }
 }
 
+// ---- 1'. two-level counting sort (default path, n <= 2^24, c <= 16) ------------------------------------
+// The (window, |digit|) key is split into a coarse part (<= 8 bits) and a fine part (<= 7 bits).
+//   k_sort_hist     per tile of scalars: LDS histogram over (window, coarse) -> global counters
+//   k_sort_scan     exclusive scan of the nwin * ncoarse counters (one block)
+//   k_sort_scatter  per tile: reserve a slice of every (window, coarse) region with one global atomic per
+//                   non-empty counter, rank the tile's entries with LDS atomics, write packed entries
+//                   (index:24 | sign:1 | fine:7)
+//   k_sort_fine     one block per (window, coarse) region: LDS histogram over the fine key, scan, place ->
+//                   `sorted` grouped by bucket and the bucket offsets `offs` (no global scan over the buckets)
+// Compared with one global atomic + one random 4-byte gather/scatter per entry, almost all atomics are LDS
+// atomics and the random traffic stays inside a 16 KB region.
+constexpr int SORT_TILE = 2048;                 // scalars per block in k_sort_hist / k_sort_scatter
+constexpr int SORT_MAX_COUNTERS = 8192;         // nwin * ncoarse upper bound (LDS: 32 KB)
+
+struct DigitIter {
+  u32 s[9]; u32 carry; int c; u32 nbw, mask;
+  DEV void init(const u32* scalars, size_t i, int c_) {
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
+    uint4 a = sp[0], b = sp[1];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w; s[8] = 0;
+    carry = 0; c = c_; nbw = 1u << (c - 1); mask = (1u << c) - 1;
+  }
+  // signed digit of window w (must be called for w = 0, 1, 2, ... in order): magnitude (0 = skip) and sign
+  DEV void next(int w, u32& mag, u32& neg) {
+    int bit = w * c, lo = bit >> 5, sh = bit & 31;
+    u32 raw = 0;
+    if (lo < 8) raw = (u32)((((u64)s[lo + 1] << 32) | s[lo]) >> sh) & mask;
+    raw += carry;
+    neg = raw > nbw;
+    mag = neg ? ((1u << c) - raw) : raw;
+    carry = neg;
+  }
+};
+
+__global__ void __launch_bounds__(256) k_sort_hist(const u32* __restrict__ scalars, u32* __restrict__ ghist, int n, int c, int nwin,
+                                                   int fine_bits, int ncoarse) {
+  extern __shared__ u32 lh[];
+  const int nc = nwin * ncoarse;
+  for (int i = threadIdx.x; i < nc; i += 256) lh[i] = 0;
+  __syncthreads();
+  for (int k = 0; k < SORT_TILE / 256; k++) {
+    int i = blockIdx.x * SORT_TILE + k * 256 + threadIdx.x;
+    if (i < n) {
+      DigitIter d; d.init(scalars, i, c);
+      for (int w = 0; w < nwin; w++) {
+        u32 mag, neg; d.next(w, mag, neg);
+        if (mag) atomicAdd(&lh[w * ncoarse + ((mag - 1) >> fine_bits)], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nc; i += 256) if (lh[i]) atomicAdd(&ghist[i], lh[i]);
+}
+// exclusive scan of nc <= 8192 counters; also zeroes the reservation cursors; gbase[nc] = total
+__global__ void __launch_bounds__(1024) k_sort_scan(const u32* __restrict__ ghist, u32* __restrict__ gbase, u32* __restrict__ gcur, int nc) {
+  __shared__ u32 sh[SORT_MAX_COUNTERS];
+  __shared__ u32 part[1024];
+  const int per = (nc + 1023) / 1024;
+  u32 t = 0;
+  for (int j = 0; j < per; j++) { int i = threadIdx.x * per + j; u32 v = i < nc ? ghist[i] : 0; if (i < nc) sh[i] = v; t += v; }
+  part[threadIdx.x] = t;
+  __syncthreads();
+  for (int st = 1; st < 1024; st <<= 1) {
+    u32 x = (int)threadIdx.x >= st ? part[threadIdx.x - st] : 0;
+    __syncthreads();
+    part[threadIdx.x] += x;
+    __syncthreads();
+  }
+  u32 run = part[threadIdx.x] - t;
+  for (int j = 0; j < per; j++) { int i = threadIdx.x * per + j; if (i < nc) { gbase[i] = run; gcur[i] = 0; run += sh[i]; } }
+  if (threadIdx.x == 1023) gbase[nc] = part[1023];
+}
+__global__ void __launch_bounds__(256) k_sort_scatter(const u32* __restrict__ scalars, const u32* __restrict__ gbase, u32* __restrict__ gcur,
+                                                      u32* __restrict__ coarse_out, int n, int c, int nwin, int fine_bits, int ncoarse) {
+  extern __shared__ u32 lh[];          // [nc] counts, then reused as running local ranks; [nc] bases
+  const int nc = nwin * ncoarse;
+  u32* lbase = lh + nc;
+  for (int i = threadIdx.x; i < nc; i += 256) lh[i] = 0;
+  __syncthreads();
+  for (int k = 0; k < SORT_TILE / 256; k++) {
+    int i = blockIdx.x * SORT_TILE + k * 256 + threadIdx.x;
+    if (i < n) {
+      DigitIter d; d.init(scalars, i, c);
+      for (int w = 0; w < nwin; w++) {
+        u32 mag, neg; d.next(w, mag, neg);
+        if (mag) atomicAdd(&lh[w * ncoarse + ((mag - 1) >> fine_bits)], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nc; i += 256) {
+    u32 cnt = lh[i];
+    lbase[i] = cnt ? gbase[i] + atomicAdd(&gcur[i], cnt) : 0;
+    lh[i] = 0;
+  }
+  __syncthreads();
+  const u32 fmask = (1u << fine_bits) - 1;
+  for (int k = 0; k < SORT_TILE / 256; k++) {
+    int i = blockIdx.x * SORT_TILE + k * 256 + threadIdx.x;
+    if (i < n) {
+      DigitIter d; d.init(scalars, i, c);
+      for (int w = 0; w < nwin; w++) {
+        u32 mag, neg; d.next(w, mag, neg);
+        if (mag) {
+          int ci = w * ncoarse + ((mag - 1) >> fine_bits);
+          u32 r = atomicAdd(&lh[ci], 1u);
+          coarse_out[lbase[ci] + r] = ((u32)i << 8) | (neg << 7) | ((mag - 1) & fmask);
+        }
+      }
+    }
+  }
+}
+// one block per (window, coarse) region
+__global__ void __launch_bounds__(256) k_sort_fine(const u32* __restrict__ coarse_in, const u32* __restrict__ gbase, u32* __restrict__ sorted,
+                                                   u32* __restrict__ offs, int fine_bits, int nc) {
+  __shared__ u32 cnt[128];
+  __shared__ u32 base[128];
+  const int region = blockIdx.x;
+  const u32 beg = gbase[region], end = gbase[region + 1];
+  const int nfine = 1 << fine_bits;
+  if (threadIdx.x < 128) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (u32 j = beg + threadIdx.x; j < end; j += 256) atomicAdd(&cnt[coarse_in[j] & 127u], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 run = beg;
+    for (int f = 0; f < nfine; f++) { base[f] = run; run += cnt[f]; }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nfine) { offs[(size_t)region * nfine + threadIdx.x] = base[threadIdx.x]; cnt[threadIdx.x] = 0; }
+  if (region == nc - 1 && threadIdx.x == 0) offs[(size_t)nc * nfine] = end;
+  __syncthreads();
+  for (u32 j = beg + threadIdx.x; j < end; j += 256) {
+    u32 e = coarse_in[j];
+    u32 f = e & 127u;
+    u32 r = atomicAdd(&cnt[f], 1u);
+    sorted[base[f] + r] = (e >> 8) | ((e & 0x80u) << 24);
+  }
+}
+
 // ---- 2. exclusive scan (three small kernels; <= 2^22 elements) --------------------------------------
 __global__ void __launch_bounds__(256) k_scan_block_sums(const u32* __restrict__ in, u32* __restrict__ bsum, int n) {
   __shared__ u32 sh[256];
