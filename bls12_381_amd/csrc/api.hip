@@ -45,6 +45,7 @@ struct blsgpu_ctx {
   int msm_c = 0;
   bool profiling = false;
   bool pipelining = false;
+  bool hist_dirty = false;
   hipEvent_t ev[9];
   float phase_ms[8] = {0};
   // MSM: the chip-filling phases run on `stream`; the latency-bound tail (bucket reduction + window
@@ -469,7 +470,12 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   int bad_alloc = 0;
   bad_alloc |= c->ent.reserve(total * 4);
   bad_alloc |= c->sorted.reserve(total * 4);
-  bad_alloc |= c->hist.reserve((nb > 3 * (size_t)SORT_MAX_COUNTERS + 4 ? nb : 3 * (size_t)SORT_MAX_COUNTERS + 4) * 4);
+  {
+    size_t hb = (nb > 3 * (size_t)SORT_MAX_COUNTERS + 4 ? nb : 3 * (size_t)SORT_MAX_COUNTERS + 4) * 4;
+    bool fresh = c->hist.cap < hb;
+    bad_alloc |= c->hist.reserve(hb);
+    if (fresh && !bad_alloc) HIPCHK(hipMemsetAsync(c->hist.p, 0, c->hist.cap, st));      // the sort keeps its counters zeroed between calls
+  }
   bad_alloc |= c->cursor.reserve(total * 4);      // per-entry rank inside its bucket
   bad_alloc |= c->offs.reserve((nb + 1) * 4);
   bad_alloc |= c->bsum.reserve(4096 * 4);
@@ -512,16 +518,16 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     const int ncoarse = 1 << coarse_bits;
     const int nc = nwin * ncoarse;
     if (nc > SORT_MAX_COUNTERS) return bad("msm: window configuration exceeds the sort's counter table");
-    u32* ghist = c->hist.as<u32>();                          // [nc] counts | [nc+1] bases | [nc] cursors
-    u32* gbase = ghist + nc;
-    u32* gcur = gbase + nc + 1;
-    HIPCHK(hipMemsetAsync(ghist, 0, (size_t)nc * 4, st));
-    HIPCHK(hipMemsetAsync(c->ctrl.p, 0, (4 + 2 * ITEM_BINS) * 4, st));
+    // fixed layout: [MAX] counts (kept zero between calls) | [MAX+1] bases | [MAX] cursors
+    u32* ghist = c->hist.as<u32>();
+    u32* gbase = ghist + SORT_MAX_COUNTERS;
+    u32* gcur = gbase + SORT_MAX_COUNTERS + 1;
+    if (c->hist_dirty) { HIPCHK(hipMemsetAsync(ghist, 0, (size_t)SORT_MAX_COUNTERS * 4, st)); c->hist_dirty = false; }
     const unsigned tiles = nblk(n, SORT_TILE);
     hipLaunchKernelGGL(k_sort_hist, dim3(tiles), dim3(256), (size_t)nc * 4, st, (const u32*)d_scalars, ghist, (int)n, cw, nwin, fine_bits, ncoarse);
     LAUNCHCHK();
     mark(1);
-    hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, st, ghist, gbase, gcur, nc);
+    hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, st, ghist, gbase, gcur, nc, c->ctrl.as<u32>(), 4 + 2 * ITEM_BINS);
     LAUNCHCHK();
     mark(2);
     hipLaunchKernelGGL(k_sort_scatter, dim3(tiles), dim3(256), (size_t)nc * 8, st, (const u32*)d_scalars, gbase, gcur, c->ent.as<u32>(), (int)n, cw, nwin,
@@ -531,6 +537,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     mark(3);
   } else {
     // 1. digits + histogram
+    c->hist_dirty = true;
     HIPCHK(hipMemsetAsync(c->hist.p, 0, nb * 4, st));
     HIPCHK(hipMemsetAsync(c->ctrl.p, 0, (4 + 2 * ITEM_BINS) * 4, st));
     hipLaunchKernelGGL(k_msm_digits, dim3(nblk(n, 256)), dim3(256), 0, st, (const u32*)d_scalars, c->ent.as<u32>(), c->cursor.as<u32>(), c->hist.as<u32>(), (int)n, cw, nwin);
@@ -564,8 +571,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   u32* records = sl.buckets.as<u32>();
   hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(max_items, 256)), dim3(256), 0, st, bases->rec + first * Store<F>::AFF_WORDS, c->sorted.as<u32>(),
                      c->items.as<ItemDesc>(), ctrl, records);
-  hipLaunchKernelGGL(k_msm_heavy_small<F>, dim3(256), dim3(256), 0, st, c->heavy.as<uint4>(), ctrl, records);
-  hipLaunchKernelGGL(k_msm_heavy_big<F>, dim3(512), dim3(256), 0, st, c->heavy.as<uint4>(), ctrl, records);
+  hipLaunchKernelGGL(k_msm_heavy<F>, dim3(HEAVY_SMALL_BLOCKS + 512), dim3(256), 0, st, c->heavy.as<uint4>(), ctrl, records);
   LAUNCHCHK();
   mark(5);
   // ---- tail on the slot's own stream ---------------------------------------------------------------

@@ -185,6 +185,19 @@ DEV Fe<1, mul_v(V1, V2)> mul(const Fe<A1, V1>& a, const Fe<A2, V2>& b) {
   static_assert(mul_v(V1, V2) <= MAX_V, "fe mul: value bound too large");
   return from_v16<mul_v(V1, V2)>(fe_mul_raw(to_v16(a), to_v16(b)));
 }
+// force-inlined variants (used by the one kernel whose whole body is a single formula and fits the I-cache)
+template <int A1, int V1, int A2, int V2>
+DEV Fe<1, mul_v(V1, V2)> mul_inl(const Fe<A1, V1>& a, const Fe<A2, V2>& b) {
+  static_assert(A1 * A2 <= MAX_A_PROD, "fe mul: limb bound too large, norm() an operand");
+  static_assert(mul_v(V1, V2) <= MAX_V, "fe mul: value bound too large");
+  return from_v16<mul_v(V1, V2)>(fe_mul_body(to_v16(a), to_v16(b)));
+}
+template <int A, int V>
+DEV Fe<1, mul_v(V, V)> sqr_inl(const Fe<A, V>& a) {
+  static_assert(A * A <= MAX_A_PROD, "fe sqr: limb bound too large");
+  return from_v16<mul_v(V, V)>(fe_sqr_body(to_v16(a)));
+}
+
 // mul that renormalises an operand only when the static limb bounds require it
 template <int A1, int V1, int A2, int V2>
 DEV Fe<1, mul_v(V1, V2)> mulx(const Fe<A1, V1>& a, const Fe<A2, V2>& b) {
