@@ -47,7 +47,7 @@ DEV Fp6 fp6_mul_by_nonresidue(const Fp6& a) {
 }
 
 // Karatsuba over Fp2 (6 Fp2 products); same element as fp6.rs:200-274
-DEVNI void fp6_mul(Fp6& r, const Fp6& a, const Fp6& b) {
+DEV void fp6_mul(Fp6& r, const Fp6& a, const Fp6& b) {
   auto v0 = mul(a.c0, b.c0);
   auto v1 = mul(a.c1, b.c1);
   auto v2 = mul(a.c2, b.c2);
@@ -77,14 +77,14 @@ DEVNI void fp6_sqr(Fp6& r, const Fp6& a) {
   r.c0 = S2(c0); r.c1 = S2(c1); r.c2 = S2(c2);
 }
 // fp6.rs:113-119
-DEVNI void fp6_mul_by_1(Fp6& r, const Fp6& a, const fe2& c1) {
+DEV void fp6_mul_by_1(Fp6& r, const Fp6& a, const fe2& c1) {
   auto t0 = mul(a.c2, c1);
   auto t1 = mul(a.c0, c1);
   auto t2 = mul(a.c1, c1);
   r.c0 = S2(mul_by_nonresidue(t0)); r.c1 = S2(t1); r.c2 = S2(t2);
 }
 // fp6.rs:121-136
-DEVNI void fp6_mul_by_01(Fp6& r, const Fp6& a, const fe2& c0, const fe2& c1) {
+DEV void fp6_mul_by_01(Fp6& r, const Fp6& a, const fe2& c0, const fe2& c1) {
   auto a_a = mul(a.c0, c0);
   auto b_b = mul(a.c1, c1);
   auto t1 = add(mul_by_nonresidue(mul(a.c2, c1)), a_a);
@@ -148,7 +148,7 @@ DEVNI void fp12_mul_by_014(Fp12& r, const Fp12& a, const fe2& c0, const fe2& c1,
   r.c1 = fp6_sub(fp6_sub(t, aa), bb);
   r.c0 = fp6_add(fp6_mul_by_nonresidue(bb), aa);
 }
-DEV void fp12_conj(Fp12& r, const Fp12& a) { r.c0 = a.c0; r.c1 = fp6_neg(a.c1); }
+DEV void fp12_conj(Fp12& r, const Fp12& a) { Fp6 n = fp6_neg(a.c1); r.c0 = a.c0; r.c1 = n; }
 // fp12.rs:145-171
 DEVNI void fp12_frobenius(Fp12& r, const Fp12& a) {
   constexpr PLimbs k0 = {BLS_FROB12_C1_0}, k1 = {BLS_FROB12_C1_1};
@@ -247,9 +247,7 @@ DEVNI void addition_step(G2Jac& r, const fe2& qx, const fe2& qy, Line& l) {
 DEVNI void ell(Fp12& f, const Line& l, const fe1& px, const fe1& py) {
   fe2 c0 = S2(mul_fp(l.a, py));
   fe2 c1 = S2(mul_fp(l.b, px));
-  Fp12 t;
-  fp12_mul_by_014(t, f, l.c, c1, c0);
-  f = t;
+  fp12_mul_by_014(f, f, l.c, c1, c0);          // in place: every read of the input precedes the first write
 }
 
 // bits of BLS_X >> 1 below the leading one, MSB first (pairings.rs:671-685): 62 iterations, 5 set bits
@@ -266,11 +264,11 @@ DEVNI void miller_loop(Fp12& f, const fe1& px, const fe1& py, const fe2& qx, con
       addition_step(r, qx, qy, l);
       ell(f, l, px, py);
     }
-    Fp12 t; fp12_sqr(t, f); f = t;
+    fp12_sqr(f, f);                         // in place
   }
   doubling_step(r, l);
   ell(f, l, px, py);
-  Fp12 t; fp12_conj(t, f); f = t;           // BLS_X_IS_NEGATIVE
+  f.c1 = fp6_neg(f.c1);                     // conjugate: BLS_X_IS_NEGATIVE
 }
 
 // ---- final exponentiation ------------------------------------------------------------------------------
@@ -305,49 +303,50 @@ DEVNI void cyclotomic_exp(Fp12& r, const Fp12& f) {
   constexpr unsigned long long X = 0xd201000000010000ull;
   Fp12 tmp = f;                       // the leading one: tmp = one * f
   for (int b = 62; b >= 0; b--) {
-    Fp12 t; cyclotomic_square(t, tmp); tmp = t;
-    if ((X >> b) & 1) { fp12_mul(t, tmp, f); tmp = t; }
+    cyclotomic_square(tmp, tmp);      // in place (inputs are copied to locals first)
+    if ((X >> b) & 1) fp12_mul(tmp, tmp, f);
   }
   fp12_conj(r, tmp);
 }
 // pairings.rs:134-173
 DEVNI void final_exponentiation(Fp12& out, const Fp12& fin) {
-  Fp12 f = fin, t0, t1, t2, t3, t4, t5, t6, x;
-  fp12_frobenius(t0, f);
-  for (int i = 0; i < 5; i++) { fp12_frobenius(x, t0); t0 = x; }
-  fp12_inv(t1, f);
+  // every Fp12 helper tolerates r aliasing an input (inputs are consumed before the first write)
+  Fp12 t0, t1, t2, t3, t4, t5, t6;
+  fp12_frobenius(t0, fin);
+  for (int i = 0; i < 5; i++) fp12_frobenius(t0, t0);
+  fp12_inv(t1, fin);
   fp12_mul(t2, t0, t1);
   t1 = t2;
-  fp12_frobenius(x, t2); fp12_frobenius(t2, x);
-  fp12_mul(x, t2, t1); t2 = x;
-  cyclotomic_square(x, t2); fp12_conj(t1, x);
+  fp12_frobenius(t2, t2); fp12_frobenius(t2, t2);
+  fp12_mul(t2, t2, t1);
+  cyclotomic_square(t1, t2); fp12_conj(t1, t1);
   cyclotomic_exp(t3, t2);
   cyclotomic_square(t4, t3);
   fp12_mul(t5, t1, t3);
   cyclotomic_exp(t1, t5);
   cyclotomic_exp(t0, t1);
   cyclotomic_exp(t6, t0);
-  fp12_mul(x, t6, t4); t6 = x;
+  fp12_mul(t6, t6, t4);
   cyclotomic_exp(t4, t6);
-  fp12_conj(x, t5); t5 = x;
-  fp12_mul(x, t5, t2);
-  Fp12 y; fp12_mul(y, t4, x); t4 = y;
+  fp12_conj(t5, t5);
+  fp12_mul(t5, t5, t2);            // t5 * t2 (t5 is overwritten next anyway)
+  fp12_mul(t4, t4, t5);
   fp12_conj(t5, t2);
-  fp12_mul(x, t1, t2); t1 = x;
-  fp12_frobenius(x, t1); fp12_frobenius(t1, x); fp12_frobenius(x, t1); t1 = x;
-  fp12_mul(x, t6, t5); t6 = x;
-  fp12_frobenius(x, t6); t6 = x;
-  fp12_mul(x, t3, t0); t3 = x;
-  fp12_frobenius(x, t3); fp12_frobenius(t3, x);
-  fp12_mul(x, t3, t1); t3 = x;
-  fp12_mul(x, t3, t6); t3 = x;
+  fp12_mul(t1, t1, t2);
+  fp12_frobenius(t1, t1); fp12_frobenius(t1, t1); fp12_frobenius(t1, t1);
+  fp12_mul(t6, t6, t5);
+  fp12_frobenius(t6, t6);
+  fp12_mul(t3, t3, t0);
+  fp12_frobenius(t3, t3); fp12_frobenius(t3, t3);
+  fp12_mul(t3, t3, t1);
+  fp12_mul(t3, t3, t6);
   fp12_mul(out, t3, t4);
 }
 
 // ---- kernels ---------------------------------------------------------------------------------------------
 // mode 0: out[i] = pairing(g1[i], g2[i]);  mode 1: out[i] = raw Miller loop value.
 // Identity on either side -> Fp12::one() (pairings.rs:636-651; multi_miller_loop skips such terms :566-569).
-__global__ void __launch_bounds__(PAIRING_BLOCK) k_pairing(int mode, const u32* __restrict__ g1, const uint8_t* __restrict__ g1inf,
+__global__ void __launch_bounds__(PAIRING_BLOCK, 1) k_pairing(int mode, const u32* __restrict__ g1, const uint8_t* __restrict__ g1inf,
                                                           const u32* __restrict__ g2, const uint8_t* __restrict__ g2inf,
                                                           u32* __restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -364,7 +363,7 @@ __global__ void __launch_bounds__(PAIRING_BLOCK) k_pairing(int mode, const u32* 
   }
   fp12_save(f, out + i * 144);
 }
-__global__ void __launch_bounds__(PAIRING_BLOCK) k_final_exp(const u32* __restrict__ in, u32* __restrict__ out, size_t n) {
+__global__ void __launch_bounds__(PAIRING_BLOCK, 1) k_final_exp(const u32* __restrict__ in, u32* __restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fp12 f, g;
