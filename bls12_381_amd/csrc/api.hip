@@ -443,6 +443,10 @@ static int pick_window(size_t n) {
   return best;
 }
 
+// a reduction level runs one chain per TEAM of lanes when that still fits comfortably on the chip
+constexpr size_t TEAM_LANES_MAX = 131072;
+#define TEAM_LDS(threads) ((size_t)team_lds_words<F>(threads) * 4)
+
 template <class F>
 static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, const void* d_scalars, size_t n, void* d_out_wire) {
   if (!c || !bases || !d_out_wire || (n && !d_scalars)) return bad("msm: NULL argument");
@@ -589,14 +593,20 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
       int G = nn / M;
       u32* Rout = sl.lvlR[cur].as<u32>();
       u32* Tout = sl.lvlT.as<u32>();
-      hipLaunchKernelGGL(k_wsum_level<F>, dim3(nblk((size_t)nwin * G, 256)), dim3(256), 0, tt, E, Rout, Tout, nwin, nn, M, off);
+      if ((size_t)nwin * G * TEAM <= TEAM_LANES_MAX)
+        hipLaunchKernelGGL(k_wsum_level_team<F>, dim3(nblk((size_t)nwin * G * TEAM, 256)), dim3(256), TEAM_LDS(256), tt, E, Rout, Tout, nwin, nn, M, off);
+      else
+        hipLaunchKernelGGL(k_wsum_level<F>, dim3(nblk((size_t)nwin * G, 256)), dim3(256), 0, tt, E, Rout, Tout, nwin, nn, M, off);
       LAUNCHCHK();
       // sum the G T-records of each window down to one
       const u32* Tin = Tout; int tn = G, tc = 0;
       while (tn > 1) {
         int TM = tn >= 8 ? 8 : tn; int TG = (tn + TM - 1) / TM;
         u32* o = sl.tsum[tc].as<u32>();
-        hipLaunchKernelGGL(k_tree_sum<F>, dim3(nblk((size_t)nwin * TG, 256)), dim3(256), 0, tt, Tin, o, nwin, tn, TM);
+        if ((size_t)nwin * TG * TEAM <= TEAM_LANES_MAX)
+          hipLaunchKernelGGL(k_tree_sum_team<F>, dim3(nblk((size_t)nwin * TG * TEAM, 256)), dim3(256), TEAM_LDS(256), tt, Tin, o, nwin, tn, TM);
+        else
+          hipLaunchKernelGGL(k_tree_sum<F>, dim3(nblk((size_t)nwin * TG, 256)), dim3(256), 0, tt, Tin, o, nwin, tn, TM);
         LAUNCHCHK();
         Tin = o; tn = TG; tc ^= 1;
       }
@@ -614,7 +624,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
       HIPCHK(hipMemcpyAsync(accbuf, tstore + (size_t)(level - 1) * nwin * PW, (size_t)nwin * PW * 4, hipMemcpyDeviceToDevice, tt));
       for (int l = level - 2; l >= 0; l--) {
         int k = 0; while ((1 << k) < Ms[l]) k++;
-        hipLaunchKernelGGL(k_shift_add<F>, dim3(nblk(nwin, 64)), dim3(64), 0, tt, accbuf, tstore + (size_t)l * nwin * PW, accbuf, nwin, k);
+        hipLaunchKernelGGL(k_shift_add_team<F>, dim3(nblk((size_t)nwin * TEAM, 256)), dim3(256), TEAM_LDS(256), tt, accbuf, tstore + (size_t)l * nwin * PW, accbuf, nwin, k);
         LAUNCHCHK();
       }
       HIPCHK(hipMemcpyAsync(sl.wsums.p, accbuf, (size_t)nwin * PW * 4, hipMemcpyDeviceToDevice, tt));
@@ -622,7 +632,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   }
   if (prof) hipEventRecord(c->ev[6], tt);
   // 7. combine windows
-  hipLaunchKernelGGL(k_msm_combine<F>, dim3(1), dim3(64), 0, tt, sl.wsums.as<u32>(), sl.result.as<u32>(), nwin, cw);
+  hipLaunchKernelGGL(k_msm_combine_team<F>, dim3(1), dim3(TEAM), TEAM_LDS(TEAM), tt, sl.wsums.as<u32>(), sl.result.as<u32>(), nwin, cw);
   LAUNCHCHK();
   hipLaunchKernelGGL(k_proj_export<F>, dim3(1), dim3(256), 0, tt, sl.result.as<u32>(), (u32*)d_out_wire, (size_t)1);
   LAUNCHCHK();
@@ -685,7 +695,7 @@ static int proj_sum(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* out)
     HIPCHK(hipMemcpyAsync(c->io_a.p, xyz, n * 3 * WW * 4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_proj_import<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), c->io_c.as<u32>(), n);
   }
-  hipLaunchKernelGGL(k_proj_sum<F>, dim3(1), dim3(64), 0, c->stream, c->io_c.as<u32>(), c->result.as<u32>(), n);
+  hipLaunchKernelGGL(k_proj_sum_team<F>, dim3(1), dim3(TEAM), TEAM_LDS(TEAM), c->stream, c->io_c.as<u32>(), c->result.as<u32>(), n);
   hipLaunchKernelGGL(k_proj_export<F>, dim3(1), dim3(256), 0, c->stream, c->result.as<u32>(), c->io_out.as<u32>(), (size_t)1);
   LAUNCHCHK();
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, 3 * WW * 4, hipMemcpyDeviceToHost, c->stream));
@@ -700,7 +710,7 @@ static int proj_sum_device(blsgpu_ctx* c, const void* d_xyz, size_t n, void* d_o
   constexpr int PW = Store<F>::PROJ_WORDS;
   if (c->io_c.reserve((n ? n : 1) * PW * 4) || c->result.reserve(PW * 4)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
   if (n) hipLaunchKernelGGL(k_proj_import<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (const u32*)d_xyz, c->io_c.as<u32>(), n);
-  hipLaunchKernelGGL(k_proj_sum<F>, dim3(1), dim3(64), 0, c->stream, c->io_c.as<u32>(), c->result.as<u32>(), n);
+  hipLaunchKernelGGL(k_proj_sum_team<F>, dim3(1), dim3(TEAM), TEAM_LDS(TEAM), c->stream, c->io_c.as<u32>(), c->result.as<u32>(), n);
   hipLaunchKernelGGL(k_proj_export<F>, dim3(1), dim3(256), 0, c->stream, c->result.as<u32>(), (u32*)d_out, (size_t)1);
   LAUNCHCHK();
   return BLSGPU_OK;

@@ -14,8 +14,10 @@ namespace bls {
 
 // ---- field policies ------------------------------------------------------------------------------
 struct FpPolicy {
-  typedef fe elem;          // working storage (value < 8p)
+  typedef fe elem;          // working storage (value < 12p)
   typedef fe1 aff_elem;     // canonical affine coordinate
+  typedef Fe<2, 2 * VS> op_sum;     // sum of two stored values (first product layer of the team formulas)
+  typedef Fe<1, 88> op_wide;        // any normalised intermediate of the complete formulas (second layer)
   template <class T> static DEV elem st(const T& a) { return store(a); }
   static DEV elem zero() { return fe_zero(); }
   static DEV elem one() { return fe_one(); }
@@ -28,6 +30,8 @@ struct FpPolicy {
 struct Fp2Policy {
   typedef fe2 elem;
   typedef fe2_1 aff_elem;
+  typedef Fe2<2, 2 * VS2> op_sum;
+  typedef Fe2<1, 88> op_wide;
   template <class T> static DEV elem st(const T& a) { return store2(a); }
   static DEV elem zero() { return fe2_zero(); }
   static DEV elem one() { return fe2_one(); }

@@ -24,6 +24,7 @@
 #pragma once
 #include <type_traits>
 #include "convert.cuh"
+#include "team.cuh"
 
 namespace bls {
 
@@ -585,6 +586,94 @@ __global__ void __launch_bounds__(64) k_shift_add(const u32* __restrict__ x, con
   for (int i = 0; i < k; i++) a = pt_double<F>(a);
   a = pt_add<F>(a, b);
   store_proj<F>(out + (size_t)seg * Store<F>::PROJ_WORDS, a);
+}
+
+// ---- 6'. team (8 lanes per chain) versions of the reduction kernels, used when a level has too few chains
+// to fill the chip with one lane each.  All control flow around the team operations is block-uniform.
+template <class F>
+__global__ void __launch_bounds__(256) k_wsum_level_team(const u32* __restrict__ E, u32* __restrict__ Rout, u32* __restrict__ Tout,
+                                                         int nseg, int n, int M, int off) {
+  extern __shared__ u32 team_lds[];
+  __builtin_amdgcn_s_setprio(3);
+  const int tl = threadIdx.x & (TEAM - 1);
+  u32* mbox = team_lds + (threadIdx.x / TEAM) * TEAM_SLOTS * TeamTraits<F>::WORDS;
+  int G = n / M, total = nseg * G;
+  int t = (blockIdx.x * blockDim.x + threadIdx.x) / TEAM;
+  bool live = t < total;
+  if (!live) t = total - 1;
+  int seg = t / G, g = t - seg * G;
+  const u32* base = E + ((size_t)seg * n + (size_t)g * M) * Store<F>::PROJ_WORDS;
+  Proj<F> run = pt_identity<F>(), tot = pt_identity<F>();
+  for (int i = M - 1; i >= 0; i--) {
+    Proj<F> e; load_proj<F>(base + (size_t)i * Store<F>::PROJ_WORDS, e);
+    run = pt_add_team<F>(run, e, mbox, tl);
+    if (i > 0 || off) tot = pt_add_team<F>(tot, run, mbox, tl);
+  }
+  if (live && tl == 0) {
+    store_proj<F>(Rout + (size_t)t * Store<F>::PROJ_WORDS, run);
+    store_proj<F>(Tout + (size_t)t * Store<F>::PROJ_WORDS, tot);
+  }
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_tree_sum_team(const u32* __restrict__ E, u32* __restrict__ out, int nseg, int n, int M) {
+  extern __shared__ u32 team_lds[];
+  __builtin_amdgcn_s_setprio(3);
+  const int tl = threadIdx.x & (TEAM - 1);
+  u32* mbox = team_lds + (threadIdx.x / TEAM) * TEAM_SLOTS * TeamTraits<F>::WORDS;
+  int G = (n + M - 1) / M, total = nseg * G;
+  int t = (blockIdx.x * blockDim.x + threadIdx.x) / TEAM;
+  bool live = t < total;
+  if (!live) t = total - 1;
+  int seg = t / G, g = t - seg * G;
+  Proj<F> acc = pt_identity<F>();
+  for (int k = 0; k < M; k++) {
+    int i = g * M + k;
+    Proj<F> e = pt_identity<F>();
+    if (i < n) load_proj<F>(E + ((size_t)seg * n + i) * Store<F>::PROJ_WORDS, e);
+    acc = pt_add_team<F>(acc, e, mbox, tl);
+  }
+  if (live && tl == 0) store_proj<F>(out + (size_t)t * Store<F>::PROJ_WORDS, acc);
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_shift_add_team(const u32* __restrict__ x, const u32* __restrict__ y, u32* __restrict__ out, int nseg, int k) {
+  extern __shared__ u32 team_lds[];
+  __builtin_amdgcn_s_setprio(3);
+  const int tl = threadIdx.x & (TEAM - 1);
+  u32* mbox = team_lds + (threadIdx.x / TEAM) * TEAM_SLOTS * TeamTraits<F>::WORDS;
+  int seg = (blockIdx.x * blockDim.x + threadIdx.x) / TEAM;
+  bool live = seg < nseg;
+  if (!live) seg = nseg - 1;
+  Proj<F> a, b;
+  load_proj<F>(x + (size_t)seg * Store<F>::PROJ_WORDS, a);
+  load_proj<F>(y + (size_t)seg * Store<F>::PROJ_WORDS, b);
+  for (int i = 0; i < k; i++) a = pt_double_team<F>(a, mbox, tl);
+  a = pt_add_team<F>(a, b, mbox, tl);
+  if (live && tl == 0) store_proj<F>(out + (size_t)seg * Store<F>::PROJ_WORDS, a);
+}
+// Horner over the windows by ONE team (launch with a single block of TEAM threads)
+template <class F>
+__global__ void __launch_bounds__(64) k_msm_combine_team(const u32* __restrict__ wsums, u32* __restrict__ out, int nwin, int c) {
+  extern __shared__ u32 team_lds[];
+  __builtin_amdgcn_s_setprio(3);
+  const int tl = threadIdx.x & (TEAM - 1);
+  u32* mbox = team_lds;
+  Proj<F> acc;
+  load_proj<F>(wsums + (size_t)(nwin - 1) * Store<F>::PROJ_WORDS, acc);
+  for (int w = nwin - 2; w >= 0; w--) {
+    for (int i = 0; i < c; i++) acc = pt_double_team<F>(acc, mbox, tl);
+    Proj<F> s; load_proj<F>(wsums + (size_t)w * Store<F>::PROJ_WORDS, s);
+    acc = pt_add_team<F>(acc, s, mbox, tl);
+  }
+  if (tl == 0) store_proj<F>(out, acc);
+}
+// sum of n records by one team (cross-rank fold)
+template <class F>
+__global__ void __launch_bounds__(64) k_proj_sum_team(const u32* __restrict__ rec, u32* __restrict__ out, size_t n) {
+  extern __shared__ u32 team_lds[];
+  const int tl = threadIdx.x & (TEAM - 1);
+  Proj<F> acc = pt_identity<F>();
+  for (size_t i = 0; i < n; i++) { Proj<F> p; load_proj<F>(rec + i * Store<F>::PROJ_WORDS, p); acc = pt_add_team<F>(acc, p, team_lds, tl); }
+  if (tl == 0) store_proj<F>(out, acc);
 }
 
 // ---- 7. window combine (Horner) ------------------------------------------------------------------------
