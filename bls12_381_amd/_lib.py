@@ -47,6 +47,10 @@ SIGNATURES = {
     "blsgpu_g2_sum_device": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g1_batch_normalize": (c_int, [c_vp, c_vp, c_sz, c_vp, c_vp]),
     "blsgpu_g2_batch_normalize": (c_int, [c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "blsgpu_g1_from_bytes_batch": (c_int, [c_vp, c_vp, c_sz, c_int, c_int, c_vp, c_vp, c_vp]),
+    "blsgpu_g2_from_bytes_batch": (c_int, [c_vp, c_vp, c_sz, c_int, c_int, c_vp, c_vp, c_vp]),
+    "blsgpu_g1_to_bytes_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
+    "blsgpu_g2_to_bytes_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
     "blsgpu_pairing_batch": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_miller_loop_batch": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_multi_miller_loop": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),

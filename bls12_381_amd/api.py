@@ -232,6 +232,29 @@ class Context:
         check(self.lib.blsgpu_point_op(self.h, group, op, _ptr(a), _ptr(b), _ptr(_flags(b_inf, n)), n, _ptr(out)), "point_op")
         return out
 
+    # -- batched (de)serialisation + validation --------------------------------------------------------------
+    def points_from_bytes(self, group, data, compressed=True, checked=True):
+        """data: (n, 48|96|192) uint8 or bytes.  Returns (xy, infinity, ok) like `from_compressed` & friends."""
+        size = (48 if group == 1 else 96) * (1 if compressed else 2)
+        buf = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+        buf = buf.reshape(-1, size)
+        n = buf.shape[0]
+        xy = np.zeros((n, 12 if group == 1 else 24), dtype=np.uint64)
+        inf = np.zeros(n, dtype=np.uint8); ok = np.zeros(n, dtype=np.uint8)
+        fn = self.lib.blsgpu_g1_from_bytes_batch if group == 1 else self.lib.blsgpu_g2_from_bytes_batch
+        check(fn(self.h, _ptr(buf), n, 1 if compressed else 0, 1 if checked else 0, _ptr(xy), _ptr(inf), _ptr(ok)), "from_bytes_batch")
+        return xy, inf, ok
+
+    def points_to_bytes(self, group, xy, infinity=None, compressed=True):
+        w = 12 if group == 1 else 24
+        xy = _u64(xy, (-1, w))
+        n = xy.shape[0]
+        size = (48 if group == 1 else 96) * (1 if compressed else 2)
+        out = np.zeros((n, size), dtype=np.uint8)
+        fn = self.lib.blsgpu_g1_to_bytes_batch if group == 1 else self.lib.blsgpu_g2_to_bytes_batch
+        check(fn(self.h, _ptr(xy), _ptr(_flags(infinity, n)), n, 1 if compressed else 0, _ptr(out)), "to_bytes_batch")
+        return out
+
     # -- field self-test hooks ---------------------------------------------------------------------------
     def _elem_op(self, fn, words, op, a, b):
         a = _u64(a, (-1, words))
@@ -456,6 +479,24 @@ class G1Affine(_Group):
         if cls.G == 1:
             return cls(np.concatenate([fp_to_limbs(vals[0]), fp_to_limbs(vals[1])]))
         return cls(np.concatenate([fp_to_limbs(vals[1]), fp_to_limbs(vals[0]), fp_to_limbs(vals[3]), fp_to_limbs(vals[2])]))
+
+    @classmethod
+    def _decode(cls, b, compressed, checked):
+        xy, inf, ok = default_context().points_from_bytes(cls.G, bytes(b), compressed, checked)
+        return cls(xy[0], bool(inf[0])) if ok[0] else None
+
+    @classmethod
+    def from_compressed(cls, b):
+        """g1.rs:326-332 / g2.rs:390-395 (decompression + subgroup check on the GPU); None = CtOption::none."""
+        return cls._decode(b, True, True)
+
+    @classmethod
+    def from_compressed_unchecked(cls, b): return cls._decode(b, True, False)
+
+    @classmethod
+    def from_uncompressed(cls, b):
+        """g1.rs:264-267 (on-curve + subgroup check on the GPU)."""
+        return cls._decode(b, False, True)
 
     def __repr__(self):
         return f"{type(self).__name__}({'identity' if self.infinity else self.to_compressed().hex()})"

@@ -11,6 +11,7 @@
 #include "../../include/bls12_381_hip.h"
 #include "msm.cuh"
 #include "pairing.cuh"
+#include "codec.cuh"
 
 using namespace bls;
 
@@ -925,4 +926,55 @@ extern "C" int blsgpu_fp12_product(blsgpu_ctx* c, const uint64_t* in, size_t n, 
   HIPCHK(hipMemcpyAsync(out, c->result.p, 576, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return BLSGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// batched point (de)serialisation + validation  (codec.cuh)
+// ---------------------------------------------------------------------------------------------------
+template <class F>
+static int point_decode(blsgpu_ctx* c, const uint8_t* bytes, size_t n, int compressed, int checked, uint64_t* xy, uint8_t* inf, uint8_t* ok) {
+  if (!c || (n && (!bytes || !xy || !inf || !ok))) return bad("decode: NULL argument");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  constexpr int CB = Codec<F>::COORD_BYTES, WW = Wire<F>::WORDS;
+  size_t ib = n * (compressed ? CB : 2 * CB), xb = n * 2 * WW * 4;
+  if (c->io_a.reserve(ib) || c->io_out.reserve(xb) || c->flags_a.reserve(n) || c->flags_b.reserve(n)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  HIPCHK(hipMemcpyAsync(c->io_a.p, bytes, ib, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_point_decode<F>, dim3(nblk(n, 128)), dim3(128), 0, c->stream, c->io_a.as<uint8_t>(), n, (compressed ? 1 : 0) | (checked ? 2 : 0),
+                     c->io_out.as<u32>(), c->flags_a.as<uint8_t>(), c->flags_b.as<uint8_t>());
+  LAUNCHCHK();
+  HIPCHK(hipMemcpyAsync(xy, c->io_out.p, xb, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(inf, c->flags_a.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(ok, c->flags_b.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+template <class F>
+static int point_encode(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, int compressed, uint8_t* out) {
+  if (!c || (n && (!xy || !out))) return bad("encode: NULL argument");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  constexpr int CB = Codec<F>::COORD_BYTES, WW = Wire<F>::WORDS;
+  size_t ob = n * (compressed ? CB : 2 * CB), xb = n * 2 * WW * 4;
+  if (c->io_a.reserve(xb) || c->io_out.reserve(ob) || c->flags_a.reserve(n)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  HIPCHK(hipMemcpyAsync(c->io_a.p, xy, xb, hipMemcpyHostToDevice, c->stream));
+  if (inf) HIPCHK(hipMemcpyAsync(c->flags_a.p, inf, n, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_point_encode<F>, dim3(nblk(n, 128)), dim3(128), 0, c->stream, c->io_a.as<u32>(), inf ? c->flags_a.as<uint8_t>() : nullptr, n, compressed,
+                     c->io_out.as<uint8_t>());
+  LAUNCHCHK();
+  HIPCHK(hipMemcpyAsync(out, c->io_out.p, ob, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_g1_from_bytes_batch(blsgpu_ctx* c, const uint8_t* b, size_t n, int compressed, int checked, uint64_t* xy, uint8_t* inf, uint8_t* ok) {
+  return point_decode<FpPolicy>(c, b, n, compressed, checked, xy, inf, ok);
+}
+extern "C" int blsgpu_g2_from_bytes_batch(blsgpu_ctx* c, const uint8_t* b, size_t n, int compressed, int checked, uint64_t* xy, uint8_t* inf, uint8_t* ok) {
+  return point_decode<Fp2Policy>(c, b, n, compressed, checked, xy, inf, ok);
+}
+extern "C" int blsgpu_g1_to_bytes_batch(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, int compressed, uint8_t* out) {
+  return point_encode<FpPolicy>(c, xy, inf, n, compressed, out);
+}
+extern "C" int blsgpu_g2_to_bytes_batch(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, int compressed, uint8_t* out) {
+  return point_encode<Fp2Policy>(c, xy, inf, n, compressed, out);
 }

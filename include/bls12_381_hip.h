@@ -107,6 +107,17 @@ int blsgpu_g2_sum_device(blsgpu_ctx* ctx, const void* d_xyz, size_t n, void* d_o
 int blsgpu_g1_batch_normalize(blsgpu_ctx* ctx, const uint64_t* xyz, size_t n, uint64_t* xy, uint8_t* infinity);
 int blsgpu_g2_batch_normalize(blsgpu_ctx* ctx, const uint64_t* xyz, size_t n, uint64_t* xy, uint8_t* infinity);
 
+/* ---- batched point (de)serialisation and validation (the step in front of the hot path) ------------------ */
+/* Decode n points from the reference's byte encodings (src/notes/serialization.rs): 48/96 B compressed or 96/192 B
+ * uncompressed.  checked = 0: `from_compressed_unchecked` / `from_uncompressed_unchecked` (src/g1.rs:273-322, 336-390);
+ * checked = 1: `from_compressed` (subgroup check, :326-332) / `from_uncompressed` (on-curve + subgroup, :264-267).
+ * ok[i] = 1 exactly where the reference returns CtOption::some; rejected entries decode to the identity. */
+int blsgpu_g1_from_bytes_batch(blsgpu_ctx* ctx, const uint8_t* bytes, size_t n, int compressed, int checked, uint64_t* xy, uint8_t* infinity, uint8_t* ok);
+int blsgpu_g2_from_bytes_batch(blsgpu_ctx* ctx, const uint8_t* bytes, size_t n, int compressed, int checked, uint64_t* xy, uint8_t* infinity, uint8_t* ok);
+/* Encode n affine points: `to_compressed` / `to_uncompressed` (src/g1.rs:221-260, src/g2.rs:254-299). */
+int blsgpu_g1_to_bytes_batch(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, size_t n, int compressed, uint8_t* out);
+int blsgpu_g2_to_bytes_batch(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, size_t n, int compressed, uint8_t* out);
+
 /* ---- pairings ------------------------------------------------------------------------------------------ */
 /* out[i] = pairing(g1[i], g2[i]) for n independent pairs (`pairing`, src/pairings.rs:607-653; 72 u64 each).
  * An identity on either side yields Gt::identity() = Fp12::one(), as the reference does. */

@@ -897,3 +897,70 @@ class SplitMix64:
             v &= (1 << 255) - 1
             if v < R_ORDER:
                 return v
+
+
+# --------------------------------------------------------------------------------------------------
+# Point validation / checked deserialisation (the step in front of the hot path)
+# --------------------------------------------------------------------------------------------------
+BETA = pow(2, (P - 1) // 3, P)                      # g1.rs:421-428 (equals the reference literal; tests check it)
+PSI_COEFF_X = fp2_inv(fp2_pow((1, 1), (P - 1) // 3))   # g2.rs:848-859
+PSI_COEFF_Y = fp2_inv(fp2_pow((1, 1), (P - 1) // 2))   # g2.rs:860-880
+
+
+def _mul_by_x(F, p, add, dbl, neg):
+    """g1.rs:777-795 / g2.rs:914-931: multiply by BLS_X (negative)."""
+    xself = _identity(F)
+    x = BLS_X >> 1
+    tmp = p
+    while x != 0:
+        tmp = dbl(tmp)
+        if x % 2 == 1:
+            xself = add(xself, tmp)
+        x >>= 1
+    return neg(xself) if BLS_X_IS_NEGATIVE else xself
+
+
+def g1_mul_by_x(p): return _mul_by_x(_FpOps, p, g1_add, g1_double, g1_neg)
+def g2_mul_by_x(p): return _mul_by_x(_Fp2Ops, p, g2_add, g2_double, g2_neg)
+
+
+def g1_is_torsion_free(a):
+    """g1.rs:401-410: endomorphism(P) == -[x^2] P."""
+    m = g1_neg(g1_mul_by_x(g1_mul_by_x(g1_from_affine(a))))
+    e = ((a[0] * BETA) % P, a[1], a[2])
+    return g1_eq(m, g1_from_affine(e))
+
+
+def g2_psi(p):
+    """g2.rs:847-890."""
+    return (fp2_mul(fp2_conj(p[0]), PSI_COEFF_X), fp2_mul(fp2_conj(p[1]), PSI_COEFF_Y), fp2_conj(p[2]))
+
+
+def g2_is_torsion_free(a):
+    """g2.rs:475-482: psi(P) == [x] P."""
+    p = g2_from_affine(a)
+    return g2_eq(g2_psi(p), g2_mul_by_x(p))
+
+
+def g1_from_compressed(b):
+    """g1.rs:326-332."""
+    p = g1_from_compressed_unchecked(b)
+    return p if (p is not None and g1_is_torsion_free(p)) else None
+
+
+def g1_from_uncompressed(b):
+    """g1.rs:264-267."""
+    p = g1_from_uncompressed_unchecked(b)
+    return p if (p is not None and g1_is_on_curve(p) and g1_is_torsion_free(p)) else None
+
+
+def g2_from_compressed(b):
+    """g2.rs:390-395."""
+    p = g2_from_compressed_unchecked(b)
+    return p if (p is not None and g2_is_torsion_free(p)) else None
+
+
+def g2_from_uncompressed(b):
+    """g2.rs:303-306."""
+    p = g2_from_uncompressed_unchecked(b)
+    return p if (p is not None and g2_is_on_curve(p) and g2_is_torsion_free(p)) else None

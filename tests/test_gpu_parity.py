@@ -396,3 +396,84 @@ def test_cpp_host_mirror(ctx, kats, tmp_path):
     kat.write_bytes(np.array(kats["consts"]["pairings.GT_GENERATOR"], dtype=np.uint64).tobytes())
     out = subprocess.run([exe, str(kat)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "host mirror ok" in out.stdout, out.stdout + out.stderr
+
+
+# ---- batched (de)serialisation + validation ------------------------------------------------
+@pytest.mark.parametrize("group", [1, 2])
+def test_codec_golden_roundtrip(ctx, group, golden_dir):
+    """All 1000 golden records of each file decode (checked and unchecked, both encodings) to k*G and re-encode
+    to the same bytes; results equal the oracle's decoders."""
+    name = "g1" if group == 1 else "g2"
+    usz = 96 if group == 1 else 192
+    unc = np.frombuffer(open(os.path.join(golden_dir, f"{name}_uncompressed_valid_test_vectors.dat"), "rb").read(), dtype=np.uint8).reshape(1000, usz)
+    cmp_ = np.frombuffer(open(os.path.join(golden_dir, f"{name}_compressed_valid_test_vectors.dat"), "rb").read(), dtype=np.uint8).reshape(1000, usz // 2)
+    xy_c, inf_c, ok_c = ctx.points_from_bytes(group, cmp_, compressed=True, checked=True)
+    xy_u, inf_u, ok_u = ctx.points_from_bytes(group, unc, compressed=False, checked=True)
+    assert ok_c.all() and ok_u.all()
+    assert np.array_equal(xy_c, xy_u) and np.array_equal(inf_c, inf_u)
+    assert inf_c[0] == 1 and not inf_c[1:].any()
+    bases = ctx.bases_from_scalars(group, list(range(1000)))
+    bxy, binf = bases.download()
+    assert np.array_equal(bxy[1:], xy_c[1:]) and np.array_equal(binf, inf_c)
+    assert np.array_equal(ctx.points_to_bytes(group, xy_c, inf_c, compressed=True), cmp_)
+    assert np.array_equal(ctx.points_to_bytes(group, xy_c, inf_c, compressed=False), unc)
+    xy_x, inf_x, ok_x = ctx.points_from_bytes(group, cmp_, compressed=True, checked=False)
+    assert ok_x.all() and np.array_equal(xy_x, xy_c)
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_codec_rejections(ctx, group, kats):
+    """Every class of invalid encoding the reference rejects (flags, non-canonical coordinates, no square root,
+    off-curve, off-subgroup), checked entry by entry against the oracle's decoders."""
+    import bls12_381_amd as b
+    r = o.SplitMix64(555 + group)
+    if group == 1:
+        enc_c, enc_u = o.g1_to_compressed, o.g1_to_uncompressed
+        dec = {(True, True): o.g1_from_compressed, (True, False): o.g1_from_compressed_unchecked,
+               (False, True): o.g1_from_uncompressed, (False, False): o.g1_from_uncompressed_unchecked}
+        v = kats["tests"]["g1.test_is_torsion_free"]["fp"]
+        off_sub = (o.fp_from_mont_limbs(v[0]), o.fp_from_mont_limbs(v[1]), False)
+        pts = [o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, r.scalar())) for _ in range(6)] + [o.G1_IDENTITY_AFF, off_sub]
+        affw, csz = g1aff_w, 48
+    else:
+        enc_c, enc_u = o.g2_to_compressed, o.g2_to_uncompressed
+        dec = {(True, True): o.g2_from_compressed, (True, False): o.g2_from_compressed_unchecked,
+               (False, True): o.g2_from_uncompressed, (False, False): o.g2_from_uncompressed_unchecked}
+        v = kats["tests"]["g2.test_is_torsion_free"]["fp"]
+        F = o.fp_from_mont_limbs
+        off_sub = ((F(v[0]), F(v[1])), (F(v[2]), F(v[3])), False)
+        pts = [o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, r.scalar())) for _ in range(6)] + [o.G2_IDENTITY_AFF, off_sub]
+        affw, csz = g2aff_w, 96
+    for compressed in (True, False):
+        enc = enc_c if compressed else enc_u
+        size = csz if compressed else 2 * csz
+        cases = [enc(p) for p in pts]
+        base = bytearray(cases[0])
+        for flip in (0x80, 0x40, 0x20, 0xc0, 0xe0, 0x60):                  # flag combinations
+            m = bytearray(base); m[0] ^= flip; cases.append(bytes(m))
+        ident = bytearray(enc(pts[6]))
+        m = bytearray(ident); m[size - 1] = 1; cases.append(bytes(m))      # infinity flag with non-zero coordinate
+        m = bytearray(ident); m[0] |= 0x20; cases.append(bytes(m))         # infinity + sort flag
+        pbytes = o.P.to_bytes(48, "big")
+        m = bytearray(base); m[0:48] = bytes([pbytes[0] | (base[0] & 0xe0)]) + pbytes[1:]; cases.append(bytes(m))   # x = p (non-canonical)
+        m = bytearray(base); m[size - 1] ^= 1; cases.append(bytes(m))      # perturbed: no sqrt / off-curve
+        m = bytearray(base); m[size - 2] ^= 0x55; cases.append(bytes(m))
+        m = bytearray(base); m[5] ^= 0x10; cases.append(bytes(m))
+        for k in range(40):                                                # random x (about half have no root)
+            m = bytearray(base)
+            for j in range(1, 48):
+                m[j] = r.next() & 0xff
+            cases.append(bytes(m))
+        data = np.frombuffer(b"".join(cases), dtype=np.uint8).reshape(len(cases), size)
+        for checked in (True, False):
+            xy, inf, ok = ctx.points_from_bytes(group, data, compressed=compressed, checked=checked)
+            for i, c in enumerate(cases):
+                want = dec[(compressed, checked)](c)
+                assert bool(ok[i]) == (want is not None), (compressed, checked, i)
+                if want is not None:
+                    ex, ei = affw(want)
+                    assert np.array_equal(xy[i], ex) and inf[i] == ei, (compressed, checked, i)
+    cls = b.G1Affine if group == 1 else b.G2Affine
+    assert cls.from_compressed(enc_c(pts[0])) == cls(*affw(pts[0]))
+    assert cls.from_compressed(enc_c(off_sub)) is None and cls.from_compressed_unchecked(enc_c(off_sub)) is not None
+    assert cls.from_uncompressed(enc_u(pts[1])) == cls(*affw(pts[1]))

