@@ -155,10 +155,16 @@ def main():
         windows = (256 + WINDOW_BITS - 1) // WINDOW_BITS
         mac32_per_launch = float(n) * windows * 11 * 300          # canonical: one complete mixed add per (point, window)
         dur = float(np.mean(acc_ms)) * 1e-3
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_msm_pmc.json")
+        if args.log_n == 20 and os.path.exists(pmc_path):
+            # HBM-side bytes per launch of this kernel on this workload, from separate rocprofv3 --pmc passes
+            # (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); see profiles/r01_msm_pmc.md
+            traffic = json.load(open(pmc_path))["hbm_bytes_per_launch_corrected"]
         roof = {
             "bound": "int-valu", "kernel": "k_msm_accumulate<G1>",
             "achieved": mac32_per_launch / dur / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s",
-            "frac": mac32_per_launch / dur / peak, "traffic": None,
+            "frac": mac32_per_launch / dur / peak, "traffic": traffic,
             "launch_ms": float(np.mean(acc_ms)), "mac32_per_launch": mac32_per_launch,
             "fp_mul_per_s_chain": fp_rate,
             "whole_msm_frac": (float(n) * 188 * 300) / (float(np.mean(tot_ms)) * 1e-3) / peak,
