@@ -31,6 +31,7 @@ SIGNATURES = {
     "blsgpu_g1_bases_from_device": (c_int, [c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
     "blsgpu_g2_bases_from_device": (c_int, [c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
     "blsgpu_bases_from_scalars": (c_int, [c_vp, c_int, c_vp, c_sz, ctypes.POINTER(c_vp)]),
+    "blsgpu_bases_precompute": (c_int, [c_vp, c_vp, c_int]),
     "blsgpu_bases_len": (c_sz, [c_vp]),
     "blsgpu_bases_download": (c_int, [c_vp, c_vp, c_sz, c_sz, c_vp, c_vp]),
     "blsgpu_bases_free": (None, [c_vp]),

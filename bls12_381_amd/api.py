@@ -81,6 +81,11 @@ class ResidentBases:
     def __len__(self):
         return int(_lib.load().blsgpu_bases_len(self.handle))
 
+    def precompute(self, window_bits=0):
+        """Build resident window-shifted tables (see blsgpu_bases_precompute); later MSMs use them automatically."""
+        check(_lib.load().blsgpu_bases_precompute(self.ctx.h, self.handle, window_bits), "bases_precompute")
+        return self
+
     def download(self, first=0, count=None):
         n = len(self) - first if count is None else count
         w = 12 if self.group == 1 else 24

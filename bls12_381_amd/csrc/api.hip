@@ -67,6 +67,8 @@ struct blsgpu_ctx {
 
 struct blsgpu_bases {
   int group = 1; size_t n = 0; int device = 0; u32* rec = nullptr;   // AFF_WORDS per point
+  // optional window-shifted tables: table[w * n + i] = [2^(table_c * w)] P_i   (blsgpu_bases_precompute)
+  u32* table = nullptr; int table_c = 0, table_w = 0;
 };
 
 template <class F> struct GroupTag;
@@ -409,8 +411,32 @@ extern "C" void blsgpu_bases_free(blsgpu_bases* b) {
   if (!b) return;
   hipSetDevice(b->device);
   if (b->rec) hipFree(b->rec);
+  if (b->table) hipFree(b->table);
   delete b;
 }
+template <class F>
+static int bases_precompute(blsgpu_ctx* c, blsgpu_bases* b, int cw) {
+  const int nwin = (256 + cw - 1) / cw;
+  if ((size_t)nwin * b->n > ((size_t)1 << 24)) return bad("bases_precompute: n * windows must not exceed 2^24");
+  if (b->table) { HIPCHK(hipFree(b->table)); b->table = nullptr; b->table_c = 0; }
+  size_t bytes = (size_t)nwin * (b->n ? b->n : 1) * Store<F>::AFF_WORDS * 4;
+  HIPCHK(hipMalloc((void**)&b->table, bytes));
+  if (b->n) {
+    hipLaunchKernelGGL(k_bases_precompute<F>, dim3(nblk(b->n, 256)), dim3(256), 0, c->stream, b->rec, b->table, b->n, cw, nwin);
+    LAUNCHCHK();
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  b->table_c = cw; b->table_w = nwin;
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_bases_precompute(blsgpu_ctx* c, blsgpu_bases* b, int window_bits) {
+  if (!c || !b) return bad("bases_precompute: NULL argument");
+  if (window_bits == 0) window_bits = 20;
+  if (window_bits < 9 || window_bits > 21) return bad("bases_precompute: window must be in [9, 21]");
+  HIPCHK(hipSetDevice(c->device));
+  return b->group == 1 ? bases_precompute<FpPolicy>(c, b, window_bits) : bases_precompute<Fp2Policy>(c, b, window_bits);
+}
+
 template <class F>
 static int bases_download(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, size_t count, uint64_t* xy, uint8_t* inf) {
   size_t xb = count * 2 * Wire<F>::WORDS * 4;
@@ -466,10 +492,13 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     LAUNCHCHK();
     return BLSGPU_OK;
   }
-  const int cw = c->msm_c ? c->msm_c : pick_window(n);
-  const int nwin = (256 + cw - 1) / cw;
+  // resident window-shifted tables (blsgpu_bases_precompute): all windows share one bucket set
+  const bool merged = bases->table != nullptr;
+  const int cw = merged ? bases->table_c : (c->msm_c ? c->msm_c : pick_window(n));
+  const int nwin = (256 + cw - 1) / cw;                 // digit windows per scalar
+  const int nseg = merged ? 1 : nwin;                   // independent bucket sets
   const u32 nbw = 1u << (cw - 1);
-  const size_t nb = (size_t)nwin * nbw;
+  const size_t nb = (size_t)nseg * nbw;
   const size_t total = (size_t)nwin * n;
   if (total > 0xfffffff0ull) return bad("msm: n * windows exceeds 2^32 entries");
   int bad_alloc = 0;
@@ -514,14 +543,14 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   auto mark = [&](int i) { if (prof) hipEventRecord(c->ev[i], st); };
 
   mark(0);
-  const bool fast_sort = (n <= ((size_t)1 << 24)) && cw <= 16 && cw >= 2;
+  const bool fast_sort = merged || ((n <= ((size_t)1 << 24)) && cw <= 16 && cw >= 2);
   if (fast_sort) {
     // 1'-3'. two-level counting sort (LDS atomics; see msm.cuh)
     const int key_bits = cw - 1;
-    const int coarse_bits = key_bits < 8 ? key_bits : 8;
+    const int coarse_bits = merged ? (key_bits > 7 ? key_bits - 7 : 0) : (key_bits < 8 ? key_bits : 8);
     const int fine_bits = key_bits - coarse_bits;           // <= 7
     const int ncoarse = 1 << coarse_bits;
-    const int nc = nwin * ncoarse;
+    const int nc = nseg * ncoarse;
     if (nc > SORT_MAX_COUNTERS) return bad("msm: window configuration exceeds the sort's counter table");
     // fixed layout: [MAX] counts (kept zero between calls) | [MAX+1] bases | [MAX] cursors
     u32* ghist = c->hist.as<u32>();
@@ -529,14 +558,14 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     u32* gcur = gbase + SORT_MAX_COUNTERS + 1;
     if (c->hist_dirty) { HIPCHK(hipMemsetAsync(ghist, 0, (size_t)SORT_MAX_COUNTERS * 4, st)); c->hist_dirty = false; }
     const unsigned tiles = nblk(n, SORT_TILE);
-    hipLaunchKernelGGL(k_sort_hist, dim3(tiles), dim3(256), (size_t)nc * 4, st, (const u32*)d_scalars, ghist, (int)n, cw, nwin, fine_bits, ncoarse);
+    hipLaunchKernelGGL(k_sort_hist, dim3(tiles), dim3(256), (size_t)nc * 4, st, (const u32*)d_scalars, ghist, (int)n, cw, nwin, fine_bits, ncoarse, merged ? 1 : 0);
     LAUNCHCHK();
     mark(1);
     hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, st, ghist, gbase, gcur, nc, c->ctrl.as<u32>(), 4 + 2 * ITEM_BINS);
     LAUNCHCHK();
     mark(2);
     hipLaunchKernelGGL(k_sort_scatter, dim3(tiles), dim3(256), (size_t)nc * 8, st, (const u32*)d_scalars, gbase, gcur, c->ent.as<u32>(), (int)n, cw, nwin,
-                       fine_bits, ncoarse);
+                       fine_bits, ncoarse, merged ? 1 : 0, (u32)bases->n);
     hipLaunchKernelGGL(k_sort_fine, dim3(nc), dim3(256), 0, st, c->ent.as<u32>(), gbase, c->sorted.as<u32>(), c->offs.as<u32>(), fine_bits, nc);
     LAUNCHCHK();
     mark(3);
@@ -574,7 +603,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   mark(4);
   // 5. accumulate (grid covers the worst-case item count; surplus lanes exit on ctrl[2])
   u32* records = sl.buckets.as<u32>();
-  hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(max_items, 256)), dim3(256), 0, st, bases->rec + first * Store<F>::AFF_WORDS, c->sorted.as<u32>(),
+  hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(max_items, 256)), dim3(256), 0, st, (merged ? bases->table : bases->rec) + first * Store<F>::AFF_WORDS, c->sorted.as<u32>(),
                      c->items.as<ItemDesc>(), ctrl, records);
   hipLaunchKernelGGL(k_msm_heavy<F>, dim3(HEAVY_SMALL_BLOCKS + 512), dim3(256), 0, st, c->heavy.as<uint4>(), ctrl, records);
   LAUNCHCHK();
@@ -587,53 +616,53 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     std::vector<int> Ms;
     const u32* E = records;
     int nn = (int)nbw, off = 1, cur = 0, level = 0;
-    // level T sums are stored consecutively in wacc[0]: level l at offset l * nwin
+    // level T sums are stored consecutively in wacc[0]: level l at offset l * nseg
     u32* tstore = sl.wacc[0].as<u32>();
     while (nn > 1) {
       int M = nn >= 8 ? 8 : nn;
       int G = nn / M;
       u32* Rout = sl.lvlR[cur].as<u32>();
       u32* Tout = sl.lvlT.as<u32>();
-      if ((size_t)nwin * G * TEAM <= TEAM_LANES_MAX)
-        hipLaunchKernelGGL(k_wsum_level_team<F>, dim3(nblk((size_t)nwin * G * TEAM, 256)), dim3(256), TEAM_LDS(256), tt, E, Rout, Tout, nwin, nn, M, off);
+      if ((size_t)nseg * G * TEAM <= TEAM_LANES_MAX)
+        hipLaunchKernelGGL(k_wsum_level_team<F>, dim3(nblk((size_t)nseg * G * TEAM, 256)), dim3(256), TEAM_LDS(256), tt, E, Rout, Tout, nseg, nn, M, off);
       else
-        hipLaunchKernelGGL(k_wsum_level<F>, dim3(nblk((size_t)nwin * G, 256)), dim3(256), 0, tt, E, Rout, Tout, nwin, nn, M, off);
+        hipLaunchKernelGGL(k_wsum_level<F>, dim3(nblk((size_t)nseg * G, 256)), dim3(256), 0, tt, E, Rout, Tout, nseg, nn, M, off);
       LAUNCHCHK();
       // sum the G T-records of each window down to one
       const u32* Tin = Tout; int tn = G, tc = 0;
       while (tn > 1) {
         int TM = tn >= 8 ? 8 : tn; int TG = (tn + TM - 1) / TM;
         u32* o = sl.tsum[tc].as<u32>();
-        if ((size_t)nwin * TG * TEAM <= TEAM_LANES_MAX)
-          hipLaunchKernelGGL(k_tree_sum_team<F>, dim3(nblk((size_t)nwin * TG * TEAM, 256)), dim3(256), TEAM_LDS(256), tt, Tin, o, nwin, tn, TM);
+        if ((size_t)nseg * TG * TEAM <= TEAM_LANES_MAX)
+          hipLaunchKernelGGL(k_tree_sum_team<F>, dim3(nblk((size_t)nseg * TG * TEAM, 256)), dim3(256), TEAM_LDS(256), tt, Tin, o, nseg, tn, TM);
         else
-          hipLaunchKernelGGL(k_tree_sum<F>, dim3(nblk((size_t)nwin * TG, 256)), dim3(256), 0, tt, Tin, o, nwin, tn, TM);
+          hipLaunchKernelGGL(k_tree_sum<F>, dim3(nblk((size_t)nseg * TG, 256)), dim3(256), 0, tt, Tin, o, nseg, tn, TM);
         LAUNCHCHK();
         Tin = o; tn = TG; tc ^= 1;
       }
-      HIPCHK(hipMemcpyAsync(tstore + (size_t)level * nwin * PW, Tin, (size_t)nwin * PW * 4, hipMemcpyDeviceToDevice, tt));
+      HIPCHK(hipMemcpyAsync(tstore + (size_t)level * nseg * PW, Tin, (size_t)nseg * PW * 4, hipMemcpyDeviceToDevice, tt));
       Ms.push_back(M);
       E = Rout; nn = G; off = 0; cur ^= 1; level++;
       if (level >= 31) return bad("msm: reduction depth");
     }
     if (level == 0) {
       // a single bucket per window (c = 1): the bucket itself is the window sum
-      HIPCHK(hipMemcpyAsync(sl.wsums.p, records, (size_t)nwin * PW * 4, hipMemcpyDeviceToDevice, tt));
+      HIPCHK(hipMemcpyAsync(sl.wsums.p, records, (size_t)nseg * PW * 4, hipMemcpyDeviceToDevice, tt));
     } else {
       // Horner over the levels: acc_L = T_L ; acc_l = T_l + M_l * acc_{l+1}
       u32* accbuf = sl.wacc[1].as<u32>();
-      HIPCHK(hipMemcpyAsync(accbuf, tstore + (size_t)(level - 1) * nwin * PW, (size_t)nwin * PW * 4, hipMemcpyDeviceToDevice, tt));
+      HIPCHK(hipMemcpyAsync(accbuf, tstore + (size_t)(level - 1) * nseg * PW, (size_t)nseg * PW * 4, hipMemcpyDeviceToDevice, tt));
       for (int l = level - 2; l >= 0; l--) {
         int k = 0; while ((1 << k) < Ms[l]) k++;
-        hipLaunchKernelGGL(k_shift_add_team<F>, dim3(nblk((size_t)nwin * TEAM, 256)), dim3(256), TEAM_LDS(256), tt, accbuf, tstore + (size_t)l * nwin * PW, accbuf, nwin, k);
+        hipLaunchKernelGGL(k_shift_add_team<F>, dim3(nblk((size_t)nseg * TEAM, 256)), dim3(256), TEAM_LDS(256), tt, accbuf, tstore + (size_t)l * nseg * PW, accbuf, nseg, k);
         LAUNCHCHK();
       }
-      HIPCHK(hipMemcpyAsync(sl.wsums.p, accbuf, (size_t)nwin * PW * 4, hipMemcpyDeviceToDevice, tt));
+      HIPCHK(hipMemcpyAsync(sl.wsums.p, accbuf, (size_t)nseg * PW * 4, hipMemcpyDeviceToDevice, tt));
     }
   }
   if (prof) hipEventRecord(c->ev[6], tt);
   // 7. combine windows
-  hipLaunchKernelGGL(k_msm_combine_team<F>, dim3(1), dim3(TEAM), TEAM_LDS(TEAM), tt, sl.wsums.as<u32>(), sl.result.as<u32>(), nwin, cw);
+  hipLaunchKernelGGL(k_msm_combine_team<F>, dim3(1), dim3(TEAM), TEAM_LDS(TEAM), tt, sl.wsums.as<u32>(), sl.result.as<u32>(), nseg, cw);
   LAUNCHCHK();
   hipLaunchKernelGGL(k_proj_export<F>, dim3(1), dim3(256), 0, tt, sl.result.as<u32>(), (u32*)d_out_wire, (size_t)1);
   LAUNCHCHK();

@@ -194,8 +194,8 @@ DEV Xyzz<FpPolicy> xyzz_add_mixed_inl(const Xyzz<FpPolicy>& p, bool& inf, const 
   if (inf) { inf = false; return xyzz_from_affine<F>(qx, qy); }
   auto U2 = mul_inl(qx, p.zz);
   auto S2 = mul_inl(qy, p.zzz);
-  auto P = norm(sub(U2, p.x));
-  auto R = norm(sub(S2, p.y));
+  auto P = sub(U2, p.x);          // limbs <= 3 * 2^28: still inside the multiplier's column bound
+  auto R = sub(S2, p.y);
   if (is_zero_fast(P)) {
     if (is_zero_fast(R)) return xyzz_double_affine<F>(qx, qy);
     inf = true;

@@ -158,6 +158,32 @@ __global__ void __launch_bounds__(256) k_msm_digits(const u32* __restrict__ scal
   }
 }
 
+// ---- 0. resident window-shifted tables (optional, fixed bases) ---------------------------------------------
+// table[w * n + i] = affine([2^(c w)] P_i): with them every window of every scalar lands in ONE set of
+// 2^(c-1) buckets -- no Horner over the windows, a 16x smaller bucket reduction, and c can grow to 20 (13
+// windows instead of 16).  Costs W x the resident memory (1.7 GB for 2^20 points: nothing against 288 GB) and
+// one pass of c doublings + an inversion per entry at upload.
+template <class F>
+__global__ void __launch_bounds__(256) k_bases_precompute(const u32* __restrict__ rec, u32* __restrict__ table, size_t n, int c, int nwin) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int EL = Store<F>::EL, AW = Store<F>::AFF_WORDS;
+  Aff<F> q; bool inf;
+  load_aff<F>(rec + i * AW, q, inf);
+  Proj<F> p; p.x = F::st(q.x); p.y = F::st(q.y); p.z = inf ? F::zero() : F::one();
+  for (int w = 0; w < nwin; w++) {
+    u32* r = table + ((size_t)w * n + i) * AW;
+    if (w > 0) for (int k = 0; k < c; k++) p = pt_double<F>(p);
+    bool zz = is_zero(p.z);
+    auto zi = inv(p.z);
+    auto x = canon_any(mul(p.x, zi));
+    auto y = canon_any(mul(p.y, zi));
+    Store<F>::st(r, x); Store<F>::st(r + EL, y);
+    r[2 * EL] = zz ? 1 : 0;
+    for (int j = 2 * EL + 1; j < AW; j++) r[j] = 0;
+  }
+}
+
 // ---- 1'. two-level counting sort (default path, n <= 2^24, c <= 16) ------------------------------------
 // The (window, |digit|) key is split into a coarse part (<= 8 bits) and a fine part (<= 7 bits).
 //   k_sort_hist     per tile of scalars: LDS histogram over (window, coarse) -> global counters
@@ -192,10 +218,11 @@ struct DigitIter {
   }
 };
 
+// merged != 0 (resident window-shifted tables): all windows share ONE bucket set, the window only selects the table
 __global__ void __launch_bounds__(256) k_sort_hist(const u32* __restrict__ scalars, u32* __restrict__ ghist, int n, int c, int nwin,
-                                                   int fine_bits, int ncoarse) {
+                                                   int fine_bits, int ncoarse, int merged) {
   extern __shared__ u32 lh[];
-  const int nc = nwin * ncoarse;
+  const int nc = (merged ? 1 : nwin) * ncoarse;
   for (int i = threadIdx.x; i < nc; i += 256) lh[i] = 0;
   __syncthreads();
   for (int k = 0; k < SORT_TILE / 256; k++) {
@@ -204,7 +231,7 @@ __global__ void __launch_bounds__(256) k_sort_hist(const u32* __restrict__ scala
       DigitIter d; d.init(scalars, i, c);
       for (int w = 0; w < nwin; w++) {
         u32 mag, neg; d.next(w, mag, neg);
-        if (mag) atomicAdd(&lh[w * ncoarse + ((mag - 1) >> fine_bits)], 1u);
+        if (mag) atomicAdd(&lh[(merged ? 0 : w) * ncoarse + ((mag - 1) >> fine_bits)], 1u);
       }
     }
   }
@@ -235,9 +262,10 @@ __global__ void __launch_bounds__(1024) k_sort_scan(u32* __restrict__ ghist, u32
   for (int i = threadIdx.x; i < nctrl; i += 1024) ctrl[i] = 0;
 }
 __global__ void __launch_bounds__(256) k_sort_scatter(const u32* __restrict__ scalars, const u32* __restrict__ gbase, u32* __restrict__ gcur,
-                                                      u32* __restrict__ coarse_out, int n, int c, int nwin, int fine_bits, int ncoarse) {
+                                                      u32* __restrict__ coarse_out, int n, int c, int nwin, int fine_bits, int ncoarse,
+                                                      int merged, u32 stride) {
   extern __shared__ u32 lh[];          // [nc] counts, then reused as running local ranks; [nc] bases
-  const int nc = nwin * ncoarse;
+  const int nc = (merged ? 1 : nwin) * ncoarse;
   u32* lbase = lh + nc;
   for (int i = threadIdx.x; i < nc; i += 256) lh[i] = 0;
   __syncthreads();
@@ -247,7 +275,7 @@ __global__ void __launch_bounds__(256) k_sort_scatter(const u32* __restrict__ sc
       DigitIter d; d.init(scalars, i, c);
       for (int w = 0; w < nwin; w++) {
         u32 mag, neg; d.next(w, mag, neg);
-        if (mag) atomicAdd(&lh[w * ncoarse + ((mag - 1) >> fine_bits)], 1u);
+        if (mag) atomicAdd(&lh[(merged ? 0 : w) * ncoarse + ((mag - 1) >> fine_bits)], 1u);
       }
     }
   }
@@ -266,9 +294,10 @@ __global__ void __launch_bounds__(256) k_sort_scatter(const u32* __restrict__ sc
       for (int w = 0; w < nwin; w++) {
         u32 mag, neg; d.next(w, mag, neg);
         if (mag) {
-          int ci = w * ncoarse + ((mag - 1) >> fine_bits);
+          int ci = (merged ? 0 : w) * ncoarse + ((mag - 1) >> fine_bits);
           u32 r = atomicAdd(&lh[ci], 1u);
-          coarse_out[lbase[ci] + r] = ((u32)i << 8) | (neg << 7) | ((mag - 1) & fmask);
+          u32 idx = merged ? (u32)w * stride + (u32)i : (u32)i;          // < 2^24 (checked by the host)
+          coarse_out[lbase[ci] + r] = (idx << 8) | (neg << 7) | ((mag - 1) & fmask);
         }
       }
     }

@@ -72,6 +72,11 @@ int blsgpu_g2_bases_from_device(blsgpu_ctx* ctx, const void* d_xy, const void* d
 /* bases[i] = [k_i] * generator for n 32-byte LE scalars (device-side fixed-base multiplication; used to
  * build synthetic inputs and SRS-style tables).  `group` is 1 or 2. */
 int blsgpu_bases_from_scalars(blsgpu_ctx* ctx, int group, const uint8_t* scalars, size_t n, blsgpu_bases** out);
+/* Optional, for bases that are reused (an SRS): build resident window-shifted tables [2^(c*w)] P_i (W x the memory;
+ * W = ceil(256/c), c = window_bits, 0 -> 20).  Later MSMs over these bases put every window into ONE bucket set:
+ * no window combine, a W-times smaller bucket reduction, fewer windows.  Requires n * W <= 2^24.  Results are the
+ * same group elements. */
+int blsgpu_bases_precompute(blsgpu_ctx* ctx, blsgpu_bases* b, int window_bits);
 size_t blsgpu_bases_len(const blsgpu_bases* b);
 /* Read points [first, first+count) back in wire format (xy: count*12 or count*24 u64; infinity: count bytes). */
 int blsgpu_bases_download(blsgpu_ctx* ctx, const blsgpu_bases* b, size_t first, size_t count, uint64_t* xy, uint8_t* infinity);

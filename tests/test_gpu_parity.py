@@ -477,3 +477,32 @@ def test_codec_rejections(ctx, group, kats):
     assert cls.from_compressed(enc_c(pts[0])) == cls(*affw(pts[0]))
     assert cls.from_compressed(enc_c(off_sub)) is None and cls.from_compressed_unchecked(enc_c(off_sub)) is not None
     assert cls.from_uncompressed(enc_u(pts[1])) == cls(*affw(pts[1]))
+
+
+@pytest.mark.parametrize("group,window", [(1, 0), (1, 12), (2, 16)])
+def test_msm_precomputed_tables(ctx, group, window):
+    """Resident window-shifted tables: same group element as the plain path and as the oracle (incl. edge scalars,
+    identity bases, sub-ranges)."""
+    r = o.SplitMix64(9000 + window)
+    n = 3000
+    rr = o.R_ORDER
+    ks = [0, 1, 5, 5, rr - 5] + [r.scalar() for _ in range(n - 5)]
+    ss = [7, rr - 1, 9, rr - 9, 9] + [r.scalar() for _ in range(n - 5)]
+    ss[100] = 0; ss[101] = (1 << 254) + 12345; ss[102] = (1 << 20) - 1; ss[103] = 1 << 19
+    bases = ctx.bases_from_scalars(group, ks)
+    plain = ctx.msm(bases, ss)
+    bases.precompute(window)
+    pre = ctx.msm(bases, ss)
+    a, ia = ctx.batch_normalize(group, plain[None, :]); b2, ib = ctx.batch_normalize(group, pre[None, :])
+    assert np.array_equal(a, b2) and np.array_equal(ia, ib)
+    tot = sum(k * s for k, s in zip(ks, ss)) % rr
+    want = (o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, tot)) if group == 1 else o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, tot)))
+    ex, ei = (g1aff_w if group == 1 else g2aff_w)(want)
+    assert np.array_equal(b2[0], ex) and ib[0] == ei
+    # sub-range of the resident tables
+    sub = ctx.msm(bases, ss[500:1500], first=500)
+    tot = sum(k * s for k, s in zip(ks[500:1500], ss[500:1500])) % rr
+    want = (o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, tot)) if group == 1 else o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, tot)))
+    ex, ei = (g1aff_w if group == 1 else g2aff_w)(want)
+    sx, si = ctx.batch_normalize(group, sub[None, :])
+    assert np.array_equal(sx[0], ex) and si[0] == ei
