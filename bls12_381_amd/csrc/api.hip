@@ -178,14 +178,6 @@ __global__ void __launch_bounds__(256) k_bases_from_scalars(const u32* __restric
   for (int j = 2 * EL + 1; j < Store<F>::AFF_WORDS; j++) r[j] = 0;
 }
 
-// n projective records -> their sum (single block; n is tiny: per-rank partials)
-template <class F>
-__global__ void __launch_bounds__(64) k_proj_sum(const u32* __restrict__ rec, u32* __restrict__ out, size_t n) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  Proj<F> acc = pt_identity<F>();
-  for (size_t i = 0; i < n; i++) { Proj<F> p; load_proj<F>(rec + i * Store<F>::PROJ_WORDS, p); acc = pt_add<F>(acc, p); }
-  store_proj<F>(out, acc);
-}
 template <class F>
 __global__ void k_store_identity(u32* out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) store_proj<F>(out, pt_identity<F>());

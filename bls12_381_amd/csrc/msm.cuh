@@ -575,18 +575,6 @@ __global__ void __launch_bounds__(256) k_wsum_level(const u32* __restrict__ E, u
   store_proj<F>(Rout + (size_t)t * Store<F>::PROJ_WORDS, run);
   store_proj<F>(Tout + (size_t)t * Store<F>::PROJ_WORDS, tot);
 }
-// plain sum of n records per segment into one record (single thread per segment; n is small)
-template <class F>
-__global__ void __launch_bounds__(64) k_seg_sum(const u32* __restrict__ E, u32* __restrict__ out, int nseg, int n) {
-  int seg = blockIdx.x * blockDim.x + threadIdx.x;
-  if (seg >= nseg) return;
-  Proj<F> acc = pt_identity<F>();
-  for (int i = 0; i < n; i++) {
-    Proj<F> e; load_proj<F>(E + ((size_t)seg * n + i) * Store<F>::PROJ_WORDS, e);
-    acc = pt_add<F>(acc, e);
-  }
-  store_proj<F>(out + (size_t)seg * Store<F>::PROJ_WORDS, acc);
-}
 // tree sum: out[seg][g] = sum of M consecutive records
 template <class F>
 __global__ void __launch_bounds__(256) k_tree_sum(const u32* __restrict__ E, u32* __restrict__ out, int nseg, int n, int M) {
@@ -602,20 +590,7 @@ __global__ void __launch_bounds__(256) k_tree_sum(const u32* __restrict__ E, u32
   }
   store_proj<F>(out + (size_t)t * Store<F>::PROJ_WORDS, acc);
 }
-// acc[seg] = 2^k * x[seg] + y[seg]   (k doublings)
-template <class F>
-__global__ void __launch_bounds__(64) k_shift_add(const u32* __restrict__ x, const u32* __restrict__ y, u32* __restrict__ out,
-                                                  int nseg, int k) {
-  __builtin_amdgcn_s_setprio(3);      // latency-bound tail: win VALU arbitration against co-resident bulk waves
-  int seg = blockIdx.x * blockDim.x + threadIdx.x;
-  if (seg >= nseg) return;
-  Proj<F> a, b;
-  load_proj<F>(x + (size_t)seg * Store<F>::PROJ_WORDS, a);
-  load_proj<F>(y + (size_t)seg * Store<F>::PROJ_WORDS, b);
-  for (int i = 0; i < k; i++) a = pt_double<F>(a);
-  a = pt_add<F>(a, b);
-  store_proj<F>(out + (size_t)seg * Store<F>::PROJ_WORDS, a);
-}
+// acc[seg] = 2^k * x[seg] + y[seg] (k doublings) exists only as a team kernel (k_shift_add_team) below.
 
 // ---- 6'. team (8 lanes per chain) versions of the reduction kernels, used when a level has too few chains
 // to fill the chip with one lane each.  All control flow around the team operations is block-uniform.
@@ -679,7 +654,8 @@ __global__ void __launch_bounds__(256) k_shift_add_team(const u32* __restrict__ 
   a = pt_add_team<F>(a, b, mbox, tl);
   if (live && tl == 0) store_proj<F>(out + (size_t)seg * Store<F>::PROJ_WORDS, a);
 }
-// Horner over the windows by ONE team (launch with a single block of TEAM threads)
+// ---- 7. window combine: Horner over the windows (c doublings + 1 addition each) by ONE team
+// (launch with a single block of TEAM threads)
 template <class F>
 __global__ void __launch_bounds__(64) k_msm_combine_team(const u32* __restrict__ wsums, u32* __restrict__ out, int nwin, int c) {
   extern __shared__ u32 team_lds[];
@@ -703,21 +679,6 @@ __global__ void __launch_bounds__(64) k_proj_sum_team(const u32* __restrict__ re
   Proj<F> acc = pt_identity<F>();
   for (size_t i = 0; i < n; i++) { Proj<F> p; load_proj<F>(rec + i * Store<F>::PROJ_WORDS, p); acc = pt_add_team<F>(acc, p, team_lds, tl); }
   if (tl == 0) store_proj<F>(out, acc);
-}
-
-// ---- 7. window combine (Horner) ------------------------------------------------------------------------
-template <class F>
-__global__ void __launch_bounds__(64) k_msm_combine(const u32* __restrict__ wsums, u32* __restrict__ out, int nwin, int c) {
-  __builtin_amdgcn_s_setprio(3);      // latency-bound tail: win VALU arbitration against co-resident bulk waves
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  Proj<F> acc;
-  load_proj<F>(wsums + (size_t)(nwin - 1) * Store<F>::PROJ_WORDS, acc);
-  for (int w = nwin - 2; w >= 0; w--) {
-    for (int i = 0; i < c; i++) acc = pt_double<F>(acc);
-    Proj<F> s; load_proj<F>(wsums + (size_t)w * Store<F>::PROJ_WORDS, s);
-    acc = pt_add<F>(acc, s);
-  }
-  store_proj<F>(out, acc);
 }
 
 }  // namespace bls
