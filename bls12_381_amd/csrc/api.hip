@@ -142,6 +142,45 @@ __global__ void __launch_bounds__(256) k_proj_to_affine(const u32* __restrict__ 
   }
   inf[i] = zz ? 1 : 0;
 }
+// Same conversion with Montgomery's trick, as the reference's batch_normalize does (g1.rs:806-839): lane t owns the
+// points t, t+T, t+2T, ... (K per lane), multiplies their non-zero z's into a running product while saving the
+// prefixes, inverts ONCE, and walks back.  5 multiplications per point + one inversion per K points instead of one
+// inversion (~410 multiplications) per point.
+constexpr int NORMALIZE_K = 32;
+template <class F>
+__global__ void __launch_bounds__(256) k_batch_normalize(const u32* __restrict__ rec, u32* __restrict__ pref, u32* __restrict__ xy,
+                                                         uint8_t* __restrict__ inf, size_t n, size_t T) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  constexpr int WW = Wire<F>::WORDS, EL = Store<F>::EL, PW = Store<F>::PROJ_WORDS;
+  typename F::elem acc = F::one();
+  for (int k = 0; k < NORMALIZE_K; k++) {
+    size_t i = t + (size_t)k * T;
+    if (i >= n) break;
+    typename F::elem z; Store<F>::ldw(rec + i * PW + 2 * EL, z);
+    Store<F>::st(pref + i * EL, acc);
+    if (!is_zero(z)) acc = F::st(mul(acc, z));
+  }
+  typename F::elem ai = F::st(inv(acc));
+  for (int k = NORMALIZE_K - 1; k >= 0; k--) {
+    size_t i = t + (size_t)k * T;
+    if (i >= n) continue;
+    Proj<F> p; load_proj<F>(rec + i * PW, p);
+    typename F::elem pr; Store<F>::ldw(pref + i * EL, pr);
+    bool zz = is_zero(p.z);
+    if (zz) {
+      Wire<F>::save(F::zero(), xy + i * 2 * WW);
+      Wire<F>::save(F::one(), xy + i * 2 * WW + WW);
+    } else {
+      auto zi = mul(pr, ai);
+      ai = F::st(mul(ai, p.z));
+      Wire<F>::save(mul(p.x, zi), xy + i * 2 * WW);
+      Wire<F>::save(mul(p.y, zi), xy + i * 2 * WW + WW);
+    }
+    inf[i] = zz ? 1 : 0;
+  }
+}
+
 // fixed-base scalar multiplication of the generator: rec[i] = affine([k_i] G)     (synthetic inputs)
 template <class F> DEV Aff<F> generator();
 template <> DEV Aff<FpPolicy> generator<FpPolicy>() {
@@ -748,12 +787,19 @@ static int batch_normalize(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_
   if (!n) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
   constexpr int WW = Wire<F>::WORDS, PW = Store<F>::PROJ_WORDS;
-  if (c->io_a.reserve(n * 3 * WW * 4) || c->io_c.reserve(n * PW * 4) || c->io_out.reserve(n * 2 * WW * 4) || c->flags_b.reserve(n)) {
+  if (c->io_a.reserve(n * 3 * WW * 4) || c->io_c.reserve(n * PW * 4) || c->io_out.reserve(n * 2 * WW * 4) || c->flags_b.reserve(n) ||
+      c->io_d.reserve(n * Store<F>::EL * 4)) {
     g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP;
   }
   HIPCHK(hipMemcpyAsync(c->io_a.p, xyz, n * 3 * WW * 4, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(k_proj_import<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), c->io_c.as<u32>(), n);
-  hipLaunchKernelGGL(k_proj_to_affine<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_c.as<u32>(), c->io_out.as<u32>(), c->flags_b.as<uint8_t>(), n);
+  if (n >= 4096) {
+    size_t T = (n + NORMALIZE_K - 1) / NORMALIZE_K;
+    hipLaunchKernelGGL(k_batch_normalize<F>, dim3(nblk(T, 256)), dim3(256), 0, c->stream, c->io_c.as<u32>(), c->io_d.as<u32>(), c->io_out.as<u32>(),
+                       c->flags_b.as<uint8_t>(), n, T);
+  } else {
+    hipLaunchKernelGGL(k_proj_to_affine<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_c.as<u32>(), c->io_out.as<u32>(), c->flags_b.as<uint8_t>(), n);
+  }
   LAUNCHCHK();
   HIPCHK(hipMemcpyAsync(xy, c->io_out.p, n * 2 * WW * 4, hipMemcpyDeviceToHost, c->stream));
   if (inf) HIPCHK(hipMemcpyAsync(inf, c->flags_b.p, n, hipMemcpyDeviceToHost, c->stream));

@@ -506,3 +506,30 @@ def test_msm_precomputed_tables(ctx, group, window):
     ex, ei = (g1aff_w if group == 1 else g2aff_w)(want)
     sx, si = ctx.batch_normalize(group, sub[None, :])
     assert np.array_equal(sx[0], ex) and si[0] == ei
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_batch_normalize_large(ctx, group):
+    """`batch_normalize` over 10 000 points (the reference's 'batch to affine n=10000' bench point) incl. identities:
+    Montgomery's-trick kernel == per-point inversion kernel == oracle on a sample."""
+    n = 10000
+    r = o.SplitMix64(31 + group)
+    ks = [r.scalar() for _ in range(n)]
+    for j in (0, 5, 4095, 4096, 9999):
+        ks[j] = 0
+    bases = ctx.bases_from_scalars(group, ks)
+    xy, inf = bases.download()
+    w = 6 if group == 1 else 12
+    # build non-trivial projective representatives: (x*z : y*z : z) with z = x of another point
+    z = np.roll(xy[:, :w], 1, axis=0).copy()
+    z[np.roll(inf, 1) == 1] = xy[1, w:2 * w]           # the rolled-in neighbour was an identity (x = 0): use a non-zero z
+    X = ctx.fp_op(0, xy[:, :6], z[:, :6]) if group == 1 else ctx.fp2_op(0, xy[:, :12], z)
+    Y = ctx.fp_op(0, xy[:, 6:], z[:, :6]) if group == 1 else ctx.fp2_op(0, xy[:, 12:], z)
+    z[inf == 1] = 0
+    xyz = np.concatenate([X, Y, z], axis=1)
+    big_xy, big_inf = ctx.batch_normalize(group, xyz)                       # n >= 4096: Montgomery's trick
+    assert np.array_equal(big_inf, inf) and np.array_equal(big_xy[inf == 0], xy[inf == 0])
+    small_xy, small_inf = ctx.batch_normalize(group, xyz[:3000])            # per-point inversion kernel
+    assert np.array_equal(small_xy, big_xy[:3000]) and np.array_equal(small_inf, big_inf[:3000])
+    ident = (np.concatenate([fpw(0), fpw(1)]) if group == 1 else np.concatenate([fp2w((0, 0)), fp2w((1, 0))]))
+    assert np.array_equal(big_xy[0], ident)
