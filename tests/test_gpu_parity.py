@@ -533,3 +533,37 @@ def test_batch_normalize_large(ctx, group):
     assert np.array_equal(small_xy, big_xy[:3000]) and np.array_equal(small_inf, big_inf[:3000])
     ident = (np.concatenate([fpw(0), fpw(1)]) if group == 1 else np.concatenate([fp2w((0, 0)), fp2w((1, 0))]))
     assert np.array_equal(big_xy[0], ident)
+
+
+# ---- multi-GPU logic as logical shards on one device (SURVEY.md 8e caveat) ------------------------------------------
+@pytest.mark.parametrize("world", [2, 8])
+def test_logical_shards_msm_and_miller(ctx, world):
+    """The N-rank path (contiguous shards -> per-rank partial -> gather -> fold) executed as N logical ranks on one
+    GPU gives the same element as the unsharded call: G1 MSM, G2 MSM and multi_miller_loop."""
+    from bls12_381_amd.distributed import shard_range
+    r = o.SplitMix64(1234 + world)
+    n = 5000
+    ks = [r.scalar() for _ in range(n)]
+    ss = [r.scalar() for _ in range(n)]
+    sb = np.stack([np.frombuffer(s.to_bytes(32, "little"), dtype=np.uint8) for s in ss])
+    for group in (1, 2):
+        bases = ctx.bases_from_scalars(group, ks)
+        full = ctx.msm(bases, sb)
+        parts = []
+        for rank in range(world):
+            lo, hi = shard_range(n, rank, world)
+            parts.append(ctx.msm(bases, sb[lo:hi], first=lo))            # what rank `rank` would compute
+        folded = ctx.point_sum(group, np.stack(parts))                     # what every rank does after the all-gather
+        assert np.array_equal(ctx.batch_normalize(group, folded[None, :])[0], ctx.batch_normalize(group, full[None, :])[0])
+    m = 64
+    g1, f1 = ctx.bases_from_scalars(1, ks[:m]).download()
+    g2, f2 = ctx.bases_from_scalars(2, ss[:m]).download()
+    f1[3] = 1; f2[10] = 1                                                  # identities are skipped (pairings.rs:566-569)
+    whole = ctx.multi_miller_loop(g1, f1, g2, f2)
+    parts = []
+    for rank in range(world):
+        lo, hi = shard_range(m, rank, world)
+        parts.append(ctx.multi_miller_loop(g1[lo:hi], f1[lo:hi], g2[lo:hi], f2[lo:hi]))
+    assert np.array_equal(ctx.fp12_product(np.stack(parts)), whole)
+    assert np.array_equal(ctx.final_exponentiation_batch(whole[None, :])[0],
+                          ctx.final_exponentiation_batch(ctx.fp12_product(np.stack(parts))[None, :])[0])
