@@ -634,8 +634,11 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   mark(4);
   // 5. accumulate (grid covers the worst-case item count; surplus lanes exit on ctrl[2])
   u32* records = sl.buckets.as<u32>();
-  hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(max_items, 256)), dim3(256), 0, st, (merged ? bases->table : bases->rec) + first * Store<F>::AFF_WORDS, c->sorted.as<u32>(),
-                     c->items.as<ItemDesc>(), ctrl, records);
+  const u32* base_rec = (merged ? bases->table : bases->rec) + first * Store<F>::AFF_WORDS;
+  if constexpr (GroupTag<F>::id == 2)
+    hipLaunchKernelGGL(k_msm_accumulate_g2pair, dim3(nblk(2 * max_items, 256)), dim3(256), 0, st, base_rec, c->sorted.as<u32>(), c->items.as<ItemDesc>(), ctrl, records);
+  else
+    hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(max_items, 256)), dim3(256), 0, st, base_rec, c->sorted.as<u32>(), c->items.as<ItemDesc>(), ctrl, records);
   hipLaunchKernelGGL(k_msm_heavy<F>, dim3(HEAVY_SMALL_BLOCKS + 512), dim3(256), 0, st, c->heavy.as<uint4>(), ctrl, records);
   LAUNCHCHK();
   mark(5);

@@ -25,6 +25,7 @@
 #include <type_traits>
 #include "convert.cuh"
 #include "team.cuh"
+#include "pairlane.cuh"
 
 namespace bls {
 
@@ -499,6 +500,41 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const u32* __restrict__ 
   }
   store_proj<F>(records + (size_t)d.dest * Store<F>::PROJ_WORDS, xyzz_to_proj<F>(acc, acc_inf));
 }
+// G2 accumulation with every Fp2 value spread over a lane pair (pairlane.cuh): lane 2k works on the c0 coefficients
+// and lane 2k+1 on the c1 coefficients of chain k.  Same items, same records, same formula.
+__global__ void __launch_bounds__(256, 2) k_msm_accumulate_g2pair(const u32* __restrict__ bases, const u32* __restrict__ sorted,
+                                                               const ItemDesc* __restrict__ items, const u32* __restrict__ ctrl,
+                                                               u32* __restrict__ records) {
+  typedef Fp2PairPolicy F;
+  constexpr int AW = Store<Fp2Policy>::AFF_WORDS, PW = Store<Fp2Policy>::PROJ_WORDS;
+  u32 t = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  if (t >= ctrl[2]) return;                     // both lanes of a pair leave together
+  const u32 par = threadIdx.x & 1;
+  ItemDesc d = items[t];
+  Xyzz<F> acc;
+  acc.x = F::zero(); acc.y = F::zero(); acc.zz = F::zero(); acc.zzz = F::zero();
+  bool acc_inf = true;
+  for (u32 j = d.start; j < d.start + d.len; j++) {
+    u32 e = sorted[j];
+    const u32* rec = bases + (size_t)(e & 0x7fffffffu) * AW;
+    if (rec[4 * NL] != 0) continue;             // identity base (same decision in both lanes)
+    FeP<1, 1> qx, qy1;
+    const uint2* px = reinterpret_cast<const uint2*>(rec + par * NL);
+    const uint2* py = reinterpret_cast<const uint2*>(rec + 2 * NL + par * NL);
+#pragma unroll
+    for (int i = 0; i < NL / 2; i++) {
+      uint2 a = px[i], b = py[i];
+      qx.v.l[2 * i] = a.x; qx.v.l[2 * i + 1] = a.y; qy1.v.l[2 * i] = b.x; qy1.v.l[2 * i + 1] = b.y;
+    }
+    FeP<2, 2> qy = select((e >> 31) != 0, neg(qy1), (FeP<2, 2>)qy1);
+    acc = xyzz_add_mixed<F>(acc, acc_inf, qx, qy);
+  }
+  Proj<F> pr = xyzz_to_proj<F>(acc, acc_inf);
+  u32* o = records + (size_t)d.dest * PW + par * NL;
+#pragma unroll
+  for (int i = 0; i < NL; i++) { o[i] = pr.x.v.l[i]; o[2 * NL + i] = pr.y.v.l[i]; o[4 * NL + i] = pr.z.v.l[i]; }
+}
+
 // fold the partial sums of the heavy buckets: one lane per bucket when it has few partials ...
 constexpr int HEAVY_SMALL_BLOCKS = 256;      // blocks [0, 256) of k_msm_heavy run the per-lane path, the rest the per-block path
 template <class F>
