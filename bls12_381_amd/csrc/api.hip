@@ -30,7 +30,12 @@ struct DevBuf {
   void* p = nullptr; size_t cap = 0;
   int reserve(size_t bytes) {
     if (bytes <= cap) return 0;
-    if (p) { if (hipFree(p) != hipSuccess) return -1; p = nullptr; cap = 0; }
+    if (p) {
+      // growing: work queued on any stream may still reference the old block
+      if (hipDeviceSynchronize() != hipSuccess) return -1;
+      if (hipFree(p) != hipSuccess) return -1;
+      p = nullptr; cap = 0;
+    }
     size_t want = bytes + bytes / 8 + 256;
     if (hipMalloc(&p, want) != hipSuccess) return -1;
     cap = want; return 0;
@@ -46,23 +51,27 @@ struct blsgpu_ctx {
   int msm_c = 0;
   bool profiling = false;
   bool pipelining = false;
-  bool hist_dirty = false;
+  hipStream_t acc_stream = nullptr;     // bucket accumulation of pipelined calls (the caller's stream is never blocked)
   hipEvent_t ev[9];
   float phase_ms[8] = {0};
   // MSM: the chip-filling phases run on `stream`; the latency-bound tail (bucket reduction + window
   // combine, a few wavefronts) of call i runs on tail_stream[i & 1] and overlaps the next call's heavy
   // phases.  Everything the tail touches is double-buffered per slot.
   struct Slot {
-    hipStream_t tail = nullptr;
-    hipEvent_t ev_acc = nullptr, ev_tail = nullptr;
+    // front: digit sort + work items (LDS/atomic bound)  ->  main stream: bucket accumulation (VALU bound)  ->
+    // tail: bucket reduction + window combine (latency bound).  Front and tail run on the slot's own streams so
+    // that they overlap the accumulation kernels of neighbouring calls.
+    hipStream_t front = nullptr, tail = nullptr;
+    hipEvent_t ev_in = nullptr, ev_front = nullptr, ev_acc = nullptr, ev_tail = nullptr;
     bool tail_pending = false;
+    bool hist_dirty = false;
     unsigned long long seq = 0;
+    DevBuf ent, sorted, hist, offs, cursor, bsum, items, heavy, ctrl;
     DevBuf buckets, lvlR[2], lvlT, tsum[2], wacc[2], wsums, result;
   } slot[NSLOT];
   int next_slot = 0;
   unsigned long long msm_calls = 0;
-  // scratch of the heavy phases (serialised on `stream`)
-  DevBuf ent, sorted, hist, offs, cursor, bsum, items, heavy, ctrl, result, io_a, io_b, io_c, io_d, io_out, flags_a, flags_b;
+  DevBuf result, io_a, io_b, io_c, io_d, io_out, flags_a, flags_b;
 };
 
 struct blsgpu_bases {
@@ -321,6 +330,10 @@ extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
   for (auto& sl : c->slot) {
     // the tail is a handful of wavefronts racing a chip-filling kernel: give its queue the highest priority
     HIPCHK(hipStreamCreateWithPriority(&sl.tail, hipStreamNonBlocking, prio_hi));
+    if (!c->acc_stream) HIPCHK(hipStreamCreateWithFlags(&c->acc_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&sl.front, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&sl.ev_front, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&sl.ev_acc, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&sl.ev_tail, hipEventDisableTiming));
   }
@@ -331,16 +344,20 @@ extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
-  DevBuf* bufs[] = {&c->ent, &c->sorted, &c->hist, &c->offs, &c->cursor, &c->bsum, &c->items, &c->heavy, &c->ctrl, &c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d,
-                    &c->io_out, &c->flags_a, &c->flags_b};
+  hipStreamSynchronize(c->acc_stream);
+  DevBuf* bufs[] = {&c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_out, &c->flags_a, &c->flags_b};
   for (auto b : bufs) b->release();
   for (auto& sl : c->slot) {
+    hipStreamSynchronize(sl.front);
     hipStreamSynchronize(sl.tail);
-    DevBuf* sb[] = {&sl.buckets, &sl.lvlR[0], &sl.lvlR[1], &sl.lvlT, &sl.tsum[0], &sl.tsum[1], &sl.wacc[0], &sl.wacc[1], &sl.wsums, &sl.result};
+    DevBuf* sb[] = {&sl.ent, &sl.sorted, &sl.hist, &sl.offs, &sl.cursor, &sl.bsum, &sl.items, &sl.heavy, &sl.ctrl,
+                    &sl.buckets, &sl.lvlR[0], &sl.lvlR[1], &sl.lvlT, &sl.tsum[0], &sl.tsum[1], &sl.wacc[0], &sl.wacc[1], &sl.wsums, &sl.result};
     for (auto b : sb) b->release();
-    hipEventDestroy(sl.ev_acc); hipEventDestroy(sl.ev_tail); hipStreamDestroy(sl.tail);
+    hipEventDestroy(sl.ev_in); hipEventDestroy(sl.ev_front); hipEventDestroy(sl.ev_acc); hipEventDestroy(sl.ev_tail);
+    hipStreamDestroy(sl.front); hipStreamDestroy(sl.tail);
   }
   for (auto& e : c->ev) hipEventDestroy(e);
+  hipStreamDestroy(c->acc_stream);
   hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -353,7 +370,8 @@ extern "C" int blsgpu_synchronize(blsgpu_ctx* c) {
   if (!c) return bad("ctx is NULL");
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
-  for (auto& sl : c->slot) { HIPCHK(hipStreamSynchronize(sl.tail)); sl.tail_pending = false; }
+  HIPCHK(hipStreamSynchronize(c->acc_stream));
+  for (auto& sl : c->slot) { HIPCHK(hipStreamSynchronize(sl.front)); HIPCHK(hipStreamSynchronize(sl.tail)); sl.tail_pending = false; }
   return BLSGPU_OK;
 }
 extern "C" int blsgpu_set_pipelining(blsgpu_ctx* c, int on) { if (!c) return bad("ctx is NULL"); c->pipelining = on != 0; return BLSGPU_OK; }
@@ -441,6 +459,7 @@ extern "C" size_t blsgpu_bases_len(const blsgpu_bases* b) { return b ? b->n : 0;
 extern "C" void blsgpu_bases_free(blsgpu_bases* b) {
   if (!b) return;
   hipSetDevice(b->device);
+  hipDeviceSynchronize();                  // an asynchronous MSM may still be reading the records
   if (b->rec) hipFree(b->rec);
   if (b->table) hipFree(b->table);
   delete b;
@@ -533,29 +552,30 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   const size_t total = (size_t)nwin * n;
   if (total > 0xfffffff0ull) return bad("msm: n * windows exceeds 2^32 entries");
   int bad_alloc = 0;
-  bad_alloc |= c->ent.reserve(total * 4);
-  bad_alloc |= c->sorted.reserve(total * 4);
+  blsgpu_ctx::Slot& sl = c->slot[c->next_slot];
+  c->next_slot = (c->next_slot + 1) % NSLOT;
+  hipStream_t ft = sl.front, tt = sl.tail;
+  // every buffer of this slot may still be in use by the call that used it last (NSLOT calls ago)
+  if (sl.tail_pending) { HIPCHK(hipStreamWaitEvent(ft, sl.ev_tail, 0)); HIPCHK(hipStreamWaitEvent(st, sl.ev_tail, 0)); }
+  bad_alloc |= sl.ent.reserve(total * 4);
+  bad_alloc |= sl.sorted.reserve(total * 4);
   {
     size_t hb = (nb > 3 * (size_t)SORT_MAX_COUNTERS + 4 ? nb : 3 * (size_t)SORT_MAX_COUNTERS + 4) * 4;
-    bool fresh = c->hist.cap < hb;
-    bad_alloc |= c->hist.reserve(hb);
-    if (fresh && !bad_alloc) HIPCHK(hipMemsetAsync(c->hist.p, 0, c->hist.cap, st));      // the sort keeps its counters zeroed between calls
+    bool fresh = sl.hist.cap < hb;
+    bad_alloc |= sl.hist.reserve(hb);
+    if (fresh && !bad_alloc) HIPCHK(hipMemsetAsync(sl.hist.p, 0, sl.hist.cap, ft));      // the sort keeps its counters zeroed between calls
   }
-  bad_alloc |= c->cursor.reserve(total * 4);      // per-entry rank inside its bucket
-  bad_alloc |= c->offs.reserve((nb + 1) * 4);
-  bad_alloc |= c->bsum.reserve(4096 * 4);
+  bad_alloc |= sl.cursor.reserve(total * 4);      // per-entry rank inside its bucket
+  bad_alloc |= sl.offs.reserve((nb + 1) * 4);
+  bad_alloc |= sl.bsum.reserve(4096 * 4);
   // item cap: ~4x the mean bucket load, so that with uniform scalars (almost) no bucket is cut
   u32 cap = 128;
   while (cap < ITEM_CAP_MAX && (size_t)cap * nbw < 4 * n) cap *= 2;
   const size_t max_items = total / cap + nb + 1;                // every bucket has >= 1 item
   const size_t max_records = nb + max_items;                    // bucket sums + partial sums of heavy buckets
-  bad_alloc |= c->items.reserve(max_items * sizeof(ItemDesc));
-  bad_alloc |= c->heavy.reserve(nb * sizeof(uint4));
-  bad_alloc |= c->ctrl.reserve((4 + 2 * ITEM_BINS) * 4);
-  blsgpu_ctx::Slot& sl = c->slot[c->next_slot];
-  c->next_slot = (c->next_slot + 1) % NSLOT;
-  // the slot's buffers may still be read by the tail of the call before last
-  if (sl.tail_pending) HIPCHK(hipStreamWaitEvent(st, sl.ev_tail, 0));
+  bad_alloc |= sl.items.reserve(max_items * sizeof(ItemDesc));
+  bad_alloc |= sl.heavy.reserve(nb * sizeof(uint4));
+  bad_alloc |= sl.ctrl.reserve((4 + 2 * ITEM_BINS) * 4);
   {
     // (re)allocation frees memory: make sure nothing of this slot is in flight
     size_t lvl = (nb / 2 + 1) * PW * 4;
@@ -569,9 +589,11 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     bad_alloc |= sl.result.reserve(PW * 4);
   }
   if (bad_alloc) { g_err = "hipMalloc(msm scratch) failed"; return BLSGPU_ERR_HIP; }
-  hipStream_t tt = sl.tail;
   const bool prof = c->profiling;
-  auto mark = [&](int i) { if (prof) hipEventRecord(c->ev[i], st); };
+  auto mark = [&](int i) { if (prof) hipEventRecord(c->ev[i], ft); };
+  // the front stream starts after whatever produced the scalars on the caller's stream
+  HIPCHK(hipEventRecord(sl.ev_in, st));
+  HIPCHK(hipStreamWaitEvent(ft, sl.ev_in, 0));
 
   mark(0);
   const bool fast_sort = merged || ((n <= ((size_t)1 << 24)) && cw <= 16 && cw >= 2);
@@ -584,66 +606,70 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     const int nc = nseg * ncoarse;
     if (nc > SORT_MAX_COUNTERS) return bad("msm: window configuration exceeds the sort's counter table");
     // fixed layout: [MAX] counts (kept zero between calls) | [MAX+1] bases | [MAX] cursors
-    u32* ghist = c->hist.as<u32>();
+    u32* ghist = sl.hist.as<u32>();
     u32* gbase = ghist + SORT_MAX_COUNTERS;
     u32* gcur = gbase + SORT_MAX_COUNTERS + 1;
-    if (c->hist_dirty) { HIPCHK(hipMemsetAsync(ghist, 0, (size_t)SORT_MAX_COUNTERS * 4, st)); c->hist_dirty = false; }
+    if (sl.hist_dirty) { HIPCHK(hipMemsetAsync(ghist, 0, (size_t)SORT_MAX_COUNTERS * 4, ft)); sl.hist_dirty = false; }
     const unsigned tiles = nblk(n, SORT_TILE);
-    hipLaunchKernelGGL(k_sort_hist, dim3(tiles), dim3(256), (size_t)nc * 4, st, (const u32*)d_scalars, ghist, (int)n, cw, nwin, fine_bits, ncoarse, merged ? 1 : 0);
+    hipLaunchKernelGGL(k_sort_hist, dim3(tiles), dim3(256), (size_t)nc * 4, ft, (const u32*)d_scalars, ghist, (int)n, cw, nwin, fine_bits, ncoarse, merged ? 1 : 0);
     LAUNCHCHK();
     mark(1);
-    hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, st, ghist, gbase, gcur, nc, c->ctrl.as<u32>(), 4 + 2 * ITEM_BINS);
+    hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, ft, ghist, gbase, gcur, nc, sl.ctrl.as<u32>(), 4 + 2 * ITEM_BINS);
     LAUNCHCHK();
     mark(2);
-    hipLaunchKernelGGL(k_sort_scatter, dim3(tiles), dim3(256), (size_t)nc * 8, st, (const u32*)d_scalars, gbase, gcur, c->ent.as<u32>(), (int)n, cw, nwin,
+    hipLaunchKernelGGL(k_sort_scatter, dim3(tiles), dim3(256), (size_t)nc * 8, ft, (const u32*)d_scalars, gbase, gcur, sl.ent.as<u32>(), (int)n, cw, nwin,
                        fine_bits, ncoarse, merged ? 1 : 0, (u32)bases->n);
-    hipLaunchKernelGGL(k_sort_fine, dim3(nc), dim3(256), 0, st, c->ent.as<u32>(), gbase, c->sorted.as<u32>(), c->offs.as<u32>(), fine_bits, nc);
+    hipLaunchKernelGGL(k_sort_fine, dim3(nc), dim3(256), 0, ft, sl.ent.as<u32>(), gbase, sl.sorted.as<u32>(), sl.offs.as<u32>(), fine_bits, nc);
     LAUNCHCHK();
     mark(3);
   } else {
     // 1. digits + histogram
-    c->hist_dirty = true;
-    HIPCHK(hipMemsetAsync(c->hist.p, 0, nb * 4, st));
-    HIPCHK(hipMemsetAsync(c->ctrl.p, 0, (4 + 2 * ITEM_BINS) * 4, st));
-    hipLaunchKernelGGL(k_msm_digits, dim3(nblk(n, 256)), dim3(256), 0, st, (const u32*)d_scalars, c->ent.as<u32>(), c->cursor.as<u32>(), c->hist.as<u32>(), (int)n, cw, nwin);
+    sl.hist_dirty = true;
+    HIPCHK(hipMemsetAsync(sl.hist.p, 0, nb * 4, ft));
+    HIPCHK(hipMemsetAsync(sl.ctrl.p, 0, (4 + 2 * ITEM_BINS) * 4, ft));
+    hipLaunchKernelGGL(k_msm_digits, dim3(nblk(n, 256)), dim3(256), 0, ft, (const u32*)d_scalars, sl.ent.as<u32>(), sl.cursor.as<u32>(), sl.hist.as<u32>(), (int)n, cw, nwin);
     LAUNCHCHK();
     mark(1);
     // 2. scan
     unsigned sb = nblk(nb, 1024);
     if (sb > 4096) return bad("msm: too many buckets");
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(sb), dim3(256), 0, st, c->hist.as<u32>(), c->bsum.as<u32>(), (int)nb);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, c->bsum.as<u32>(), (int)sb);
-    hipLaunchKernelGGL(k_scan_apply, dim3(sb), dim3(256), 0, st, c->hist.as<u32>(), c->bsum.as<u32>(), c->offs.as<u32>(), (int)nb);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(sb), dim3(256), 0, ft, sl.hist.as<u32>(), sl.bsum.as<u32>(), (int)nb);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, ft, sl.bsum.as<u32>(), (int)sb);
+    hipLaunchKernelGGL(k_scan_apply, dim3(sb), dim3(256), 0, ft, sl.hist.as<u32>(), sl.bsum.as<u32>(), sl.offs.as<u32>(), (int)nb);
     LAUNCHCHK();
     mark(2);
     // 3. scatter
-    hipLaunchKernelGGL(k_msm_scatter, dim3(nblk(total, 256)), dim3(256), 0, st, c->ent.as<u32>(), c->cursor.as<u32>(), c->offs.as<u32>(), c->sorted.as<u32>(),
+    hipLaunchKernelGGL(k_msm_scatter, dim3(nblk(total, 256)), dim3(256), 0, ft, sl.ent.as<u32>(), sl.cursor.as<u32>(), sl.offs.as<u32>(), sl.sorted.as<u32>(),
                        (int)n, total);
     LAUNCHCHK();
     mark(3);
   }
   // 4. work items
-  u32* ctrl = c->ctrl.as<u32>();
+  u32* ctrl = sl.ctrl.as<u32>();
   u32* bins = ctrl + 4;
   u32* bcur = ctrl + 4 + ITEM_BINS;
-  hipLaunchKernelGGL(k_item_count, dim3(nblk(nb, 256)), dim3(256), 0, st, c->offs.as<u32>(), bins, ctrl, (int)nb, cap);
-  hipLaunchKernelGGL(k_item_scan, dim3(1), dim3(256), 0, st, bins, ctrl, cap);
-  hipLaunchKernelGGL(k_item_fill, dim3(nblk(nb, 256)), dim3(256), 0, st, c->offs.as<u32>(), bins, bcur, ctrl, c->items.as<ItemDesc>(),
-                     c->heavy.as<uint4>(), (int)nb, cap);
+  hipLaunchKernelGGL(k_item_count, dim3(nblk(nb, 256)), dim3(256), 0, ft, sl.offs.as<u32>(), bins, ctrl, (int)nb, cap);
+  hipLaunchKernelGGL(k_item_scan, dim3(1), dim3(256), 0, ft, bins, ctrl, cap);
+  hipLaunchKernelGGL(k_item_fill, dim3(nblk(nb, 256)), dim3(256), 0, ft, sl.offs.as<u32>(), bins, bcur, ctrl, sl.items.as<ItemDesc>(),
+                     sl.heavy.as<uint4>(), (int)nb, cap);
   LAUNCHCHK();
   mark(4);
+  HIPCHK(hipEventRecord(sl.ev_front, ft));
+  // pipelined calls accumulate on the library's own stream: front(i+1) must not queue behind accumulate(i)
+  hipStream_t as = c->pipelining ? c->acc_stream : st;
+  HIPCHK(hipStreamWaitEvent(as, sl.ev_front, 0));
   // 5. accumulate (grid covers the worst-case item count; surplus lanes exit on ctrl[2])
   u32* records = sl.buckets.as<u32>();
   const u32* base_rec = (merged ? bases->table : bases->rec) + first * Store<F>::AFF_WORDS;
   if constexpr (GroupTag<F>::id == 2)
-    hipLaunchKernelGGL(k_msm_accumulate_g2pair, dim3(nblk(2 * max_items, 256)), dim3(256), 0, st, base_rec, c->sorted.as<u32>(), c->items.as<ItemDesc>(), ctrl, records);
+    hipLaunchKernelGGL(k_msm_accumulate_g2pair, dim3(nblk(2 * max_items, 256)), dim3(256), 0, as, base_rec, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
   else
-    hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(max_items, 256)), dim3(256), 0, st, base_rec, c->sorted.as<u32>(), c->items.as<ItemDesc>(), ctrl, records);
-  hipLaunchKernelGGL(k_msm_heavy<F>, dim3(HEAVY_SMALL_BLOCKS + 512), dim3(256), 0, st, c->heavy.as<uint4>(), ctrl, records);
+    hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(max_items, 256)), dim3(256), 0, as, base_rec, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
+  hipLaunchKernelGGL(k_msm_heavy<F>, dim3(HEAVY_SMALL_BLOCKS + 512), dim3(256), 0, as, sl.heavy.as<uint4>(), ctrl, records);
   LAUNCHCHK();
-  mark(5);
+  if (prof) hipEventRecord(c->ev[5], as);
   // ---- tail on the slot's own stream ---------------------------------------------------------------
-  HIPCHK(hipEventRecord(sl.ev_acc, st));
+  HIPCHK(hipEventRecord(sl.ev_acc, as));
   HIPCHK(hipStreamWaitEvent(tt, sl.ev_acc, 0));
   // 6. per-window weighted sums:  wsum = sum_g T_g + M * wsum0(R)
   {
