@@ -852,7 +852,7 @@ static int elem_op(blsgpu_ctx* c, int words, int kind, int op, const uint64_t* a
   const u32* bp = b ? c->io_b.as<u32>() : nullptr;
   if (kind == 1) hipLaunchKernelGGL(k_fp_op, dim3(nblk(n, 256)), dim3(256), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
   else if (kind == 2) hipLaunchKernelGGL(k_fp2_op, dim3(nblk(n, 256)), dim3(256), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
-  else hipLaunchKernelGGL(k_fp12_op, dim3(nblk(n, 64)), dim3(64), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
+  else hipLaunchKernelGGL(k_fp12_op, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
   LAUNCHCHK();
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -921,7 +921,7 @@ extern "C" int blsgpu_mad_throughput(blsgpu_ctx* c, int iters, double* r) { retu
 // ---------------------------------------------------------------------------------------------------
 static int pairing_launch(blsgpu_ctx* c, int mode, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) {
   // mode 0: full pairing, 1: Miller loop only
-  hipLaunchKernelGGL(k_pairing, dim3(nblk(n, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, mode, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2,
+  hipLaunchKernelGGL(k_pairing, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, mode, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2,
                      (const uint8_t*)g2inf, (u32*)out, n);
   LAUNCHCHK();
   return BLSGPU_OK;
@@ -968,7 +968,7 @@ static int fp12_product_device(blsgpu_ctx* c, const u32* d_in, size_t n, u32* d_
   while (n > 1) {
     size_t m = (n + FP12_PROD_FAN - 1) / FP12_PROD_FAN;
     u32* o = (m == 1) ? d_out : (flip ? c->io_d.as<u32>() : c->io_c.as<u32>());
-    hipLaunchKernelGGL(k_fp12_prod, dim3(nblk(m, 64)), dim3(64), 0, c->stream, in, o, n, m);
+    hipLaunchKernelGGL(k_fp12_prod, dim3(nblk(m * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, in, o, n, m);
     LAUNCHCHK();
     in = o; n = m; flip ^= 1;
   }
@@ -1006,7 +1006,7 @@ extern "C" int blsgpu_final_exponentiation_batch(blsgpu_ctx* c, const uint64_t* 
   HIPCHK(hipSetDevice(c->device));
   if (c->io_a.reserve(n * 576) || c->io_out.reserve(n * 576)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
   HIPCHK(hipMemcpyAsync(c->io_a.p, in, n * 576, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_final_exp, dim3(nblk(n, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, c->io_a.as<u32>(), c->io_out.as<u32>(), n);
+  hipLaunchKernelGGL(k_final_exp, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, c->io_a.as<u32>(), c->io_out.as<u32>(), n);
   LAUNCHCHK();
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, n * 576, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));

@@ -480,12 +480,14 @@ DEV bool fe_eq(const Fe<A1, V1>& a, const Fe<A2, V2>& b) {
 DEVNI v16 fe_inv_raw(v16 xin) {
   constexpr u64 e[6] = BLS_P_MINUS_2_U64;
   fe x = (fe)from_v16<2>(xin);
-  // table x^1..x^15
+  // table x^1..x^15, indexed with a run-time digit: it lives in per-lane scratch, not in 210 registers
   fe tab[15];
   tab[0] = x;
+#pragma nounroll
   for (int i = 1; i < 15; i++) tab[i] = (fe)mul(tab[i - 1], x);
   fe acc = fe_one();
   bool started = false;
+#pragma nounroll
   for (int w = 95; w >= 0; w--) {
     u32 d = (u32)(e[w >> 4] >> ((w & 15) * 4)) & 15u;
     if (started) {
@@ -493,8 +495,7 @@ DEVNI v16 fe_inv_raw(v16 xin) {
     }
     if (d) {
       // uniform across the wave: exponent is a constant
-      fe t = tab[0];
-      for (int j = 1; j < 15; j++) if ((int)d == j + 1) t = tab[j];
+      fe t = tab[d - 1];
       acc = started ? (fe)mul(acc, t) : t;
       started = true;
     }

@@ -1,4 +1,4 @@
-// pairing.cuh -- Fp6 / Fp12 towers, Miller loop and final exponentiation, one pairing per lane.
+// pairing.cuh -- Fp6 / Fp12 towers, Miller loop and final exponentiation.
 //
 // Reference: /root/reference/src/fp6.rs (mul :200-274, square :277-291, mul_by_1 :113-119, mul_by_01
 // :121-136, mul_by_nonresidue :139-150, frobenius_map :154-188, invert :294-312), src/fp12.rs (mul
@@ -14,46 +14,80 @@
 // different (Karatsuba / sum-of-products) groupings than the reference's, which changes nothing: every
 // value is an exact field element and is serialised only after full reduction.
 //
-// The loop schedule is a compile-time constant, so all 64 lanes of a wavefront stay converged.  Tower
-// elements live in the storage form fe2 (limbs normalised, value < 32p); the out-of-line helpers take
-// them by reference, i.e. operands are staged in per-lane scratch and streamed through the VGPRs.
+// The loop schedule is a compile-time constant, so all 64 lanes of a wavefront stay converged.  The code is
+// generic over the Fp2 element type E:
+//   E = fe2          one pairing per lane (Fp2 = two Fe in one lane; Fp12 = 168 registers),
+//   E = fp2p         one pairing per PAIR of lanes (pairlane.cuh: lane 2k holds every c0 coefficient, lane 2k+1
+//                    every c1; Fp12 = 84 registers per lane), the form the kernels use.
+// Tower elements live in the storage form (limbs normalised, value < 32p); the out-of-line helpers take them by
+// reference, i.e. operands are staged in per-lane scratch and streamed through the VGPRs.
 #pragma once
 #include "convert.cuh"
+#include "pairlane.cuh"
 
 namespace bls {
 
-struct Fp6 { fe2 c0, c1, c2; };
-struct Fp12 { Fp6 c0, c1; };
+template <class E> struct Fp6T { E c0, c1, c2; };
+template <class E> struct Fp12T { Fp6T<E> c0, c1; };
+typedef FeP<1, VS2> fp2p;             // working Fp2 value over a lane pair
 
-constexpr int PAIRING_BLOCK = 64;
+// ---- element traits: what differs between the one-lane and the pair-lane Fp2 ------------------------------
+template <class E> struct E2;
+template <> struct E2<fe2> {
+  static constexpr int LANES = 1;                 // lanes per tower element
+  static DEV fe2 zero() { return fe2_zero(); }
+  static DEV fe2 one() { return fe2_one(); }
+  static DEV fe2 konst(const PLimbs& k0, const PLimbs& k1) { fe2 K; K.c0 = (Fe<1, VS2>)fe1_const(k0); K.c1 = (Fe<1, VS2>)fe1_const(k1); return K; }
+  static DEV fe2 load(const u32* w) { return (fe2)fe2_from_ref(w); }
+  static DEV void save(const fe2& a, u32* w) { fe2_to_ref(a, w); }
+};
+template <> struct E2<fp2p> {
+  static constexpr int LANES = 2;
+  static DEV fp2p zero() { return Fp2PairPolicy::zero(); }
+  static DEV fp2p one() { return Fp2PairPolicy::one(); }
+  static DEV fp2p konst(const PLimbs& k0, const PLimbs& k1) { fp2p K; K.v = select(lane_is_c1(), (Fe<1, VS2>)fe1_const(k1), (Fe<1, VS2>)fe1_const(k0)); return K; }
+  static DEV fp2p load(const u32* w) { fp2p r; r.v = (Fe<1, VS2>)fe_from_ref(w + (lane_is_c1() ? 12 : 0)); return r; }
+  static DEV void save(const fp2p& a, u32* w) { fe_to_ref(a.v, w + (lane_is_c1() ? 12 : 0)); }
+};
+template <int A, int V> DEV fe2 st2(const Fe2<A, V>& a) { return store2(a); }
+template <int A, int V> DEV fp2p st2(const FeP<A, V>& a) { return Fp2PairPolicy::st(a); }
+template <int A1, int V1, int A2, int V2> DEV auto pmul(const Fe2<A1, V1>& a, const Fe2<A2, V2>& b) { return mul(a, b); }
+template <int A1, int V1, int A2, int V2> DEV auto pmul(const FeP<A1, V1>& a, const FeP<A2, V2>& b) { return mul_ni(a, b); }
+template <int A, int V> DEV auto psqr(const Fe2<A, V>& a) { return sqr(a); }
+template <int A, int V> DEV auto psqr(const FeP<A, V>& a) { return sqr_ni(a); }
+// (a0 + a1 u) u = -a1 + a0 u
+template <int A, int V> DEV auto mul_by_u(const Fe2<A, V>& a) { Fe2<A + 1, V + 1> r; r.c0 = neg(a.c1); r.c1 = a.c0; return r; }
+
+constexpr int PAIRING_BLOCK = 256;       // 128 pairings per workgroup
+constexpr int PAIRING_WAVES = 2;         // wavefronts per SIMD the register budget is set for
 constexpr int FP12_PROD_FAN = 8;
 
-#define S2(x) store2(x)
+#define S2(x) st2(x)
 
-DEV Fp6 fp6_zero() { Fp6 r; r.c0 = fe2_zero(); r.c1 = fe2_zero(); r.c2 = fe2_zero(); return r; }
-DEV Fp6 fp6_one() { Fp6 r; r.c0 = fe2_one(); r.c1 = fe2_zero(); r.c2 = fe2_zero(); return r; }
-DEV Fp12 fp12_one() { Fp12 r; r.c0 = fp6_one(); r.c1 = fp6_zero(); return r; }
+template <class E> DEV Fp6T<E> fp6_zero() { Fp6T<E> r; r.c0 = E2<E>::zero(); r.c1 = E2<E>::zero(); r.c2 = E2<E>::zero(); return r; }
+template <class E> DEV Fp6T<E> fp6_one() { Fp6T<E> r; r.c0 = E2<E>::one(); r.c1 = E2<E>::zero(); r.c2 = E2<E>::zero(); return r; }
+template <class E> DEV Fp12T<E> fp12_one() { Fp12T<E> r; r.c0 = fp6_one<E>(); r.c1 = fp6_zero<E>(); return r; }
 
-DEV Fp6 fp6_add(const Fp6& a, const Fp6& b) {
-  Fp6 r; r.c0 = S2(add(a.c0, b.c0)); r.c1 = S2(add(a.c1, b.c1)); r.c2 = S2(add(a.c2, b.c2)); return r;
+template <class E> DEV Fp6T<E> fp6_add(const Fp6T<E>& a, const Fp6T<E>& b) {
+  Fp6T<E> r; r.c0 = S2(add(a.c0, b.c0)); r.c1 = S2(add(a.c1, b.c1)); r.c2 = S2(add(a.c2, b.c2)); return r;
 }
-DEV Fp6 fp6_sub(const Fp6& a, const Fp6& b) {
-  Fp6 r; r.c0 = S2(sub(a.c0, b.c0)); r.c1 = S2(sub(a.c1, b.c1)); r.c2 = S2(sub(a.c2, b.c2)); return r;
+template <class E> DEV Fp6T<E> fp6_sub(const Fp6T<E>& a, const Fp6T<E>& b) {
+  Fp6T<E> r; r.c0 = S2(sub(a.c0, b.c0)); r.c1 = S2(sub(a.c1, b.c1)); r.c2 = S2(sub(a.c2, b.c2)); return r;
 }
-DEV Fp6 fp6_neg(const Fp6& a) { Fp6 r; r.c0 = S2(neg(a.c0)); r.c1 = S2(neg(a.c1)); r.c2 = S2(neg(a.c2)); return r; }
+template <class E> DEV Fp6T<E> fp6_neg(const Fp6T<E>& a) { Fp6T<E> r; r.c0 = S2(neg(a.c0)); r.c1 = S2(neg(a.c1)); r.c2 = S2(neg(a.c2)); return r; }
 // multiply by v  (fp6.rs:139-150)
-DEV Fp6 fp6_mul_by_nonresidue(const Fp6& a) {
-  Fp6 r; r.c0 = S2(mul_by_nonresidue(a.c2)); r.c1 = a.c0; r.c2 = a.c1; return r;
+template <class E> DEV Fp6T<E> fp6_mul_by_nonresidue(const Fp6T<E>& a) {
+  Fp6T<E> r; r.c0 = S2(mul_by_nonresidue(a.c2)); r.c1 = a.c0; r.c2 = a.c1; return r;
 }
 
 // Karatsuba over Fp2 (6 Fp2 products); same element as fp6.rs:200-274
-DEV void fp6_mul(Fp6& r, const Fp6& a, const Fp6& b) {
-  auto v0 = mul(a.c0, b.c0);
-  auto v1 = mul(a.c1, b.c1);
-  auto v2 = mul(a.c2, b.c2);
-  auto t12 = mul(add(a.c1, a.c2), add(b.c1, b.c2));
-  auto t01 = mul(add(a.c0, a.c1), add(b.c0, b.c1));
-  auto t02 = mul(add(a.c0, a.c2), add(b.c0, b.c2));
+template <class E> DEV void fp6_mul(Fp6T<E>& r, const Fp6T<E>& a, const Fp6T<E>& b) {
+  auto v0 = pmul(a.c0, b.c0);
+  auto v1 = pmul(a.c1, b.c1);
+  auto v2 = pmul(a.c2, b.c2);
+  auto t12 = pmul(add(a.c1, a.c2), add(b.c1, b.c2));
+  auto t01 = pmul(add(a.c0, a.c1), add(b.c0, b.c1));
+  auto t02 = pmul(add(a.c0, a.c2), add(b.c0, b.c2));
   auto x12 = norm(sub(sub(t12, v1), v2));                 // a1 b2 + a2 b1
   auto c0 = add(v0, mul_by_nonresidue(x12));
   auto x01 = norm(sub(sub(t01, v0), v1));                 // a0 b1 + a1 b0
@@ -63,178 +97,178 @@ DEV void fp6_mul(Fp6& r, const Fp6& a, const Fp6& b) {
   r.c0 = S2(c0); r.c1 = S2(c1); r.c2 = S2(c2);
 }
 // fp6.rs:277-291
-DEVNI void fp6_sqr(Fp6& r, const Fp6& a) {
-  auto s0 = sqr(a.c0);
-  auto ab = mul(a.c0, a.c1);
+template <class E> DEVNI void fp6_sqr(Fp6T<E>& r, const Fp6T<E>& a) {
+  auto s0 = psqr(a.c0);
+  auto ab = pmul(a.c0, a.c1);
   auto s1 = dbl(ab);
-  auto s2 = sqr(norm(add(sub(a.c0, a.c1), a.c2)));
-  auto bc = mul(a.c1, a.c2);
+  auto s2 = psqr(norm(add(sub(a.c0, a.c1), a.c2)));
+  auto bc = pmul(a.c1, a.c2);
   auto s3 = dbl(bc);
-  auto s4 = sqr(a.c2);
+  auto s4 = psqr(a.c2);
   auto c0 = add(mul_by_nonresidue(norm(s3)), s0);
   auto c1 = add(mul_by_nonresidue(s4), s1);
   auto c2 = sub(sub(norm(add(add(s1, s2), s3)), s0), s4);
   r.c0 = S2(c0); r.c1 = S2(c1); r.c2 = S2(c2);
 }
 // fp6.rs:113-119
-DEV void fp6_mul_by_1(Fp6& r, const Fp6& a, const fe2& c1) {
-  auto t0 = mul(a.c2, c1);
-  auto t1 = mul(a.c0, c1);
-  auto t2 = mul(a.c1, c1);
+template <class E> DEV void fp6_mul_by_1(Fp6T<E>& r, const Fp6T<E>& a, const E& c1) {
+  auto t0 = pmul(a.c2, c1);
+  auto t1 = pmul(a.c0, c1);
+  auto t2 = pmul(a.c1, c1);
   r.c0 = S2(mul_by_nonresidue(t0)); r.c1 = S2(t1); r.c2 = S2(t2);
 }
 // fp6.rs:121-136
-DEV void fp6_mul_by_01(Fp6& r, const Fp6& a, const fe2& c0, const fe2& c1) {
-  auto a_a = mul(a.c0, c0);
-  auto b_b = mul(a.c1, c1);
-  auto t1 = add(mul_by_nonresidue(mul(a.c2, c1)), a_a);
-  auto t2 = sub(sub(mul(add(c0, c1), add(a.c0, a.c1)), a_a), b_b);
-  auto t3 = add(mul(a.c2, c0), b_b);
+template <class E> DEV void fp6_mul_by_01(Fp6T<E>& r, const Fp6T<E>& a, const E& c0, const E& c1) {
+  auto a_a = pmul(a.c0, c0);
+  auto b_b = pmul(a.c1, c1);
+  auto t1 = add(mul_by_nonresidue(pmul(a.c2, c1)), a_a);
+  auto t2 = sub(sub(pmul(add(c0, c1), add(a.c0, a.c1)), a_a), b_b);
+  auto t3 = add(pmul(a.c2, c0), b_b);
   r.c0 = S2(t1); r.c1 = S2(t2); r.c2 = S2(t3);
 }
 // fp6.rs:154-188
-DEVNI void fp6_frobenius(Fp6& r, const Fp6& a) {
+template <class E> DEVNI void fp6_frobenius(Fp6T<E>& r, const Fp6T<E>& a) {
   constexpr PLimbs k1 = {BLS_FROB6_C1_1}, k2 = {BLS_FROB6_C2_0};
   auto c0 = conj(a.c0);
   auto c1 = norm(conj(a.c1));
   auto c2 = norm(conj(a.c2));
-  // c1 * (0 + k1 u) = (-c1.c1 k1) + (c1.c0 k1) u
+  // c1 * (0 + k1 u) = (c1 u) k1
   fe1 K1 = fe1_const(k1), K2 = fe1_const(k2);
-  Fe2<1, 2> m1; m1.c0 = (Fe<1, 2>)mul(norm(neg(c1.c1)), K1); m1.c1 = (Fe<1, 2>)mul(c1.c0, K1);
+  auto m1 = mul_fp(norm(mul_by_u(c1)), K1);
   auto m2 = mul_fp(c2, K2);
   r.c0 = S2(c0); r.c1 = S2(m1); r.c2 = S2(m2);
 }
 // fp6.rs:294-312
-DEVNI void fp6_inv(Fp6& r, const Fp6& a) {
-  auto c0 = norm(sub(sqr(a.c0), mul_by_nonresidue(mul(a.c1, a.c2))));
-  auto c1 = norm(sub(mul_by_nonresidue(sqr(a.c2)), mul(a.c0, a.c1)));
-  auto c2 = norm(sub(sqr(a.c1), mul(a.c0, a.c2)));
-  auto t = norm(add(mul_by_nonresidue(norm(add(mul(a.c1, c2), mul(a.c2, c1)))), mul(a.c0, c0)));
+template <class E> DEVNI void fp6_inv(Fp6T<E>& r, const Fp6T<E>& a) {
+  auto c0 = norm(sub(psqr(a.c0), mul_by_nonresidue(pmul(a.c1, a.c2))));
+  auto c1 = norm(sub(mul_by_nonresidue(psqr(a.c2)), pmul(a.c0, a.c1)));
+  auto c2 = norm(sub(psqr(a.c1), pmul(a.c0, a.c2)));
+  auto t = norm(add(mul_by_nonresidue(norm(add(pmul(a.c1, c2), pmul(a.c2, c1)))), pmul(a.c0, c0)));
   auto ti = inv(t);
-  r.c0 = S2(mul(ti, c0)); r.c1 = S2(mul(ti, c1)); r.c2 = S2(mul(ti, c2));
+  r.c0 = S2(pmul(ti, c0)); r.c1 = S2(pmul(ti, c1)); r.c2 = S2(pmul(ti, c2));
 }
 
-// ---- Fp12 --------------------------------------------------------------------------------------------
+// ---- Fp12T<E> --------------------------------------------------------------------------------------------
 // fp12.rs:197-214
-DEVNI void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) {
-  Fp6 aa, bb, t;
+template <class E> DEVNI void fp12_mul(Fp12T<E>& r, const Fp12T<E>& a, const Fp12T<E>& b) {
+  Fp6T<E> aa, bb, t;
   fp6_mul(aa, a.c0, b.c0);
   fp6_mul(bb, a.c1, b.c1);
-  Fp6 o = fp6_add(b.c0, b.c1);
-  Fp6 s = fp6_add(a.c1, a.c0);
+  Fp6T<E> o = fp6_add(b.c0, b.c1);
+  Fp6T<E> s = fp6_add(a.c1, a.c0);
   fp6_mul(t, s, o);
   r.c1 = fp6_sub(fp6_sub(t, aa), bb);
   r.c0 = fp6_add(fp6_mul_by_nonresidue(bb), aa);
 }
 // fp12.rs:174-185
-DEVNI void fp12_sqr(Fp12& r, const Fp12& a) {
-  Fp6 ab, t;
+template <class E> DEVNI void fp12_sqr(Fp12T<E>& r, const Fp12T<E>& a) {
+  Fp6T<E> ab, t;
   fp6_mul(ab, a.c0, a.c1);
-  Fp6 c0c1 = fp6_add(a.c0, a.c1);
-  Fp6 c0 = fp6_add(fp6_mul_by_nonresidue(a.c1), a.c0);
+  Fp6T<E> c0c1 = fp6_add(a.c0, a.c1);
+  Fp6T<E> c0 = fp6_add(fp6_mul_by_nonresidue(a.c1), a.c0);
   fp6_mul(t, c0, c0c1);
   t = fp6_sub(t, ab);
   r.c1 = fp6_add(ab, ab);
   r.c0 = fp6_sub(t, fp6_mul_by_nonresidue(ab));
 }
 // fp12.rs:116-128
-DEVNI void fp12_mul_by_014(Fp12& r, const Fp12& a, const fe2& c0, const fe2& c1, const fe2& c4) {
-  Fp6 aa, bb, t;
+template <class E> DEVNI void fp12_mul_by_014(Fp12T<E>& r, const Fp12T<E>& a, const E& c0, const E& c1, const E& c4) {
+  Fp6T<E> aa, bb, t;
   fp6_mul_by_01(aa, a.c0, c0, c1);
   fp6_mul_by_1(bb, a.c1, c4);
-  fe2 o = S2(add(c1, c4));
-  Fp6 s = fp6_add(a.c1, a.c0);
+  E o = S2(add(c1, c4));
+  Fp6T<E> s = fp6_add(a.c1, a.c0);
   fp6_mul_by_01(t, s, c0, o);
   r.c1 = fp6_sub(fp6_sub(t, aa), bb);
   r.c0 = fp6_add(fp6_mul_by_nonresidue(bb), aa);
 }
-DEV void fp12_conj(Fp12& r, const Fp12& a) { Fp6 n = fp6_neg(a.c1); r.c0 = a.c0; r.c1 = n; }
+template <class E> DEV void fp12_conj(Fp12T<E>& r, const Fp12T<E>& a) { Fp6T<E> n = fp6_neg(a.c1); r.c0 = a.c0; r.c1 = n; }
 // fp12.rs:145-171
-DEVNI void fp12_frobenius(Fp12& r, const Fp12& a) {
+template <class E> DEVNI void fp12_frobenius(Fp12T<E>& r, const Fp12T<E>& a) {
   constexpr PLimbs k0 = {BLS_FROB12_C1_0}, k1 = {BLS_FROB12_C1_1};
-  Fp6 c0, c1;
+  Fp6T<E> c0, c1;
   fp6_frobenius(c0, a.c0);
   fp6_frobenius(c1, a.c1);
-  fe2 K; K.c0 = (Fe<1, VS2>)fe1_const(k0); K.c1 = (Fe<1, VS2>)fe1_const(k1);
+  E K = E2<E>::konst(k0, k1);
   r.c0 = c0;
-  r.c1.c0 = S2(mul(c1.c0, K)); r.c1.c1 = S2(mul(c1.c1, K)); r.c1.c2 = S2(mul(c1.c2, K));
+  r.c1.c0 = S2(pmul(c1.c0, K)); r.c1.c1 = S2(pmul(c1.c1, K)); r.c1.c2 = S2(pmul(c1.c2, K));
 }
 // fp12.rs:187-194
-DEVNI void fp12_inv(Fp12& r, const Fp12& a) {
-  Fp6 s0, s1, t, ti;
+template <class E> DEVNI void fp12_inv(Fp12T<E>& r, const Fp12T<E>& a) {
+  Fp6T<E> s0, s1, t, ti;
   fp6_sqr(s0, a.c0);
   fp6_sqr(s1, a.c1);
   t = fp6_sub(s0, fp6_mul_by_nonresidue(s1));
   fp6_inv(ti, t);
   fp6_mul(r.c0, a.c0, ti);
-  Fp6 nt = fp6_neg(ti);
+  Fp6T<E> nt = fp6_neg(ti);
   fp6_mul(r.c1, a.c1, nt);
 }
 
 // ---- wire I/O ------------------------------------------------------------------------------------------
-DEV void fp12_load(Fp12& f, const u32* w) {
-  fe2* e[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+template <class E> DEV void fp12_load(Fp12T<E>& f, const u32* w) {
+  E* e[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
 #pragma unroll
-  for (int i = 0; i < 6; i++) { fe2_1 t = fe2_from_ref(w + 24 * i); *e[i] = (fe2)t; }
+  for (int i = 0; i < 6; i++) *e[i] = E2<E>::load(w + 24 * i);
 }
-DEV void fp12_save(const Fp12& f, u32* w) {
-  const fe2* e[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+template <class E> DEV void fp12_save(const Fp12T<E>& f, u32* w) {
+  const E* e[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
 #pragma unroll
-  for (int i = 0; i < 6; i++) fe2_to_ref(*e[i], w + 24 * i);
+  for (int i = 0; i < 6; i++) E2<E>::save(*e[i], w + 24 * i);
 }
 
 // ---- Miller loop -------------------------------------------------------------------------------------
-struct G2Jac { fe2 x, y, z; };       // the pairing's running point R (pairings.rs:709-770 operate on G2Projective fields)
-struct Line { fe2 a, b, c; };        // the (Fp2, Fp2, Fp2) coefficient triple
+template <class E> struct G2JacT { E x, y, z; };       // the pairing's running point R (pairings.rs:709-770 operate on G2Projective fields)
+template <class E> struct LineT { E a, b, c; };        // the (Fp2, Fp2, Fp2) coefficient triple
 
 // pairings.rs:709-738 (CLN Algorithm 26)
-DEVNI void doubling_step(G2Jac& r, Line& l) {
-  auto tmp0 = sqr(r.x);
-  auto tmp1 = sqr(r.y);
-  auto tmp2 = sqr(tmp1);
-  auto tmp3 = norm(sub(sub(sqr(add(tmp1, r.x)), tmp0), tmp2));
+template <class E> DEVNI void doubling_step(G2JacT<E>& r, LineT<E>& l) {
+  auto tmp0 = psqr(r.x);
+  auto tmp1 = psqr(r.y);
+  auto tmp2 = psqr(tmp1);
+  auto tmp3 = norm(sub(sub(psqr(add(tmp1, r.x)), tmp0), tmp2));
   auto tmp3d = norm(dbl(tmp3));
   auto tmp4 = norm(add(dbl(tmp0), tmp0));
   auto tmp6 = add(r.x, tmp4);
-  auto tmp5 = sqr(tmp4);
-  auto zsq = sqr(r.z);
+  auto tmp5 = psqr(tmp4);
+  auto zsq = psqr(r.z);
   auto rx = norm(sub(sub(tmp5, tmp3d), tmp3d));
-  auto rz = sub(sub(sqr(add(r.z, r.y)), tmp1), zsq);
-  auto ry = mul(norm(sub(tmp3d, rx)), tmp4);
+  auto rz = sub(sub(psqr(add(r.z, r.y)), tmp1), zsq);
+  auto ry = pmul(norm(sub(tmp3d, rx)), tmp4);
   auto tmp2o = norm(mul_small<8>(tmp2));
   auto ryo = sub(ry, tmp2o);
-  auto t3 = mul(tmp4, zsq);
+  auto t3 = pmul(tmp4, zsq);
   auto t3n = neg(norm(dbl(t3)));
-  auto t6 = sub(sub(sqr(norm(tmp6)), tmp0), tmp5);
+  auto t6 = sub(sub(psqr(norm(tmp6)), tmp0), tmp5);
   auto t1q = norm(mul_small<4>(tmp1));
   auto t6o = sub(norm(t6), t1q);
-  fe2 rzs = S2(rz);
-  auto t0 = mul(rzs, zsq);
+  E rzs = S2(rz);
+  auto t0 = pmul(rzs, zsq);
   r.x = S2(rx); r.y = S2(ryo); r.z = rzs;
   l.a = S2(dbl(t0)); l.b = S2(t3n); l.c = S2(t6o);
 }
 // pairings.rs:740-770 (CLN Algorithm 27)
-DEVNI void addition_step(G2Jac& r, const fe2& qx, const fe2& qy, Line& l) {
-  auto zsq = sqr(r.z);
-  auto ysq = sqr(qy);
-  auto t0 = mul(zsq, qx);
-  auto t1 = mul(norm(sub(sub(sqr(add(qy, r.z)), ysq), zsq)), zsq);
+template <class E> DEVNI void addition_step(G2JacT<E>& r, const E& qx, const E& qy, LineT<E>& l) {
+  auto zsq = psqr(r.z);
+  auto ysq = psqr(qy);
+  auto t0 = pmul(zsq, qx);
+  auto t1 = pmul(norm(sub(sub(psqr(add(qy, r.z)), ysq), zsq)), zsq);
   auto t2 = norm(sub(t0, r.x));
-  auto t3 = sqr(t2);
+  auto t3 = psqr(t2);
   auto t4 = norm(mul_small<4>(t3));
-  auto t5 = mul(t4, t2);
+  auto t5 = pmul(t4, t2);
   auto t6 = norm(sub(sub(t1, r.y), r.y));
-  auto t9 = mul(t6, qx);
-  auto t7 = mul(t4, r.x);
-  auto rx = norm(sub(sub(sub(sqr(t6), t5), t7), t7));
-  auto rz = sub(sub(sqr(add(r.z, t2)), zsq), t3);
-  fe2 rzs = S2(rz);
+  auto t9 = pmul(t6, qx);
+  auto t7 = pmul(t4, r.x);
+  auto rx = norm(sub(sub(sub(psqr(t6), t5), t7), t7));
+  auto rz = sub(sub(psqr(add(r.z, t2)), zsq), t3);
+  E rzs = S2(rz);
   auto t10 = add(qy, rzs);
-  auto t8 = mul(norm(sub(t7, rx)), t6);
-  auto t0b = mul(r.y, t5);
+  auto t8 = pmul(norm(sub(t7, rx)), t6);
+  auto t0b = pmul(r.y, t5);
   auto ry = sub(t8, norm(dbl(t0b)));
-  auto t10b = sub(sqr(t10), ysq);
-  auto ztsq = sqr(rzs);
+  auto t10b = sub(psqr(t10), ysq);
+  auto ztsq = psqr(rzs);
   auto t10c = sub(norm(t10b), ztsq);
   auto t9b = sub(norm(dbl(t9)), norm(t10c));
   auto t10d = dbl(rzs);
@@ -244,19 +278,19 @@ DEVNI void addition_step(G2Jac& r, const fe2& qx, const fe2& qy, Line& l) {
   l.a = S2(t10d); l.b = S2(t1b); l.c = S2(t9b);
 }
 // pairings.rs:696-707
-DEVNI void ell(Fp12& f, const Line& l, const fe1& px, const fe1& py) {
-  fe2 c0 = S2(mul_fp(l.a, py));
-  fe2 c1 = S2(mul_fp(l.b, px));
+template <class E> DEVNI void ell(Fp12T<E>& f, const LineT<E>& l, const fe1& px, const fe1& py) {
+  E c0 = S2(mul_fp(l.a, py));
+  E c1 = S2(mul_fp(l.b, px));
   fp12_mul_by_014(f, f, l.c, c1, c0);          // in place: every read of the input precedes the first write
 }
 
 // bits of BLS_X >> 1 below the leading one, MSB first (pairings.rs:671-685): 62 iterations, 5 set bits
 constexpr unsigned long long X_HALF = 0xd201000000010000ull >> 1;
 
-DEVNI void miller_loop(Fp12& f, const fe1& px, const fe1& py, const fe2& qx, const fe2& qy) {
-  G2Jac r; r.x = qx; r.y = qy; r.z = fe2_one();
-  f = fp12_one();
-  Line l;
+template <class E> DEVNI void miller_loop(Fp12T<E>& f, const fe1& px, const fe1& py, const E& qx, const E& qy) {
+  G2JacT<E> r; r.x = qx; r.y = qy; r.z = E2<E>::one();
+  f = fp12_one<E>();
+  LineT<E> l;
   for (int b = 61; b >= 0; b--) {           // bit 62 is the leading one
     doubling_step(r, l);
     ell(f, l, px, py);
@@ -273,35 +307,35 @@ DEVNI void miller_loop(Fp12& f, const fe1& px, const fe1& py, const fe2& qx, con
 
 // ---- final exponentiation ------------------------------------------------------------------------------
 // pairings.rs:50-62
-DEV void fp4_square(fe2& c0, fe2& c1, const fe2& a, const fe2& b) {
-  auto t0 = sqr(a);
-  auto t1 = sqr(b);
+template <class E> DEV void fp4_square(E& c0, E& c1, const E& a, const E& b) {
+  auto t0 = psqr(a);
+  auto t1 = psqr(b);
   auto t2 = mul_by_nonresidue(t1);
   c0 = S2(add(t2, t0));
-  auto t3 = sqr(add(a, b));
+  auto t3 = psqr(add(a, b));
   c1 = S2(sub(sub(t3, t0), t1));
 }
 // pairings.rs:66-112
-DEVNI void cyclotomic_square(Fp12& r, const Fp12& f) {
-  fe2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
-  fe2 t0, t1, t2, t3;
+template <class E> DEVNI void cyclotomic_square(Fp12T<E>& r, const Fp12T<E>& f) {
+  E z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
+  E t0, t1, t2, t3;
   fp4_square(t0, t1, z0, z1);
-  fe2 nz0 = S2(add(dbl(norm(sub(t0, z0))), t0));
-  fe2 nz1 = S2(add(dbl(norm(add(t1, z1))), t1));
+  E nz0 = S2(add(dbl(norm(sub(t0, z0))), t0));
+  E nz1 = S2(add(dbl(norm(add(t1, z1))), t1));
   fp4_square(t0, t1, z2, z3);
   fp4_square(t2, t3, z4, z5);
-  fe2 nz4 = S2(add(dbl(norm(sub(t0, z4))), t0));
-  fe2 nz5 = S2(add(dbl(norm(add(t1, z5))), t1));
-  fe2 t0b = S2(mul_by_nonresidue(t3));
-  fe2 nz2 = S2(add(dbl(norm(add(t0b, z2))), t0b));
-  fe2 nz3 = S2(add(dbl(norm(sub(t2, z3))), t2));
+  E nz4 = S2(add(dbl(norm(sub(t0, z4))), t0));
+  E nz5 = S2(add(dbl(norm(add(t1, z5))), t1));
+  E t0b = S2(mul_by_nonresidue(t3));
+  E nz2 = S2(add(dbl(norm(add(t0b, z2))), t0b));
+  E nz3 = S2(add(dbl(norm(sub(t2, z3))), t2));
   r.c0.c0 = nz0; r.c0.c1 = nz4; r.c0.c2 = nz3;
   r.c1.c0 = nz2; r.c1.c1 = nz1; r.c1.c2 = nz5;
 }
 // pairings.rs:114-132 (`cycolotomic_exp`): f^|x| then conjugate
-DEVNI void cyclotomic_exp(Fp12& r, const Fp12& f) {
+template <class E> DEVNI void cyclotomic_exp(Fp12T<E>& r, const Fp12T<E>& f) {
   constexpr unsigned long long X = 0xd201000000010000ull;
-  Fp12 tmp = f;                       // the leading one: tmp = one * f
+  Fp12T<E> tmp = f;                       // the leading one: tmp = one * f
   for (int b = 62; b >= 0; b--) {
     cyclotomic_square(tmp, tmp);      // in place (inputs are copied to locals first)
     if ((X >> b) & 1) fp12_mul(tmp, tmp, f);
@@ -309,9 +343,9 @@ DEVNI void cyclotomic_exp(Fp12& r, const Fp12& f) {
   fp12_conj(r, tmp);
 }
 // pairings.rs:134-173
-DEVNI void final_exponentiation(Fp12& out, const Fp12& fin) {
-  // every Fp12 helper tolerates r aliasing an input (inputs are consumed before the first write)
-  Fp12 t0, t1, t2, t3, t4, t5, t6;
+template <class E> DEVNI void final_exponentiation(Fp12T<E>& out, const Fp12T<E>& fin) {
+  // every Fp12T<E> helper tolerates r aliasing an input (inputs are consumed before the first write)
+  Fp12T<E> t0, t1, t2, t3, t4, t5, t6;
   fp12_frobenius(t0, fin);
   for (int i = 0; i < 5; i++) fp12_frobenius(t0, t0);
   fp12_inv(t1, fin);
@@ -344,52 +378,56 @@ DEVNI void final_exponentiation(Fp12& out, const Fp12& fin) {
 }
 
 // ---- kernels ---------------------------------------------------------------------------------------------
+// Every kernel works on lane pairs: pairing / product chain i lives on lanes 2i and 2i+1 of the grid.
+typedef fp2p PE;
+constexpr int PL = E2<PE>::LANES;
+#define PAIR_KERNEL __global__ void __launch_bounds__(PAIRING_BLOCK, PAIRING_WAVES)
+
 // mode 0: out[i] = pairing(g1[i], g2[i]);  mode 1: out[i] = raw Miller loop value.
 // Identity on either side -> Fp12::one() (pairings.rs:636-651; multi_miller_loop skips such terms :566-569).
-__global__ void __launch_bounds__(PAIRING_BLOCK, 1) k_pairing(int mode, const u32* __restrict__ g1, const uint8_t* __restrict__ g1inf,
-                                                          const u32* __restrict__ g2, const uint8_t* __restrict__ g2inf,
-                                                          u32* __restrict__ out, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+PAIR_KERNEL k_pairing(int mode, const u32* __restrict__ g1, const uint8_t* __restrict__ g1inf, const u32* __restrict__ g2,
+                      const uint8_t* __restrict__ g2inf, u32* __restrict__ out, size_t n) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / PL;
   if (i >= n) return;
   bool ident = (g1inf && g1inf[i]) || (g2inf && g2inf[i]);
-  Fp12 f;
+  Fp12T<PE> f;
   if (ident) {
-    f = fp12_one();
+    f = fp12_one<PE>();
   } else {
     fe1 px = fe_from_ref(g1 + i * 24), py = fe_from_ref(g1 + i * 24 + 12);
-    fe2 qx = (fe2)fe2_from_ref(g2 + i * 48), qy = (fe2)fe2_from_ref(g2 + i * 48 + 24);
+    PE qx = E2<PE>::load(g2 + i * 48), qy = E2<PE>::load(g2 + i * 48 + 24);
     miller_loop(f, px, py, qx, qy);
-    if (mode == 0) { Fp12 g; final_exponentiation(g, f); f = g; }
+    if (mode == 0) { Fp12T<PE> g; final_exponentiation(g, f); f = g; }
   }
   fp12_save(f, out + i * 144);
 }
-__global__ void __launch_bounds__(PAIRING_BLOCK, 1) k_final_exp(const u32* __restrict__ in, u32* __restrict__ out, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+PAIR_KERNEL k_final_exp(const u32* __restrict__ in, u32* __restrict__ out, size_t n) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / PL;
   if (i >= n) return;
-  Fp12 f, g;
+  Fp12T<PE> f, g;
   fp12_load(f, in + i * 144);
   final_exponentiation(g, f);
   fp12_save(g, out + i * 144);
 }
 // out[j] = product of in[j*FAN .. min(n, (j+1)*FAN))
-__global__ void __launch_bounds__(64) k_fp12_prod(const u32* __restrict__ in, u32* __restrict__ out, size_t n, size_t m) {
-  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+PAIR_KERNEL k_fp12_prod(const u32* __restrict__ in, u32* __restrict__ out, size_t n, size_t m) {
+  size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / PL;
   if (j >= m) return;
   size_t beg = j * FP12_PROD_FAN, end = beg + FP12_PROD_FAN < n ? beg + FP12_PROD_FAN : n;
-  Fp12 acc; fp12_load(acc, in + beg * 144);
+  Fp12T<PE> acc; fp12_load(acc, in + beg * 144);
   for (size_t i = beg + 1; i < end; i++) {
-    Fp12 x, t; fp12_load(x, in + i * 144);
+    Fp12T<PE> x, t; fp12_load(x, in + i * 144);
     fp12_mul(t, acc, x); acc = t;
   }
   fp12_save(acc, out + j * 144);
 }
 __global__ void k_fp12_one(u32* out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) { Fp12 f = fp12_one(); fp12_save(f, out); }
+  if (threadIdx.x < PL && blockIdx.x == 0) { Fp12T<PE> f = fp12_one<PE>(); fp12_save(f, out); }
 }
-__global__ void __launch_bounds__(64) k_fp12_op(int op, const u32* __restrict__ a, const u32* __restrict__ b, u32* __restrict__ out, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+PAIR_KERNEL k_fp12_op(int op, const u32* __restrict__ a, const u32* __restrict__ b, u32* __restrict__ out, size_t n) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / PL;
   if (i >= n) return;
-  Fp12 x, y, r;
+  Fp12T<PE> x, y, r;
   fp12_load(x, a + i * 144);
   if (b) fp12_load(y, b + i * 144); else y = x;
   switch (op) {

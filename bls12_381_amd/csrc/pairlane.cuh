@@ -49,20 +49,17 @@ template <int A, int V> DEV auto mul_by_nonresidue(const FeP<A, V>& a) {
 
 constexpr int pair_mul_v(int v1, int v2) { return 1 + (v1 * v2 + (v1 + 1) * v2 + V_DIV - 1) / V_DIV; }
 
-// Fp2 product: one sum of two products per lane
+// Fp2 product: one sum of two products per lane.  With a / b this lane's coefficients and a' / b' the partner's:
+//   c0 lane:  a0 b0 - a1 b1 = a * b + (-a') * b'        c1 lane:  a0 b1 + a1 b0 = a' * b + a * b'
 template <int A1, int V1, int A2, int V2>
 DEV FeP<1, pair_mul_v(V1, V2)> mul(const FeP<A1, V1>& a, const FeP<A2, V2>& b) {
   static_assert(A1 * A2 + (A1 + 1) * A2 + 1 <= MAX_A_PROD + 1, "pair-lane fe2 mul: limb bound too large, norm() an operand");
   const bool c1 = lane_is_c1();
   auto ao = partner(a.v); auto bo = partner(b.v);
-  // a0 / a1 / b0 / b1 as seen from this lane
-  auto a0 = select(c1, ao, a.v), a1 = select(c1, a.v, ao);
-  auto b0 = select(c1, bo, b.v), b1 = select(c1, b.v, bo);
-  // c0 lane: a0 b0 + (-a1) b1 ; c1 lane: a0 b1 + a1 b0
-  Fe<A1 + 1, V1 + 1> t1 = select(c1, (Fe<A1 + 1, V1 + 1>)a1, neg(a1));
-  auto y0 = select(c1, b1, b0), y1 = select(c1, b0, b1);
+  auto x0 = select(c1, ao, a.v);
+  Fe<A1 + 1, V1 + 1> x1 = select(c1, (Fe<A1 + 1, V1 + 1>)a.v, neg(ao));
   FeP<1, pair_mul_v(V1, V2)> r;
-  r.v = from_v16<pair_mul_v(V1, V2)>(fe_sop2_body(to_v16(a0), to_v16(y0), to_v16(t1), to_v16(y1)));      // inlined: 4 vector operands do not fit the call ABI
+  r.v = from_v16<pair_mul_v(V1, V2)>(fe_sop2_body(to_v16(x0), to_v16(b.v), to_v16(x1), to_v16(bo)));
   return r;
 }
 // Fp2 square: c0 = (a0 + a1)(a0 - a1), c1 = 2 a0 a1 -- one multiplication per lane
@@ -71,11 +68,10 @@ DEV auto sqr(const FeP<A, V>& a) {
   static_assert(2 * A * (2 * A + 1) <= MAX_A_PROD, "pair-lane fe2 sqr: norm() the operand");
   const bool c1 = lane_is_c1();
   auto ao = partner(a.v);
-  auto a0 = select(c1, ao, a.v), a1 = select(c1, a.v, ao);
   typedef Fe<2 * A, 2 * V> XT;
   typedef Fe<2 * A + 1, 2 * V + 1> YT;
-  XT x = select(c1, dbl(a0), add(a0, a1));
-  YT y = select(c1, (YT)a1, sub(a0, a1));
+  XT x = select(c1, dbl(ao), add(a.v, ao));
+  YT y = select(c1, (YT)a.v, sub(a.v, ao));
   FeP<1, mul_v(2 * V, 2 * V + 1)> r;
   r.v = mul_inl(x, y);
   return r;
@@ -88,6 +84,71 @@ template <int A, int V> DEV bool is_zero_fast(const FeP<A, V>& a) {
   bool z = is_zero(a.v);
   bool pz = partner_flag(z);
   return z && pz;
+}
+
+
+// ---- operations of the pairing code (pairing.cuh) ---------------------------------------------------------
+// out-of-line product / square with fixed operand bounds (limbs <= 2 (2^28-1), value < 128 p): the pairing code
+// has hundreds of call sites
+constexpr int FEP_IN_A = 2, FEP_IN_V = 128;
+DEVNI v16 fep_mul_raw(v16 a, v16 b) {
+  constexpr PLimbs bias = make_bias(FEP_IN_V + 1, FEP_IN_A);
+  const bool c1 = lane_is_c1();
+  v16 x0, x1, bo;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    u32 ao = dpp_swap1(a[i]);
+    bo[i] = dpp_swap1(b[i]);
+    x0[i] = c1 ? ao : a[i];
+    x1[i] = c1 ? a[i] : bias.l[i] - ao;
+  }
+  x0[14] = x0[15] = x1[14] = x1[15] = bo[14] = bo[15] = 0;
+  return fe_sop2_body(x0, b, x1, bo);
+}
+constexpr int fep_mul_v(int v1, int v2) { return 1 + (v1 * v2 + (FEP_IN_V + 1) * v2 + V_DIV - 1) / V_DIV; }
+template <int A1, int V1, int A2, int V2>
+DEV FeP<1, fep_mul_v(V1, V2)> mul_ni(const FeP<A1, V1>& a, const FeP<A2, V2>& b) {
+  static_assert(V1 <= FEP_IN_V && V2 <= FEP_IN_V, "pair-lane fe2 mul: operand value bound too large");
+  FeP<1, fep_mul_v(V1, V2)> r;
+  if constexpr (A1 <= FEP_IN_A && A2 <= FEP_IN_A) r.v = from_v16<fep_mul_v(V1, V2)>(fep_mul_raw(to_v16(a.v), to_v16(b.v)));
+  else r.v = from_v16<fep_mul_v(V1, V2)>(fep_mul_raw(to_v16(norm(a.v)), to_v16(norm(b.v))));
+  return r;
+}
+template <int A, int V>
+DEV auto sqr_ni(const FeP<A, V>& a) {
+  const bool c1 = lane_is_c1();
+  auto ao = partner(a.v);
+  typedef Fe<2 * A, 2 * V> XT;
+  typedef Fe<2 * A + 1, 2 * V + 1> YT;
+  XT x = select(c1, dbl(ao), add(a.v, ao));
+  YT y = select(c1, (YT)a.v, sub(a.v, ao));
+  auto p = mulx(x, y);
+  FeP<1, decltype(p)::kV> r; r.v = p;
+  return r;
+}
+// a0 - a1 u
+template <int A, int V> DEV auto conj(const FeP<A, V>& a) {
+  FeP<A + 1, V + 1> r; r.v = select(lane_is_c1(), neg(a.v), (Fe<A + 1, V + 1>)a.v); return r;
+}
+// (a0 + a1 u) u = -a1 + a0 u
+template <int A, int V> DEV auto mul_by_u(const FeP<A, V>& a) {
+  auto o = partner(a.v);
+  FeP<A + 1, V + 1> r; r.v = select(lane_is_c1(), (Fe<A + 1, V + 1>)o, neg(o)); return r;
+}
+// Fp2 x Fp (k identical in both lanes)
+template <int A1, int V1, int A2, int V2> DEV auto mul_fp(const FeP<A1, V1>& a, const Fe<A2, V2>& k) {
+  FeP<1, mul_v(V1, V2)> r; r.v = mul(a.v, k); return r;
+}
+// 1/(a0 + a1 u) = (a0 - a1 u)/(a0^2 + a1^2); both lanes run the same base-field inversion
+template <int A, int V> DEV auto inv(const FeP<A, V>& a) {
+  auto s = sqr(a.v);
+  auto n = add(s, partner(s));
+  auto t = inv(n);
+  typedef Fe<decltype(t)::kA + 1, decltype(t)::kV + 1> TT;
+  TT ts = select(lane_is_c1(), neg(t), (TT)t);
+  auto p = mul(a.v, ts);
+  static_assert(decltype(p)::kV <= 2, "pair-lane fe2 inv bound");
+  FeP<1, 2> r; r.v = p; return r;
 }
 
 // ---- field policy: G2 over lane pairs --------------------------------------------------------------------
