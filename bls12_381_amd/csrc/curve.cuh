@@ -205,7 +205,7 @@ DEV Xyzz<FpPolicy> xyzz_add_mixed_inl(const Xyzz<FpPolicy>& p, bool& inf, const 
   auto PPP = mul_inl(P, PP);
   auto Q = mul_inl(p.x, PP);
   auto X3 = norm(sub(sqr_inl(R), add(PPP, dbl(Q))));
-  auto Y3 = sub(mul_inl(R, norm(sub(Q, X3))), mul_inl(p.y, PPP));
+  auto Y3 = sop2_inl(R, norm(sub(Q, X3)), neg(p.y), PPP);       // R (Q - X3) - Y1 PPP with one reduction
   auto ZZ3 = mul_inl(p.zz, PP);
   auto ZZZ3 = mul_inl(p.zzz, PPP);
   Xyzz<F> r; r.x = F::st(X3); r.y = F::st(Y3); r.zz = F::st(ZZ3); r.zzz = F::st(ZZZ3); return r;

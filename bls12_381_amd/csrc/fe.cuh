@@ -250,6 +250,15 @@ DEV v16 fe_sop2_body(v16 a0, v16 b0, v16 a1, v16 b1) {
   return r;
 }
 
+// typed, inlined form: a0*b0 + a1*b1 with one reduction
+constexpr int sop2_v(int v00, int v01, int v10, int v11) { return 1 + (v00 * v01 + v10 * v11 + V_DIV - 1) / V_DIV; }
+template <int A00, int V00, int A01, int V01, int A10, int V10, int A11, int V11>
+DEV Fe<1, sop2_v(V00, V01, V10, V11)> sop2_inl(const Fe<A00, V00>& a0, const Fe<A01, V01>& b0, const Fe<A10, V10>& a1, const Fe<A11, V11>& b1) {
+  static_assert(A00 * A01 + A10 * A11 + 1 <= MAX_A_PROD + 1, "fe sop2: limb bound too large, norm() an operand");
+  static_assert(sop2_v(V00, V01, V10, V11) <= MAX_V, "fe sop2: value bound too large");
+  return from_v16<sop2_v(V00, V01, V10, V11)>(fe_sop2_body(to_v16(a0), to_v16(b0), to_v16(a1), to_v16(b1)));
+}
+
 // Fp2 product core: c0 = a0 b0 - a1 b1, c1 = a0 b1 + a1 b0, two reductions in total.
 // Contract (checked by the typed wrapper in fp2.cuh): every operand has limbs <= 2*(2^28-1) and
 // value < FE2_IN_V * p.  -a1 is formed against the fixed multiple (FE2_IN_V+1)*p.

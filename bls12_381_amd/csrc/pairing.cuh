@@ -29,7 +29,11 @@ namespace bls {
 
 template <class E> struct Fp6T { E c0, c1, c2; };
 template <class E> struct Fp12T { Fp6T<E> c0, c1; };
-typedef FeP<1, VS2> fp2p;             // working Fp2 value over a lane pair
+#ifndef BLS_VSP
+#define BLS_VSP 64
+#endif
+constexpr int VSP = BLS_VSP;          // value bound of a stored pair-lane element (sums of two still fit the product's operand bound)
+typedef FeP<1, VSP> fp2p;             // working Fp2 value over a lane pair
 
 // ---- element traits: what differs between the one-lane and the pair-lane Fp2 ------------------------------
 template <class E> struct E2;
@@ -43,14 +47,18 @@ template <> struct E2<fe2> {
 };
 template <> struct E2<fp2p> {
   static constexpr int LANES = 2;
-  static DEV fp2p zero() { return Fp2PairPolicy::zero(); }
-  static DEV fp2p one() { return Fp2PairPolicy::one(); }
-  static DEV fp2p konst(const PLimbs& k0, const PLimbs& k1) { fp2p K; K.v = select(lane_is_c1(), (Fe<1, VS2>)fe1_const(k1), (Fe<1, VS2>)fe1_const(k0)); return K; }
-  static DEV fp2p load(const u32* w) { fp2p r; r.v = (Fe<1, VS2>)fe_from_ref(w + (lane_is_c1() ? 12 : 0)); return r; }
+  static DEV fp2p zero() { fp2p r; r.v = (Fe<1, VSP>)fe_zero(); return r; }
+  static DEV fp2p one() { fp2p r; r.v = select(lane_is_c1(), (Fe<1, VSP>)fe_zero(), (Fe<1, VSP>)fe_one()); return r; }
+  static DEV fp2p konst(const PLimbs& k0, const PLimbs& k1) { fp2p K; K.v = select(lane_is_c1(), (Fe<1, VSP>)fe1_const(k1), (Fe<1, VSP>)fe1_const(k0)); return K; }
+  static DEV fp2p load(const u32* w) { fp2p r; r.v = (Fe<1, VSP>)fe_from_ref(w + (lane_is_c1() ? 12 : 0)); return r; }
   static DEV void save(const fp2p& a, u32* w) { fe_to_ref(a.v, w + (lane_is_c1() ? 12 : 0)); }
 };
 template <int A, int V> DEV fe2 st2(const Fe2<A, V>& a) { return store2(a); }
-template <int A, int V> DEV fp2p st2(const FeP<A, V>& a) { return Fp2PairPolicy::st(a); }
+template <int A, int V> DEV fp2p st2(const FeP<A, V>& a) {
+  fp2p r;
+  if constexpr (V <= VSP) r.v = norm(a.v); else r.v = reduce_v(norm(a.v));
+  return r;
+}
 template <int A1, int V1, int A2, int V2> DEV auto pmul(const Fe2<A1, V1>& a, const Fe2<A2, V2>& b) { return mul(a, b); }
 template <int A1, int V1, int A2, int V2> DEV auto pmul(const FeP<A1, V1>& a, const FeP<A2, V2>& b) { return mul_ni(a, b); }
 template <int A, int V> DEV auto psqr(const Fe2<A, V>& a) { return sqr(a); }
@@ -58,8 +66,14 @@ template <int A, int V> DEV auto psqr(const FeP<A, V>& a) { return sqr_ni(a); }
 // (a0 + a1 u) u = -a1 + a0 u
 template <int A, int V> DEV auto mul_by_u(const Fe2<A, V>& a) { Fe2<A + 1, V + 1> r; r.c0 = neg(a.c1); r.c1 = a.c0; return r; }
 
-constexpr int PAIRING_BLOCK = 256;       // 128 pairings per workgroup
-constexpr int PAIRING_WAVES = 2;         // wavefronts per SIMD the register budget is set for
+#ifndef BLS_PAIRING_BLOCK
+#define BLS_PAIRING_BLOCK 256
+#endif
+#ifndef BLS_PAIRING_WAVES
+#define BLS_PAIRING_WAVES 2
+#endif
+constexpr int PAIRING_BLOCK = BLS_PAIRING_BLOCK;       // two lanes per pairing
+constexpr int PAIRING_WAVES = BLS_PAIRING_WAVES;       // wavefronts per SIMD the register budget is set for
 constexpr int FP12_PROD_FAN = 8;
 
 #define S2(x) st2(x)

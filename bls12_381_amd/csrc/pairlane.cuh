@@ -70,7 +70,7 @@ DEV auto sqr(const FeP<A, V>& a) {
   auto ao = partner(a.v);
   typedef Fe<2 * A, 2 * V> XT;
   typedef Fe<2 * A + 1, 2 * V + 1> YT;
-  XT x = select(c1, dbl(ao), add(a.v, ao));
+  XT x = add(ao, select(c1, ao, a.v));               // c1 lane: 2 a0 ; c0 lane: a0 + a1
   YT y = select(c1, (YT)a.v, sub(a.v, ao));
   FeP<1, mul_v(2 * V, 2 * V + 1)> r;
   r.v = mul_inl(x, y);
@@ -88,9 +88,9 @@ template <int A, int V> DEV bool is_zero_fast(const FeP<A, V>& a) {
 
 
 // ---- operations of the pairing code (pairing.cuh) ---------------------------------------------------------
-// out-of-line product / square with fixed operand bounds (limbs <= 2 (2^28-1), value < 128 p): the pairing code
+// out-of-line product / square with fixed operand bounds (limbs <= 2 (2^28-1), value < 160 p): the pairing code
 // has hundreds of call sites
-constexpr int FEP_IN_A = 2, FEP_IN_V = 128;
+constexpr int FEP_IN_A = 2, FEP_IN_V = 160;
 DEVNI v16 fep_mul_raw(v16 a, v16 b) {
   constexpr PLimbs bias = make_bias(FEP_IN_V + 1, FEP_IN_A);
   const bool c1 = lane_is_c1();
@@ -120,7 +120,7 @@ DEV auto sqr_ni(const FeP<A, V>& a) {
   auto ao = partner(a.v);
   typedef Fe<2 * A, 2 * V> XT;
   typedef Fe<2 * A + 1, 2 * V + 1> YT;
-  XT x = select(c1, dbl(ao), add(a.v, ao));
+  XT x = add(ao, select(c1, ao, a.v));               // c1 lane: 2 a0 ; c0 lane: a0 + a1
   YT y = select(c1, (YT)a.v, sub(a.v, ao));
   auto p = mulx(x, y);
   FeP<1, decltype(p)::kV> r; r.v = p;

@@ -9,9 +9,14 @@ bb = r.randint(0,256,size=(n,32),dtype=np.uint8); bb[:,31]&=0x3f
 g1,f1 = ctx.bases_from_scalars(1,a).download(); g2,f2 = ctx.bases_from_scalars(2,bb).download()
 dev=torch.device('cuda',0)
 d_g1=torch.from_numpy(g1.view(np.int64)).to(dev); d_g2=torch.from_numpy(g2.view(np.int64)).to(dev); d_gt=torch.zeros((n,72),dtype=torch.int64,device=dev)
-for m in (1<<16, 1<<17, 1<<18):
+for m in (1<<16, 1<<18):
     for rep in range(2):
         torch.cuda.synchronize(); t0=time.time()
         b._lib.check(ctx.lib.blsgpu_pairing_batch_device(ctx.h, d_g1.data_ptr(), None, d_g2.data_ptr(), None, m, d_gt.data_ptr()),"p")
         ctx.synchronize(); t1=time.time()
     print(f"pairing_batch_device n={m}: {1e3*(t1-t0):.1f} ms -> {m/(t1-t0):.0f}/s")
+    for rep in range(2):
+        torch.cuda.synchronize(); t0=time.time()
+        b._lib.check(ctx.lib.blsgpu_multi_miller_loop_device(ctx.h, d_g1.data_ptr(), None, d_g2.data_ptr(), None, m, d_gt.data_ptr()),"p")
+        ctx.synchronize(); t1=time.time()
+    print(f"multi_miller_loop_device n={m}: {1e3*(t1-t0):.1f} ms -> {m/(t1-t0):.0f} terms/s")
