@@ -243,6 +243,7 @@ __global__ void __launch_bounds__(256) k_fp_op(int op, const u32* __restrict__ a
     case 2: fe_to_ref(sub(x, y), out + i * 12); break;
     case 3: fe_to_ref(sqr(x), out + i * 12); break;
     case 4: fe_to_ref(inv(x), out + i * 12); break;
+    case 6: fe_to_ref(from_v16<2>(fe_inv_fermat_raw(to_v16(x))), out + i * 12); break;     // x^(p-2): cross-check of op 4
     default: fe_to_ref(neg(x), out + i * 12); break;
   }
 }
@@ -859,7 +860,7 @@ static int elem_op(blsgpu_ctx* c, int words, int kind, int op, const uint64_t* a
   return BLSGPU_OK;
 }
 extern "C" int blsgpu_fp_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
-  if (op < 0 || op > 5) return bad("fp_op: unknown op");
+  if (op < 0 || op > 6) return bad("fp_op: unknown op");
   return elem_op(c, 12, 1, op, a, b, n, out);
 }
 extern "C" int blsgpu_fp2_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {

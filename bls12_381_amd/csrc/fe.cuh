@@ -484,9 +484,10 @@ DEV bool fe_eq(const Fe<A1, V1>& a, const Fe<A2, V2>& b) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// inversion  x^(p-2)   (reference: fp.rs:346-358 pow_vartime; 4-bit fixed window here)
+// inversion by x^(p-2)  (reference: fp.rs:346-358 pow_vartime; 4-bit fixed window here).  Kept as the
+// independent cross-check of the safegcd inversion below (self-test op); ~480 field multiplications.
 // ---------------------------------------------------------------------------------------------
-DEVNI v16 fe_inv_raw(v16 xin) {
+DEVNI v16 fe_inv_fermat_raw(v16 xin) {
   constexpr u64 e[6] = BLS_P_MINUS_2_U64;
   fe x = (fe)from_v16<2>(xin);
   // table x^1..x^15, indexed with a run-time digit: it lives in per-lane scratch, not in 210 registers
@@ -510,6 +511,113 @@ DEVNI v16 fe_inv_raw(v16 xin) {
     }
   }
   return to_v16(acc);
+}
+// ---------------------------------------------------------------------------------------------
+// inversion by the Bernstein-Yang "safegcd" divstep iteration (eprint 2019/266), the fixed-iteration form
+// with eta = -delta: 40 batches of 28 divsteps on the low limb, each batch folded into a 2x2 transition
+// matrix t (entries |.| <= 2^28) that is then applied to the full-size (f, g) and, modulo p, to (d, e).
+// 40 * 28 = 1120 >= (49 * 381 + 57) / 17 = 1102 divsteps, the proven bound for 381-bit inputs, so every
+// lane runs exactly the same instruction stream.  Cost ~ 34 k ALU operations, i.e. ~ 36 field
+// multiplications (the exponentiation above: ~ 480).  The reference inverts by exponentiation
+// (fp.rs:346-358); the result is the same field element, 0 for input 0.
+// Signed limbs: 14 x 28 bits, low 13 in [0, 2^28), the top limb carries the sign.
+// ---------------------------------------------------------------------------------------------
+struct SgMat { int32_t u, v, q, r; };
+DEV SgMat sg_divsteps(int32_t& eta, u32 f, u32 g) {
+  int32_t u = 1, v = 0, q = 0, r = 1;
+#pragma unroll
+  for (int i = 0; i < LW; i++) {
+    int32_t c1 = eta >> 31;                    // eta < 0
+    int32_t c2 = -(int32_t)(g & 1u);           // g odd
+    u32 x = (f ^ (u32)c1) - (u32)c1;           // +-f, +-u, +-v
+    int32_t y = (u ^ c1) - c1, z = (v ^ c1) - c1;
+    g += x & (u32)c2; q += y & c2; r += z & c2;
+    c1 &= c2;
+    eta = (eta ^ c1) - (c1 + 1);
+    f += g & (u32)c1; u += q & c1; v += r & c1;
+    g >>= 1; u <<= 1; v <<= 1;
+  }
+  SgMat t; t.u = u; t.v = v; t.q = q; t.r = r;
+  return t;
+}
+// (f, g) <- t (f, g) / 2^28   (exact)
+DEV void sg_update_fg(int32_t* f, int32_t* g, const SgMat& t) {
+  int64_t cf = (int64_t)t.u * f[0] + (int64_t)t.v * g[0];
+  int64_t cg = (int64_t)t.q * f[0] + (int64_t)t.r * g[0];
+  cf >>= LW; cg >>= LW;
+#pragma unroll
+  for (int i = 1; i < NL; i++) {
+    cf += (int64_t)t.u * f[i] + (int64_t)t.v * g[i];
+    cg += (int64_t)t.q * f[i] + (int64_t)t.r * g[i];
+    f[i - 1] = (int32_t)((u32)cf & LMASK); cf >>= LW;
+    g[i - 1] = (int32_t)((u32)cg & LMASK); cg >>= LW;
+  }
+  f[NL - 1] = (int32_t)cf; g[NL - 1] = (int32_t)cg;
+}
+// (d, e) <- t (d, e) / 2^28 mod p, both kept in (-2p, p)
+DEV void sg_update_de(int32_t* d, int32_t* e, const SgMat& t) {
+  constexpr PLimbs p = P_L;
+  const int32_t sd = d[NL - 1] >> 31, se = e[NL - 1] >> 31;
+  int32_t md = (t.u & sd) + (t.v & se), me = (t.q & sd) + (t.r & se);
+  int64_t cd = (int64_t)t.u * d[0] + (int64_t)t.v * e[0];
+  int64_t ce = (int64_t)t.q * d[0] + (int64_t)t.r * e[0];
+  md -= (int32_t)((BLS_PINV28 * (u32)cd + (u32)md) & LMASK);
+  me -= (int32_t)((BLS_PINV28 * (u32)ce + (u32)me) & LMASK);
+  cd += (int64_t)md * (int32_t)p.l[0]; ce += (int64_t)me * (int32_t)p.l[0];
+  cd >>= LW; ce >>= LW;
+#pragma unroll
+  for (int i = 1; i < NL; i++) {
+    cd += (int64_t)t.u * d[i] + (int64_t)t.v * e[i] + (int64_t)md * (int32_t)p.l[i];
+    ce += (int64_t)t.q * d[i] + (int64_t)t.r * e[i] + (int64_t)me * (int32_t)p.l[i];
+    d[i - 1] = (int32_t)((u32)cd & LMASK); cd >>= LW;
+    e[i - 1] = (int32_t)((u32)ce & LMASK); ce >>= LW;
+  }
+  d[NL - 1] = (int32_t)cd; e[NL - 1] = (int32_t)ce;
+}
+// d <- (d + (add_p ? p : 0)) with optional negation first; carries propagated
+DEV void sg_fix(int32_t* d, int32_t neg_mask, bool add_when_negative) {
+  constexpr PLimbs p = P_L;
+  int32_t c = 0;
+  // negate (two's complement over the limb vector) if neg_mask
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    int32_t t = ((d[i] ^ neg_mask) - neg_mask) + c;
+    if (i < NL - 1) { d[i] = (int32_t)((u32)t & LMASK); c = t >> LW; } else d[i] = t;
+  }
+  if (add_when_negative) {
+    const int32_t m = d[NL - 1] >> 31;
+    c = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      int32_t t = d[i] + ((int32_t)p.l[i] & m) + c;
+      if (i < NL - 1) { d[i] = (int32_t)((u32)t & LMASK); c = t >> LW; } else d[i] = t;
+    }
+  }
+}
+DEVNI v16 fe_inv_raw(v16 xin) {
+  constexpr PLimbs p = P_L;
+  fe1 a = canon(from_v16<VS>(xin));           // g must be the canonical integer (the divstep bound needs |g| <= f)
+  int32_t f[NL], g[NL], d[NL], e[NL];
+#pragma unroll
+  for (int i = 0; i < NL; i++) { f[i] = (int32_t)p.l[i]; g[i] = (int32_t)a.l[i]; d[i] = 0; e[i] = 0; }
+  e[0] = 1;
+  int32_t eta = -1;
+#pragma nounroll
+  for (int b = 0; b < 40; b++) {
+    u32 fl = (u32)f[0] | ((u32)f[1] << LW), gl = (u32)g[0] | ((u32)g[1] << LW);
+    SgMat t = sg_divsteps(eta, fl, gl);
+    sg_update_de(d, e, t);
+    sg_update_fg(f, g, t);
+  }
+  // g = 0, f = +-1 (or +-p for input 0, where d = 0): inverse = sign(f) * d, brought into [0, p)
+  sg_fix(d, 0, true);                         // (-2p, p) -> (-p, p)
+  sg_fix(d, f[NL - 1] >> 31, true);           // negate if f < 0, then -> [0, p)
+  fe1 r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.l[i] = (u32)d[i];
+  // r = (x R')^-1  ->  x^-1 R'
+  constexpr PLimbs k = {BLS_R3};
+  return to_v16(mul(r, fe1_const(k)));
 }
 // 1/x; returns 0 for x == 0 (the reference's `invert().unwrap_or(Fp::zero())` use, g1.rs:51)
 template <int A, int V>

@@ -487,16 +487,26 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const u32* __restrict__ 
   Xyzz<F> acc;
   acc.x = F::zero(); acc.y = F::zero(); acc.zz = F::zero(); acc.zzz = F::zero();
   bool acc_inf = true;
-  for (u32 j = d.start; j < d.start + d.len; j++) {
-    u32 e = sorted[j];
-    Aff<F> q; bool inf;
-    load_aff<F>(bases + (size_t)(e & 0x7fffffffu) * Store<F>::AFF_WORDS, q, inf);
-    if (inf) continue;                                    // identity base: contributes nothing
-    auto qy = cond_neg(q.y, (e >> 31) != 0);
-    // G1: the ten field products are inlined (one ~35 KB straight-line body; measured 8% faster than calls even
-    // at 2 waves/SIMD).  G2 keeps the out-of-line Fp2 products (its body would not fit the instruction cache).
-    if constexpr (std::is_same<F, FpPolicy>::value) acc = xyzz_add_mixed_inl(acc, acc_inf, q.x, qy);
-    else acc = xyzz_add_mixed<F>(acc, acc_inf, q.x, qy);
+  // software pipeline: while addition j runs, the record of entry j+1 and the index of entry j+2 are in flight
+  // (two dependent loads per entry; with two wavefronts per SIMD nothing else hides their latency)
+  const u32 end = d.start + d.len;
+  u32 e = sorted[d.start];
+  u32 e_next = d.len > 1 ? sorted[d.start + 1] : 0;
+  Aff<F> q; bool inf;
+  load_aff<F>(bases + (size_t)(e & 0x7fffffffu) * Store<F>::AFF_WORDS, q, inf);
+  for (u32 j = d.start; j < end; j++) {
+    Aff<F> qn = q; bool infn = true;
+    u32 e_next2 = 0;
+    if (j + 1 < end) load_aff<F>(bases + (size_t)(e_next & 0x7fffffffu) * Store<F>::AFF_WORDS, qn, infn);
+    if (j + 2 < end) e_next2 = sorted[j + 2];
+    if (!inf) {                                             // identity base: contributes nothing
+      auto qy = cond_neg(q.y, (e >> 31) != 0);
+      // G1: the ten field products are inlined (one ~35 KB straight-line body; measured 8% faster than calls even
+      // at 2 waves/SIMD).  G2 keeps the out-of-line Fp2 products (its body would not fit the instruction cache).
+      if constexpr (std::is_same<F, FpPolicy>::value) acc = xyzz_add_mixed_inl(acc, acc_inf, q.x, qy);
+      else acc = xyzz_add_mixed<F>(acc, acc_inf, q.x, qy);
+    }
+    q = qn; inf = infn; e = e_next; e_next = e_next2;
   }
   store_proj<F>(records + (size_t)d.dest * Store<F>::PROJ_WORDS, xyzz_to_proj<F>(acc, acc_inf));
 }

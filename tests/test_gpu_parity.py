@@ -101,6 +101,11 @@ def test_fp_ops(ctx, kats):
     assert np.array_equal(ctx.fp_op(5, A), np.stack([fpw(o.fp_neg(x)) for x in a]))
     inv = ctx.fp_op(4, A[:200])
     assert np.array_equal(inv, np.stack([fpw(o.fp_inv(x) or 0) for x in a[:200]]))
+    # the safegcd inversion (op 4) against the on-device x^(p-2) (op 6) on every operand, and a * a^-1 = 1
+    inv_all = ctx.fp_op(4, A)
+    assert np.array_equal(inv_all, ctx.fp_op(6, A))
+    nz = [i for i, x in enumerate(a) if x % o.P]
+    assert np.array_equal(ctx.fp_op(0, A[nz], inv_all[nz]), np.stack([fpw(1)] * len(nz)))
     # KAT results verbatim
     assert np.array_equal(ctx.fp_op(0, np.array([t["fp.test_multiplication"]["fp"][0]], dtype=np.uint64),
                                     np.array([t["fp.test_multiplication"]["fp"][1]], dtype=np.uint64))[0],
