@@ -42,7 +42,6 @@ SIGNATURES = {
     "blsgpu_g1_msm_host": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g2_msm_host": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_set_msm_window": (c_int, [c_vp, c_int]),
-    "blsgpu_set_msm_affine_rounds": (c_int, [c_vp, c_int]),
     "blsgpu_g1_sum": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g2_sum": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g1_sum_device": (c_int, [c_vp, c_vp, c_sz, c_vp]),

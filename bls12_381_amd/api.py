@@ -143,10 +143,6 @@ class Context:
     def set_msm_window(self, c):
         check(self.lib.blsgpu_set_msm_window(self.h, c), "set_msm_window")
 
-    def set_msm_affine_rounds(self, rounds):
-        """G1 MSM: batched-affine pre-reduction rounds per bucket (-1 = automatic, 0 = off, 1..3 = fixed)."""
-        check(self.lib.blsgpu_set_msm_affine_rounds(self.h, rounds), "set_msm_affine_rounds")
-
     def set_profiling(self, on):
         check(self.lib.blsgpu_set_profiling(self.h, 1 if on else 0), "set_profiling")
 

@@ -51,7 +51,6 @@ struct blsgpu_ctx {
   int msm_c = 0;
   bool profiling = false;
   bool pipelining = false;
-  int affine_rounds = -1;               // batched-affine pre-reduction rounds of the G1 MSM: -1 = chosen per call, 0..3 = fixed
   hipStream_t acc_stream = nullptr;     // bucket accumulation of pipelined calls (the caller's stream is never blocked)
   hipEvent_t ev[9];
   float phase_ms[8] = {0};
@@ -68,7 +67,6 @@ struct blsgpu_ctx {
     bool hist_dirty = false;
     unsigned long long seq = 0;
     DevBuf ent, sorted, hist, offs, cursor, bsum, items, heavy, ctrl;
-    DevBuf ba_offs[3], ba_cnt, ba_buf[2], ba_pre, ba_tot;       // batched-affine rounds (msm.cuh 4b)
     DevBuf buckets, lvlR[2], lvlT, tsum[2], wacc[2], wsums, result;
   } slot[NSLOT];
   int next_slot = 0;
@@ -354,7 +352,6 @@ extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
     hipStreamSynchronize(sl.front);
     hipStreamSynchronize(sl.tail);
     DevBuf* sb[] = {&sl.ent, &sl.sorted, &sl.hist, &sl.offs, &sl.cursor, &sl.bsum, &sl.items, &sl.heavy, &sl.ctrl,
-                    &sl.ba_offs[0], &sl.ba_offs[1], &sl.ba_offs[2], &sl.ba_cnt, &sl.ba_buf[0], &sl.ba_buf[1], &sl.ba_pre, &sl.ba_tot,
                     &sl.buckets, &sl.lvlR[0], &sl.lvlR[1], &sl.lvlT, &sl.tsum[0], &sl.tsum[1], &sl.wacc[0], &sl.wacc[1], &sl.wsums, &sl.result};
     for (auto b : sb) b->release();
     hipEventDestroy(sl.ev_in); hipEventDestroy(sl.ev_front); hipEventDestroy(sl.ev_acc); hipEventDestroy(sl.ev_tail);
@@ -387,11 +384,6 @@ extern "C" int blsgpu_join_lag(blsgpu_ctx* c, int lag) {
   return BLSGPU_OK;
 }
 extern "C" int blsgpu_join(blsgpu_ctx* c) { return blsgpu_join_lag(c, 0); }
-extern "C" int blsgpu_set_msm_affine_rounds(blsgpu_ctx* c, int r) {
-  if (!c) return bad("ctx is NULL");
-  if (r < -1 || r > 3) return bad("affine rounds must be -1 (auto) or 0..3");
-  c->affine_rounds = r; return BLSGPU_OK;
-}
 extern "C" int blsgpu_set_msm_window(blsgpu_ctx* c, int w) {
   if (!c) return bad("ctx is NULL");
   if (w != 0 && (w < 4 || w > 20)) return bad("msm window must be 0 or in [4,20]");
@@ -597,32 +589,6 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     bad_alloc |= sl.wsums.reserve((size_t)nwin * PW * 4);
     bad_alloc |= sl.result.reserve(PW * 4);
   }
-  // batched-affine pre-reduction (G1): rounds by mean bucket load; each round halves a bucket
-  int ba_R = 0;
-  u32 ba_L[3] = {0, 0, 0}; unsigned ba_blocks[3] = {0, 0, 0};
-  if constexpr (GroupTag<F>::id == 1) {
-    const double mean = (double)total / (double)nb;
-    if (c->affine_rounds >= 0) ba_R = c->affine_rounds;
-    else ba_R = 0;      // measured: HBM-bound (3.3 TB/s), slower than the XYZZ accumulation at 2^20
-    if (nb > (size_t)4096 * 1024) ba_R = 0;
-    size_t pre_bytes = 0;
-    for (int r = 0; r < ba_R; r++) {
-      const size_t e_ub = (total >> r) + nb;                        // elements entering round r
-      size_t L = (e_ub + 131071) / 131072; if (L < 64) L = 64; L = (L + 1) & ~(size_t)1;
-      const size_t lanes = (e_ub + L - 1) / L;
-      ba_L[r] = (u32)L; ba_blocks[r] = nblk(lanes, 256);
-      const size_t pb = (L / 2 + 1) * (size_t)ba_blocks[r] * 256 * BA_PRE_WORDS * 4;
-      if (pb > pre_bytes) pre_bytes = pb;
-      bad_alloc |= sl.ba_offs[r].reserve((nb + 1) * 4);
-    }
-    if (ba_R) {
-      bad_alloc |= sl.ba_cnt.reserve(nb * 4);
-      bad_alloc |= sl.ba_pre.reserve(pre_bytes);
-      bad_alloc |= sl.ba_tot.reserve((size_t)ba_blocks[0] * 256 * BA_TOT_WORDS * 4 + (size_t)ba_blocks[1] * 256 * BA_TOT_WORDS * 4 + (size_t)ba_blocks[2] * 256 * BA_TOT_WORDS * 4);
-      bad_alloc |= sl.ba_buf[0].reserve((total / 2 + nb + 16) * Store<F>::AFF_WORDS * 4);
-      if (ba_R > 1) bad_alloc |= sl.ba_buf[1].reserve((total / 4 + nb + 16) * Store<F>::AFF_WORDS * 4);
-    }
-  }
   if (bad_alloc) { g_err = "hipMalloc(msm scratch) failed"; return BLSGPU_ERR_HIP; }
   const bool prof = c->profiling;
   auto mark = [&](int i) { if (prof) hipEventRecord(c->ev[i], ft); };
@@ -679,25 +645,13 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     LAUNCHCHK();
     mark(3);
   }
-  // 3b. bucket offsets of the batched-affine rounds (they depend on the sort's offsets only)
-  const u32* item_offs = sl.offs.as<u32>();
-  for (int r = 0; r < ba_R; r++) {
-    const u32* oin = r == 0 ? sl.offs.as<u32>() : sl.ba_offs[r - 1].as<u32>();
-    const unsigned sb = nblk(nb, 1024);
-    hipLaunchKernelGGL(k_ba_counts, dim3(nblk(nb, 256)), dim3(256), 0, ft, oin, sl.ba_cnt.as<u32>(), (int)nb);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(sb), dim3(256), 0, ft, sl.ba_cnt.as<u32>(), sl.bsum.as<u32>(), (int)nb);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, ft, sl.bsum.as<u32>(), (int)sb);
-    hipLaunchKernelGGL(k_scan_apply, dim3(sb), dim3(256), 0, ft, sl.ba_cnt.as<u32>(), sl.bsum.as<u32>(), sl.ba_offs[r].as<u32>(), (int)nb);
-    LAUNCHCHK();
-    item_offs = sl.ba_offs[r].as<u32>();
-  }
   // 4. work items
   u32* ctrl = sl.ctrl.as<u32>();
   u32* bins = ctrl + 4;
   u32* bcur = ctrl + 4 + ITEM_BINS;
-  hipLaunchKernelGGL(k_item_count, dim3(nblk(nb, 256)), dim3(256), 0, ft, item_offs, bins, ctrl, (int)nb, cap);
+  hipLaunchKernelGGL(k_item_count, dim3(nblk(nb, 256)), dim3(256), 0, ft, sl.offs.as<u32>(), bins, ctrl, (int)nb, cap);
   hipLaunchKernelGGL(k_item_scan, dim3(1), dim3(256), 0, ft, bins, ctrl, cap);
-  hipLaunchKernelGGL(k_item_fill, dim3(nblk(nb, 256)), dim3(256), 0, ft, item_offs, bins, bcur, ctrl, sl.items.as<ItemDesc>(),
+  hipLaunchKernelGGL(k_item_fill, dim3(nblk(nb, 256)), dim3(256), 0, ft, sl.offs.as<u32>(), bins, bcur, ctrl, sl.items.as<ItemDesc>(),
                      sl.heavy.as<uint4>(), (int)nb, cap);
   LAUNCHCHK();
   mark(4);
@@ -708,24 +662,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   // 5. accumulate (grid covers the worst-case item count; surplus lanes exit on ctrl[2])
   u32* records = sl.buckets.as<u32>();
   const u32* base_rec = (merged ? bases->table : bases->rec) + first * Store<F>::AFF_WORDS;
-  if constexpr (GroupTag<F>::id == 1) {
-    for (int r = 0; r < ba_R; r++) {
-      const u32* in = r == 0 ? base_rec : sl.ba_buf[(r - 1) & 1].as<u32>();
-      const u32* oin = r == 0 ? sl.offs.as<u32>() : sl.ba_offs[r - 1].as<u32>();
-      u32* o = sl.ba_buf[r & 1].as<u32>();
-      if (r == 0) {
-        hipLaunchKernelGGL(k_ba_fwd<true>, dim3(ba_blocks[r]), dim3(256), 0, as, in, sl.sorted.as<u32>(), oin, sl.ba_offs[r].as<u32>(), o, sl.ba_pre.as<u32>(), sl.ba_tot.as<u32>(), (int)nb, ba_L[r]);
-        hipLaunchKernelGGL(k_ba_bwd<true>, dim3(ba_blocks[r]), dim3(256), 0, as, in, o, sl.ba_pre.as<u32>(), sl.ba_tot.as<u32>());
-      } else {
-        hipLaunchKernelGGL(k_ba_fwd<false>, dim3(ba_blocks[r]), dim3(256), 0, as, in, (const u32*)nullptr, oin, sl.ba_offs[r].as<u32>(), o, sl.ba_pre.as<u32>(), sl.ba_tot.as<u32>(), (int)nb, ba_L[r]);
-        hipLaunchKernelGGL(k_ba_bwd<false>, dim3(ba_blocks[r]), dim3(256), 0, as, in, o, sl.ba_pre.as<u32>(), sl.ba_tot.as<u32>());
-      }
-      LAUNCHCHK();
-    }
-  }
-  if (ba_R)
-    hipLaunchKernelGGL(k_msm_accumulate_direct, dim3(nblk(max_items, 256)), dim3(256), 0, as, sl.ba_buf[(ba_R - 1) & 1].as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
-  else if constexpr (GroupTag<F>::id == 2)
+  if constexpr (GroupTag<F>::id == 2)
     hipLaunchKernelGGL(k_msm_accumulate_g2pair, dim3(nblk(2 * max_items, 256)), dim3(256), 0, as, base_rec, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
   else
     hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(max_items, 256)), dim3(256), 0, as, base_rec, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);

@@ -476,172 +476,6 @@ __global__ void __launch_bounds__(256) k_item_fill(const u32* __restrict__ offs,
   }
 }
 
-// ---- 4b. batched-affine bucket pre-reduction (G1) ---------------------------------------------------------
-// A bucket's sum is first reduced by rounds of pairwise AFFINE additions: in a round the points of a bucket
-// (contiguous in the round's input) are added in pairs (0,1), (2,3), ..., an odd last point is copied, and the
-// results form the next round's (half as long) input.  An affine addition needs 1/(x2 - x1); a lane takes
-// the inverse of the PRODUCT of all its denominators once (Montgomery's trick: 3 multiplications per
-// addition) with the ~36-multiplication safegcd inversion (fe.cuh), so an addition costs 5 M + 1 S instead of
-// the 8 M + 2 S of the XYZZ mixed addition (curve.cuh).  Three rounds remove 7/8 of the additions; the rest
-// (and every exceptional case's follow-up) goes through k_msm_accumulate as before.  Formulas: the textbook
-// chord/tangent rule lambda = (y2-y1)/(x2-x1) resp. 3 x^2 / 2y, x3 = lambda^2 - x1 - x2, y3 = lambda (x1 - x3)
-// - y1; exceptional pairs (P + (-P), identities) are resolved exactly without touching the shared inversion.
-// The reference adds complete projective points (g1.rs:715-752); sums are the same group elements.
-//
-// A lane owns the elements [t*L, (t+1)*L) of the round's input: it handles every pair / single whose FIRST
-// element (even offset inside its bucket) lies in that range.
-//   pass 1  walk forward, classify each pair, multiply the denominators up, park the running product together
-//           with the pair's position in `pre` (64-byte records, [pair j][lane] so that lanes coalesce)
-//   pass 2  invert the product, walk the parked pairs backwards, peel the individual inverses off and finish
-//           the additions.
-constexpr int BA_PRE_WORDS = 20;           // prefix product (14) | element 1 | element 2 | output index + kind bit | pad (80 B)
-constexpr int BA_TOT_WORDS = 16;           // per lane: product of all denominators (14) | number of parked pairs | pad
-struct BaPoint { Fe<1, 2> x; Fe<2, 3> y; bool inf; };
-// element reference -> record: FIRST round: `e` is a `sorted` entry (base index | sign << 31); later rounds: e = position
-template <bool FIRST>
-DEV void ba_gather(const u32* __restrict__ bases, u32 e, BaPoint& p) {
-  constexpr int AW = Store<FpPolicy>::AFF_WORDS;
-  const uint4* v = reinterpret_cast<const uint4*>(bases + (size_t)(e & 0x7fffffffu) * AW);
-  u32 w[32];
-#pragma unroll
-  for (int k = 0; k < 8; k++) { uint4 q = v[k]; w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w; }
-  Fe<1, 2> y;
-#pragma unroll
-  for (int k = 0; k < NL; k++) { p.x.l[k] = w[k]; y.l[k] = w[NL + k]; }
-  p.inf = w[2 * NL] != 0;
-  if (FIRST) p.y = select((e >> 31) != 0, neg(y), (Fe<2, 3>)y); else p.y = (Fe<2, 3>)y;
-}
-DEV void ba_store(u32* __restrict__ out, u32 o, const Fe<1, 2>& x, const Fe<1, 2>& y, bool inf) {
-  uint4* v = reinterpret_cast<uint4*>(out + (size_t)o * Store<FpPolicy>::AFF_WORDS);
-  u32 w[32];
-#pragma unroll
-  for (int k = 0; k < NL; k++) { w[k] = x.l[k]; w[NL + k] = y.l[k]; }
-  w[28] = inf ? 1u : 0u; w[29] = 0; w[30] = 0; w[31] = 0;
-#pragma unroll
-  for (int k = 0; k < 8; k++) v[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
-}
-typedef Fe<4, 6> BaDen;
-typedef Fe<5, 7> BaNum;
-// next-round bucket sizes: cnt_out[b] = ceil(load_in[b] / 2)
-__global__ void __launch_bounds__(256) k_ba_counts(const u32* __restrict__ offs_in, u32* __restrict__ cnt_out, int nb) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < nb) cnt_out[b] = (offs_in[b + 1] - offs_in[b] + 1) >> 1;
-}
-// pass 1: walk, classify, multiply the denominators up (light on registers: many wavefronts hide the gathers)
-template <bool FIRST>
-__global__ void __launch_bounds__(256) k_ba_fwd(const u32* __restrict__ in, const u32* __restrict__ sorted, const u32* __restrict__ offs_in,
-                                                const u32* __restrict__ offs_out, u32* __restrict__ out, u32* __restrict__ pre,
-                                                u32* __restrict__ tot, int nb, u32 L) {
-  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  const u32 nl = gridDim.x * blockDim.x;
-  const u32 E = offs_in[nb];
-  const u32 s = t * L;
-  u32* mytot = tot + (size_t)t * BA_TOT_WORDS;
-  if (s >= E) { mytot[14] = 0; return; }
-  const u32 e_end = s + L < E ? s + L : E;
-  // bucket holding element s: offs_in[lo] <= s < offs_in[lo + 1]
-  u32 lo = 0, hi = (u32)nb;
-  while (hi - lo > 1) { u32 mid = (lo + hi) >> 1; if (offs_in[mid] <= s) lo = mid; else hi = mid; }
-  u32 b = lo, bbeg = offs_in[b], bend = offs_in[b + 1];
-  constexpr PLimbs one_l = {BLS_ONE_MONT};
-  Fe<1, 2> acc = (Fe<1, 2>)fe1_const(one_l);
-  u32 J = 0;
-  u32 i = s;
-  while (i < e_end) {
-    while (i >= bend) { b++; bbeg = bend; bend = offs_in[b + 1]; }
-    const u32 off = i - bbeg;
-    if (off & 1u) { i++; continue; }                 // second element of the previous lane's last pair
-    const u32 o = offs_out[b] + (off >> 1);
-    const u32 e1 = FIRST ? sorted[i] : i;
-    BaPoint p1; ba_gather<FIRST>(in, e1, p1);
-    if (i + 1 >= bend) {                             // odd last point of the bucket: carried over
-      ba_store(out, o, p1.x, reduce_v(norm(p1.y)), p1.inf);
-      i++; continue;
-    }
-    const u32 e2 = FIRST ? sorted[i + 1] : i + 1;
-    BaPoint p2; ba_gather<FIRST>(in, e2, p2);
-    i += 2;
-    if (p1.inf | p2.inf) {                           // identity operand(s): the other point (or the identity)
-      if (p1.inf) ba_store(out, o, p2.x, reduce_v(norm(p2.y)), p2.inf); else ba_store(out, o, p1.x, reduce_v(norm(p1.y)), false);
-      continue;
-    }
-    auto dx = sub(p2.x, p1.x);
-    BaDen den = (BaDen)dx;
-    u32 kind = 0;
-    if (is_zero_fast(dx)) {
-      bool same = is_zero(sub(p2.y, p1.y));
-      if (!same || is_zero(p1.y)) {                  // P + (-P) (or a 2-torsion point): the identity
-        ba_store(out, o, p1.x, reduce_v(norm(p1.y)), true);
-        continue;
-      }
-      kind = 1; den = (BaDen)dbl(p1.y);              // doubling: lambda = 3 x^2 / 2 y
-    }
-    uint4* pv = reinterpret_cast<uint4*>(pre + ((size_t)J * nl + t) * BA_PRE_WORDS);
-    pv[0] = make_uint4(acc.l[0], acc.l[1], acc.l[2], acc.l[3]);
-    pv[1] = make_uint4(acc.l[4], acc.l[5], acc.l[6], acc.l[7]);
-    pv[2] = make_uint4(acc.l[8], acc.l[9], acc.l[10], acc.l[11]);
-    pv[3] = make_uint4(acc.l[12], acc.l[13], e1, e2);
-    pv[4] = make_uint4(o | (kind << 31), 0, 0, 0);
-    J++;
-    acc = mul_inl(acc, den);
-  }
-  uint4* tv = reinterpret_cast<uint4*>(mytot);
-  tv[0] = make_uint4(acc.l[0], acc.l[1], acc.l[2], acc.l[3]);
-  tv[1] = make_uint4(acc.l[4], acc.l[5], acc.l[6], acc.l[7]);
-  tv[2] = make_uint4(acc.l[8], acc.l[9], acc.l[10], acc.l[11]);
-  tv[3] = make_uint4(acc.l[12], acc.l[13], J, 0);
-}
-// pass 2: one inversion per lane, then the parked pairs backwards.  The parked record of pair j-2 and the two points of
-// pair j-1 are in flight while pair j is computed.
-struct BaRec { Fe<1, 2> prefix; u32 e1, e2, ok; };
-DEV void ba_load_rec(const u32* __restrict__ pre, size_t idx, BaRec& r) {
-  const uint4* pv = reinterpret_cast<const uint4*>(pre + idx * BA_PRE_WORDS);
-  uint4 a0 = pv[0], a1 = pv[1], a2 = pv[2], a3 = pv[3], a4 = pv[4];
-  r.prefix.l[0] = a0.x; r.prefix.l[1] = a0.y; r.prefix.l[2] = a0.z; r.prefix.l[3] = a0.w; r.prefix.l[4] = a1.x; r.prefix.l[5] = a1.y;
-  r.prefix.l[6] = a1.z; r.prefix.l[7] = a1.w; r.prefix.l[8] = a2.x; r.prefix.l[9] = a2.y; r.prefix.l[10] = a2.z; r.prefix.l[11] = a2.w;
-  r.prefix.l[12] = a3.x; r.prefix.l[13] = a3.y; r.e1 = a3.z; r.e2 = a3.w; r.ok = a4.x;
-}
-template <bool FIRST>
-__global__ void __launch_bounds__(256) k_ba_bwd(const u32* __restrict__ in, u32* __restrict__ out, const u32* __restrict__ pre,
-                                                const u32* __restrict__ tot) {
-  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  const u32 nl = gridDim.x * blockDim.x;
-  const uint4* tv = reinterpret_cast<const uint4*>(tot + (size_t)t * BA_TOT_WORDS);
-  uint4 t3 = tv[3];
-  const u32 J = t3.z;
-  if (J == 0) return;
-  BaRec r1, r2;
-  ba_load_rec(pre, (size_t)(J - 1) * nl + t, r1);
-  r2 = r1;
-  if (J >= 2) ba_load_rec(pre, (size_t)(J - 2) * nl + t, r2);
-  BaPoint c1, c2;
-  ba_gather<FIRST>(in, r1.e1, c1); ba_gather<FIRST>(in, r1.e2, c2);
-  Fe<1, 2> acc;
-  {
-    uint4 t0 = tv[0], t1 = tv[1], t2 = tv[2];
-    acc.l[0] = t0.x; acc.l[1] = t0.y; acc.l[2] = t0.z; acc.l[3] = t0.w; acc.l[4] = t1.x; acc.l[5] = t1.y; acc.l[6] = t1.z; acc.l[7] = t1.w;
-    acc.l[8] = t2.x; acc.l[9] = t2.y; acc.l[10] = t2.z; acc.l[11] = t2.w; acc.l[12] = t3.x; acc.l[13] = t3.y;
-  }
-  Fe<1, 2> inv_run = inv(acc);
-  for (u32 j = J; j-- > 0;) {
-    BaPoint n1 = c1, n2 = c2;
-    BaRec r3 = r2;
-    if (j >= 1) { ba_gather<FIRST>(in, r2.e1, n1); ba_gather<FIRST>(in, r2.e2, n2); }
-    if (j >= 2) ba_load_rec(pre, (size_t)(j - 2) * nl + t, r3);
-    const u32 o = r1.ok & 0x7fffffffu;
-    BaDen den = (BaDen)sub(c2.x, c1.x);
-    BaNum num = (BaNum)sub(c2.y, c1.y);
-    if ((r1.ok >> 31) != 0) { den = (BaDen)dbl(c1.y); num = (BaNum)mul_small<3>(sqr(c1.x)); }
-    auto dinv = mul_inl(inv_run, r1.prefix);
-    inv_run = mul_inl(inv_run, den);
-    auto lam = mul_inl(num, dinv);
-    Fe<1, 2> x3 = reduce_v(norm(sub(sub(sqr_inl(lam), c1.x), c2.x)));
-    Fe<1, 2> y3 = reduce_v(norm(sub(mul_inl(lam, sub(c1.x, x3)), c1.y)));
-    ba_store(out, o, x3, y3, false);
-    r1 = r2; r2 = r3; c1 = n1; c2 = n2;
-  }
-}
-
 // ---- 5. bucket accumulation ---------------------------------------------------------------------------
 template <class F>
 __global__ void __launch_bounds__(256) k_msm_accumulate(const u32* __restrict__ bases, const u32* __restrict__ sorted,
@@ -673,28 +507,6 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const u32* __restrict__ 
       else acc = xyzz_add_mixed<F>(acc, acc_inf, q.x, qy);
     }
     q = qn; inf = infn; e = e_next; e_next = e_next2;
-  }
-  store_proj<F>(records + (size_t)d.dest * Store<F>::PROJ_WORDS, xyzz_to_proj<F>(acc, acc_inf));
-}
-// G1 accumulation over the output of the batched-affine rounds: entry j IS record j of `recs` (no index list, no
-// sign), coordinates in the lazy form the rounds store (value < 2p).
-__global__ void __launch_bounds__(256) k_msm_accumulate_direct(const u32* __restrict__ recs, const ItemDesc* __restrict__ items,
-                                                               const u32* __restrict__ ctrl, u32* __restrict__ records) {
-  typedef FpPolicy F;
-  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ctrl[2]) return;
-  ItemDesc d = items[t];
-  Xyzz<F> acc;
-  acc.x = F::zero(); acc.y = F::zero(); acc.zz = F::zero(); acc.zzz = F::zero();
-  bool acc_inf = true;
-  const u32 end = d.start + d.len;
-  BaPoint q; q.inf = true;
-  if (d.len) ba_gather<false>(recs, d.start, q);
-  for (u32 j = d.start; j < end; j++) {
-    BaPoint qn = q; qn.inf = true;
-    if (j + 1 < end) ba_gather<false>(recs, j + 1, qn);
-    if (!q.inf) acc = xyzz_add_mixed_inl(acc, acc_inf, q.x, q.y);
-    q = qn;
   }
   store_proj<F>(records + (size_t)d.dest * Store<F>::PROJ_WORDS, xyzz_to_proj<F>(acc, acc_inf));
 }

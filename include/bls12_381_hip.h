@@ -98,10 +98,6 @@ int blsgpu_g1_msm_host(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infin
 int blsgpu_g2_msm_host(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, const uint8_t* scalars, size_t n, uint64_t out_xyz[36]);
 /* Window width c (bits) used by Pippenger; 0 = automatic. */
 int blsgpu_set_msm_window(blsgpu_ctx* ctx, int c);
-/* G1 MSM: number of batched-affine pre-reduction rounds applied to every bucket before the projective
- * accumulation (each round halves a bucket with 5M+1S affine additions sharing one inversion per lane);
- * -1 = chosen per call from the mean bucket load (default), 0 = off, 1..3 = fixed.  Results are identical. */
-int blsgpu_set_msm_affine_rounds(blsgpu_ctx* ctx, int rounds);
 
 /* ---- group helpers ----------------------------------------------------------------------------------- */
 /* out = sum of n projective points (`Sum for G1Projective`, src/g1.rs:161-171) -- the fold used after the

@@ -280,31 +280,6 @@ def test_msm_edge_cases(ctx, group):
     _msm_case(ctx, group, [4, rr - 4], [77, 77])                          # P + (-P) inside one bucket
 
 
-@pytest.mark.parametrize("rounds", [1, 2, 3])
-def test_msm_g1_batched_affine_rounds(ctx, rounds):
-    """The batched-affine bucket pre-reduction (forced on, also for tiny inputs) gives the same sums: exceptional pairs
-    (equal points -> tangent rule, P + (-P), identity bases), one bucket holding everything, odd bucket sizes."""
-    r = o.SplitMix64(777 + rounds)
-    rr = o.R_ORDER
-    ctx.set_msm_affine_rounds(rounds)
-    try:
-        ks = [1, 2, 3, 0, 5, 5, 5, rr - 5, 7, rr - 7, 0, 11] + [r.scalar() for _ in range(20)]
-        ss = [0, 1, rr - 1, 12345, 9, 9, rr - 9, 9, (1 << 254), (1 << 254), 0, (1 << 16) - 1] + \
-             [(1 << (16 * i)) - 1 for i in range(1, 11)] + [(1 << 15) + (1 << (16 * i + 15)) for i in range(10)]
-        for w in (0, 4, 7, 16):
-            _msm_case(ctx, 1, ks, ss, window=w)
-        for m in (1, 2, 3, 7, 8, 9, 300):
-            _msm_case(ctx, 1, [3] * m, [1] * m)                  # equal points in one bucket: doublings all the way
-        _msm_case(ctx, 1, [3, 3, 0, 3, rr - 3, 0, 0, 5], [6] * 8, window=4)   # identities and cancellations in one bucket
-        _msm_case(ctx, 1, [4, rr - 4], [77, 77])
-        _msm_case(ctx, 1, [r.scalar() for _ in range(64)], [0] * 64)
-        ks = [r.scalar() for _ in range(5000)]
-        _msm_case(ctx, 1, ks, [r.scalar() % 1000 for _ in range(5000)], window=8)      # ~40 entries per bucket, ragged
-        _msm_case(ctx, 1, ks, [r.scalar() for _ in range(5000)])
-    finally:
-        ctx.set_msm_affine_rounds(-1)
-
-
 @pytest.mark.parametrize("group,logn", [(1, 14), (1, 16), (2, 14)])
 def test_msm_medium(ctx, group, logn):
     n = 1 << logn
