@@ -216,7 +216,28 @@ def main():
         extras["pairings_per_s"] = np_ / pdt
         extras["pairing_batch"] = {"n": np_, "ms": 1e3 * pdt, "note": "2^16 independent pairing(P_i, Q_i), inputs and outputs in HBM",
                                    "frac_of_fp_mul_chain_rate": (np_ * 16000 / pdt) / fp_rate}
-        n2 = 1 << 18
+        def mml():
+            bls._lib.check(ctx.lib.blsgpu_multi_miller_loop_device(ctx.h, d_g1.data_ptr(), None, d_g2.data_ptr(), None, np_, d_gt.data_ptr()), "multi_miller_loop_device")
+        mml(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            mml()
+        torch.cuda.synchronize()
+        mdt = (time.perf_counter() - t1) / 3
+        extras["multi_miller_loop_terms_per_s"] = np_ / mdt
+        extras["multi_miller_loop"] = {"n": np_, "ms": 1e3 * mdt, "note": "one product of 2^16 Miller values (no final exponentiation)"}
+        # Fr transform of the MSM's scalar vector
+        d_fr = d_scalars.clone()
+        ctx.fr_ntt_device(d_fr.data_ptr(), args.log_n, False); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            ctx.fr_ntt_device(d_fr.data_ptr(), args.log_n, False)
+        torch.cuda.synchronize()
+        ndt = (time.perf_counter() - t1) / 10
+        extras["fr_ntt"] = {"log_n": args.log_n, "ms": 1e3 * ndt, "elements_per_s": n / ndt,
+                            "note": "radix-2 NTT over the scalar field, in place, natural order; 6 passes over the data at 2^20"}
+        del d_fr
+        n2 = min(1 << 20, n)
         k2 = rs.randint(0, 256, size=(n2, 32), dtype=np.uint8); k2[:, 31] &= 0x3F
         b2 = ctx.bases_from_scalars(2, k2)
         d_s2 = torch.from_numpy(sb[:n2].copy()).to(dev)

@@ -41,6 +41,10 @@ SIGNATURES = {
     "blsgpu_g2_msm_device": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
     "blsgpu_g1_msm_host": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g2_msm_host": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_fr_op": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "blsgpu_fr_op_device": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "blsgpu_fr_ntt": (c_int, [c_vp, c_vp, c_int, c_int]),
+    "blsgpu_fr_ntt_device": (c_int, [c_vp, c_vp, c_int, c_int]),
     "blsgpu_set_msm_window": (c_int, [c_vp, c_int]),
     "blsgpu_g1_sum": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g2_sum": (c_int, [c_vp, c_vp, c_sz, c_vp]),

@@ -278,6 +278,31 @@ class Context:
     def fp12_op(self, op, a, b=None):
         return self._elem_op(self.lib.blsgpu_fp12_op, 72, op, a, b)
 
+    # ---- scalar field Fr (reference: src/scalar.rs) ----
+    def fr_op(self, op, a, b=None, return_flags=False):
+        """element-wise Scalar arithmetic on (n, 4) u64 Montgomery limbs; op 0 mul, 1 add, 2 sub, 3 square, 4 invert,
+        5 neg, 6 double.  For invert, return_flags also returns the `is_some` bytes (0 where the input was zero)."""
+        a = _u64(a, (-1, 4))
+        if b is not None:
+            b = _u64(b, (a.shape[0], 4))
+        out = np.zeros_like(a)
+        flags = np.ones(a.shape[0], dtype=np.uint8)
+        check(self.lib.blsgpu_fr_op(self.h, op, _ptr(a), _ptr(b), a.shape[0], _ptr(out), _ptr(flags)), "fr_op")
+        return (out, flags) if return_flags else out
+
+    def fr_ntt(self, values, inverse=False):
+        """radix-2 transform of 2^k Scalars ((n, 4) u64 Montgomery limbs), natural order in and out; see
+        include/bls12_381_hip.h for the definition."""
+        v = _u64(values, (-1, 4)).copy()
+        n = v.shape[0]
+        if n == 0 or n & (n - 1):
+            raise ValueError("fr_ntt: length must be a power of two")
+        check(self.lib.blsgpu_fr_ntt(self.h, _ptr(v), n.bit_length() - 1, 1 if inverse else 0), "fr_ntt")
+        return v
+
+    def fr_ntt_device(self, d_ptr, log_n, inverse=False):
+        check(self.lib.blsgpu_fr_ntt_device(self.h, d_ptr, log_n, 1 if inverse else 0), "fr_ntt_device")
+
     def fp_mul_throughput(self, iters=2000):
         v = ctypes.c_double()
         check(self.lib.blsgpu_fp_mul_throughput(self.h, iters, ctypes.byref(v)), "fp_mul_throughput")

@@ -11,6 +11,7 @@
 #include "../../include/bls12_381_hip.h"
 #include "msm.cuh"
 #include "pairing.cuh"
+#include "fr.cuh"
 #include "codec.cuh"
 
 using namespace bls;
@@ -72,6 +73,8 @@ struct blsgpu_ctx {
   int next_slot = 0;
   unsigned long long msm_calls = 0;
   DevBuf result, io_a, io_b, io_c, io_d, io_out, flags_a, flags_b;
+  DevBuf fr_tw[2], fr_tmp, fr_ninv;     // Fr transform: twiddle tables (forward / inverse), permutation target, n^-1
+  int fr_tw_log[2] = {-1, -1};
 };
 
 struct blsgpu_bases {
@@ -346,7 +349,7 @@ extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   hipStreamSynchronize(c->acc_stream);
-  DevBuf* bufs[] = {&c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_out, &c->flags_a, &c->flags_b};
+  DevBuf* bufs[] = {&c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_out, &c->flags_a, &c->flags_b, &c->fr_tw[0], &c->fr_tw[1], &c->fr_tmp, &c->fr_ninv};
   for (auto b : bufs) b->release();
   for (auto& sl : c->slot) {
     hipStreamSynchronize(sl.front);
@@ -919,6 +922,89 @@ extern "C" int blsgpu_mad_throughput(blsgpu_ctx* c, int iters, double* r) { retu
 
 // ---------------------------------------------------------------------------------------------------
 // pairings
+// ---------------------------------------------------------------------------------------------------
+// scalar field Fr: element-wise vector operations and the radix-2 transform (fr.cuh)
+// ---------------------------------------------------------------------------------------------------
+extern "C" int blsgpu_fr_op_device(blsgpu_ctx* c, int op, const void* a, const void* b, size_t n, void* out, void* nonzero_flags) {
+  if (!c || (n && (!a || !out))) return bad("fr_op: NULL argument");
+  if (op < 0 || op > 6) return bad("fr_op: unknown op");
+  if (op <= 2 && n && !b) return bad("fr_op: binary op needs b");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_fr_op, dim3(nblk(n, 256)), dim3(256), 0, c->stream, op, (const u32*)a, op <= 2 ? (const u32*)b : (const u32*)nullptr, (u32*)out,
+                     (uint8_t*)nonzero_flags, n);
+  LAUNCHCHK();
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_fr_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, uint8_t* nonzero_flags) {
+  if (!c || (n && (!a || !out))) return bad("fr_op: NULL argument");
+  if (op < 0 || op > 6) return bad("fr_op: unknown op");
+  if (op <= 2 && n && !b) return bad("fr_op: binary op needs b");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  if (c->io_a.reserve(n * 32) || c->io_b.reserve(n * 32) || c->io_out.reserve(n * 32) || c->flags_a.reserve(n)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  HIPCHK(hipMemcpyAsync(c->io_a.p, a, n * 32, hipMemcpyHostToDevice, c->stream));
+  if (op <= 2) HIPCHK(hipMemcpyAsync(c->io_b.p, b, n * 32, hipMemcpyHostToDevice, c->stream));
+  int rc = blsgpu_fr_op_device(c, op, c->io_a.p, c->io_b.p, n, c->io_out.p, (op == 4 && nonzero_flags) ? c->flags_a.p : nullptr);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(out, c->io_out.p, n * 32, hipMemcpyDeviceToHost, c->stream));
+  if (op == 4 && nonzero_flags) HIPCHK(hipMemcpyAsync(nonzero_flags, c->flags_a.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+// in-place transform of 2^log_n scalars in device memory (natural order in and out)
+extern "C" int blsgpu_fr_ntt_device(blsgpu_ctx* c, void* d_data, int log_n, int inverse) {
+  if (!c || !d_data) return bad("fr_ntt: NULL argument");
+  if (log_n < 0 || log_n > 28) return bad("fr_ntt: log_n must be in [0, 28]");
+  if (log_n == 0) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const int dir = inverse ? 1 : 0;
+  const size_t n = (size_t)1 << log_n, half = n >> 1;
+  if (c->fr_tw[dir].reserve(half * 32) || c->fr_tmp.reserve(n * 32) || c->fr_ninv.reserve(64)) { g_err = "hipMalloc(fr scratch) failed"; return BLSGPU_ERR_HIP; }
+  if (c->fr_tw_log[dir] != log_n) {
+    hipLaunchKernelGGL(k_fr_twiddles, dim3(nblk((half + FR_TW_RUN - 1) / FR_TW_RUN, 256)), dim3(256), 0, st, c->fr_tw[dir].as<u32>(), log_n, dir);
+    LAUNCHCHK();
+    c->fr_tw_log[dir] = log_n;
+  }
+  u32* data = (u32*)d_data;
+  u32* tmp = c->fr_tmp.as<u32>();
+  const u32* tw = c->fr_tw[dir].as<u32>();
+  const int tl = log_n < FR_TILE_LOG ? log_n : FR_TILE_LOG;
+  int lh = log_n - 1;                                   // log2 of the current half-span
+  // The tile kernel permutes, so it cannot run in place.  With global passes the first one moves the data to the
+  // scratch buffer (the rest run there in place) and the tile kernel brings the result home; a transform that fits
+  // one tile goes through the scratch buffer and is copied back.
+  const u32* src = data;
+  u32* cur = lh >= tl ? tmp : data;
+  while (lh - 1 >= tl) {                                // two stages per pass over the data
+    hipLaunchKernelGGL(k_fr_stage2, dim3(nblk(n / 4, 256)), dim3(256), 0, st, src, cur, tw, log_n, lh);
+    src = cur; lh -= 2;
+  }
+  if (lh >= tl) { hipLaunchKernelGGL(k_fr_stage1, dim3(nblk(n / 2, 256)), dim3(256), 0, st, src, cur, tw, log_n, lh); src = cur; lh--; }
+  LAUNCHCHK();
+  const u32* scale = nullptr;
+  if (inverse) { hipLaunchKernelGGL(k_fr_ninv, dim3(1), dim3(64), 0, st, c->fr_ninv.as<u32>(), log_n); scale = c->fr_ninv.as<u32>(); }
+  u32* dst = src == data ? tmp : data;
+  hipLaunchKernelGGL(k_fr_tile, dim3((unsigned)(n >> tl)), dim3(256), ((size_t)8 << tl) * 4, st, src, dst, tw, log_n, tl, scale);
+  LAUNCHCHK();
+  if (dst != data) HIPCHK(hipMemcpyAsync(data, tmp, n * 32, hipMemcpyDeviceToDevice, st));
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_fr_ntt(blsgpu_ctx* c, uint64_t* data, int log_n, int inverse) {
+  if (!c || !data) return bad("fr_ntt: NULL argument");
+  if (log_n < 0 || log_n > 28) return bad("fr_ntt: log_n must be in [0, 28]");
+  HIPCHK(hipSetDevice(c->device));
+  const size_t n = (size_t)1 << log_n;
+  if (c->io_a.reserve(n * 32)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  HIPCHK(hipMemcpyAsync(c->io_a.p, data, n * 32, hipMemcpyHostToDevice, c->stream));
+  int rc = blsgpu_fr_ntt_device(c, c->io_a.p, log_n, inverse);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(data, c->io_a.p, n * 32, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 static int pairing_launch(blsgpu_ctx* c, int mode, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) {
   // mode 0: full pairing, 1: Miller loop only

@@ -160,6 +160,22 @@ int blsgpu_mad_throughput(blsgpu_ctx* ctx, int iters, double* mads_per_second);
 int blsgpu_last_msm_phase_ms(blsgpu_ctx* ctx, int phase, float* ms);
 int blsgpu_set_profiling(blsgpu_ctx* ctx, int enabled);
 
+/* ---- scalar field Fr (the producer side of the MSM's scalars) ----------------------- */
+/* A scalar is the reference's `Scalar([u64; 4])`: four little-endian u64 Montgomery limbs (R = 2^256), canonical
+ * (scalar.rs:23-27).  Element-wise vector operation over n scalars; op: 0 mul (scalar.rs:452-503), 1 add (:435-449),
+ * 2 sub (:420-432), 3 square (:334-369), 4 invert (:573-628; a zero input yields 0 and nonzero_flags[i] = 0, the
+ * reference's CtOption::none), 5 neg (:552-568), 6 double (:246-250).  `b` is ignored for unary ops,
+ * `nonzero_flags` (n bytes) may be NULL. */
+int blsgpu_fr_op(blsgpu_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, uint8_t* nonzero_flags);
+int blsgpu_fr_op_device(blsgpu_ctx* ctx, int op, const void* d_a, const void* d_b, size_t n, void* d_out, void* d_nonzero_flags);
+/* Radix-2 number-theoretic transform of 2^log_n scalars, in place, natural order in and out:
+ *   forward  y_k = sum_j x_j w^(jk),   inverse  x_j = n^-1 sum_k y_k w^(-jk),   w = ROOT_OF_UNITY^(2^(32 - log_n))
+ * with the reference's ROOT_OF_UNITY / S = 32 (scalar.rs:191-205, exported through ff::PrimeField :703-712).
+ * The reference crate has no transform of its own; this is the operation its callers build on those constants.
+ * log_n in [0, 28]. */
+int blsgpu_fr_ntt(blsgpu_ctx* ctx, uint64_t* data, int log_n, int inverse);
+int blsgpu_fr_ntt_device(blsgpu_ctx* ctx, void* d_data, int log_n, int inverse);
+
 #ifdef __cplusplus
 }
 #endif

@@ -964,3 +964,100 @@ def g2_from_uncompressed(b):
     """g2.rs:303-306."""
     p = g2_from_uncompressed_unchecked(b)
     return p if (p is not None and g2_is_on_curve(p) and g2_is_torsion_free(p)) else None
+
+
+# --------------------------------------------------------------------------------------------------
+# Scalar field Fr (src/scalar.rs) -- SURVEY.md 8(f) rank 3: the caller-side producer of MSM scalars.
+# A `Scalar` is four little-endian u64 limbs in Montgomery form with R = 2^256 (scalar.rs:23-27,155-165);
+# every operation returns the canonical representative, so parity is on those limbs.
+# --------------------------------------------------------------------------------------------------
+FR_S = 32                                   # scalar.rs:191  (2^S * t = r - 1, t odd)
+FR_GENERATOR = 7                            # scalar.rs:99-105
+FR_ROOT_OF_UNITY = pow(FR_GENERATOR, (R_ORDER - 1) >> FR_S, R_ORDER)     # scalar.rs:193-205 (GENERATOR^t)
+
+
+def fr_to_mont_limbs(x):
+    v = (int(x) % R_ORDER) * FR_MONT_R % R_ORDER
+    return [(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+
+
+def fr_from_mont_limbs(limbs):
+    v = sum(int(l) << (64 * i) for i, l in enumerate(limbs))
+    assert v < R_ORDER, "non-canonical Scalar limbs"
+    return v * pow(FR_MONT_R, -1, R_ORDER) % R_ORDER
+
+
+def fr_add(a, b): return (a + b) % R_ORDER            # scalar.rs:435-449
+def fr_sub(a, b): return (a - b) % R_ORDER            # scalar.rs:420-432
+def fr_neg(a): return (-a) % R_ORDER                  # scalar.rs:552-568
+def fr_mul(a, b): return a * b % R_ORDER              # scalar.rs:452-503 (schoolbook + montgomery_reduce :506-550)
+def fr_sqr(a): return a * a % R_ORDER                 # scalar.rs:334-369
+def fr_double(a): return 2 * a % R_ORDER              # scalar.rs:246-250
+
+
+def fr_pow(a, e):
+    """scalar.rs:371-404 (`pow` / `pow_vartime`): e is an integer exponent (the reference takes [u64; 4])."""
+    return pow(a, e, R_ORDER)
+
+
+def fr_inv(a):
+    """scalar.rs:573-628: a^(r-2); None for zero (CtOption::none)."""
+    return None if a % R_ORDER == 0 else pow(a, R_ORDER - 2, R_ORDER)
+
+
+def fr_from_bytes_wide(b):
+    """scalar.rs:300-331: 64 little-endian bytes reduced mod r."""
+    assert len(b) == 64
+    return int.from_bytes(bytes(b), "little") % R_ORDER
+
+
+def fr_omega(log_n):
+    """primitive 2^log_n-th root of unity: ROOT_OF_UNITY^(2^(S - log_n)) (how ff::PrimeField::ROOT_OF_UNITY is used)."""
+    assert 0 <= log_n <= FR_S
+    return pow(FR_ROOT_OF_UNITY, 1 << (FR_S - log_n), R_ORDER)
+
+
+def fr_ntt(values, inverse=False):
+    """Number-theoretic transform over Fr, natural order in and out:
+         forward  y_k = sum_j x_j w^(jk)          inverse  x_j = n^-1 sum_k y_k w^(-jk),   w = fr_omega(log2 n).
+    The reference crate provides the field and ROOT_OF_UNITY (scalar.rs:193-205, 688-713) but no transform; this is the
+    definition the GPU kernels are tested against (recursive radix-2 evaluation of exactly that sum)."""
+    n = len(values)
+    assert n and n & (n - 1) == 0
+    w = fr_omega(n.bit_length() - 1)
+    if inverse:
+        w = pow(w, -1, R_ORDER)
+
+    def rec(x, w):
+        m = len(x)
+        if m == 1:
+            return list(x)
+        w2 = w * w % R_ORDER
+        ev, od = rec(x[0::2], w2), rec(x[1::2], w2)
+        out = [0] * m
+        t = 1
+        for k in range(m // 2):
+            u = od[k] * t % R_ORDER
+            out[k] = (ev[k] + u) % R_ORDER
+            out[k + m // 2] = (ev[k] - u) % R_ORDER
+            t = t * w % R_ORDER
+        return out
+
+    y = rec([int(v) % R_ORDER for v in values], w)
+    if inverse:
+        ninv = pow(n, -1, R_ORDER)
+        y = [v * ninv % R_ORDER for v in y]
+    return y
+
+
+def fr_ntt_naive(values, inverse=False):
+    """the defining O(n^2) sums (used to pin fr_ntt itself on small sizes)."""
+    n = len(values)
+    w = fr_omega(n.bit_length() - 1)
+    if inverse:
+        w = pow(w, -1, R_ORDER)
+    y = [sum(int(values[j]) * pow(w, j * k, R_ORDER) for j in range(n)) % R_ORDER for k in range(n)]
+    if inverse:
+        ninv = pow(n, -1, R_ORDER)
+        y = [v * ninv % R_ORDER for v in y]
+    return y

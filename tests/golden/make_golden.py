@@ -59,6 +59,18 @@ C["fp6.FROBENIUS_C1"] = arrays(lines(f"{REF}/fp6.rs", 159, 171), HEX6)
 C["fp6.FROBENIUS_C2"] = arrays(lines(f"{REF}/fp6.rs", 173, 186), HEX6)
 C["fp12.FROBENIUS_C1"] = arrays(lines(f"{REF}/fp12.rs", 149, 168), HEX6)
 C["scalar.MODULUS"] = arrays(lines(f"{REF}/scalar.rs", 76, 81), HEX4)[0]
+C["scalar.GENERATOR"] = arrays(lines(f"{REF}/scalar.rs", 99, 105), HEX4)[0]
+C["scalar.INV"] = int(re.search(r"const INV: u64 = (0x[0-9a-f_]+);", open(f"{REF}/scalar.rs").read()).group(1).replace("_", ""), 16)
+C["scalar.R"] = arrays(lines(f"{REF}/scalar.rs", 159, 164), HEX4)[0]
+C["scalar.R2"] = arrays(lines(f"{REF}/scalar.rs", 167, 172), HEX4)[0]
+C["scalar.R3"] = arrays(lines(f"{REF}/scalar.rs", 175, 180), HEX4)[0]
+C["scalar.TWO_INV"] = arrays(lines(f"{REF}/scalar.rs", 183, 188), HEX4)[0]
+C["scalar.S"] = int(re.search(r"const S: u32 = (\d+);", open(f"{REF}/scalar.rs").read()).group(1))
+C["scalar.ROOT_OF_UNITY"] = arrays(lines(f"{REF}/scalar.rs", 200, 205), HEX4)[0]
+C["scalar.ROOT_OF_UNITY_INV"] = arrays(lines(f"{REF}/scalar.rs", 208, 213), HEX4)[0]
+C["scalar.DELTA"] = arrays(lines(f"{REF}/scalar.rs", 217, 222), HEX4)[0]
+C["scalar.LARGEST"] = arrays(lines(f"{REF}/scalar.rs", 1051, 1056), HEX4)[0]
+C["scalar.FROM_BYTES_WIDE_MAXIMUM"] = arrays(lines(f"{REF}/scalar.rs", 1029, 1040), HEX4)[0]      # from_bytes_wide(&[0xff; 64])
 gt = arrays(lines(f"{REF}/pairings.rs", 359, 475), HEX6)
 assert len(gt) == 12, len(gt)
 C["pairings.GT_GENERATOR"] = gt

@@ -572,3 +572,83 @@ def test_logical_shards_msm_and_miller(ctx, world):
     assert np.array_equal(ctx.fp12_product(np.stack(parts)), whole)
     assert np.array_equal(ctx.final_exponentiation_batch(whole[None, :])[0],
                           ctx.final_exponentiation_batch(ctx.fp12_product(np.stack(parts))[None, :])[0])
+
+
+# ---- scalar field Fr and its transform (reference src/scalar.rs) --------------------------
+def frw(x):
+    return np.array(o.fr_to_mont_limbs(x), dtype=np.uint64)
+
+
+def frs(a):
+    return [o.fr_from_mont_limbs(row) for row in a]
+
+
+EDGE_FR = [0, 1, 2, o.R_ORDER - 1, o.R_ORDER - 2, (o.R_ORDER - 1) // 2, (1 << 254), (1 << 64) - 1, 7, o.FR_ROOT_OF_UNITY]
+
+
+def test_fr_ops(ctx, kats):
+    r = o.SplitMix64(0xF2)
+    a = EDGE_FR + [r.scalar() for _ in range(2000)]
+    b = list(reversed(EDGE_FR)) + [r.scalar() for _ in range(2000)]
+    A, B = np.stack([frw(x) for x in a]), np.stack([frw(x) for x in b])
+    for op, fn in [(0, o.fr_mul), (1, o.fr_add), (2, o.fr_sub)]:
+        assert np.array_equal(ctx.fr_op(op, A, B), np.stack([frw(fn(x, y)) for x, y in zip(a, b)])), f"fr op {op}"
+    assert np.array_equal(ctx.fr_op(3, A), np.stack([frw(o.fr_sqr(x)) for x in a]))
+    assert np.array_equal(ctx.fr_op(5, A), np.stack([frw(o.fr_neg(x)) for x in a]))
+    assert np.array_equal(ctx.fr_op(6, A), np.stack([frw(o.fr_double(x)) for x in a]))
+    inv, some = ctx.fr_op(4, A[:300], return_flags=True)
+    assert np.array_equal(inv, np.stack([frw(o.fr_inv(x) or 0) for x in a[:300]]))
+    assert list(some) == [0 if x == 0 else 1 for x in a[:300]]          # CtOption::none exactly for zero (scalar.rs:573-628)
+    # the reference's stored limb patterns go through unchanged: R2 * R2 = R3 * R ... (R2 limbs = value 2^256)
+    c = kats["consts"]
+    R2 = np.array([c["scalar.R2"]], dtype=np.uint64)
+    assert np.array_equal(ctx.fr_op(0, R2, R2)[0], np.array(c["scalar.R3"], dtype=np.uint64))
+    root, root_inv = np.array([c["scalar.ROOT_OF_UNITY"]], dtype=np.uint64), np.array([c["scalar.ROOT_OF_UNITY_INV"]], dtype=np.uint64)
+    assert np.array_equal(ctx.fr_op(0, root, root_inv)[0], np.array(c["scalar.R"], dtype=np.uint64))
+    assert np.array_equal(ctx.fr_op(4, root)[0], root_inv[0])
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 9, 10, 11, 12, 13])
+def test_fr_ntt_vs_oracle(ctx, log_n):
+    n = 1 << log_n
+    r = o.SplitMix64(1000 + log_n)
+    x = [r.scalar() for _ in range(n)]
+    if n >= 4:
+        x[0], x[1], x[2] = 0, o.R_ORDER - 1, 1
+    X = np.stack([frw(v) for v in x])
+    Y = ctx.fr_ntt(X)
+    assert frs(Y) == o.fr_ntt(x)
+    assert np.array_equal(ctx.fr_ntt(Y, inverse=True), X)
+    assert frs(ctx.fr_ntt(X, inverse=True)) == o.fr_ntt(x, inverse=True)
+
+
+def test_fr_ntt_large_properties(ctx):
+    """2^20 scalars (the MSM's scalar vector at the headline size): round trip, linearity, sampled outputs against the
+    defining sum, and the convolution theorem on a sparse product."""
+    log_n = 20
+    n = 1 << log_n
+    rs = np.random.RandomState(5)
+    raw = rs.randint(0, 256, size=(n, 32), dtype=np.uint8); raw[:, 31] &= 0x3F                  # < 2^254 < r: canonical limbs
+    X = raw.view(np.uint64).reshape(n, 4).copy()
+    Y = ctx.fr_ntt(X)
+    assert np.array_equal(ctx.fr_ntt(Y, inverse=True), X)
+    # sampled outputs: y_k = sum_j x_j w^(jk) with x_j = limbs interpreted through the Montgomery map
+    w = o.fr_omega(log_n)
+    rinv = pow(o.FR_MONT_R, -1, o.R_ORDER)
+    xs = [int.from_bytes(raw[j].tobytes(), "little") for j in range(n)]                          # raw limb integers = x_j * R
+    for k in (0, 1, n // 2, 777777):
+        wk = pow(w, k, o.R_ORDER)
+        acc, t = 0, 1
+        for j in range(n):
+            acc += xs[j] * t
+            t = t * wk % o.R_ORDER
+        assert o.fr_from_mont_limbs(Y[k]) == acc * rinv % o.R_ORDER
+    # linearity: NTT(x + x') = NTT(x) + NTT(x')
+    X2 = np.roll(X, 12345, axis=0)
+    assert np.array_equal(ctx.fr_ntt(ctx.fr_op(1, X, X2)), ctx.fr_op(1, Y, ctx.fr_ntt(X2)))
+    # convolution theorem: multiplying by the monomial z^s in the coefficient domain = pointwise w^(ks)
+    s = 3
+    mono = np.zeros((n, 4), dtype=np.uint64); mono[s] = frw(1)
+    M = ctx.fr_ntt(mono)
+    prod = ctx.fr_ntt(ctx.fr_op(0, Y, M), inverse=True)
+    assert np.array_equal(prod, np.roll(X, s, axis=0))                                          # cyclic shift by s

@@ -300,3 +300,60 @@ def test_validation_kats(kats, golden_dir):
     # not on the curve
     bad = bytearray(o.g1_to_uncompressed(o.G1_GEN)); bad[95] ^= 1
     assert o.g1_from_uncompressed_unchecked(bytes(bad)) is not None and o.g1_from_uncompressed(bytes(bad)) is None
+
+
+def test_scalar_field_kats(kats):
+    """Fr restatement against the reference's constants and stored answers (src/scalar.rs:76-222, tests :786-1056)."""
+    c = kats["consts"]
+    S = o.fr_from_mont_limbs
+    r = o.R_ORDER
+    assert sum(l << (64 * i) for i, l in enumerate(c["scalar.MODULUS"])) == r
+    assert (c["scalar.INV"] * c["scalar.MODULUS"][0]) % (1 << 64) == (1 << 64) - 1          # test_inv :818-832
+    assert S(c["scalar.R"]) == 1 and o.fr_to_mont_limbs(1) == c["scalar.R"]
+    assert S(c["scalar.R2"]) == pow(2, 256, r) and S(c["scalar.R3"]) == pow(2, 512, r)
+    assert S(c["scalar.GENERATOR"]) == o.FR_GENERATOR == 7
+    assert c["scalar.S"] == o.FR_S and (r - 1) % (1 << o.FR_S) == 0 and ((r - 1) >> o.FR_S) & 1
+    root, root_inv, delta, two_inv = S(c["scalar.ROOT_OF_UNITY"]), S(c["scalar.ROOT_OF_UNITY_INV"]), S(c["scalar.DELTA"]), S(c["scalar.TWO_INV"])
+    assert root == o.FR_ROOT_OF_UNITY
+    # test_constants :786-816
+    assert o.fr_mul(2, two_inv) == 1 and o.fr_mul(root, root_inv) == 1
+    assert o.fr_pow(root, 1 << o.FR_S) == 1 and o.fr_pow(root, 1 << (o.FR_S - 1)) != 1
+    assert o.fr_pow(delta, (r - 1) >> o.FR_S) == 1 and delta == pow(7, 1 << o.FR_S, r)
+    # from_bytes_wide :1005-1040
+    assert S(c["scalar.FROM_BYTES_WIDE_MAXIMUM"]) == o.fr_from_bytes_wide([0xFF] * 64)
+    assert o.fr_from_bytes_wide([254, 255, 255, 255, 1, 0, 0, 0, 2, 72, 3, 0, 250, 183, 132, 88, 245, 79, 188, 236, 239, 79, 140, 153, 111, 5,
+                                 197, 172, 89, 177, 36, 24] + [0] * 32) == S(c["scalar.R2"])
+    # test_multiplication / test_squaring / test_inversion :1107-1181 walk multiples of LARGEST (= r - 1) and R2
+    cur = S(c["scalar.LARGEST"])         # the largest LIMB pattern (raw limbs = r - 1), i.e. the value (r - 1) / R
+    assert sum(l << (64 * i) for i, l in enumerate(c["scalar.LARGEST"])) == r - 1
+    largest = cur
+    for _ in range(20):
+        acc = 0
+        for bit in bin(cur)[2:]:
+            acc = o.fr_add(acc, acc)
+            if bit == "1":
+                acc = o.fr_add(acc, cur)
+        assert o.fr_mul(cur, cur) == acc == o.fr_sqr(cur)
+        cur = o.fr_add(cur, largest)
+    assert o.fr_inv(0) is None and o.fr_inv(1) == 1 and o.fr_inv(r - 1) == r - 1
+    t = S(c["scalar.R2"])
+    for _ in range(20):
+        assert o.fr_mul(o.fr_inv(t), t) == 1
+        t = o.fr_add(t, S(c["scalar.R2"]))
+
+
+def test_fr_ntt_definition():
+    """the recursive transform equals the defining sums; inverse undoes forward; omega has exact order n"""
+    rng = o.SplitMix64(99)
+    for log_n in range(0, 7):
+        n = 1 << log_n
+        x = [rng.scalar() for _ in range(n)]
+        y = o.fr_ntt(x)
+        assert y == o.fr_ntt_naive(x)
+        assert o.fr_ntt(y, inverse=True) == x == o.fr_ntt_naive(y, inverse=True)
+        w = o.fr_omega(log_n)
+        assert pow(w, n, o.R_ORDER) == 1 and (n == 1 or pow(w, n // 2, o.R_ORDER) == o.R_ORDER - 1)
+    # polynomial evaluation view: y_k = p(w^k)
+    x = [rng.scalar() for _ in range(16)]
+    w = o.fr_omega(4)
+    assert o.fr_ntt(x)[5] == sum(c * pow(w, 5 * j, o.R_ORDER) for j, c in enumerate(x)) % o.R_ORDER
