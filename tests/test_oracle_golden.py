@@ -357,3 +357,33 @@ def test_fr_ntt_definition():
     x = [rng.scalar() for _ in range(16)]
     w = o.fr_omega(4)
     assert o.fr_ntt(x)[5] == sum(c * pow(w, 5 * j, o.R_ORDER) for j, c in enumerate(x)) % o.R_ORDER
+
+
+def test_hash_to_curve_vectors(kats, golden_dir):
+    """oracle/h2c_ref.py against the RFC 9380 (draft-16) vectors of the reference's integration tests
+    (tests/hash_to_curve_g1.rs, hash_to_curve_g2.rs, expand_msg.rs) and the SSWU answers of map_g1.rs:655-760."""
+    import json
+    from oracle import h2c_ref as h
+    v = json.load(open(os.path.join(golden_dir, "h2c_vectors.json")))
+    for t in v["expand_msg"]:
+        assert h.expand_message_xmd(bytes.fromhex(t["msg"]), bytes.fromhex(t["dst"]), t["len_in_bytes"]).hex() == t["out"]
+    for t in v["g1"]:
+        fn = h.g1_hash_to_curve if t["test"].endswith("_ro") else h.g1_encode_to_curve
+        p = fn(bytes.fromhex(t["msg"]), bytes.fromhex(t["dst"]))
+        a = o.g1_to_affine(p)
+        assert o.g1_to_uncompressed(a).hex() == t["out"]
+        assert o.g1_is_on_curve(a) and o.g1_is_torsion_free(a)
+    for t in v["g2"]:
+        fn = h.g2_hash_to_curve if t["test"].endswith("_ro") else h.g2_encode_to_curve
+        a = o.g2_to_affine(fn(bytes.fromhex(t["msg"]), bytes.fromhex(t["dst"])))
+        assert o.g2_to_uncompressed(a).hex() == t["out"]
+        assert o.g2_is_torsion_free(a)
+    # exceptional SSWU inputs (u = 0 and u = sqrt(-1/XI)) with the reference's stored projective answer
+    F = o.fp_from_mont_limbs
+    s = kats["tests"]["h2c_g1.test_simple_swu_expected"]["fp"]
+    xo, yo, zo, excp = F(s[0]), F(s[1]), F(s[2]), F(s[3])
+    assert h.g1_map_to_curve_simple_swu(0) == (xo, yo, zo)
+    assert h.g1_map_to_curve_simple_swu(excp) == (xo, yo, zo)
+    # F_2_256 is 2^256, sgn0 is the parity of the canonical value (map_g1.rs:790-806)
+    assert h._consts()["F_2_256"] == pow(2, 256, o.P)
+    assert h.sgn0_fp(0) == 0 and h.sgn0_fp(1) == 1 and h.sgn0_fp(o.P - 1) == 0
