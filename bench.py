@@ -237,6 +237,22 @@ def main():
         extras["fr_ntt"] = {"log_n": args.log_n, "ms": 1e3 * ndt, "elements_per_s": n / ndt,
                             "note": "radix-2 NTT over the scalar field, in place, natural order; 6 passes over the data at 2^20"}
         del d_fr
+        # hash-to-curve in front of the pairings: 2^16 32-byte messages -> G2
+        hm = torch.from_numpy(rs.randint(0, 256, size=np_ * 32, dtype=np.uint8)).to(dev)
+        ho = torch.arange(0, (np_ + 1) * 32, 32, dtype=torch.int64, device=dev)
+        hdst = b"BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_"
+        hd = torch.from_numpy(np.frombuffer(hdst, dtype=np.uint8).copy()).to(dev)
+        hout = torch.zeros((np_, 36), dtype=torch.int64, device=dev)
+        def h2c():
+            bls._lib.check(ctx.lib.blsgpu_hash_to_curve_device(ctx.h, 2, hm.data_ptr(), ho.data_ptr(), np_, hd.data_ptr(), len(hdst), 0, hout.data_ptr()), "hash_to_curve_device")
+        h2c(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            h2c()
+        torch.cuda.synchronize()
+        hdt = (time.perf_counter() - t1) / 3
+        extras["hash_to_g2"] = {"n": np_, "ms": 1e3 * hdt, "hashes_per_s": np_ / hdt, "note": "hash_to_curve (XMD:SHA-256, SSWU, RO) of 32-byte messages to G2"}
+        del hm, ho, hout
         n2 = min(1 << 20, n)
         k2 = rs.randint(0, 256, size=(n2, 32), dtype=np.uint8); k2[:, 31] &= 0x3F
         b2 = ctx.bases_from_scalars(2, k2)

@@ -278,6 +278,21 @@ class Context:
     def fp12_op(self, op, a, b=None):
         return self._elem_op(self.lib.blsgpu_fp12_op, 72, op, a, b)
 
+    # ---- hash-to-curve (reference: src/hash_to_curve/) ----
+    def hash_to_curve(self, group, msgs, dst, encode_only=False):
+        """`G::hash_to_curve(msg, dst)` (or `encode_to_curve`) with ExpandMsgXmd<Sha256> for a list of byte strings;
+        returns (n, 18 | 36) u64 projective points in the reference's limbs."""
+        msgs = [bytes(m) for m in msgs]
+        n = len(msgs)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64) if n else 0
+        blob = np.frombuffer(b"".join(msgs) + b"\0", dtype=np.uint8).copy()
+        d = np.frombuffer(bytes(dst) + b"\0", dtype=np.uint8).copy()
+        out = np.zeros((n, 18 if group == 1 else 36), dtype=np.uint64)
+        fn = self.lib.blsgpu_g1_hash_to_curve_batch if group == 1 else self.lib.blsgpu_g2_hash_to_curve_batch
+        check(fn(self.h, _ptr(blob), _ptr(offs), n, _ptr(d), len(dst), 1 if encode_only else 0, _ptr(out)), "hash_to_curve")
+        return out
+
     # ---- scalar field Fr (reference: src/scalar.rs) ----
     def fr_op(self, op, a, b=None, return_flags=False):
         """element-wise Scalar arithmetic on (n, 4) u64 Montgomery limbs; op 0 mul, 1 add, 2 sub, 3 square, 4 invert,

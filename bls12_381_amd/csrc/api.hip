@@ -12,6 +12,7 @@
 #include "msm.cuh"
 #include "pairing.cuh"
 #include "fr.cuh"
+#include "h2c.cuh"
 #include "codec.cuh"
 
 using namespace bls;
@@ -922,6 +923,71 @@ extern "C" int blsgpu_mad_throughput(blsgpu_ctx* c, int iters, double* r) { retu
 
 // ---------------------------------------------------------------------------------------------------
 // pairings
+// ---------------------------------------------------------------------------------------------------
+// hash-to-curve (h2c.cuh)
+// ---------------------------------------------------------------------------------------------------
+template <class F>
+static int h2c_host(blsgpu_ctx* c, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst, size_t dst_len, int encode_only,
+                    uint64_t* out) {
+  if (!c || (n && (!offsets || !out)) || (dst_len && !dst)) return bad("hash_to_curve: NULL argument");
+  if (!n) return BLSGPU_OK;
+  const size_t total = (size_t)offsets[n];
+  for (size_t i = 0; i < n; i++) if (offsets[i] > offsets[i + 1]) return bad("hash_to_curve: offsets must be non-decreasing");
+  if (total && !msgs) return bad("hash_to_curve: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  // a DST longer than 255 bytes is replaced by H("H2C-OVERSIZE-DST-" || DST)  (expand_msg.rs:74-95)
+  uint8_t d[255]; u32 dlen;
+  if (dst_len > 255) {
+    Sha256 s; sha_init(s);
+    const char* salt = "H2C-OVERSIZE-DST-";
+    for (int i = 0; salt[i]; i++) sha_put(s, (uint8_t)salt[i]);
+    for (size_t i = 0; i < dst_len; i++) sha_put(s, dst[i]);
+    u32 hw[8]; sha_finish(s, hw);
+    for (int i = 0; i < 32; i++) d[i] = (uint8_t)(hw[i >> 2] >> (24 - 8 * (i & 3)));
+    dlen = 32;
+  } else {
+    for (size_t i = 0; i < dst_len; i++) d[i] = dst[i];
+    dlen = (u32)dst_len;
+  }
+  constexpr int WW = Wire<F>::WORDS;
+  if (c->io_a.reserve(total + 16) || c->io_b.reserve((n + 1) * 8) || c->io_c.reserve(256) || c->io_out.reserve(n * 3 * WW * 4)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  if (total) HIPCHK(hipMemcpyAsync(c->io_a.p, msgs, total, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->io_b.p, offsets, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  if (dlen) HIPCHK(hipMemcpyAsync(c->io_c.p, d, dlen, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));                 // `d` lives on this stack frame
+  hipLaunchKernelGGL(k_hash_to_curve<F>, dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->io_a.as<uint8_t>(), (const unsigned long long*)c->io_b.p, n,
+                     c->io_c.as<uint8_t>(), dlen, encode_only ? 1 : 0, c->io_out.as<u32>());
+  LAUNCHCHK();
+  HIPCHK(hipMemcpyAsync(out, c->io_out.p, n * 3 * WW * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_g1_hash_to_curve_batch(blsgpu_ctx* c, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst, size_t dst_len,
+                                             int encode_only, uint64_t* out_xyz) {
+  return h2c_host<FpPolicy>(c, msgs, offsets, n, dst, dst_len, encode_only, out_xyz);
+}
+extern "C" int blsgpu_g2_hash_to_curve_batch(blsgpu_ctx* c, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst, size_t dst_len,
+                                             int encode_only, uint64_t* out_xyz) {
+  return h2c_host<Fp2Policy>(c, msgs, offsets, n, dst, dst_len, encode_only, out_xyz);
+}
+// device-resident variant: messages, offsets (n + 1 u64) and the DST (<= 255 bytes) already in device memory
+extern "C" int blsgpu_hash_to_curve_device(blsgpu_ctx* c, int group, const void* d_msgs, const void* d_offsets, size_t n, const void* d_dst, size_t dst_len,
+                                           int encode_only, void* d_out_xyz) {
+  if (!c || (n && (!d_offsets || !d_out_xyz)) || (dst_len && !d_dst)) return bad("hash_to_curve: NULL argument");
+  if (dst_len > 255) return bad("hash_to_curve_device: reduce a DST longer than 255 bytes on the host first");
+  if (group != 1 && group != 2) return bad("hash_to_curve: group must be 1 or 2");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  if (group == 1)
+    hipLaunchKernelGGL(k_hash_to_curve<FpPolicy>, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (const uint8_t*)d_msgs, (const unsigned long long*)d_offsets, n,
+                       (const uint8_t*)d_dst, (u32)dst_len, encode_only ? 1 : 0, (u32*)d_out_xyz);
+  else
+    hipLaunchKernelGGL(k_hash_to_curve<Fp2Policy>, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (const uint8_t*)d_msgs, (const unsigned long long*)d_offsets, n,
+                       (const uint8_t*)d_dst, (u32)dst_len, encode_only ? 1 : 0, (u32*)d_out_xyz);
+  LAUNCHCHK();
+  return BLSGPU_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // scalar field Fr: element-wise vector operations and the radix-2 transform (fr.cuh)
 // ---------------------------------------------------------------------------------------------------

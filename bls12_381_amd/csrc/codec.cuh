@@ -16,22 +16,24 @@
 
 namespace bls {
 
-// x^e for a fixed 384-bit exponent (4-bit fixed window, the table lives in scratch)
+// x^e for a fixed 384-bit exponent (4-bit fixed window, the table is indexed at run time and lives in scratch)
 DEVNI v16 fe_pow_raw(v16 xin, int which) {
-  constexpr u64 e_inv[6] = BLS_P_MINUS_2_U64, e_sqrt[6] = BLS_EXP_SQRT_U64;
-  fe x = (fe)from_v16<2>(xin);
+  // which: 0 = p - 2, 1 = (p + 1) / 4 (square root), 2 = (p - 3) / 4 (hash-to-curve's chain_pm3div4)
+  constexpr u64 e_inv[6] = BLS_P_MINUS_2_U64, e_sqrt[6] = BLS_EXP_SQRT_U64, e_pm3[6] = BLS_EXP_P_MINUS_3_DIV_4_U64;
+  fe x = (fe)from_v16<VS>(xin);
   fe tab[15];
   tab[0] = x;
+#pragma nounroll
   for (int i = 1; i < 15; i++) tab[i] = (fe)mul(tab[i - 1], x);
   fe acc = fe_one();
   bool started = false;
+#pragma nounroll
   for (int w = 95; w >= 0; w--) {
-    u64 word = which == 0 ? e_inv[w >> 4] : e_sqrt[w >> 4];
+    u64 word = which == 0 ? e_inv[w >> 4] : which == 1 ? e_sqrt[w >> 4] : e_pm3[w >> 4];
     u32 d = (u32)(word >> ((w & 15) * 4)) & 15u;
     if (started) { acc = (fe)sqr(acc); acc = (fe)sqr(acc); acc = (fe)sqr(acc); acc = (fe)sqr(acc); }
     if (d) {
-      fe t = tab[0];
-      for (int j = 1; j < 15; j++) if ((int)d == j + 1) t = tab[j];
+      fe t = tab[d - 1];
       acc = started ? (fe)mul(acc, t) : t;
       started = true;
     }

@@ -1,0 +1,346 @@
+// h2c.cuh -- batched hash-to-curve: what stands in front of `multi_miller_loop` when BLS
+// signatures are verified in bulk.  One message per lane: expand_message_xmd(SHA-256) -> hash_to_field ->
+// simplified SWU onto the isogenous curve -> isogeny -> (sum of the two points) -> cofactor clearing.
+//
+// Reference: /root/reference/src/hash_to_curve/  expand_msg.rs:230-328 (ExpandMsgXmd; DST reduction :74-95),
+// mod.rs:32-49 (hash_to_field), :86-108 (hash_to_curve / encode_to_curve); map_g1.rs:513-531 (from_okm), :535-543
+// (sgn0), :550-586 (map_to_curve_simple_swu), :589-630 (iso_map); map_g2.rs:374-378, :382-388, :391-454, :457-492;
+// src/g1.rs:800-802 and src/g2.rs:847-947 (psi, psi2, clear_cofactor).  The formulas are the reference's, step for
+// step, so even the projective coordinates of the result are the reference's (tests compare X, Y and Z); its
+// fixed addition chains (chain.rs) are replaced by windowed exponentiation with the same exponents.
+// Only the XMD/SHA-256 expander (the BLS-signature suites) is provided.
+#pragma once
+#include "codec.cuh"
+
+namespace bls {
+
+#define HD __host__ __device__ inline
+
+// ---- SHA-256 (FIPS 180-4), byte-oriented streaming; also used on the host to shorten an oversize DST ---------
+struct Sha256 {
+  u32 h[8];
+  u32 w[16];
+  u32 fill;            // bytes in w
+  u64 total;           // bytes absorbed
+};
+HD u32 sha_rotr(u32 x, int n) { return (x >> n) | (x << (32 - n)); }
+HD void sha256_compress(u32* h, const u32* blk) {
+  constexpr u32 K[64] = {
+      0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u, 0xd807aa98u, 0x12835b01u, 0x243185beu,
+      0x550c7dc3u, 0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u, 0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu, 0x4a7484aau,
+      0x5cb0a9dcu, 0x76f988dau, 0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u, 0x27b70a85u,
+      0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u, 0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u, 0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u,
+      0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u, 0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu,
+      0x682e6ff3u, 0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+  u32 w[16];
+  for (int i = 0; i < 16; i++) w[i] = blk[i];
+  u32 a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+  for (int i = 0; i < 64; i++) {
+    if (i >= 16) {
+      u32 w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
+      u32 s0 = sha_rotr(w15, 7) ^ sha_rotr(w15, 18) ^ (w15 >> 3);
+      u32 s1 = sha_rotr(w2, 17) ^ sha_rotr(w2, 19) ^ (w2 >> 10);
+      w[i & 15] = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
+    }
+    u32 S1 = sha_rotr(e, 6) ^ sha_rotr(e, 11) ^ sha_rotr(e, 25);
+    u32 ch = (e & f) ^ (~e & g);
+    u32 t1 = hh + S1 + ch + K[i] + w[i & 15];
+    u32 S0 = sha_rotr(a, 2) ^ sha_rotr(a, 13) ^ sha_rotr(a, 22);
+    u32 mj = (a & b) ^ (a & c) ^ (b & c);
+    u32 t2 = S0 + mj;
+    hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+  }
+  h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+HD void sha_init(Sha256& s) {
+  const u32 iv[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+  for (int i = 0; i < 8; i++) s.h[i] = iv[i];
+  for (int i = 0; i < 16; i++) s.w[i] = 0;
+  s.fill = 0; s.total = 0;
+}
+HD void sha_put(Sha256& s, uint8_t b) {
+  s.w[s.fill >> 2] |= (u32)b << (24 - 8 * (s.fill & 3));
+  s.fill++; s.total++;
+  if (s.fill == 64) { sha256_compress(s.h, s.w); for (int i = 0; i < 16; i++) s.w[i] = 0; s.fill = 0; }
+}
+HD void sha_put_words(Sha256& s, const u32* words, int n) {          // n big-endian words
+  for (int i = 0; i < n; i++) for (int k = 0; k < 4; k++) sha_put(s, (uint8_t)(words[i] >> (24 - 8 * k)));
+}
+HD void sha_finish(Sha256& s, u32* out) {                             // 8 big-endian words
+  const u64 bits = s.total * 8;
+  sha_put(s, 0x80);
+  while (s.fill != 56) sha_put(s, 0);
+  for (int k = 7; k >= 0; k--) sha_put(s, (uint8_t)(bits >> (8 * k)));
+  for (int i = 0; i < 8; i++) out[i] = s.h[i];
+}
+
+// expand_message_xmd (expand_msg.rs:247-328): ell blocks of 8 big-endian words into `out` (dst already <= 255 bytes)
+DEVNI void h2c_expand_xmd(const uint8_t* __restrict__ msg, size_t mlen, const uint8_t* __restrict__ dst, u32 dlen, u32 len_in_bytes,
+                          int ell, u32* out) {
+  Sha256 s;
+  u32 b0[8], bi[8];
+  sha_init(s);
+  for (int i = 0; i < 64; i++) sha_put(s, 0);                         // Z_pad: one block of zeros
+  for (size_t i = 0; i < mlen; i++) sha_put(s, msg[i]);
+  sha_put(s, (uint8_t)(len_in_bytes >> 8)); sha_put(s, (uint8_t)len_in_bytes); sha_put(s, 0);
+  for (u32 i = 0; i < dlen; i++) sha_put(s, dst[i]);
+  sha_put(s, (uint8_t)dlen);
+  sha_finish(s, b0);
+  for (int k = 1; k <= ell; k++) {
+    u32 x[8];
+    for (int j = 0; j < 8; j++) x[j] = k == 1 ? b0[j] : (b0[j] ^ bi[j]);
+    sha_init(s);
+    sha_put_words(s, x, 8);
+    sha_put(s, (uint8_t)k);
+    for (u32 i = 0; i < dlen; i++) sha_put(s, dst[i]);
+    sha_put(s, (uint8_t)dlen);
+    sha_finish(s, bi);
+    for (int j = 0; j < 8; j++) out[8 * (k - 1) + j] = bi[j];
+  }
+}
+// map_g1.rs:513-531: 64 uniform bytes (16 big-endian words) -> db * 2^256 + da
+DEV fe h2c_from_okm(const u32* W) {
+  constexpr PLimbs f256 = {BLS_H2C_F_2_256};
+  u32 hi[12], lo[12];
+#pragma unroll
+  for (int j = 0; j < 8; j++) { hi[j] = W[7 - j]; lo[j] = W[15 - j]; }
+#pragma unroll
+  for (int j = 8; j < 12; j++) { hi[j] = 0; lo[j] = 0; }
+  return store(add(mul(fe_from_plain(hi), fe1_const(f256)), fe_from_plain(lo)));
+}
+// sgn0: parity of the canonical integer (map_g1.rs:535-543, map_g2.rs:382-388)
+DEV bool h2c_sgn0(const fe& a) { u32 w[12]; fe_to_plain(a, w); return (w[0] & 1u) != 0; }
+DEV bool h2c_sgn0(const fe2& a) {
+  u32 w0[12], w1[12]; fe_to_plain(a.c0, w0); fe_to_plain(a.c1, w1);
+  u32 z = 0;
+  for (int i = 0; i < 12; i++) z |= w0[i];
+  return ((w0[0] & 1u) != 0) || (z == 0 && (w1[0] & 1u) != 0);
+}
+
+// ---- constant tables (internal Montgomery form, generated from the reference's literals) ----------------------
+__device__ const u32 H2C_ISO11_T[55][NL] = BLS_H2C_ISO11;
+__device__ const u32 H2C_ISO3_T[30][NL] = BLS_H2C_ISO3;
+__device__ const u32 H2C_G2_T[16][NL] = BLS_H2C_G2_CONSTS;          // A, B, XI, RV1, ETAS[4], each (c0, c1)
+DEV fe h2c_row(const u32 (*t)[NL], int i) {
+  fe1 r;
+#pragma unroll
+  for (int k = 0; k < NL; k++) r.l[k] = t[i][k];
+  return (fe)r;
+}
+DEV fe2 h2c_row2(const u32 (*t)[NL], int i) {
+  fe2 r;
+#pragma unroll
+  for (int k = 0; k < NL; k++) { r.c0.l[k] = t[2 * i][k]; r.c1.l[k] = t[2 * i + 1][k]; }
+  return r;
+}
+
+// ---- exponentiations ---------------------------------------------------------------------------------------------
+// a^((p-3)/4)  (chain_pm3div4): (p-3)/4 = (p+1)/4 - 1, i.e. the square-root exponent with the last multiplication left out;
+// computed directly with the generic windowed power (codec.cuh, exponent selector 2)
+DEV fe h2c_pow_pm3div4(const fe& a) { return (fe)from_v16<2>(fe_pow_raw(to_v16(a), 2)); }
+// a^((p^2-9)/16) in Fp2 (chain_p2m9div16): 4-bit fixed windows over the 762-bit exponent
+DEVNI void h2c_pow_p2m9div16(fe2& r, const fe2& a) {
+  constexpr u64 e[12] = BLS_EXP_P2_MINUS_9_DIV_16_U64;
+  fe2 tab[15];
+  tab[0] = a;
+#pragma nounroll
+  for (int i = 1; i < 15; i++) tab[i] = store2(mul(tab[i - 1], a));
+  fe2 acc = fe2_one();
+  bool started = false;
+#pragma nounroll
+  for (int w = 191; w >= 0; w--) {
+    u32 d = (u32)(e[w >> 4] >> ((w & 15) * 4)) & 15u;
+    if (started) { acc = store2(sqr(acc)); acc = store2(sqr(acc)); acc = store2(sqr(acc)); acc = store2(sqr(acc)); }
+    if (d) { acc = started ? store2(mul(acc, tab[d - 1])) : tab[d - 1]; started = true; }
+  }
+  r = acc;
+}
+
+// ---- simplified SWU onto the isogenous curves -----------------------------------------------------------------------
+// map_g1.rs:550-586
+DEVNI void h2c_sswu_g1(Proj<FpPolicy>& out, const fe& u) {
+  typedef FpPolicy F;
+  constexpr PLimbs la = {BLS_H2C_G1_SSWU_ELLP_A}, lb = {BLS_H2C_G1_SSWU_ELLP_B}, lxi = {BLS_H2C_G1_SSWU_XI}, lsq = {BLS_H2C_G1_SQRT_M_XI_CUBED};
+  const fe A = (fe)fe1_const(la), B = (fe)fe1_const(lb), XI = (fe)fe1_const(lxi), SQ = (fe)fe1_const(lsq);
+  fe usq = F::st(sqr(u));
+  fe xi_usq = F::st(mul(XI, usq));
+  fe xisq_u4 = F::st(sqr(xi_usq));
+  fe nd_common = F::st(add(xisq_u4, xi_usq));
+  fe x_den = F::st(mul(A, select(is_zero(nd_common), XI, F::st(neg(nd_common)))));
+  fe x0_num = F::st(mul(B, F::st(add(fe_one(), nd_common))));
+  fe x_densq = F::st(sqr(x_den));
+  fe gx_den = F::st(mul(x_densq, x_den));
+  fe gx0_num = F::st(add(mul(F::st(add(sqr(x0_num), mul(A, x_densq))), x0_num), mul(B, gx_den)));
+  fe u_v = F::st(mul(gx0_num, gx_den));
+  fe vsq = F::st(sqr(gx_den));
+  fe cand = F::st(mul(u_v, h2c_pow_pm3div4(F::st(mul(u_v, vsq)))));
+  const bool gx0_square = el_eq(F::st(mul(F::st(sqr(cand)), gx_den)), gx0_num);
+  fe x1_num = F::st(mul(x0_num, xi_usq));
+  fe y1 = F::st(mul(F::st(mul(F::st(mul(SQ, usq)), u)), cand));
+  fe x_num = select(gx0_square, x0_num, x1_num);
+  fe y = select(gx0_square, cand, y1);
+  if (h2c_sgn0(y) != h2c_sgn0(u)) y = F::st(neg(y));
+  out.x = x_num; out.y = F::st(mul(y, x_den)); out.z = x_den;
+}
+// map_g2.rs:391-454
+DEVNI void h2c_sswu_g2(Proj<Fp2Policy>& out, const fe2& u) {
+  const fe2 A = h2c_row2(H2C_G2_T, 0), B = h2c_row2(H2C_G2_T, 1), XI = h2c_row2(H2C_G2_T, 2), RV1 = h2c_row2(H2C_G2_T, 3);
+  fe2 usq = store2(sqr(u));
+  fe2 xi_usq = store2(mul(XI, usq));
+  fe2 xisq_u4 = store2(sqr(xi_usq));
+  fe2 nd_common = store2(add(xisq_u4, xi_usq));
+  fe2 x_den = store2(mul(A, select(is_zero(nd_common), XI, store2(neg(nd_common)))));
+  fe2 x0_num = store2(mul(B, store2(add(fe2_one(), nd_common))));
+  fe2 x_densq = store2(sqr(x_den));
+  fe2 gx_den = store2(mul(x_densq, x_den));
+  fe2 gx0_num = store2(add(mul(store2(add(sqr(x0_num), mul(A, x_densq))), x0_num), mul(B, gx_den)));
+  fe2 vsq = store2(sqr(gx_den));
+  fe2 v_3 = store2(mul(vsq, gx_den));
+  fe2 v_4 = store2(sqr(vsq));
+  fe2 uv_7 = store2(mul(store2(mul(gx0_num, v_3)), v_4));
+  fe2 uv_15 = store2(mul(uv_7, store2(sqr(v_4))));
+  fe2 pw; h2c_pow_p2m9div16(pw, uv_15);
+  fe2 cand = store2(mul(uv_7, pw));
+  // the candidate times each fourth root of unity (1, u, RV1 (1+u), RV1 (1-u))
+  fe2 y = cand;
+  fe2 tmp = store2(mul_by_u(cand));
+  if (el_eq(store2(mul(store2(sqr(tmp)), gx_den)), gx0_num)) y = tmp;
+  tmp = store2(mul(cand, RV1));
+  if (el_eq(store2(mul(store2(sqr(tmp)), gx_den)), gx0_num)) y = tmp;
+  { fe2 t2; t2.c0 = tmp.c1; t2.c1 = (Fe<1, VS2>)reduce_v(norm(neg(tmp.c0))); tmp = t2; }          // (c1, -c0)
+  if (el_eq(store2(mul(store2(sqr(tmp)), gx_den)), gx0_num)) y = tmp;
+  fe2 gx1_num = store2(mul(store2(mul(gx0_num, xi_usq)), xisq_u4));
+  fe2 sc = store2(mul(store2(mul(cand, usq)), u));
+  bool eta_found = false;
+#pragma nounroll
+  for (int k = 0; k < 4; k++) {
+    fe2 t = store2(mul(sc, h2c_row2(H2C_G2_T, 4 + k)));
+    bool found = el_eq(store2(mul(store2(sqr(t)), gx_den)), gx1_num);
+    if (found) y = t;
+    eta_found = eta_found || found;
+  }
+  fe2 x_num = eta_found ? store2(mul(x0_num, xi_usq)) : x0_num;
+  if (h2c_sgn0(u) != h2c_sgn0(y)) y = store2(neg(y));
+  out.x = x_num; out.y = store2(mul(y, x_den)); out.z = x_den;
+}
+
+// ---- isogenies (map_g1.rs:589-630, map_g2.rs:457-492): Horner in x with powers of z --------------------------------
+template <class F> struct H2cIso;
+template <> struct H2cIso<FpPolicy> {
+  static constexpr int NZ = 15;
+  static constexpr int LEN[4] = {12, 11, 16, 16};
+  static DEV fe coeff(int base, int k) { return h2c_row(H2C_ISO11_T, base + k); }
+};
+template <> struct H2cIso<Fp2Policy> {
+  static constexpr int NZ = 3;
+  static constexpr int LEN[4] = {4, 3, 4, 4};
+  static DEV fe2 coeff(int base, int k) { return h2c_row2(H2C_ISO3_T, base + k); }
+};
+template <class F>
+DEVNI void h2c_iso_map(Proj<F>& out, const Proj<F>& in) {
+  typedef typename F::elem E;
+  typedef H2cIso<F> I;
+  E zpows[I::NZ];
+  zpows[0] = in.z;
+#pragma nounroll
+  for (int j = 1; j < I::NZ; j++) zpows[j] = F::st(mul(zpows[j - 1], in.z));
+  E mapvals[4];
+  int base = 0;
+#pragma nounroll
+  for (int idx = 0; idx < 4; idx++) {
+    const int clast = I::LEN[idx] - 1;
+    E v = I::coeff(base, clast);
+#pragma nounroll
+    for (int j = 0; j < clast; j++) v = F::st(add(mul(v, in.x), mul(zpows[j], I::coeff(base, clast - 1 - j))));
+    mapvals[idx] = v;
+    base += I::LEN[idx];
+  }
+  mapvals[1] = F::st(mul(mapvals[1], in.z));
+  mapvals[2] = F::st(mul(mapvals[2], in.y));
+  mapvals[3] = F::st(mul(mapvals[3], in.z));
+  out.x = F::st(mul(mapvals[0], mapvals[3]));
+  out.y = F::st(mul(mapvals[2], mapvals[1]));
+  out.z = F::st(mul(mapvals[1], mapvals[3]));
+}
+
+// ---- cofactor clearing ------------------------------------------------------------------------------------------------
+// g1.rs:800-802: self - [x] self
+DEVNI void h2c_clear_cofactor(Proj<FpPolicy>& out, const Proj<FpPolicy>& p) {
+  Proj<FpPolicy> t;
+  pt_mul_by_x<FpPolicy>(t, p);
+  out = pt_add<FpPolicy>(p, pt_neg<FpPolicy>(t));
+}
+// g2.rs:847-890 / :890-912
+DEV Proj<Fp2Policy> pt_psi(const Proj<Fp2Policy>& p) {
+  constexpr PLimbs px1 = {BLS_PSI_X_1}, py0 = {BLS_PSI_Y_0}, py1 = {BLS_PSI_Y_1};
+  fe2 cx; cx.c0 = (Fe<1, VS2>)fe_zero(); cx.c1 = (Fe<1, VS2>)fe1_const(px1);
+  fe2 cy; cy.c0 = (Fe<1, VS2>)fe1_const(py0); cy.c1 = (Fe<1, VS2>)fe1_const(py1);
+  Proj<Fp2Policy> s;
+  s.x = store2(mul(store2(conj(p.x)), cx));
+  s.y = store2(mul(store2(conj(p.y)), cy));
+  s.z = store2(conj(p.z));
+  return s;
+}
+DEV Proj<Fp2Policy> pt_psi2(const Proj<Fp2Policy>& p) {
+  constexpr PLimbs k = {BLS_PSI2_X};
+  Proj<Fp2Policy> s;
+  s.x = store2(mul_fp(p.x, fe1_const(k)));
+  s.y = store2(neg(p.y));
+  s.z = p.z;
+  return s;
+}
+// g2.rs:938-947
+DEVNI void h2c_clear_cofactor(Proj<Fp2Policy>& out, const Proj<Fp2Policy>& p) {
+  typedef Fp2Policy F;
+  Proj<F> t1, t2 = pt_psi(p), t3;
+  pt_mul_by_x<F>(t1, p);
+  Proj<F> r = pt_psi2(pt_double<F>(p));
+  pt_mul_by_x<F>(t3, pt_add<F>(t1, t2));
+  r = pt_add<F>(r, t3);
+  r = pt_add<F>(r, pt_neg<F>(t1));
+  r = pt_add<F>(r, pt_neg<F>(t2));
+  out = pt_add<F>(r, pt_neg<F>(p));
+}
+
+template <class F> struct H2cField;
+template <> struct H2cField<FpPolicy> {
+  static constexpr int M = 1;
+  static DEV fe from_okm(const u32* W) { return h2c_from_okm(W); }
+  static DEV void sswu(Proj<FpPolicy>& o, const fe& u) { h2c_sswu_g1(o, u); }
+};
+template <> struct H2cField<Fp2Policy> {
+  static constexpr int M = 2;
+  static DEV fe2 from_okm(const u32* W) { fe2 r; r.c0 = (Fe<1, VS2>)h2c_from_okm(W); r.c1 = (Fe<1, VS2>)h2c_from_okm(W + 16); return r; }
+  static DEV void sswu(Proj<Fp2Policy>& o, const fe2& u) { h2c_sswu_g2(o, u); }
+};
+
+// mod.rs:86-108.  msgs = the messages back to back, offs[i] .. offs[i+1] the bytes of message i; dst <= 255 bytes.
+// out[i] = projective (X : Y : Z) in wire limbs.  encode_only: one field element (the *_NU_ suites).
+template <class F>
+__global__ void __launch_bounds__(64) k_hash_to_curve(const uint8_t* __restrict__ msgs, const unsigned long long* __restrict__ offs, size_t n,
+                                                      const uint8_t* __restrict__ dst, u32 dlen, int encode_only, u32* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int M = H2cField<F>::M, WW = Wire<F>::WORDS;
+  const int count = encode_only ? 1 : 2;
+  const int ell = count * M * 2;
+  u32 ub[64];
+  h2c_expand_xmd(msgs + offs[i], (size_t)(offs[i + 1] - offs[i]), dst, dlen, (u32)(ell * 32), ell, ub);
+  Proj<F> q, t;
+  H2cField<F>::sswu(t, H2cField<F>::from_okm(ub));
+  h2c_iso_map<F>(q, t);
+  if (!encode_only) {
+    Proj<F> q1;
+    H2cField<F>::sswu(t, H2cField<F>::from_okm(ub + 16 * M));
+    h2c_iso_map<F>(q1, t);
+    q = pt_add<F>(q, q1);
+  }
+  Proj<F> r;
+  h2c_clear_cofactor(r, q);
+  Wire<F>::save(r.x, out + i * 3 * WW);
+  Wire<F>::save(r.y, out + i * 3 * WW + WW);
+  Wire<F>::save(r.z, out + i * 3 * WW + 2 * WW);
+}
+
+}  // namespace bls

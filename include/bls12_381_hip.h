@@ -176,6 +176,20 @@ int blsgpu_fr_op_device(blsgpu_ctx* ctx, int op, const void* d_a, const void* d_
 int blsgpu_fr_ntt(blsgpu_ctx* ctx, uint64_t* data, int log_n, int inverse);
 int blsgpu_fr_ntt_device(blsgpu_ctx* ctx, void* d_data, int log_n, int inverse);
 
+/* ---- hash-to-curve (the step in front of multi_miller_loop in bulk signature checks) ---- */
+/* `<G as HashToCurve<ExpandMsgXmd<Sha256>>>::hash_to_curve(msg, dst)` / `encode_to_curve` (encode_only != 0) for n
+ * messages (src/hash_to_curve/mod.rs:86-108; expand_msg.rs:230-328; map_g1.rs:513-638; map_g2.rs:374-504;
+ * g1.rs:800-802, g2.rs:938-947).  `msgs` holds the messages back to back, message i = bytes offsets[i] ..
+ * offsets[i+1] (n + 1 offsets).  `dst` of any length (longer than 255 bytes: reduced as expand_msg.rs:74-95 does).
+ * out_xyz: n projective points (X : Y : Z), 18 (G1) / 36 (G2) u64 each -- the reference's own coordinates. */
+int blsgpu_g1_hash_to_curve_batch(blsgpu_ctx* ctx, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst, size_t dst_len,
+                                  int encode_only, uint64_t* out_xyz);
+int blsgpu_g2_hash_to_curve_batch(blsgpu_ctx* ctx, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst, size_t dst_len,
+                                  int encode_only, uint64_t* out_xyz);
+/* Same with messages, offsets and DST (<= 255 bytes) already in device memory; group = 1 | 2. */
+int blsgpu_hash_to_curve_device(blsgpu_ctx* ctx, int group, const void* d_msgs, const void* d_offsets, size_t n, const void* d_dst, size_t dst_len,
+                                int encode_only, void* d_out_xyz);
+
 #ifdef __cplusplus
 }
 #endif

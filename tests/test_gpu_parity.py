@@ -652,3 +652,53 @@ def test_fr_ntt_large_properties(ctx):
     M = ctx.fr_ntt(mono)
     prod = ctx.fr_ntt(ctx.fr_op(0, Y, M), inverse=True)
     assert np.array_equal(prod, np.roll(X, s, axis=0))                                          # cyclic shift by s
+
+
+# ---- hash-to-curve (reference src/hash_to_curve/) --------------------------------------------------
+def _h2c_vectors(golden_dir):
+    import json
+    return json.load(open(os.path.join(golden_dir, "h2c_vectors.json")))
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_hash_to_curve_rfc_vectors(ctx, golden_dir, group):
+    """the RFC 9380 (draft-16) vectors of the reference's tests/hash_to_curve_g{1,2}.rs, compared on uncompressed bytes"""
+    import bls12_381_amd as b
+    vecs = _h2c_vectors(golden_dir)["g1" if group == 1 else "g2"]
+    for encode in (False, True):
+        sel = [t for t in vecs if t["test"].endswith("_nu") == encode]
+        assert len(sel) == 5
+        dst = bytes.fromhex(sel[0]["dst"])
+        out = ctx.hash_to_curve(group, [bytes.fromhex(t["msg"]) for t in sel], dst, encode_only=encode)
+        xy, inf = ctx.batch_normalize(group, out)
+        for k, t in enumerate(sel):
+            pt = (b.G1Affine if group == 1 else b.G2Affine)(xy[k], bool(inf[k]))
+            assert pt.to_uncompressed().hex() == t["out"], (group, encode, k)
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_hash_to_curve_vs_oracle(ctx, group):
+    """random and edge-case messages / DSTs against the oracle, on the PROJECTIVE coordinates (the kernels follow the
+    reference's formulas step for step), plus subgroup membership of the results"""
+    from oracle import h2c_ref as h
+    r = o.SplitMix64(31 + group)
+    msgs = [b"", b"a", bytes(55), bytes(56), bytes(63), bytes(64), bytes(65), bytes(range(256)) * 3] + \
+           [bytes((r.next() >> 8) & 0xFF for _ in range(int(r.next() % 200))) for _ in range(24)]
+    for dst in (b"QUUX-V01-CS02-with-BLS12381G%d_XMD:SHA-256_SSWU_RO_" % group, b"", b"x" * 255, b"long-dst-" * 40):
+        for encode in (False, True):
+            out = ctx.hash_to_curve(group, msgs, dst, encode_only=encode)
+            for k, m in enumerate(msgs if dst.startswith(b"QUUX") else msgs[:6]):
+                if group == 1:
+                    p = (h.g1_encode_to_curve if encode else h.g1_hash_to_curve)(m, dst)
+                    want = np.concatenate([fpw(c) for c in p])
+                else:
+                    p = (h.g2_encode_to_curve if encode else h.g2_hash_to_curve)(m, dst)
+                    want = np.concatenate([fp2w(c) for c in p])
+                assert np.array_equal(out[k], want), (group, len(dst), encode, k)
+    # results are in the prime-order subgroup: the checked decoder accepts their encodings
+    out = ctx.hash_to_curve(group, msgs, b"subgroup-check")
+    xy, inf = ctx.batch_normalize(group, out)
+    enc = ctx.points_to_bytes(group, xy, inf, compressed=True)
+    _, _, ok = ctx.points_from_bytes(group, enc, compressed=True, checked=True)
+    assert ok.all() and not inf.any()
+    assert ctx.hash_to_curve(group, [], b"x").shape[0] == 0
