@@ -187,6 +187,35 @@ inline MillerLoopResult multi_miller_loop(const std::vector<std::pair<G1Affine, 
 }
 inline Gt Gt::generator() { return pairing(G1Affine::generator(), G2Affine::generator()); }            // src/pairings.rs:359-475
 
+// src/hash_to_curve/mod.rs:86-108 with ExpandMsgXmd<Sha256>: `G::hash_to_curve(msg, dst)` / `G::encode_to_curve(msg, dst)` for a batch
+template <int G> std::vector<Projective<G>> hash_to_curve(const std::vector<std::string>& msgs, const std::string& dst, bool encode_only = false) {
+  std::vector<Projective<G>> out(msgs.size());
+  if (msgs.empty()) return out;
+  std::vector<uint64_t> offs(msgs.size() + 1, 0); std::string blob;
+  for (size_t i = 0; i < msgs.size(); i++) { blob += msgs[i]; offs[i + 1] = blob.size(); }
+  std::vector<uint64_t> xyz(msgs.size() * Projective<G>::W);
+  check((G == 1 ? blsgpu_g1_hash_to_curve_batch : blsgpu_g2_hash_to_curve_batch)(Context::instance().handle(), (const uint8_t*)blob.data(), offs.data(), msgs.size(),
+                                                                                 (const uint8_t*)dst.data(), dst.size(), encode_only ? 1 : 0, xyz.data()), "hash_to_curve");
+  for (size_t i = 0; i < msgs.size(); i++) std::memcpy(out[i].xyz.data(), xyz.data() + i * Projective<G>::W, Projective<G>::W * 8);
+  return out;
+}
+
+// src/scalar.rs: vectors of `Scalar([u64; 4])` (Montgomery limbs) -- element-wise arithmetic and the radix-2 transform built on ROOT_OF_UNITY
+using FrLimbs = std::array<uint64_t, 4>;
+enum class FrOp { Mul = 0, Add = 1, Sub = 2, Square = 3, Invert = 4, Neg = 5, Double = 6 };
+inline std::vector<FrLimbs> fr_op(FrOp op, const std::vector<FrLimbs>& a, const std::vector<FrLimbs>& b = {}) {
+  std::vector<FrLimbs> out(a.size());
+  if (a.empty()) return out;
+  if ((int)op <= 2 && b.size() != a.size()) throw std::invalid_argument("fr_op: operands differ in length");
+  check(blsgpu_fr_op(Context::instance().handle(), (int)op, a[0].data(), b.empty() ? nullptr : b[0].data(), a.size(), out[0].data(), nullptr), "fr_op");
+  return out;
+}
+inline void fr_ntt(std::vector<FrLimbs>& v, bool inverse = false) {         // natural order in and out; v.size() a power of two
+  if (v.empty() || (v.size() & (v.size() - 1))) throw std::invalid_argument("fr_ntt: length must be a power of two");
+  int log_n = 0; while (((size_t)1 << log_n) < v.size()) log_n++;
+  check(blsgpu_fr_ntt(Context::instance().handle(), v[0].data(), log_n, inverse ? 1 : 0), "fr_ntt");
+}
+
 struct Bls12 {                                              // `pairing::Engine` / `MultiMillerLoop`, src/pairings.rs:790-824
   static Gt pairing(const G1Affine& p, const G2Affine& q) { return bls::pairing(p, q); }
   static MillerLoopResult multi_miller_loop(const std::vector<std::pair<G1Affine, G2Prepared>>& t) { return bls::multi_miller_loop(t); }

@@ -28,6 +28,17 @@ int main(int argc, char** argv) {
   REQUIRE((gp + G1Affine::generator()) == gp.dbl());
   auto m = msm<1>({G1Affine::generator(), ga}, {b, Scalar::from_u64(1)});
   REQUIRE(m == gp * b + G1Projective{(G1Affine::generator() * a).xyz});
+  // hash_to_curve: deterministic, in the subgroup ([r]P = O is implied by pairing bilinearity below), encode != hash
+  auto h = hash_to_curve<1>({"abc", "abc", ""}, "QUUX-V01-CS02-with-BLS12381G1_XMD:SHA-256_SSWU_RO_");
+  REQUIRE(h[0] == h[1] && !(h[0] == h[2]));
+  auto h2 = hash_to_curve<2>({"abc"}, "QUUX-V01-CS02-with-BLS12381G2_XMD:SHA-256_SSWU_RO_");
+  REQUIRE(pairing((h[0] * a).to_affine(), h2[0].to_affine()) == pairing(h[0].to_affine(), (h2[0] * a).to_affine()));
+  // Fr: x * x^-1 = 1 (R in Montgomery form), NTT round trip
+  FrLimbs one = {0x00000001fffffffeull, 0x5884b7fa00034802ull, 0x998c4fefecbc4ff5ull, 0x1824b159acc5056full};     // scalar.rs:159-164
+  std::vector<FrLimbs> x = {{5, 6, 7, 8}, one, {1, 0, 0, 0}, {9, 9, 9, 9}};
+  auto xi = fr_op(FrOp::Invert, x);
+  REQUIRE(fr_op(FrOp::Mul, x, xi)[0] == one && fr_op(FrOp::Mul, x, xi)[3] == one);
+  auto y = x; fr_ntt(y); REQUIRE(!(y == x)); fr_ntt(y, true); REQUIRE(y == x);
   std::printf("host mirror ok\n");
   return 0;
 }
