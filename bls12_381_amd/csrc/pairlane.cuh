@@ -52,7 +52,7 @@ constexpr int pair_mul_v(int v1, int v2) { return 1 + (v1 * v2 + (v1 + 1) * v2 +
 // Fp2 product: one sum of two products per lane.  With a / b this lane's coefficients and a' / b' the partner's:
 //   c0 lane:  a0 b0 - a1 b1 = a * b + (-a') * b'        c1 lane:  a0 b1 + a1 b0 = a' * b + a * b'
 template <int A1, int V1, int A2, int V2>
-DEV FeP<1, pair_mul_v(V1, V2)> mul(const FeP<A1, V1>& a, const FeP<A2, V2>& b) {
+DEV FeP<1, pair_mul_v(V1, V2)> mul_inl(const FeP<A1, V1>& a, const FeP<A2, V2>& b) {
   static_assert(A1 * A2 + (A1 + 1) * A2 + 1 <= MAX_A_PROD + 1, "pair-lane fe2 mul: limb bound too large, norm() an operand");
   const bool c1 = lane_is_c1();
   auto ao = partner(a.v); auto bo = partner(b.v);
@@ -64,7 +64,7 @@ DEV FeP<1, pair_mul_v(V1, V2)> mul(const FeP<A1, V1>& a, const FeP<A2, V2>& b) {
 }
 // Fp2 square: c0 = (a0 + a1)(a0 - a1), c1 = 2 a0 a1 -- one multiplication per lane
 template <int A, int V>
-DEV auto sqr(const FeP<A, V>& a) {
+DEV auto sqr_inl(const FeP<A, V>& a) {
   static_assert(2 * A * (2 * A + 1) <= MAX_A_PROD, "pair-lane fe2 sqr: norm() the operand");
   const bool c1 = lane_is_c1();
   auto ao = partner(a.v);
@@ -126,6 +126,15 @@ DEV auto sqr_ni(const FeP<A, V>& a) {
   FeP<1, decltype(p)::kV> r; r.v = p;
   return r;
 }
+// the product / square the generic curve formulas pick up: out of line by default (the ten products of a mixed
+// addition inlined are ~63 KB of code, more than the instruction cache)
+#ifdef BLS_PAIR_MUL_INLINE
+template <int A1, int V1, int A2, int V2> DEV auto mul(const FeP<A1, V1>& a, const FeP<A2, V2>& b) { return mul_inl(a, b); }
+template <int A, int V> DEV auto sqr(const FeP<A, V>& a) { return sqr_inl(a); }
+#else
+template <int A1, int V1, int A2, int V2> DEV auto mul(const FeP<A1, V1>& a, const FeP<A2, V2>& b) { return mul_ni(a, b); }
+template <int A, int V> DEV auto sqr(const FeP<A, V>& a) { return sqr_ni(a); }
+#endif
 // a0 - a1 u
 template <int A, int V> DEV auto conj(const FeP<A, V>& a) {
   FeP<A + 1, V + 1> r; r.v = select(lane_is_c1(), neg(a.v), (Fe<A + 1, V + 1>)a.v); return r;
