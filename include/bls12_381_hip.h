@@ -49,12 +49,14 @@ int blsgpu_device_count(void);
  * the context's own stream. */
 int blsgpu_set_stream(blsgpu_ctx* ctx, void* hip_stream);
 int blsgpu_synchronize(blsgpu_ctx* ctx);
-/* MSM pipelining.  An MSM ends with a latency-bound tail (bucket reduction + window combine: a few
- * wavefronts for ~ms) that the library runs on an internal stream.  By default the context's stream waits
- * for it, so results are ordered like any other work on that stream.  With pipelining on, `*_msm_device`
- * returns without that wait and the tail of call i overlaps the chip-filling phases of call i+1 (up to two
- * calls in flight, each with its own output buffer); the caller must `blsgpu_join` (stream-level wait, no
- * host sync) or `blsgpu_synchronize` before consuming results. */
+/* MSM pipelining.  An MSM is three phases with different bottlenecks: digit sort (LDS atomics), bucket
+ * accumulation (integer VALU) and a latency-bound tail (bucket reduction + window combine: a few wavefronts
+ * for ~ms).  The library runs them on internal streams chained by events.  By default the context's stream
+ * waits for the tail, so results are ordered like any other work on that stream.  With pipelining on,
+ * `*_msm_device` only records a dependency on the work already queued on the context's stream (the producer
+ * of the scalars) and returns; sort, accumulation and tail of up to four calls then overlap one another.
+ * The caller must keep each call's scalars and output buffer untouched, and use `blsgpu_join` (stream-level
+ * wait, no host sync) or `blsgpu_synchronize` before consuming results. */
 int blsgpu_set_pipelining(blsgpu_ctx* ctx, int enabled);
 int blsgpu_join(blsgpu_ctx* ctx);
 /* As blsgpu_join, but leaves the `lag` most recent MSM calls in flight (lag = 1: wait for everything except

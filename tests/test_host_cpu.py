@@ -132,3 +132,13 @@ def test_two_rank_gloo_sharding(tmp_path):
     for rk, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, out
         assert f"rank {rk} ok" in out
+
+
+def test_header_is_plain_c():
+    """the drop-in boundary must be consumable by a C compiler (cgo / bindgen / ctypes users): C99, no C++, no torch types"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "bls12_381_hip.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    text = open(hdr).read()
+    assert "torch" not in text and "at::" not in text and "std::" not in text
