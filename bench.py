@@ -235,7 +235,7 @@ def main():
         torch.cuda.synchronize()
         ndt = (time.perf_counter() - t1) / 10
         extras["fr_ntt"] = {"log_n": args.log_n, "ms": 1e3 * ndt, "elements_per_s": n / ndt,
-                            "note": "radix-2 NTT over the scalar field, in place, natural order; 6 passes over the data at 2^20"}
+                            "note": "radix-2 NTT over the scalar field, in place, natural order; 5 radix-4 passes over the data + one LDS pass at 2^20"}
         del d_fr
         # hash-to-curve in front of the pairings: 2^16 32-byte messages -> G2
         hm = torch.from_numpy(rs.randint(0, 256, size=np_ * 32, dtype=np.uint8)).to(dev)

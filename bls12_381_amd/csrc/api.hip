@@ -76,6 +76,7 @@ struct blsgpu_ctx {
   DevBuf result, io_a, io_b, io_c, io_d, io_out, flags_a, flags_b;
   DevBuf fr_tw[2], fr_tmp, fr_ninv;     // Fr transform: twiddle tables (forward / inverse), permutation target, n^-1
   int fr_tw_log[2] = {-1, -1};
+  int fr_ninv_log = -1;
 };
 
 struct blsgpu_bases {
@@ -1027,9 +1028,10 @@ extern "C" int blsgpu_fr_ntt_device(blsgpu_ctx* c, void* d_data, int log_n, int 
   hipStream_t st = c->stream;
   const int dir = inverse ? 1 : 0;
   const size_t n = (size_t)1 << log_n, half = n >> 1;
-  if (c->fr_tw[dir].reserve(half * 32) || c->fr_tmp.reserve(n * 32) || c->fr_ninv.reserve(64)) { g_err = "hipMalloc(fr scratch) failed"; return BLSGPU_ERR_HIP; }
+  if (c->fr_tw[dir].reserve(n * 32) || c->fr_tmp.reserve(n * 32) || c->fr_ninv.reserve(64)) { g_err = "hipMalloc(fr scratch) failed"; return BLSGPU_ERR_HIP; }
   if (c->fr_tw_log[dir] != log_n) {
     hipLaunchKernelGGL(k_fr_twiddles, dim3(nblk((half + FR_TW_RUN - 1) / FR_TW_RUN, 256)), dim3(256), 0, st, c->fr_tw[dir].as<u32>(), log_n, dir);
+    if (log_n > 1) hipLaunchKernelGGL(k_fr_tw_levels, dim3(nblk(half, 256)), dim3(256), 0, st, c->fr_tw[dir].as<u32>(), log_n);
     LAUNCHCHK();
     c->fr_tw_log[dir] = log_n;
   }
@@ -1050,9 +1052,12 @@ extern "C" int blsgpu_fr_ntt_device(blsgpu_ctx* c, void* d_data, int log_n, int 
   if (lh >= tl) { hipLaunchKernelGGL(k_fr_stage1, dim3(nblk(n / 2, 256)), dim3(256), 0, st, src, cur, tw, log_n, lh); src = cur; lh--; }
   LAUNCHCHK();
   const u32* scale = nullptr;
-  if (inverse) { hipLaunchKernelGGL(k_fr_ninv, dim3(1), dim3(64), 0, st, c->fr_ninv.as<u32>(), log_n); scale = c->fr_ninv.as<u32>(); }
+  if (inverse) {
+    if (c->fr_ninv_log != log_n) { hipLaunchKernelGGL(k_fr_ninv, dim3(1), dim3(64), 0, st, c->fr_ninv.as<u32>(), log_n); c->fr_ninv_log = log_n; }
+    scale = c->fr_ninv.as<u32>();
+  }
   u32* dst = src == data ? tmp : data;
-  hipLaunchKernelGGL(k_fr_tile, dim3((unsigned)(n >> tl)), dim3(256), ((size_t)8 << tl) * 4, st, src, dst, tw, log_n, tl, scale);
+  hipLaunchKernelGGL(k_fr_tile, dim3((unsigned)(n >> tl)), dim3(256), ((size_t)9 << tl) * 4, st, src, dst, tw, log_n, tl, scale);
   LAUNCHCHK();
   if (dst != data) HIPCHK(hipMemcpyAsync(data, tmp, n * 32, hipMemcpyDeviceToDevice, st));
   return BLSGPU_OK;

@@ -153,8 +153,9 @@ __global__ void __launch_bounds__(256) k_fr_op(int op, const u32* __restrict__ a
   fr_store(out + i * 8, r);
 }
 
-// ---- twiddle table: tw[j] = w^j, j < n/2 ------------------------------------------------------------------
+// ---- twiddle table: tw[j] = 2^5 w^j, j < n/2 ---------------------------------------------------------------
 // each lane starts from w^(64 t) (one exponentiation) and walks 64 consecutive powers
+DEV size_t fr_tw_off(int lh) { return ((size_t)1 << lh) - 1; }      // element offset of level lh in the twiddle buffer (see below)
 constexpr int FR_TW_RUN = 64;
 __global__ void __launch_bounds__(256) k_fr_twiddles(u32* __restrict__ tw, int log_n, int inverse) {
   const size_t half = (size_t)1 << (log_n - 1);
@@ -164,13 +165,118 @@ __global__ void __launch_bounds__(256) k_fr_twiddles(u32* __restrict__ tw, int l
   Fr w = fr_pow2k(fr_root_of_unity(), 32 - log_n);
   if (inverse) w = fr_inv(w);
   Fr cur = fr_pow_u64(w, (u64)j0);
-  for (int k = 0; k < FR_TW_RUN && j0 + k < half; k++) { fr_store(tw + (j0 + k) * 8, cur); cur = fr_mul(cur, w); }
+  for (int k = 0; k < 5; k++) cur = fr_add(cur, cur);          // the table holds w^j * 2^5 (see frl_mul)
+  u32* top = tw + fr_tw_off(log_n - 1) * 8;
+  for (int k = 0; k < FR_TW_RUN && j0 + k < half; k++) { fr_store(top + (j0 + k) * 8, cur); cur = fr_mul(cur, w); }
 }
+
+// compact per-stage tables: level lh (half-span 2^lh) holds 2^5 w_{2^(lh+1)}^i, i < 2^lh, at element offset 2^lh - 1, so
+// that every stage reads its twiddles with unit stride (the full table is level log_n - 1)
+__global__ void __launch_bounds__(256) k_fr_tw_levels(u32* __restrict__ tw, int log_n) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;        // t + 1 in [1, 2^(log_n-1)): level = floor(log2(t+1))
+  const int top = log_n - 1;
+  if (t + 1 >= ((size_t)1 << top)) return;
+  const int lh = 63 - __clzll((unsigned long long)(t + 1));
+  const size_t i = (t + 1) - ((size_t)1 << lh);
+  fr_store(tw + t * 8, fr_load(tw + (fr_tw_off(top) + (i << (top - lh))) * 8));
+}
+
+// ---- lazy 9 x 29-bit arithmetic for the butterflies -------------------------------------------------------------------
+// Inside the transform kernels an element is nine 29-bit limbs (three spare bits per word) and the Montgomery factor is
+// 2^261: a column of the product is at most 9 + 9 partial products below 2^58 times a small slack, so it accumulates in
+// one 64-bit register with no carries (171 v_mad_u64_u32 against ~500 instructions for the 8 x 32-bit CIOS product), and
+// additions / subtractions are nine carry-free VOP2 instructions.  The twiddles are stored multiplied by 2^5, so that
+// frl_mul(x, w') = x w 2^5 / 2^261 = x w / 2^256 is still the reference's Montgomery product.  Bounds are tracked by hand
+// ("A": limbs < A * 2^29, "V": value < V * r):
+//   load        A1 V2   (memory between passes holds values in [0, 2r): r < 2^255, so 2r still fits eight words)
+//   R-stage     a + b -> A2 V4 (kept);  (a + 4r - b) w' : A3 V6 -> product A1 V2
+//   F-stage     inputs up to A2 V4:  a + b -> A4 V8 -> frl_reduce -> A1 V2;  (a + 8r - b) w' : A5 V12 -> A1 V2
+// Column bound of the product: 9 * A * 2^58 + 9 * 2^58 < 2^64 needs A <= 6; value bound: a w' / 2^261 + r < 2r needs
+// V <= 70 (2^261 / r = 70.6).
+struct FrL { u32 l[9]; };
+constexpr u32 M29 = (1u << 29) - 1;
+struct FrL9 { u32 w[9]; };
+constexpr FrL9 FR_MOD_L = {BLS_FR_MOD_L29};
+DEV FrL frl_unpack(const Fr& a) {                  // eight 32-bit words -> nine 29-bit limbs
+  FrL r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const int bit = 29 * i, k = bit >> 5, sh = bit & 31;
+    u64 two = (u64)a.l[k] | (k + 1 < 8 ? (u64)a.l[k + 1] << 32 : 0ull);
+    r.l[i] = (u32)(two >> sh) & M29;
+  }
+  return r;
+}
+DEV Fr frl_pack(const FrL& a) {                    // normalised limbs (A1), value < 2^256
+  Fr r;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int bit = 32 * k, i = bit / 29, sh = bit - 29 * i;       // word k starts inside limb i at bit sh
+    u32 v = a.l[i] >> sh;
+    if (i + 1 < 9) v |= a.l[i + 1] << (29 - sh);
+    if (i + 2 < 9 && 58 - sh < 32) v |= a.l[i + 2] << (58 - sh);
+    r.l[k] = v;
+  }
+  return r;
+}
+DEV FrL frl_load(const u32* p) { return frl_unpack(fr_load(p)); }
+DEV FrL frl_add(const FrL& a, const FrL& b) { FrL r; for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + b.l[i]; return r; }
+template <int WHICH> DEV FrL frl_sub(const FrL& a, const FrL& b) {        // a + K r - b with the bias matching b's bounds
+  constexpr FrL9 bias = WHICH == 1 ? FrL9{BLS_FR_BIAS_4_1} : FrL9{BLS_FR_BIAS_8_2};
+  FrL r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + bias.w[i] - b.l[i];
+  return r;
+}
+// (a * b) / 2^261 mod r, result A1 V2; a: A <= 6 / (A of b), b: A1 canonical twiddle (see the bound table above)
+DEV FrL frl_mul(const FrL& a, const FrL& b) {
+  u32 m[9];
+  FrL r;
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) acc += (u64)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = 0; i < k; i++) acc += (u64)m[i] * FR_MOD_L.w[k - i];
+    m[k] = (0u - (u32)acc) & M29;                   // -r^-1 mod 2^29 = -1 (r = 1 mod 2^32)
+    acc += (u64)m[k] * FR_MOD_L.w[0];
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = 9; k < 17; k++) {
+#pragma unroll
+    for (int i = k - 8; i < 9; i++) acc += (u64)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = k - 8; i < 9; i++) acc += (u64)m[i] * FR_MOD_L.w[k - i];
+    r.l[k - 9] = (u32)acc & M29;
+    acc >>= 29;
+  }
+  r.l[8] = (u32)acc;
+  return r;
+}
+// A <= 4, V <= 8  ->  A1, value in [0, 2r): carry propagation, then q = floor(top / ((r >> 232) + 1)) <= floor(x / r)
+// undershoots by at most one, so x - q r < 2r
+DEV FrL frl_reduce(const FrL& a) {
+  FrL t; u32 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { u32 v = a.l[i] + c; t.l[i] = v & M29; c = v >> 29; }
+  t.l[8] = a.l[8] + c;
+  const u32 q = t.l[8] / BLS_FR_TOP_P1;
+  FrL r; int64_t cc = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { int64_t v = (int64_t)t.l[i] - (int64_t)((u64)q * FR_MOD_L.w[i]) + cc; r.l[i] = (u32)v & M29; cc = v >> 29; }
+  r.l[8] = (u32)((int64_t)t.l[8] - (int64_t)((u64)q * FR_MOD_L.w[8]) + cc);
+  return r;
+}
+// A1, value < 2r  ->  canonical eight words
+DEV Fr frl_canon(const FrL& a) { return fr_cond_sub(frl_pack(a), 0); }
 
 // ---- decimation-in-frequency stages over global memory ------------------------------------------------------
 // One radix-2 DIF stage with half-span h on a length-n vector: for each block of 2h elements,
 //   (a, b) = (x[i], x[i+h])  ->  x[i] = a + b,  x[i+h] = (a - b) w^(i * n/(2h))
-// k_fr_stage2 performs TWO consecutive stages (h and h/2) on four elements per lane.
+// k_fr_stage2 performs TWO consecutive stages (h and h/2) on four elements per lane.  Values in memory between
+// passes are in [0, 2r) (only the last kernel canonicalises).
 // (src and dst may be the same buffer: every lane reads its own elements before it writes them)
 __global__ void __launch_bounds__(256) k_fr_stage1(const u32* src, u32* x, const u32* __restrict__ tw, int log_n, int log_h) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -179,10 +285,10 @@ __global__ void __launch_bounds__(256) k_fr_stage1(const u32* src, u32* x, const
   const size_t h = (size_t)1 << log_h;
   const size_t i = t & (h - 1), blk = t >> log_h;
   const size_t p = (blk << (log_h + 1)) + i;
-  Fr a = fr_load(src + p * 8), b = fr_load(src + (p + h) * 8);
-  Fr w = fr_load(tw + (i << (log_n - 1 - log_h)) * 8);
-  fr_store(x + p * 8, fr_add(a, b));
-  fr_store(x + (p + h) * 8, fr_mul(fr_sub(a, b), w));
+  FrL a = frl_load(src + p * 8), b = frl_load(src + (p + h) * 8);
+  FrL w = frl_load(tw + (fr_tw_off(log_h) + i) * 8);
+  fr_store(x + p * 8, frl_pack(frl_reduce(frl_add(a, b))));
+  fr_store(x + (p + h) * 8, frl_pack(frl_mul(frl_sub<1>(a, b), w)));
 }
 __global__ void __launch_bounds__(256) k_fr_stage2(const u32* src, u32* x, const u32* __restrict__ tw, int log_n, int log_h) {
   // stages with half-spans h = 2^log_h and h/2; lane t owns elements p, p + h/2, p + h, p + 3h/2
@@ -192,59 +298,65 @@ __global__ void __launch_bounds__(256) k_fr_stage2(const u32* src, u32* x, const
   const size_t q = (size_t)1 << (log_h - 1);           // h / 2
   const size_t i = t & (q - 1), blk = t >> (log_h - 1);
   const size_t p = (blk << (log_h + 1)) + i;
-  Fr a0 = fr_load(src + p * 8), a1 = fr_load(src + (p + q) * 8), a2 = fr_load(src + (p + 2 * q) * 8), a3 = fr_load(src + (p + 3 * q) * 8);
-  const int sh = log_n - 1 - log_h;                      // twiddle stride of the first stage
-  Fr w0 = fr_load(tw + (i << sh) * 8), w1 = fr_load(tw + ((i + q) << sh) * 8);
-  Fr w2 = fr_load(tw + (i << (sh + 1)) * 8);            // second stage: index i (mod q), stride doubled
-  // stage h: pairs (a0, a2), (a1, a3)
-  Fr b0 = fr_add(a0, a2), b2 = fr_mul(fr_sub(a0, a2), w0);
-  Fr b1 = fr_add(a1, a3), b3 = fr_mul(fr_sub(a1, a3), w1);
-  // stage h/2: pairs (b0, b1), (b2, b3)
-  fr_store(x + p * 8, fr_add(b0, b1));
-  fr_store(x + (p + q) * 8, fr_mul(fr_sub(b0, b1), w2));
-  fr_store(x + (p + 2 * q) * 8, fr_add(b2, b3));
-  fr_store(x + (p + 3 * q) * 8, fr_mul(fr_sub(b2, b3), w2));
+  FrL a0 = frl_load(src + p * 8), a1 = frl_load(src + (p + q) * 8), a2 = frl_load(src + (p + 2 * q) * 8), a3 = frl_load(src + (p + 3 * q) * 8);
+  FrL w0 = frl_load(tw + (fr_tw_off(log_h) + i) * 8), w1 = frl_load(tw + (fr_tw_off(log_h) + i + q) * 8);
+  FrL w2 = frl_load(tw + (fr_tw_off(log_h - 1) + i) * 8);          // second stage: half-span q, same offset i
+  // stage h (R): pairs (a0, a2), (a1, a3)
+  FrL b0 = frl_add(a0, a2), b2 = frl_mul(frl_sub<1>(a0, a2), w0);
+  FrL b1 = frl_add(a1, a3), b3 = frl_mul(frl_sub<1>(a1, a3), w1);
+  // stage h/2 (F): pairs (b0, b1), (b2, b3)
+  fr_store(x + p * 8, frl_pack(frl_reduce(frl_add(b0, b1))));
+  fr_store(x + (p + q) * 8, frl_pack(frl_mul(frl_sub<2>(b0, b1), w2)));
+  fr_store(x + (p + 2 * q) * 8, frl_pack(frl_reduce(frl_add(b2, b3))));
+  fr_store(x + (p + 3 * q) * 8, frl_pack(frl_mul(frl_sub<2>(b2, b3), w2)));
 }
 
 // ---- the last stages on a tile in LDS + bit-reversed store ---------------------------------------------------
-constexpr int FR_TILE_LOG = 10;                  // 1024 elements = 32 KB of LDS per workgroup
+constexpr int FR_TILE_LOG = 10;                  // 1024 elements x 9 limbs = 36 KB of LDS per workgroup
 // Runs the stages with half-spans 2^(tl-1) ... 1 on each aligned tile of 2^tl elements (tl = min(FR_TILE_LOG,
 // log_n)), then writes element p of the (bit-reversed) result to its natural position bitrev(p), optionally
-// scaled (the inverse transform's n^-1).  `x` is read, `y` written (they differ: the permutation is not in place).
+// scaled (the inverse transform's n^-1), in canonical form.  `x` is read, `y` written (they differ: the permutation
+// is not in place).  Stages alternate R (sums kept unreduced) and F (sums reduced), see the bound table above.
 __global__ void __launch_bounds__(256) k_fr_tile(const u32* __restrict__ x, u32* __restrict__ y, const u32* __restrict__ tw, int log_n,
                                                  int tl, const u32* __restrict__ scale) {
-  extern __shared__ u32 lds[];                   // 2^tl elements, word-interleaved: word k of element e at lds[k * 2^tl + e]
+  extern __shared__ u32 lds[];                   // 2^tl elements, limb-interleaved: limb k of element e at lds[k * 2^tl + e]
   const int T = 1 << tl;
   const size_t base = (size_t)blockIdx.x << tl;
   for (int e = threadIdx.x; e < T; e += blockDim.x) {
-    Fr v = fr_load(x + (base + e) * 8);
+    FrL v = frl_load(x + (base + e) * 8);
 #pragma unroll
-    for (int k = 0; k < 8; k++) lds[k * T + e] = v.l[k];
+    for (int k = 0; k < 9; k++) lds[k * T + e] = v.l[k];
   }
   __syncthreads();
+  bool relaxed = true;                           // R-stage next (all elements A1 V2)
   for (int lh = tl - 1; lh >= 0; lh--) {
     const int h = 1 << lh;
     for (int t = threadIdx.x; t < T / 2; t += blockDim.x) {
       const int i = t & (h - 1), p = ((t >> lh) << (lh + 1)) + i;
-      Fr a, b;
+      FrL a, b;
 #pragma unroll
-      for (int k = 0; k < 8; k++) { a.l[k] = lds[k * T + p]; b.l[k] = lds[k * T + p + h]; }
-      Fr w = fr_load(tw + ((size_t)i << (log_n - 1 - lh)) * 8);
-      Fr s = fr_add(a, b), d = fr_mul(fr_sub(a, b), w);
+      for (int k = 0; k < 9; k++) { a.l[k] = lds[k * T + p]; b.l[k] = lds[k * T + p + h]; }
+      FrL w = frl_load(tw + (fr_tw_off(lh) + i) * 8);
+      FrL s = frl_add(a, b), d;
+      if (relaxed) d = frl_mul(frl_sub<1>(a, b), w);
+      else { d = frl_mul(frl_sub<2>(a, b), w); s = frl_reduce(s); }
 #pragma unroll
-      for (int k = 0; k < 8; k++) { lds[k * T + p] = s.l[k]; lds[k * T + p + h] = d.l[k]; }
+      for (int k = 0; k < 9; k++) { lds[k * T + p] = s.l[k]; lds[k * T + p + h] = d.l[k]; }
     }
+    relaxed = !relaxed;
     __syncthreads();
   }
-  Fr sc; if (scale) sc = fr_load(scale);
+  FrL sc;
+  if (scale) sc = frl_load(scale);
   for (int e = threadIdx.x; e < T; e += blockDim.x) {
-    Fr v;
+    FrL v;
 #pragma unroll
-    for (int k = 0; k < 8; k++) v.l[k] = lds[k * T + e];
-    if (scale) v = fr_mul(v, sc);
+    for (int k = 0; k < 9; k++) v.l[k] = lds[k * T + e];
+    if (scale) v = frl_mul(v, sc);                // A <= 2 V <= 4 -> A1 V2
+    else v = frl_reduce(v);
     const size_t p = base + e;
     const size_t r = (size_t)(__brevll((unsigned long long)p) >> (64 - log_n));
-    fr_store(y + r * 8, v);
+    fr_store(y + r * 8, frl_canon(v));
   }
 }
 // n^-1 in Montgomery form (n = 2^log_n): (2^-1)^log_n
@@ -255,6 +367,7 @@ __global__ void k_fr_ninv(u32* __restrict__ out, int log_n) {
   for (int i = 0; i < 8; i++) h.l[i] = k.w[i];
   Fr r = fr_one();
   for (int i = 0; i < log_n; i++) r = fr_mul(r, h);
+  for (int k = 0; k < 5; k++) r = fr_add(r, r);               // pre-scaled by 2^5 like the twiddles
   fr_store(out, r);
 }
 
