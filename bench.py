@@ -99,14 +99,17 @@ def main():
     def step():
         i = state["i"]; state["i"] = i + 1
         ctx.msm_device(bases, d_scalars.data_ptr(), n, d_out[i & 3].data_ptr())
-        if world > 1 and i > 0:
-            ctx.join(1)              # result i-1 is complete (stream-level wait); MSM i stays in flight
-            exchange(d_out[(i - 1) & 3])
+        if world > 1 and i >= 2:
+            # consume result i-2: by now its tail has long finished, so the wait (and the exchange queued behind it on this
+            # stream) does not hold back the front of MSM i+1, whose dependency on this stream is recorded at its launch
+            ctx.join(2)
+            exchange(d_out[(i - 2) & 3])
 
     def drain():
         ctx.join(0)
-        if world > 1 and state["i"] > 0:
-            exchange(d_out[(state["i"] - 1) & 3])
+        if world > 1:
+            for k in range(max(0, state["i"] - 2), state["i"]):
+                exchange(d_out[k & 3])
         state["i"] = 0
 
     def fence():
