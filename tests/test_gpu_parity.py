@@ -702,3 +702,41 @@ def test_hash_to_curve_vs_oracle(ctx, group):
     _, _, ok = ctx.points_from_bytes(group, enc, compressed=True, checked=True)
     assert ok.all() and not inf.any()
     assert ctx.hash_to_curve(group, [], b"x").shape[0] == 0
+
+
+# ---- BASELINE.json full sizes (configs[2] and the per-GPU share of configs[4]) through size-independent identities --------
+def _rand_scalars_np(n, seed):
+    rs = np.random.RandomState(seed)
+    b = rs.randint(0, 256, size=(n, 32), dtype=np.uint8); b[:, 31] &= 0x3F          # < 2^254 < r
+    return b, [int.from_bytes(b[i].tobytes(), "little") for i in range(n)]
+
+
+def test_msm_g2_full_size_2_20(ctx):
+    """2^20-point G2 MSM: MSM(s, [k_i] G2) == [sum s_i k_i] G2, compared on uncompressed bytes"""
+    import bls12_381_amd as b
+    n = 1 << 20
+    kb, ks = _rand_scalars_np(n, 21)
+    sb, ss = _rand_scalars_np(n, 22)
+    out = ctx.msm(ctx.bases_from_scalars(2, kb), sb)
+    xy, inf = ctx.batch_normalize(2, out[None, :])
+    tot = sum(k * s for k, s in zip(ks, ss)) % o.R_ORDER
+    assert b.G2Affine(xy[0], bool(inf[0])).to_uncompressed() == o.g2_to_uncompressed(o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, tot)))
+
+
+def test_pairings_full_size_2_16_and_multi_miller_2_18(ctx):
+    """2^16 independent pairings (product identity + sampled exact values) and one 2^18-term multi_miller_loop:
+    final_exponentiation(prod_i ML(a_i G1, b_i G2)) == e(G1, G2)^(sum a_i b_i)   (pairings.rs:871-921 at scale)"""
+    n = 1 << 18
+    ab, a = _rand_scalars_np(n, 31)
+    bb, bs = _rand_scalars_np(n, 32)
+    g1, f1 = ctx.bases_from_scalars(1, ab).download()
+    g2, f2 = ctx.bases_from_scalars(2, bb).download()
+    gen = o.pairing(o.G1_GEN, o.G2_GEN)
+    m = 1 << 16
+    gt = ctx.pairing_batch(g1[:m], f1[:m], g2[:m], f2[:m])
+    assert np.array_equal(ctx.fp12_product(gt), fp12w(o.gt_mul_scalar(gen, sum(x * y for x, y in zip(a[:m], bs[:m])) % o.R_ORDER)))
+    for i in (0, 12345, m - 1):
+        assert np.array_equal(gt[i], fp12w(o.gt_mul_scalar(gen, a[i] * bs[i] % o.R_ORDER)))
+    ml = ctx.multi_miller_loop(g1, f1, g2, f2)
+    fe = ctx.final_exponentiation_batch(ml[None, :] if ml.ndim == 1 else ml)
+    assert np.array_equal(np.asarray(fe).reshape(-1), fp12w(o.gt_mul_scalar(gen, sum(x * y for x, y in zip(a, bs)) % o.R_ORDER)))
