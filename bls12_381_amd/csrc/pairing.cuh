@@ -346,8 +346,8 @@ template <class E> DEVNI void cyclotomic_square(Fp12T<E>& r, const Fp12T<E>& f) 
   r.c0.c0 = nz0; r.c0.c1 = nz4; r.c0.c2 = nz3;
   r.c1.c0 = nz2; r.c1.c1 = nz1; r.c1.c2 = nz5;
 }
-// pairings.rs:114-132 (`cycolotomic_exp`): f^|x| then conjugate
-template <class E> DEVNI void cyclotomic_exp(Fp12T<E>& r, const Fp12T<E>& f) {
+// pairings.rs:114-132 (`cycolotomic_exp`): f^|x| then conjugate -- the reference's square-and-multiply schedule
+template <class E> DEVNI void cyclotomic_exp_plain(Fp12T<E>& r, const Fp12T<E>& f) {
   constexpr unsigned long long X = 0xd201000000010000ull;
   Fp12T<E> tmp = f;                       // the leading one: tmp = one * f
   for (int b = 62; b >= 0; b--) {
@@ -355,6 +355,72 @@ template <class E> DEVNI void cyclotomic_exp(Fp12T<E>& r, const Fp12T<E>& f) {
     if ((X >> b) & 1) fp12_mul(tmp, tmp, f);
   }
   fp12_conj(r, tmp);
+}
+// The same power with Karabina's compressed squarings (eprint 2010/542).  In the notation of cyclotomic_square an element
+// of the cyclotomic subgroup is (A, B, C) = ((z0,z1), (z2,z3), (z4,z5)) over Fp4 = Fp2[s]/(s^2 - xi), and the squaring
+// rule B' = 3 s C^2 + 2 conj(B), C' = 3 B^2 - 2 conj(C) does not involve A: a run of squarings can carry (B, C) only
+// (two Fp4 squarings instead of three) and recover A where a power is needed,
+//     z1 = (xi z5^2 + 3 z4^2 - 2 z3) / (4 z2)      [z2 = 0:  z1 = 2 z4 z5 / z3]         z0 = (2 z1^2 + z2 z5 - 3 z3 z4) xi + 1,
+// with ONE shared inversion for the six powers f^(2^i), i in {16, 48, 57, 60, 62, 63}, whose product is f^|x|.  Both
+// routes compute the same field element, so the result is bit-identical; `false` is returned (nothing written) in the
+// degenerate case z2 = z3 = 0 (e.g. f = 1), which the caller sends down the plain route.
+template <class E> struct CycC { E z2, z3, z4, z5; };
+template <class E> DEVNI void cyclotomic_square_compressed(CycC<E>& r, const CycC<E>& c) {
+  E z2 = c.z2, z3 = c.z3, z4 = c.z4, z5 = c.z5;
+  E t0, t1, t2, t3;
+  fp4_square(t0, t1, z2, z3);
+  fp4_square(t2, t3, z4, z5);
+  E nz4 = S2(add(dbl(norm(sub(t0, z4))), t0));
+  E nz5 = S2(add(dbl(norm(add(t1, z5))), t1));
+  E t0b = S2(mul_by_nonresidue(t3));
+  E nz2 = S2(add(dbl(norm(add(t0b, z2))), t0b));
+  E nz3 = S2(add(dbl(norm(sub(t2, z3))), t2));
+  r.z2 = nz2; r.z3 = nz3; r.z4 = nz4; r.z5 = nz5;
+}
+constexpr int CYC_NSNAP = 6;
+template <class E> DEVNI bool cyclotomic_exp_compressed(Fp12T<E>& r, const Fp12T<E>& f) {
+  constexpr unsigned long long X = 0xd201000000010000ull;
+  CycC<E> c; c.z2 = f.c1.c0; c.z3 = f.c0.c2; c.z4 = f.c0.c1; c.z5 = f.c1.c2;
+  CycC<E> snap[CYC_NSNAP];
+  int ns = 0;
+  for (int i = 1; i <= 63; i++) {
+    cyclotomic_square_compressed(c, c);
+    if ((X >> i) & 1) snap[ns++] = c;
+  }
+  // denominators and their shared inverse (Montgomery's trick)
+  E den[CYC_NSNAP], pre[CYC_NSNAP];
+  bool z2zero[CYC_NSNAP];
+  bool ok = true;
+  for (int j = 0; j < CYC_NSNAP; j++) {
+    z2zero[j] = is_zero_fast(snap[j].z2);
+    if (z2zero[j]) { den[j] = snap[j].z3; ok = ok && !is_zero_fast(snap[j].z3); }
+    else den[j] = S2(mul_small<4>(snap[j].z2));
+  }
+  if (!ok) return false;
+  pre[0] = den[0];
+  for (int j = 1; j < CYC_NSNAP; j++) pre[j] = S2(pmul(pre[j - 1], den[j]));
+  E run = S2(inv(pre[CYC_NSNAP - 1]));
+  Fp12T<E> acc;
+  for (int j = CYC_NSNAP - 1; j >= 0; j--) {
+    E dinv = j ? S2(pmul(run, pre[j - 1])) : run;
+    if (j) run = S2(pmul(run, den[j]));
+    const CycC<E>& q = snap[j];
+    E num;
+    if (z2zero[j]) num = S2(dbl(pmul(q.z4, q.z5)));
+    else num = S2(sub(add(mul_by_nonresidue(psqr(q.z5)), mul_small<3>(psqr(q.z4))), dbl(q.z3)));
+    E z1 = S2(pmul(num, dinv));
+    E w = S2(sub(add(dbl(psqr(z1)), pmul(q.z2, q.z5)), mul_small<3>(pmul(q.z3, q.z4))));
+    E z0 = S2(add(mul_by_nonresidue(w), E2<E>::one()));
+    Fp12T<E> g;
+    g.c0.c0 = z0; g.c0.c1 = q.z4; g.c0.c2 = q.z3;
+    g.c1.c0 = q.z2; g.c1.c1 = z1; g.c1.c2 = q.z5;
+    if (j == CYC_NSNAP - 1) acc = g; else fp12_mul(acc, acc, g);
+  }
+  fp12_conj(r, acc);
+  return true;
+}
+template <class E> DEV void cyclotomic_exp(Fp12T<E>& r, const Fp12T<E>& f) {
+  if (!cyclotomic_exp_compressed(r, f)) cyclotomic_exp_plain(r, f);
 }
 // pairings.rs:134-173
 template <class E> DEVNI void final_exponentiation(Fp12T<E>& out, const Fp12T<E>& fin) {
