@@ -48,6 +48,7 @@ SIGNATURES = {
     "blsgpu_g1_hash_to_curve_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp, c_sz, c_int, c_vp]),
     "blsgpu_g2_hash_to_curve_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp, c_sz, c_int, c_vp]),
     "blsgpu_hash_to_curve_device": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp, c_sz, c_int, c_vp]),
+    "blsgpu_gt_mul_scalar_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_set_msm_window": (c_int, [c_vp, c_int]),
     "blsgpu_g1_sum": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g2_sum": (c_int, [c_vp, c_vp, c_sz, c_vp]),

@@ -361,6 +361,16 @@ class Context:
         check(self.lib.blsgpu_final_exponentiation_batch(self.h, _ptr(f), f.shape[0], _ptr(out)), "final_exponentiation")
         return out
 
+    def gt_mul_scalar_batch(self, gt, scalars):
+        """out[i] = gt[i] * scalars[i] (`&Gt * &Scalar`, pairings.rs:297-322); scalars: ints or (n, 32) little-endian bytes"""
+        gt = _u64(gt, (-1, 72))
+        sb = scalars_to_bytes(scalars)
+        if sb.shape[0] != gt.shape[0]:
+            raise ValueError("gt_mul_scalar_batch: lengths differ")
+        out = np.zeros_like(gt)
+        check(self.lib.blsgpu_gt_mul_scalar_batch(self.h, _ptr(gt), _ptr(sb), gt.shape[0], _ptr(out)), "gt_mul_scalar_batch")
+        return out
+
     def fp12_product(self, f):
         f = _u64(f, (-1, 72))
         out = np.zeros(72, dtype=np.uint64)
@@ -651,13 +661,7 @@ class Gt:
     def __mul__(self, s):
         """`&Gt * &Scalar` (pairings.rs:297-322): double-and-add over the 255 low bits."""
         v = s.value if isinstance(s, Scalar) else int(s) % R_ORDER
-        ctx = default_context()
-        acc = Gt.identity().f
-        for bit in range(254, -1, -1):
-            acc = ctx.fp12_op(3, acc[None, :])[0]
-            if (v >> bit) & 1:
-                acc = ctx.fp12_op(0, acc[None, :], self.f[None, :])[0]
-        return Gt(acc)
+        return Gt(default_context().gt_mul_scalar_batch(self.f[None, :], [v])[0])
 
     @staticmethod
     def sum(items):

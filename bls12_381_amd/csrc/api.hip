@@ -1170,6 +1170,19 @@ extern "C" int blsgpu_final_exponentiation_batch(blsgpu_ctx* c, const uint64_t* 
   HIPCHK(hipStreamSynchronize(c->stream));
   return BLSGPU_OK;
 }
+extern "C" int blsgpu_gt_mul_scalar_batch(blsgpu_ctx* c, const uint64_t* gt, const uint8_t* scalars, size_t n, uint64_t* out) {
+  if (!c || (n && (!gt || !scalars || !out))) return bad("gt_mul_scalar: NULL argument");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  if (c->io_a.reserve(n * 576) || c->io_b.reserve(n * 32) || c->io_out.reserve(n * 576)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  HIPCHK(hipMemcpyAsync(c->io_a.p, gt, n * 576, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->io_b.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_gt_mul_scalar, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, c->io_a.as<u32>(), c->io_b.as<u32>(), c->io_out.as<u32>(), n);
+  LAUNCHCHK();
+  HIPCHK(hipMemcpyAsync(out, c->io_out.p, n * 576, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
 extern "C" int blsgpu_fp12_product(blsgpu_ctx* c, const uint64_t* in, size_t n, uint64_t* out) {
   if (!c || !out || (n && !in)) return bad("fp12_product: NULL argument");
   HIPCHK(hipSetDevice(c->device));

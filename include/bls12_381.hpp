@@ -138,6 +138,9 @@ struct Gt {
   Gt operator+(const Gt& o) const { Gt r; check(blsgpu_fp12_op(Context::instance().handle(), 0, f.data(), o.f.data(), 1, r.f.data()), "Gt add"); return r; }
   Gt operator-() const { Gt r; check(blsgpu_fp12_op(Context::instance().handle(), 8, f.data(), nullptr, 1, r.f.data()), "Gt neg"); return r; }
   Gt dbl() const { Gt r; check(blsgpu_fp12_op(Context::instance().handle(), 3, f.data(), nullptr, 1, r.f.data()), "Gt double"); return r; }
+  Gt operator*(const Scalar& s) const {                      // `&Gt * &Scalar`, src/pairings.rs:297-322
+    Gt r; check(blsgpu_gt_mul_scalar_batch(Context::instance().handle(), f.data(), s.bytes.data(), 1, r.f.data()), "Gt mul"); return r;
+  }
   bool operator==(const Gt& o) const { return f == o.f; }
   static Gt generator();
 };

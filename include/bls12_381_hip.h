@@ -139,6 +139,9 @@ int blsgpu_multi_miller_loop(blsgpu_ctx* ctx, const uint64_t* g1_xy, const uint8
 int blsgpu_final_exponentiation_batch(blsgpu_ctx* ctx, const uint64_t* in_f, size_t n, uint64_t* out_gt);
 /* out = prod of n Fp12 values (`MillerLoopResult + MillerLoopResult`, src/pairings.rs:179-186; `Gt + Gt`). */
 int blsgpu_fp12_product(blsgpu_ctx* ctx, const uint64_t* in_f, size_t n, uint64_t out_f[72]);
+/* `&Gt * &Scalar` (src/pairings.rs:297-322) for n (element, scalar) pairs: out[i] = gt[i] "times" scalars[i], i.e. the
+ * Fp12 power by the canonical little-endian 32-byte scalar (double-and-add over its 255 low bits). */
+int blsgpu_gt_mul_scalar_batch(blsgpu_ctx* ctx, const uint64_t* gt, const uint8_t* scalars, size_t n, uint64_t* out);
 /* Device-pointer variants (inputs/outputs in device memory, asynchronous on the context's stream). */
 int blsgpu_pairing_batch_device(blsgpu_ctx* ctx, const void* d_g1_xy, const void* d_g1_inf, const void* d_g2_xy, const void* d_g2_inf, size_t n, void* d_out_gt);
 int blsgpu_multi_miller_loop_device(blsgpu_ctx* ctx, const void* d_g1_xy, const void* d_g1_inf, const void* d_g2_xy, const void* d_g2_inf, size_t n, void* d_out_f);

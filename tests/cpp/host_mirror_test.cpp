@@ -18,6 +18,7 @@ int main(int argc, char** argv) {
   REQUIRE(p == pairing((G1Affine::generator() * ab).to_affine(), G2Affine::generator()));   // bilinearity
   REQUIRE(pairing(G1Affine::identity(), hb) == Gt::identity());
   REQUIRE((p + (-p)) == Gt::identity());
+  REQUIRE(g * ab == p && g * Scalar::from_u64(2) == g.dbl());          // Gt * Scalar, src/pairings.rs:297-322
   auto ml = multi_miller_loop({{ga, G2Prepared(hb)}, {G1Affine::identity(), G2Prepared(hb)}, {G1Affine::generator(), G2Prepared(G2Affine::generator())}});
   REQUIRE(ml.final_exponentiation() == p + g);
   REQUIRE(MillerLoopResult::default_value().final_exponentiation() == Gt::identity());

@@ -740,3 +740,22 @@ def test_pairings_full_size_2_16_and_multi_miller_2_18(ctx):
     ml = ctx.multi_miller_loop(g1, f1, g2, f2)
     fe = ctx.final_exponentiation_batch(ml[None, :] if ml.ndim == 1 else ml)
     assert np.array_equal(np.asarray(fe).reshape(-1), fp12w(o.gt_mul_scalar(gen, sum(x * y for x, y in zip(a, bs)) % o.R_ORDER)))
+
+
+def test_gt_mul_scalar_batch(ctx):
+    """`&Gt * &Scalar` (pairings.rs:297-322) on the device against the oracle, edge scalars included, and its group law"""
+    gen = o.pairing(o.G1_GEN, o.G2_GEN)
+    r = o.SplitMix64(404)
+    ss = [0, 1, 2, o.R_ORDER - 1, (1 << 254) + 12345] + [r.scalar() for _ in range(27)]
+    G = np.stack([fp12w(gen)] * len(ss))
+    out = ctx.gt_mul_scalar_batch(G, ss)
+    for k in (0, 1, 2, 3, 4, 5, 17, 31):
+        assert np.array_equal(out[k], fp12w(o.gt_mul_scalar(gen, ss[k]))), k
+    # (g * a) * b == g * (a b) and g*a + g*b == g*(a+b), all on the device
+    a, b = ss[7], ss[9]
+    ga = ctx.gt_mul_scalar_batch(G[:1], [a])
+    assert np.array_equal(ctx.gt_mul_scalar_batch(ga, [b])[0], ctx.gt_mul_scalar_batch(G[:1], [a * b % o.R_ORDER])[0])
+    gb = ctx.gt_mul_scalar_batch(G[:1], [b])
+    assert np.array_equal(ctx.fp12_op(0, ga, gb)[0], ctx.gt_mul_scalar_batch(G[:1], [(a + b) % o.R_ORDER])[0])
+    import bls12_381_amd as bl
+    assert bl.Gt(fp12w(gen)) * bl.Scalar(5) == bl.Gt(out[1]) + bl.Gt(out[1]) + bl.Gt(out[1]) + bl.Gt(out[1]) + bl.Gt(out[1])
