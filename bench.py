@@ -45,8 +45,8 @@ def synth_inputs(n, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log-n", type=int, default=LOG_N, help="log2 of points per GPU (default 20 = BASELINE configs[1])")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for single-GPU plumbing tests)")
     ap.add_argument("--same-device", action="store_true", help="testing aid: all ranks use GPU 0 (needs --backend gloo)")
@@ -171,7 +171,7 @@ def main():
             "launch_ms": float(np.mean(acc_ms)), "mac32_per_launch": mac32_per_launch,
             "fp_mul_per_s_chain": fp_rate,
             "whole_msm_frac": (float(n) * 188 * 300) / (float(np.mean(tot_ms)) * 1e-3) / peak,
-            "note": "integer-VALU bound (no MFMA, HBM << 1% of peak): canonical 300 MAC32 per Fp mul, 11 Fp mul per mixed add, "
+            "note": "integer-VALU bound (no MFMA, HBM traffic ~13% of peak, see traffic): canonical 300 MAC32 per Fp mul, 11 Fp mul per mixed add, "
                     "16 windows (SURVEY.md 8d); peak = v_mad_u64_u32 issue rate measured in this run",
         }
 
