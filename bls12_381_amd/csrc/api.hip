@@ -691,6 +691,8 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
       u32* Tout = sl.lvlT.as<u32>();
       if ((size_t)nseg * G * TEAM <= TEAM_LANES_MAX)
         hipLaunchKernelGGL(k_wsum_level_team<F>, dim3(nblk((size_t)nseg * G * TEAM, 256)), dim3(256), TEAM_LDS(256), tt, E, Rout, Tout, nseg, nn, M, off);
+      else if constexpr (GroupTag<F>::id == 2)
+        hipLaunchKernelGGL(k_wsum_level_g2pair, dim3(nblk((size_t)nseg * G * 2, 256)), dim3(256), 0, tt, E, Rout, Tout, nseg, nn, M, off);
       else
         hipLaunchKernelGGL(k_wsum_level<F>, dim3(nblk((size_t)nseg * G, 256)), dim3(256), 0, tt, E, Rout, Tout, nseg, nn, M, off);
       LAUNCHCHK();

@@ -621,6 +621,36 @@ __global__ void __launch_bounds__(256) k_wsum_level(const u32* __restrict__ E, u
   store_proj<F>(Rout + (size_t)t * Store<F>::PROJ_WORDS, run);
   store_proj<F>(Tout + (size_t)t * Store<F>::PROJ_WORDS, tot);
 }
+// G2 bottom level over lane pairs (pairlane.cuh): chain t on lanes 2t / 2t+1, c0 / c1 coefficients; same records, same sums.
+// Half the registers of the one-lane form, and twice the lanes: the 2^16 chains of a 2^20-point MSM fill two wavefronts per SIMD.
+DEV void load_proj_pair(const u32* rec, u32 par, Proj<Fp2PairPolicy>& p) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) { p.x.v.l[i] = rec[par * NL + i]; p.y.v.l[i] = rec[2 * NL + par * NL + i]; p.z.v.l[i] = rec[4 * NL + par * NL + i]; }
+}
+DEV void store_proj_pair(u32* rec, u32 par, const Proj<Fp2PairPolicy>& p) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) { rec[par * NL + i] = p.x.v.l[i]; rec[2 * NL + par * NL + i] = p.y.v.l[i]; rec[4 * NL + par * NL + i] = p.z.v.l[i]; }
+}
+__global__ void __launch_bounds__(256, 2) k_wsum_level_g2pair(const u32* __restrict__ E, u32* __restrict__ Rout, u32* __restrict__ Tout,
+                                                              int nseg, int n, int M, int off) {
+  typedef Fp2PairPolicy F;
+  constexpr int PW = Store<Fp2Policy>::PROJ_WORDS;
+  __builtin_amdgcn_s_setprio(3);
+  int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  const u32 par = threadIdx.x & 1;
+  int G = n / M;
+  if (t >= nseg * G) return;
+  int seg = t / G, g = t - seg * G;
+  const u32* base = E + ((size_t)seg * n + (size_t)g * M) * PW;
+  Proj<F> run = pt_identity<F>(), tot = pt_identity<F>();
+  for (int i = M - 1; i >= 0; i--) {
+    Proj<F> e; load_proj_pair(base + (size_t)i * PW, par, e);
+    run = pt_add<F>(run, e);
+    if (i > 0 || off) tot = pt_add<F>(tot, run);
+  }
+  store_proj_pair(Rout + (size_t)t * PW, par, run);
+  store_proj_pair(Tout + (size_t)t * PW, par, tot);
+}
 // tree sum: out[seg][g] = sum of M consecutive records
 template <class F>
 __global__ void __launch_bounds__(256) k_tree_sum(const u32* __restrict__ E, u32* __restrict__ out, int nseg, int n, int M) {

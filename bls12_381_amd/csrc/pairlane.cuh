@@ -169,6 +169,11 @@ struct Fp2PairPolicy {
     if constexpr (V <= VS2) r.v = norm(a.v); else r.v = reduce_v(norm(a.v));
     return r;
   }
+  // 3b' * a = 12 (1 + u) a     (g2.rs:196,650-652)
+  template <int A, int V> static DEV auto mul_by_3b(const FeP<A, V>& a) {
+    auto t = norm(mul_by_nonresidue(norm(a)));
+    return reduce_v(norm(mul_small<12>(t)));
+  }
   static DEV elem zero() { elem r; r.v = (Fe<1, VS2>)fe_zero(); return r; }
   static DEV elem one() { elem r; r.v = select(lane_is_c1(), (Fe<1, VS2>)fe_zero(), (Fe<1, VS2>)fe_one()); return r; }
 };
