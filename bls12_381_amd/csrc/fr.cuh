@@ -120,7 +120,8 @@ DEV Fr fr_pow2k(Fr a, int k) { for (int i = 0; i < k; i++) a = fr_sqr(a); return
 // a^n for a 64-bit n
 DEVNI Fr fr_pow_u64(const Fr& a, u64 n) {
   Fr r = fr_one();
-  for (int i = 63; i >= 0; i--) { r = fr_sqr(r); if ((n >> i) & 1ull) r = fr_mul(r, a); }
+  if (n == 0) return r;
+  for (int i = 63 - __clzll((unsigned long long)n); i >= 0; i--) { r = fr_sqr(r); if ((n >> i) & 1ull) r = fr_mul(r, a); }
   return r;
 }
 
@@ -163,7 +164,7 @@ __global__ void __launch_bounds__(256) k_fr_twiddles(u32* __restrict__ tw, int l
   const size_t j0 = t * FR_TW_RUN;
   if (j0 >= half) return;
   Fr w = fr_pow2k(fr_root_of_unity(), 32 - log_n);
-  if (inverse) w = fr_inv(w);
+  if (inverse) w = fr_pow_u64(w, ((u64)1 << log_n) - 1);          // w^-1 = w^(n-1): a short power instead of an inversion per lane
   Fr cur = fr_pow_u64(w, (u64)j0);
   for (int k = 0; k < 5; k++) cur = fr_add(cur, cur);          // the table holds w^j * 2^5 (see frl_mul)
   u32* top = tw + fr_tw_off(log_n - 1) * 8;
