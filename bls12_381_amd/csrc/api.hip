@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <string>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/bls12_381_hip.h"
@@ -53,6 +54,7 @@ struct blsgpu_ctx {
   int msm_c = 0;
   bool profiling = false;
   bool pipelining = false;
+  bool force_slow_sort = false;        // test hook (env BLSGPU_FORCE_SLOW_SORT at create): the global-atomic sort used beyond 2^24 points
   hipStream_t acc_stream = nullptr;     // bucket accumulation of pipelined calls (the caller's stream is never blocked)
   hipEvent_t ev[9];
   float phase_ms[8] = {0};
@@ -328,6 +330,7 @@ extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
   HIPCHK(hipSetDevice(device));
   blsgpu_ctx* c = new blsgpu_ctx();
   c->device = device;
+  c->force_slow_sort = getenv("BLSGPU_FORCE_SLOW_SORT") != nullptr;
   HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
   for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
@@ -602,7 +605,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   HIPCHK(hipStreamWaitEvent(ft, sl.ev_in, 0));
 
   mark(0);
-  const bool fast_sort = merged || ((n <= ((size_t)1 << 24)) && cw <= 16 && cw >= 2);
+  const bool fast_sort = merged || ((n <= ((size_t)1 << 24)) && cw <= 16 && cw >= 2 && !c->force_slow_sort);
   if (fast_sort) {
     // 1'-3'. two-level counting sort (LDS atomics; see msm.cuh)
     const int key_bits = cw - 1;

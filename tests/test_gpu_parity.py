@@ -759,3 +759,20 @@ def test_gt_mul_scalar_batch(ctx):
     assert np.array_equal(ctx.fp12_op(0, ga, gb)[0], ctx.gt_mul_scalar_batch(G[:1], [(a + b) % o.R_ORDER])[0])
     import bls12_381_amd as bl
     assert bl.Gt(fp12w(gen)) * bl.Scalar(5) == bl.Gt(out[1]) + bl.Gt(out[1]) + bl.Gt(out[1]) + bl.Gt(out[1]) + bl.Gt(out[1])
+
+
+def test_msm_fallback_sort_path(monkeypatch):
+    """the global-atomic digit sort that takes over beyond 2^24 points per call (forced here through the library's test hook),
+    alternating with the default path on the same sizes and on a skewed input"""
+    import bls12_381_amd as b
+    monkeypatch.setenv("BLSGPU_FORCE_SLOW_SORT", "1")
+    slow = b.Context(0)
+    monkeypatch.delenv("BLSGPU_FORCE_SLOW_SORT")
+    r = o.SplitMix64(2424)
+    for n, w in ((300, 0), (5000, 0), (5000, 13), (20000, 16)):
+        ks = [r.scalar() for _ in range(n)]
+        ss = [r.scalar() for _ in range(n)]
+        _msm_case(slow, 1, ks, ss, window=w)
+    _msm_case(slow, 2, [r.scalar() for _ in range(3000)], [r.scalar() for _ in range(3000)])
+    _msm_case(slow, 1, [3] * 3000, [7] * 3000)                      # one bucket per window holds everything
+    slow.close() if hasattr(slow, "close") else None
