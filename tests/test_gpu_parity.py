@@ -776,3 +776,38 @@ def test_msm_fallback_sort_path(monkeypatch):
     _msm_case(slow, 2, [r.scalar() for _ in range(3000)], [r.scalar() for _ in range(3000)])
     _msm_case(slow, 1, [3] * 3000, [7] * 3000)                      # one bucket per window holds everything
     slow.close() if hasattr(slow, "close") else None
+
+
+def test_abi_error_behaviour(ctx):
+    """status codes instead of undefined behaviour: NULL / out-of-range / mismatched arguments are rejected with
+    BLSGPU_ERR_ARG and a message, and the context stays usable (INTEGRATION.md "Error behaviour")"""
+    import ctypes
+    import bls12_381_amd as b
+    lib, h = ctx.lib, ctx.h
+    ERR_ARG = -2
+    r = o.SplitMix64(5)
+    ks = [r.scalar() for _ in range(8)]
+    b1 = ctx.bases_from_scalars(1, ks)
+    b2 = ctx.bases_from_scalars(2, ks)
+    sc = np.zeros((8, 32), dtype=np.uint8); sc[:, 0] = 1
+    out18 = np.zeros(18, dtype=np.uint64); out36 = np.zeros(36, dtype=np.uint64)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert lib.blsgpu_g1_msm(h, b2.handle, 0, P(sc), 8, P(out18)) == ERR_ARG            # G2 bases handed to the G1 entry point
+    assert b"other group" in lib.blsgpu_last_error()
+    assert lib.blsgpu_g1_msm(h, b1.handle, 4, P(sc), 8, P(out18)) == ERR_ARG            # range runs past the resident bases
+    assert lib.blsgpu_g1_msm(h, b1.handle, 0, None, 8, P(out18)) == ERR_ARG             # NULL scalars with n > 0
+    assert lib.blsgpu_g1_msm(h, None, 0, P(sc), 8, P(out18)) == ERR_ARG
+    assert lib.blsgpu_fp_op(h, 99, P(out18), P(out18), 1, P(out18)) == ERR_ARG
+    assert lib.blsgpu_fr_ntt(h, P(out36), 40, 0) == ERR_ARG                              # log_n out of range
+    assert lib.blsgpu_set_msm_window(h, 3) == ERR_ARG
+    assert lib.blsgpu_pairing_batch(h, None, None, None, None, 4, P(out36)) == ERR_ARG
+    with pytest.raises(b.BlsGpuError):
+        ctx.fr_op(0, np.zeros((2, 4), dtype=np.uint64))                                  # binary op without b
+    with pytest.raises(ValueError):
+        ctx.fr_ntt(np.zeros((3, 4), dtype=np.uint64))
+    # n = 0 is a value, not an error: identity / Fp12::one (src/pairings.rs:554-603 with no terms)
+    assert lib.blsgpu_g1_msm(h, b1.handle, 0, None, 0, P(out18)) == 0
+    xy, inf = ctx.batch_normalize(1, out18[None, :])
+    assert bool(inf[0])
+    # the context still works
+    _msm_case(ctx, 1, ks, [1] * 8)
