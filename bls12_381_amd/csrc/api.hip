@@ -1142,8 +1142,18 @@ extern "C" int blsgpu_multi_miller_loop_device(blsgpu_ctx* c, const void* g1, co
   if (!c || !out || (n && (!g1 || !g2))) return bad("multi_miller_loop: NULL argument");
   HIPCHK(hipSetDevice(c->device));
   if (c->io_out.reserve((n ? n : 1) * 576)) { g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP; }
-  if (n) { int rc = pairing_launch(c, 1, g1, g1inf, g2, g2inf, n, c->io_out.p); if (rc) return rc; }
-  return fp12_product_device(c, c->io_out.as<u32>(), n, (u32*)out);
+  // terms per accumulator: as many as still leave two wavefronts per SIMD (2^17 lanes) busy
+  int K = 1;
+  while (K < MML_MAX_K && n / (2 * (size_t)K) >= 65536) K *= 2;
+  if (K == 1) {
+    if (n) { int rc = pairing_launch(c, 1, g1, g1inf, g2, g2inf, n, c->io_out.p); if (rc) return rc; }
+    return fp12_product_device(c, c->io_out.as<u32>(), n, (u32*)out);
+  }
+  const size_t groups = (n + K - 1) / K;
+  hipLaunchKernelGGL(k_multi_miller_shared, dim3(nblk(groups * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)g1, (const uint8_t*)g1inf,
+                     (const u32*)g2, (const uint8_t*)g2inf, c->io_out.as<u32>(), n, K);
+  LAUNCHCHK();
+  return fp12_product_device(c, c->io_out.as<u32>(), groups, (u32*)out);
 }
 extern "C" int blsgpu_multi_miller_loop(blsgpu_ctx* c, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, size_t n, uint64_t* out) {
   if (!c || !out || (n && (!g1 || !g2))) return bad("multi_miller_loop: NULL argument");

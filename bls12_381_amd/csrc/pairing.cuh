@@ -319,6 +319,35 @@ template <class E> DEVNI void miller_loop(Fp12T<E>& f, const fe1& px, const fe1&
   f.c1 = fp6_neg(f.c1);                     // conjugate: BLS_X_IS_NEGATIVE
 }
 
+// pairings.rs:554-603 as the reference schedules it: ONE accumulator for K terms -- per bit every term contributes its
+// line(s) and the accumulator is squared once, instead of K accumulators each paying the 62 squarings.  Same element
+// as the product of the K separate Miller values (f <- f^2 * prod l_k = prod (f_k^2 l_k)).  Identity terms are skipped
+// (:566-569).  Per-term state (P, Q in internal form and the running point R) lives in per-lane scratch.
+constexpr int MML_MAX_K = 8;
+template <class E> struct MmlTerm { fe1 px, py; E qx, qy; G2JacT<E> r; bool skip; };
+template <class E> DEVNI void multi_miller_shared(Fp12T<E>& f, MmlTerm<E>* t, int K) {
+  f = fp12_one<E>();
+  LineT<E> l;
+  for (int b = 61; b >= 0; b--) {
+    for (int k = 0; k < K; k++) {
+      if (t[k].skip) continue;
+      doubling_step(t[k].r, l);
+      ell(f, l, t[k].px, t[k].py);
+      if ((X_HALF >> b) & 1) {
+        addition_step(t[k].r, t[k].qx, t[k].qy, l);
+        ell(f, l, t[k].px, t[k].py);
+      }
+    }
+    fp12_sqr(f, f);
+  }
+  for (int k = 0; k < K; k++) {
+    if (t[k].skip) continue;
+    doubling_step(t[k].r, l);
+    ell(f, l, t[k].px, t[k].py);
+  }
+  f.c1 = fp6_neg(f.c1);
+}
+
 // ---- final exponentiation ------------------------------------------------------------------------------
 // pairings.rs:50-62
 template <class E> DEV void fp4_square(E& c0, E& c1, const E& a, const E& b) {
@@ -480,6 +509,25 @@ PAIR_KERNEL k_pairing(int mode, const u32* __restrict__ g1, const uint8_t* __res
     if (mode == 0) { Fp12T<PE> g; final_exponentiation(g, f); f = g; }
   }
   fp12_save(f, out + i * 144);
+}
+// out[j] = Miller value of terms [j*K, (j+1)*K) with shared squarings (the partial products are then multiplied up)
+PAIR_KERNEL k_multi_miller_shared(const u32* __restrict__ g1, const uint8_t* __restrict__ g1inf, const u32* __restrict__ g2,
+                                  const uint8_t* __restrict__ g2inf, u32* __restrict__ out, size_t n, int K) {
+  size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / PL;
+  const size_t groups = (n + K - 1) / K;
+  if (j >= groups) return;
+  MmlTerm<PE> t[MML_MAX_K];
+  for (int k = 0; k < K; k++) {
+    const size_t i = j * K + k;
+    t[k].skip = i >= n || (g1inf && g1inf[i]) || (g2inf && g2inf[i]);
+    if (t[k].skip) continue;
+    t[k].px = fe_from_ref(g1 + i * 24); t[k].py = fe_from_ref(g1 + i * 24 + 12);
+    t[k].qx = E2<PE>::load(g2 + i * 48); t[k].qy = E2<PE>::load(g2 + i * 48 + 24);
+    t[k].r.x = t[k].qx; t[k].r.y = t[k].qy; t[k].r.z = E2<PE>::one();
+  }
+  Fp12T<PE> f;
+  multi_miller_shared(f, t, K);
+  fp12_save(f, out + j * 144);
 }
 PAIR_KERNEL k_final_exp(const u32* __restrict__ in, u32* __restrict__ out, size_t n) {
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / PL;

@@ -811,3 +811,27 @@ def test_abi_error_behaviour(ctx):
     assert bool(inf[0])
     # the context still works
     _msm_case(ctx, 1, ks, [1] * 8)
+
+
+@pytest.mark.parametrize("n", [(1 << 17) + 5, (1 << 18) + 1, (1 << 19) + 3])
+def test_multi_miller_shared_squarings(ctx, n):
+    """large multi_miller_loop calls put K = 2 / 4 / 8 terms on one accumulator (one squaring per bit for all of them);
+    the raw value must equal the product of the individual Miller values limb for limb, identity terms skipped, ragged n"""
+    m = 4096                                                    # distinct points; terms cycle through them
+    r = o.SplitMix64(n)
+    g1, f1 = ctx.bases_from_scalars(1, [r.scalar() for _ in range(m)]).download()
+    g2, f2 = ctx.bases_from_scalars(2, [r.scalar() for _ in range(m)]).download()
+    idx = np.arange(n) % m
+    G1, G2 = g1[idx], g2[(idx * 7 + 3) % m]
+    F1 = np.zeros(n, dtype=np.uint8); F2 = np.zeros(n, dtype=np.uint8)
+    F1[[0, 5, n - 1]] = 1; F2[[5, 77, n - 2]] = 1               # identities on either side, including the ragged tail
+    got = ctx.multi_miller_loop(G1, F1, G2, F2)
+    each = ctx.miller_loop_batch(G1[:m], np.zeros(m, dtype=np.uint8), G2[:m], np.zeros(m, dtype=np.uint8))   # first m terms individually
+    # product over all n terms from per-term values: terms repeat with period lcm; evaluate through the batch API in chunks
+    acc = None
+    for s0 in range(0, n, 1 << 16):
+        e0 = min(n, s0 + (1 << 16))
+        part = ctx.fp12_product(ctx.miller_loop_batch(G1[s0:e0], F1[s0:e0], G2[s0:e0], F2[s0:e0]))
+        acc = part if acc is None else ctx.fp12_op(0, acc[None, :], part[None, :])[0]
+    assert np.array_equal(got, acc)
+    assert np.array_equal(each[1], ctx.miller_loop_batch(G1[1:2], F1[1:2], G2[1:2], F2[1:2])[0])
