@@ -961,8 +961,12 @@ static int h2c_host(blsgpu_ctx* c, const uint8_t* msgs, const uint64_t* offsets,
   HIPCHK(hipMemcpyAsync(c->io_b.p, offsets, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
   if (dlen) HIPCHK(hipMemcpyAsync(c->io_c.p, d, dlen, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));                 // `d` lives on this stack frame
-  hipLaunchKernelGGL(k_hash_to_curve<F>, dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->io_a.as<uint8_t>(), (const unsigned long long*)c->io_b.p, n,
-                     c->io_c.as<uint8_t>(), dlen, encode_only ? 1 : 0, c->io_out.as<u32>());
+  if constexpr (GroupTag<F>::id == 1)
+    hipLaunchKernelGGL(k_hash_to_curve<FpPolicy>, dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->io_a.as<uint8_t>(), (const unsigned long long*)c->io_b.p, n,
+                       c->io_c.as<uint8_t>(), dlen, encode_only ? 1 : 0, c->io_out.as<u32>());
+  else                                               // G2: one message per lane pair (pairlane.cuh)
+    hipLaunchKernelGGL(k_hash_to_curve<Fp2PairPolicy>, dim3(nblk(n * 2, 256)), dim3(256), 0, c->stream, c->io_a.as<uint8_t>(), (const unsigned long long*)c->io_b.p, n,
+                       c->io_c.as<uint8_t>(), dlen, encode_only ? 1 : 0, c->io_out.as<u32>());
   LAUNCHCHK();
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, n * 3 * WW * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -988,7 +992,7 @@ extern "C" int blsgpu_hash_to_curve_device(blsgpu_ctx* c, int group, const void*
     hipLaunchKernelGGL(k_hash_to_curve<FpPolicy>, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (const uint8_t*)d_msgs, (const unsigned long long*)d_offsets, n,
                        (const uint8_t*)d_dst, (u32)dst_len, encode_only ? 1 : 0, (u32*)d_out_xyz);
   else
-    hipLaunchKernelGGL(k_hash_to_curve<Fp2Policy>, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (const uint8_t*)d_msgs, (const unsigned long long*)d_offsets, n,
+    hipLaunchKernelGGL(k_hash_to_curve<Fp2PairPolicy>, dim3(nblk(n * 2, 256)), dim3(256), 0, c->stream, (const uint8_t*)d_msgs, (const unsigned long long*)d_offsets, n,
                        (const uint8_t*)d_dst, (u32)dst_len, encode_only ? 1 : 0, (u32*)d_out_xyz);
   LAUNCHCHK();
   return BLSGPU_OK;

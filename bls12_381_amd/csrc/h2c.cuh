@@ -118,6 +118,15 @@ DEV bool h2c_sgn0(const fe2& a) {
   return ((w0[0] & 1u) != 0) || (z == 0 && (w1[0] & 1u) != 0);
 }
 
+DEV bool h2c_sgn0(const FeP<1, VS2>& a) {                            // same rule with the coefficients on two lanes
+  u32 w[12]; fe_to_plain(a.v, w);
+  u32 z = 0;
+  for (int i = 0; i < 12; i++) z |= w[i];
+  const bool p_me = (w[0] & 1u) != 0, z_me = z == 0;
+  const bool p_o = partner_flag(p_me), z_o = partner_flag(z_me);
+  return lane_is_c1() ? (p_o || (z_o && p_me)) : (p_me || (z_me && p_o));
+}
+
 // ---- constant tables (internal Montgomery form, generated from the reference's literals) ----------------------
 __device__ const u32 H2C_ISO11_T[55][NL] = BLS_H2C_ISO11;
 __device__ const u32 H2C_ISO3_T[30][NL] = BLS_H2C_ISO3;
@@ -135,24 +144,44 @@ DEV fe2 h2c_row2(const u32 (*t)[NL], int i) {
   return r;
 }
 
+// Fp2 policy glue: the G2 path below is written once over F2 in {Fp2Policy (one lane), Fp2PairPolicy (lane pair)}
+template <class F2> struct H2c2;
+template <> struct H2c2<Fp2Policy> {
+  typedef Fp2Policy G;                     // the group-level policy whose records / wire format are used
+  static constexpr int LANES = 1;
+  static DEV fe2 row2(const u32 (*t)[NL], int i) { return h2c_row2(t, i); }
+  static DEV fe2 from_okm(const u32* W) { fe2 r; r.c0 = (Fe<1, VS2>)h2c_from_okm(W); r.c1 = (Fe<1, VS2>)h2c_from_okm(W + 16); return r; }
+  static DEV fe2 konst(const PLimbs& k0, const PLimbs& k1) { fe2 K; K.c0 = (Fe<1, VS2>)fe1_const(k0); K.c1 = (Fe<1, VS2>)fe1_const(k1); return K; }
+  template <class T> static DEV void save(const T& a, u32* w) { Wire<Fp2Policy>::save(a, w); }
+};
+template <> struct H2c2<Fp2PairPolicy> {
+  typedef Fp2Policy G;
+  static constexpr int LANES = 2;
+  static DEV FeP<1, VS2> row2(const u32 (*t)[NL], int i) { FeP<1, VS2> r; r.v = (Fe<1, VS2>)h2c_row(t, 2 * i + (lane_is_c1() ? 1 : 0)); return r; }
+  static DEV FeP<1, VS2> from_okm(const u32* W) { FeP<1, VS2> r; r.v = (Fe<1, VS2>)h2c_from_okm(W + (lane_is_c1() ? 16 : 0)); return r; }
+  static DEV FeP<1, VS2> konst(const PLimbs& k0, const PLimbs& k1) { FeP<1, VS2> K; K.v = select(lane_is_c1(), (Fe<1, VS2>)fe1_const(k1), (Fe<1, VS2>)fe1_const(k0)); return K; }
+  template <class T> static DEV void save(const T& a, u32* w) { fe_to_ref(a.v, w + (lane_is_c1() ? 12 : 0)); }
+};
+
 // ---- exponentiations ---------------------------------------------------------------------------------------------
 // a^((p-3)/4)  (chain_pm3div4): (p-3)/4 = (p+1)/4 - 1, i.e. the square-root exponent with the last multiplication left out;
 // computed directly with the generic windowed power (codec.cuh, exponent selector 2)
 DEV fe h2c_pow_pm3div4(const fe& a) { return (fe)from_v16<2>(fe_pow_raw(to_v16(a), 2)); }
 // a^((p^2-9)/16) in Fp2 (chain_p2m9div16): 4-bit fixed windows over the 762-bit exponent
-DEVNI void h2c_pow_p2m9div16(fe2& r, const fe2& a) {
+template <class F2> DEVNI void h2c_pow_p2m9div16(typename F2::elem& r, const typename F2::elem& a) {
+  typedef typename F2::elem E;
   constexpr u64 e[12] = BLS_EXP_P2_MINUS_9_DIV_16_U64;
-  fe2 tab[15];
+  E tab[15];
   tab[0] = a;
 #pragma nounroll
-  for (int i = 1; i < 15; i++) tab[i] = store2(mul(tab[i - 1], a));
-  fe2 acc = fe2_one();
+  for (int i = 1; i < 15; i++) tab[i] = F2::st(mul(tab[i - 1], a));
+  E acc = F2::one();
   bool started = false;
 #pragma nounroll
   for (int w = 191; w >= 0; w--) {
     u32 d = (u32)(e[w >> 4] >> ((w & 15) * 4)) & 15u;
-    if (started) { acc = store2(sqr(acc)); acc = store2(sqr(acc)); acc = store2(sqr(acc)); acc = store2(sqr(acc)); }
-    if (d) { acc = started ? store2(mul(acc, tab[d - 1])) : tab[d - 1]; started = true; }
+    if (started) { acc = F2::st(sqr(acc)); acc = F2::st(sqr(acc)); acc = F2::st(sqr(acc)); acc = F2::st(sqr(acc)); }
+    if (d) { acc = started ? F2::st(mul(acc, tab[d - 1])) : tab[d - 1]; started = true; }
   }
   r = acc;
 }
@@ -184,45 +213,47 @@ DEVNI void h2c_sswu_g1(Proj<FpPolicy>& out, const fe& u) {
   out.x = x_num; out.y = F::st(mul(y, x_den)); out.z = x_den;
 }
 // map_g2.rs:391-454
-DEVNI void h2c_sswu_g2(Proj<Fp2Policy>& out, const fe2& u) {
-  const fe2 A = h2c_row2(H2C_G2_T, 0), B = h2c_row2(H2C_G2_T, 1), XI = h2c_row2(H2C_G2_T, 2), RV1 = h2c_row2(H2C_G2_T, 3);
-  fe2 usq = store2(sqr(u));
-  fe2 xi_usq = store2(mul(XI, usq));
-  fe2 xisq_u4 = store2(sqr(xi_usq));
-  fe2 nd_common = store2(add(xisq_u4, xi_usq));
-  fe2 x_den = store2(mul(A, select(is_zero(nd_common), XI, store2(neg(nd_common)))));
-  fe2 x0_num = store2(mul(B, store2(add(fe2_one(), nd_common))));
-  fe2 x_densq = store2(sqr(x_den));
-  fe2 gx_den = store2(mul(x_densq, x_den));
-  fe2 gx0_num = store2(add(mul(store2(add(sqr(x0_num), mul(A, x_densq))), x0_num), mul(B, gx_den)));
-  fe2 vsq = store2(sqr(gx_den));
-  fe2 v_3 = store2(mul(vsq, gx_den));
-  fe2 v_4 = store2(sqr(vsq));
-  fe2 uv_7 = store2(mul(store2(mul(gx0_num, v_3)), v_4));
-  fe2 uv_15 = store2(mul(uv_7, store2(sqr(v_4))));
-  fe2 pw; h2c_pow_p2m9div16(pw, uv_15);
-  fe2 cand = store2(mul(uv_7, pw));
+template <class F2> DEVNI void h2c_sswu_g2(Proj<F2>& out, const typename F2::elem& u) {
+  typedef typename F2::elem E;
+  typedef H2c2<F2> H;
+  const E A = H::row2(H2C_G2_T, 0), B = H::row2(H2C_G2_T, 1), XI = H::row2(H2C_G2_T, 2), RV1 = H::row2(H2C_G2_T, 3);
+  E usq = F2::st(sqr(u));
+  E xi_usq = F2::st(mul(XI, usq));
+  E xisq_u4 = F2::st(sqr(xi_usq));
+  E nd_common = F2::st(add(xisq_u4, xi_usq));
+  E x_den = F2::st(mul(A, select(is_zero(nd_common), XI, F2::st(neg(nd_common)))));
+  E x0_num = F2::st(mul(B, F2::st(add(F2::one(), nd_common))));
+  E x_densq = F2::st(sqr(x_den));
+  E gx_den = F2::st(mul(x_densq, x_den));
+  E gx0_num = F2::st(add(mul(F2::st(add(sqr(x0_num), mul(A, x_densq))), x0_num), mul(B, gx_den)));
+  E vsq = F2::st(sqr(gx_den));
+  E v_3 = F2::st(mul(vsq, gx_den));
+  E v_4 = F2::st(sqr(vsq));
+  E uv_7 = F2::st(mul(F2::st(mul(gx0_num, v_3)), v_4));
+  E uv_15 = F2::st(mul(uv_7, F2::st(sqr(v_4))));
+  E pw; h2c_pow_p2m9div16<F2>(pw, uv_15);
+  E cand = F2::st(mul(uv_7, pw));
   // the candidate times each fourth root of unity (1, u, RV1 (1+u), RV1 (1-u))
-  fe2 y = cand;
-  fe2 tmp = store2(mul_by_u(cand));
-  if (el_eq(store2(mul(store2(sqr(tmp)), gx_den)), gx0_num)) y = tmp;
-  tmp = store2(mul(cand, RV1));
-  if (el_eq(store2(mul(store2(sqr(tmp)), gx_den)), gx0_num)) y = tmp;
-  { fe2 t2; t2.c0 = tmp.c1; t2.c1 = (Fe<1, VS2>)reduce_v(norm(neg(tmp.c0))); tmp = t2; }          // (c1, -c0)
-  if (el_eq(store2(mul(store2(sqr(tmp)), gx_den)), gx0_num)) y = tmp;
-  fe2 gx1_num = store2(mul(store2(mul(gx0_num, xi_usq)), xisq_u4));
-  fe2 sc = store2(mul(store2(mul(cand, usq)), u));
+  E y = cand;
+  E tmp = F2::st(mul_by_u(cand));
+  if (el_eq(F2::st(mul(F2::st(sqr(tmp)), gx_den)), gx0_num)) y = tmp;
+  tmp = F2::st(mul(cand, RV1));
+  if (el_eq(F2::st(mul(F2::st(sqr(tmp)), gx_den)), gx0_num)) y = tmp;
+  tmp = F2::st(neg(F2::st(mul_by_u(tmp))));                       // (c1, -c0) = -u (c0 + c1 u)
+  if (el_eq(F2::st(mul(F2::st(sqr(tmp)), gx_den)), gx0_num)) y = tmp;
+  E gx1_num = F2::st(mul(F2::st(mul(gx0_num, xi_usq)), xisq_u4));
+  E sc = F2::st(mul(F2::st(mul(cand, usq)), u));
   bool eta_found = false;
 #pragma nounroll
   for (int k = 0; k < 4; k++) {
-    fe2 t = store2(mul(sc, h2c_row2(H2C_G2_T, 4 + k)));
-    bool found = el_eq(store2(mul(store2(sqr(t)), gx_den)), gx1_num);
+    E t = F2::st(mul(sc, H::row2(H2C_G2_T, 4 + k)));
+    bool found = el_eq(F2::st(mul(F2::st(sqr(t)), gx_den)), gx1_num);
     if (found) y = t;
     eta_found = eta_found || found;
   }
-  fe2 x_num = eta_found ? store2(mul(x0_num, xi_usq)) : x0_num;
-  if (h2c_sgn0(u) != h2c_sgn0(y)) y = store2(neg(y));
-  out.x = x_num; out.y = store2(mul(y, x_den)); out.z = x_den;
+  E x_num = eta_found ? F2::st(mul(x0_num, xi_usq)) : x0_num;
+  if (h2c_sgn0(u) != h2c_sgn0(y)) y = F2::st(neg(y));
+  out.x = x_num; out.y = F2::st(mul(y, x_den)); out.z = x_den;
 }
 
 // ---- isogenies (map_g1.rs:589-630, map_g2.rs:457-492): Horner in x with powers of z --------------------------------
@@ -236,6 +267,11 @@ template <> struct H2cIso<Fp2Policy> {
   static constexpr int NZ = 3;
   static constexpr int LEN[4] = {4, 3, 4, 4};
   static DEV fe2 coeff(int base, int k) { return h2c_row2(H2C_ISO3_T, base + k); }
+};
+template <> struct H2cIso<Fp2PairPolicy> {
+  static constexpr int NZ = 3;
+  static constexpr int LEN[4] = {4, 3, 4, 4};
+  static DEV FeP<1, VS2> coeff(int base, int k) { return H2c2<Fp2PairPolicy>::row2(H2C_ISO3_T, base + k); }
 };
 template <class F>
 DEVNI void h2c_iso_map(Proj<F>& out, const Proj<F>& in) {
@@ -272,57 +308,69 @@ DEVNI void h2c_clear_cofactor(Proj<FpPolicy>& out, const Proj<FpPolicy>& p) {
   out = pt_add<FpPolicy>(p, pt_neg<FpPolicy>(t));
 }
 // g2.rs:847-890 / :890-912
-DEV Proj<Fp2Policy> pt_psi(const Proj<Fp2Policy>& p) {
-  constexpr PLimbs px1 = {BLS_PSI_X_1}, py0 = {BLS_PSI_Y_0}, py1 = {BLS_PSI_Y_1};
-  fe2 cx; cx.c0 = (Fe<1, VS2>)fe_zero(); cx.c1 = (Fe<1, VS2>)fe1_const(px1);
-  fe2 cy; cy.c0 = (Fe<1, VS2>)fe1_const(py0); cy.c1 = (Fe<1, VS2>)fe1_const(py1);
-  Proj<Fp2Policy> s;
-  s.x = store2(mul(store2(conj(p.x)), cx));
-  s.y = store2(mul(store2(conj(p.y)), cy));
-  s.z = store2(conj(p.z));
+template <class F2> DEV Proj<F2> pt_psi(const Proj<F2>& p) {
+  constexpr PLimbs zero = {{0}}, px1 = {BLS_PSI_X_1}, py0 = {BLS_PSI_Y_0}, py1 = {BLS_PSI_Y_1};
+  const typename F2::elem cx = H2c2<F2>::konst(zero, px1), cy = H2c2<F2>::konst(py0, py1);
+  Proj<F2> s;
+  s.x = F2::st(mul(F2::st(conj(p.x)), cx));
+  s.y = F2::st(mul(F2::st(conj(p.y)), cy));
+  s.z = F2::st(conj(p.z));
   return s;
 }
-DEV Proj<Fp2Policy> pt_psi2(const Proj<Fp2Policy>& p) {
+template <class F2> DEV Proj<F2> pt_psi2(const Proj<F2>& p) {
   constexpr PLimbs k = {BLS_PSI2_X};
-  Proj<Fp2Policy> s;
-  s.x = store2(mul_fp(p.x, fe1_const(k)));
-  s.y = store2(neg(p.y));
+  Proj<F2> s;
+  s.x = F2::st(mul_fp(p.x, fe1_const(k)));
+  s.y = F2::st(neg(p.y));
   s.z = p.z;
   return s;
 }
 // g2.rs:938-947
-DEVNI void h2c_clear_cofactor(Proj<Fp2Policy>& out, const Proj<Fp2Policy>& p) {
-  typedef Fp2Policy F;
-  Proj<F> t1, t2 = pt_psi(p), t3;
-  pt_mul_by_x<F>(t1, p);
-  Proj<F> r = pt_psi2(pt_double<F>(p));
-  pt_mul_by_x<F>(t3, pt_add<F>(t1, t2));
-  r = pt_add<F>(r, t3);
-  r = pt_add<F>(r, pt_neg<F>(t1));
-  r = pt_add<F>(r, pt_neg<F>(t2));
-  out = pt_add<F>(r, pt_neg<F>(p));
+template <class F2> DEVNI void h2c_clear_cofactor_g2(Proj<F2>& out, const Proj<F2>& p) {
+  Proj<F2> t1, t2 = pt_psi<F2>(p), t3;
+  pt_mul_by_x<F2>(t1, p);
+  Proj<F2> r = pt_psi2<F2>(pt_double<F2>(p));
+  pt_mul_by_x<F2>(t3, pt_add<F2>(t1, t2));
+  r = pt_add<F2>(r, t3);
+  r = pt_add<F2>(r, pt_neg<F2>(t1));
+  r = pt_add<F2>(r, pt_neg<F2>(t2));
+  out = pt_add<F2>(r, pt_neg<F2>(p));
 }
 
 template <class F> struct H2cField;
 template <> struct H2cField<FpPolicy> {
-  static constexpr int M = 1;
+  static constexpr int M = 1, LANES = 1;
   static DEV fe from_okm(const u32* W) { return h2c_from_okm(W); }
   static DEV void sswu(Proj<FpPolicy>& o, const fe& u) { h2c_sswu_g1(o, u); }
+  static DEV void clear(Proj<FpPolicy>& o, const Proj<FpPolicy>& p) { h2c_clear_cofactor(o, p); }
+  template <class T> static DEV void save(const T& a, u32* w) { Wire<FpPolicy>::save(a, w); }
 };
 template <> struct H2cField<Fp2Policy> {
-  static constexpr int M = 2;
-  static DEV fe2 from_okm(const u32* W) { fe2 r; r.c0 = (Fe<1, VS2>)h2c_from_okm(W); r.c1 = (Fe<1, VS2>)h2c_from_okm(W + 16); return r; }
-  static DEV void sswu(Proj<Fp2Policy>& o, const fe2& u) { h2c_sswu_g2(o, u); }
+  static constexpr int M = 2, LANES = 1;
+  static DEV fe2 from_okm(const u32* W) { return H2c2<Fp2Policy>::from_okm(W); }
+  static DEV void sswu(Proj<Fp2Policy>& o, const fe2& u) { h2c_sswu_g2<Fp2Policy>(o, u); }
+  static DEV void clear(Proj<Fp2Policy>& o, const Proj<Fp2Policy>& p) { h2c_clear_cofactor_g2<Fp2Policy>(o, p); }
+  template <class T> static DEV void save(const T& a, u32* w) { Wire<Fp2Policy>::save(a, w); }
+};
+template <> struct H2cField<Fp2PairPolicy> {
+  static constexpr int M = 2, LANES = 2;
+  static DEV FeP<1, VS2> from_okm(const u32* W) { return H2c2<Fp2PairPolicy>::from_okm(W); }
+  static DEV void sswu(Proj<Fp2PairPolicy>& o, const FeP<1, VS2>& u) { h2c_sswu_g2<Fp2PairPolicy>(o, u); }
+  static DEV void clear(Proj<Fp2PairPolicy>& o, const Proj<Fp2PairPolicy>& p) { h2c_clear_cofactor_g2<Fp2PairPolicy>(o, p); }
+  template <class T> static DEV void save(const T& a, u32* w) { H2c2<Fp2PairPolicy>::save(a, w); }
 };
 
 // mod.rs:86-108.  msgs = the messages back to back, offs[i] .. offs[i+1] the bytes of message i; dst <= 255 bytes.
 // out[i] = projective (X : Y : Z) in wire limbs.  encode_only: one field element (the *_NU_ suites).
+// F = FpPolicy: one message per lane; F = Fp2PairPolicy: one message per lane PAIR (both lanes hash the message, each keeps
+// its coefficient of every Fp2 value); F = Fp2Policy: the one-lane G2 form (kept for cross-checking).
 template <class F>
-__global__ void __launch_bounds__(64) k_hash_to_curve(const uint8_t* __restrict__ msgs, const unsigned long long* __restrict__ offs, size_t n,
-                                                      const uint8_t* __restrict__ dst, u32 dlen, int encode_only, u32* __restrict__ out) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(H2cField<F>::LANES == 2 ? 256 : 64, H2cField<F>::LANES == 2 ? 2 : 1)
+k_hash_to_curve(const uint8_t* __restrict__ msgs, const unsigned long long* __restrict__ offs, size_t n, const uint8_t* __restrict__ dst, u32 dlen,
+                int encode_only, u32* __restrict__ out) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / H2cField<F>::LANES;
   if (i >= n) return;
-  constexpr int M = H2cField<F>::M, WW = Wire<F>::WORDS;
+  constexpr int M = H2cField<F>::M, WW = M * 12;
   const int count = encode_only ? 1 : 2;
   const int ell = count * M * 2;
   u32 ub[64];
@@ -337,10 +385,10 @@ __global__ void __launch_bounds__(64) k_hash_to_curve(const uint8_t* __restrict_
     q = pt_add<F>(q, q1);
   }
   Proj<F> r;
-  h2c_clear_cofactor(r, q);
-  Wire<F>::save(r.x, out + i * 3 * WW);
-  Wire<F>::save(r.y, out + i * 3 * WW + WW);
-  Wire<F>::save(r.z, out + i * 3 * WW + 2 * WW);
+  H2cField<F>::clear(r, q);
+  H2cField<F>::save(r.x, out + i * 3 * WW);
+  H2cField<F>::save(r.y, out + i * 3 * WW + WW);
+  H2cField<F>::save(r.z, out + i * 3 * WW + 2 * WW);
 }
 
 }  // namespace bls

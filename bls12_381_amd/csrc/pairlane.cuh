@@ -160,6 +160,9 @@ template <int A, int V> DEV auto inv(const FeP<A, V>& a) {
   FeP<1, 2> r; r.v = p; return r;
 }
 
+// exact zero test (both coefficients), decided identically in both lanes
+template <int A, int V> DEV bool is_zero(const FeP<A, V>& a) { bool z = is_zero(a.v); return z && partner_flag(z); }
+
 // ---- field policy: G2 over lane pairs --------------------------------------------------------------------
 struct Fp2PairPolicy {
   typedef FeP<1, VS2> elem;
