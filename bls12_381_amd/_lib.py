@@ -93,6 +93,15 @@ def load():
         raise BlsGpuError(
             f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
             "There is no CPU fallback for the bls12_381_amd compute path.")
+    # PyTorch-ROCm bundles its own HIP runtime; a process that uses both must load torch's copy first, otherwise torch finds
+    # "No HIP GPUs" after libblsgpu.so has pulled in /opt/rocm's.  torch is optional plumbing (device tensors, streams,
+    # torch.distributed): if it is installed and not yet imported, import it before the library (BLSGPU_NO_TORCH_PRELOAD=1 skips this).
+    import sys
+    if "torch" not in sys.modules and not os.environ.get("BLSGPU_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the ABI drifted from the header

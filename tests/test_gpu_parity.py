@@ -835,3 +835,38 @@ def test_multi_miller_shared_squarings(ctx, n):
         acc = part if acc is None else ctx.fp12_op(0, acc[None, :], part[None, :])[0]
     assert np.array_equal(got, acc)
     assert np.array_equal(each[1], ctx.miller_loop_batch(G1[1:2], F1[1:2], G2[1:2], F2[1:2])[0])
+
+
+def test_msm_pipelined_slots_are_independent(ctx):
+    """twelve asynchronous MSMs of different sizes, groups and scalars through the four pipeline slots (three streams
+    each), results compared with the synchronous calls: catches any scratch shared between calls in flight"""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    rs = np.random.RandomState(77)
+    nmax = 1 << 16
+    kb = rs.randint(0, 256, size=(nmax, 32), dtype=np.uint8); kb[:, 31] &= 0x3F
+    bases = {1: ctx.bases_from_scalars(1, kb), 2: ctx.bases_from_scalars(2, kb[:1 << 14])}
+    jobs = []
+    for j in range(12):
+        g = 2 if j % 3 == 2 else 1
+        n = [1 << 16, 40000, 1 << 12, 1 << 14, 777, 1 << 15][j % 6]
+        if g == 2:
+            n = min(n, 1 << 14)
+        sb = rs.randint(0, 256, size=(n, 32), dtype=np.uint8); sb[:, 31] &= 0x3F
+        jobs.append((g, n, sb, torch.from_numpy(sb).to(dev), torch.zeros(18 * g, dtype=torch.int64, device=dev)))
+    want = [ctx.msm(bases[g], sb) for g, n, sb, _, _ in jobs]             # synchronous reference results
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_pipelining(True)
+    try:
+        for rep in range(2):
+            for g, n, sb, d_s, d_o in jobs:
+                ctx.msm_device(bases[g], d_s.data_ptr(), n, d_o.data_ptr())
+            ctx.join(0)
+            torch.cuda.synchronize()
+            for (g, n, sb, d_s, d_o), w in zip(jobs, want):
+                got = d_o.cpu().numpy().view(np.uint64)
+                assert np.array_equal(ctx.batch_normalize(g, got[None, :])[0], ctx.batch_normalize(g, w[None, :])[0]), (rep, g, n)
+                d_o.zero_()
+    finally:
+        ctx.set_pipelining(False)
+        ctx.set_stream(0)
