@@ -49,6 +49,8 @@ SIGNATURES = {
     "blsgpu_g2_hash_to_curve_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp, c_sz, c_int, c_vp]),
     "blsgpu_hash_to_curve_device": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp, c_sz, c_int, c_vp]),
     "blsgpu_gt_mul_scalar_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_g1_msm_bytes": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_g2_msm_bytes": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_set_msm_window": (c_int, [c_vp, c_int]),
     "blsgpu_g1_sum": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g2_sum": (c_int, [c_vp, c_vp, c_sz, c_vp]),

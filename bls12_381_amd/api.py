@@ -192,6 +192,20 @@ class Context:
         fn = self.lib.blsgpu_g1_msm_device if bases.group == 1 else self.lib.blsgpu_g2_msm_device
         check(fn(self.h, bases.handle, first, ctypes.c_void_p(d_scalars), n, ctypes.c_void_p(d_out)), "msm_device")
 
+    def msm_bytes(self, group, bases_uncompressed, scalars):
+        """MSM on the reference's public encodings: bases = n uncompressed encodings (bytes), scalars = ints / (n,32) bytes;
+        returns the uncompressed encoding of the sum."""
+        size = 96 if group == 1 else 192
+        buf = np.frombuffer(bytes(bases_uncompressed), dtype=np.uint8).copy() if not isinstance(bases_uncompressed, np.ndarray) else np.ascontiguousarray(bases_uncompressed, dtype=np.uint8)
+        n = buf.size // size
+        s = scalars_to_bytes(scalars)
+        if s.shape[0] != n:
+            raise ValueError("msm_bytes: bases and scalars differ in length")
+        out = np.zeros(size, dtype=np.uint8)
+        fn = self.lib.blsgpu_g1_msm_bytes if group == 1 else self.lib.blsgpu_g2_msm_bytes
+        check(fn(self.h, _ptr(buf), _ptr(s), n, _ptr(out)), "msm_bytes")
+        return out.tobytes()
+
     def msm_host(self, group, xy, infinity, scalars):
         w = 12 if group == 1 else 24
         xy = _u64(xy, (-1, w))

@@ -929,6 +929,32 @@ extern "C" int blsgpu_mad_throughput(blsgpu_ctx* c, int iters, double* r) { retu
 
 // ---------------------------------------------------------------------------------------------------
 // pairings
+// MSM on the reference's public encodings (for a wrapper crate that cannot see limbs): bases as uncompressed
+// bytes (`to_uncompressed`, decoded like `from_uncompressed_unchecked`), scalars as `Scalar::to_bytes`, result as the
+// uncompressed bytes of the affine sum.  A composition of the entry points above.
+template <int G>
+static int msm_bytes(blsgpu_ctx* c, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t* out) {
+  constexpr int W = G == 1 ? 12 : 24, BYTES = G == 1 ? 96 : 192;
+  if (!c || !out || (n && (!bases || !scalars))) return bad("msm_bytes: NULL argument");
+  std::vector<uint64_t> xy(n * W + 1), xyz(3 * W), axy(2 * W);
+  std::vector<uint8_t> inf(n + 1), ok(n + 1);
+  uint8_t ainf = 0;
+  int rc = BLSGPU_OK;
+  if (n) {
+    rc = G == 1 ? blsgpu_g1_from_bytes_batch(c, bases, n, 0, 0, xy.data(), inf.data(), ok.data()) : blsgpu_g2_from_bytes_batch(c, bases, n, 0, 0, xy.data(), inf.data(), ok.data());
+    if (rc) return rc;
+    for (size_t i = 0; i < n; i++) if (!ok[i]) return bad("msm_bytes: a base is not a valid uncompressed encoding");
+  }
+  rc = G == 1 ? blsgpu_g1_msm_host(c, xy.data(), inf.data(), scalars, n, xyz.data()) : blsgpu_g2_msm_host(c, xy.data(), inf.data(), scalars, n, xyz.data());
+  if (rc) return rc;
+  rc = G == 1 ? blsgpu_g1_batch_normalize(c, xyz.data(), 1, axy.data(), &ainf) : blsgpu_g2_batch_normalize(c, xyz.data(), 1, axy.data(), &ainf);
+  if (rc) return rc;
+  (void)BYTES;
+  return G == 1 ? blsgpu_g1_to_bytes_batch(c, axy.data(), &ainf, 1, 0, out) : blsgpu_g2_to_bytes_batch(c, axy.data(), &ainf, 1, 0, out);
+}
+extern "C" int blsgpu_g1_msm_bytes(blsgpu_ctx* c, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]) { return msm_bytes<1>(c, bases, scalars, n, out); }
+extern "C" int blsgpu_g2_msm_bytes(blsgpu_ctx* c, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[192]) { return msm_bytes<2>(c, bases, scalars, n, out); }
+
 // ---------------------------------------------------------------------------------------------------
 // hash-to-curve (h2c.cuh)
 // ---------------------------------------------------------------------------------------------------

@@ -98,6 +98,11 @@ int blsgpu_g2_msm_device(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t firs
 /* One-shot convenience: upload, multiply, free. */
 int blsgpu_g1_msm_host(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, const uint8_t* scalars, size_t n, uint64_t out_xyz[18]);
 int blsgpu_g2_msm_host(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, const uint8_t* scalars, size_t n, uint64_t out_xyz[36]);
+/* The same on the reference's PUBLIC encodings, for a wrapper crate that cannot reach limbs (`pub(crate)`, src/g1.rs:28-32):
+ * bases = n x 96 (G1) / n x 192 (G2) bytes of `to_uncompressed()` (decoded like `from_uncompressed_unchecked`,
+ * src/g1.rs:271-322), scalars = n x 32 bytes of `Scalar::to_bytes()`, out = `to_uncompressed()` of the affine sum. */
+int blsgpu_g1_msm_bytes(blsgpu_ctx* ctx, const uint8_t* bases_uncompressed, const uint8_t* scalars, size_t n, uint8_t out[96]);
+int blsgpu_g2_msm_bytes(blsgpu_ctx* ctx, const uint8_t* bases_uncompressed, const uint8_t* scalars, size_t n, uint8_t out[192]);
 /* Window width c (bits) used by Pippenger; 0 = automatic. */
 int blsgpu_set_msm_window(blsgpu_ctx* ctx, int c);
 

@@ -870,3 +870,26 @@ def test_msm_pipelined_slots_are_independent(ctx):
     finally:
         ctx.set_pipelining(False)
         ctx.set_stream(0)
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_msm_on_public_encodings(ctx, golden_dir, group):
+    """`blsgpu_g{1,2}_msm_bytes`: the golden k*G records (uncompressed bytes, k = 0..999, identity included) as bases,
+    random scalars -> uncompressed bytes of [sum s_k k] G; invalid encodings are refused"""
+    import bls12_381_amd as b
+    size = 96 if group == 1 else 192
+    raw = open(os.path.join(golden_dir, f"g{group}_uncompressed_valid_test_vectors.dat"), "rb").read()
+    n = 300
+    r = o.SplitMix64(group)
+    ss = [r.scalar() for _ in range(n)]
+    got = ctx.msm_bytes(group, raw[:n * size], ss)
+    tot = sum(k * s for k, s in enumerate(ss)) % o.R_ORDER
+    if group == 1:
+        want = o.g1_to_uncompressed(o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, tot)))
+    else:
+        want = o.g2_to_uncompressed(o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, tot)))
+    assert got == want
+    assert ctx.msm_bytes(group, b"", []) == (o.g1_to_uncompressed(o.G1_IDENTITY_AFF) if group == 1 else o.g2_to_uncompressed(o.G2_IDENTITY_AFF))
+    bad = bytearray(raw[size:2 * size]); bad[0] |= 0x80                       # compression flag on an uncompressed encoding
+    with pytest.raises(b.BlsGpuError):
+        ctx.msm_bytes(group, bytes(bad), [1])
