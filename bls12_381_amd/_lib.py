@@ -51,6 +51,7 @@ SIGNATURES = {
     "blsgpu_gt_mul_scalar_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g1_msm_bytes": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g2_msm_bytes": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_msm_accumulate_stats": (c_int, [c_vp, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint)]),
     "blsgpu_set_msm_window": (c_int, [c_vp, c_int]),
     "blsgpu_g1_sum": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g2_sum": (c_int, [c_vp, c_vp, c_sz, c_vp]),

@@ -143,6 +143,13 @@ class Context:
     def set_msm_window(self, c):
         check(self.lib.blsgpu_set_msm_window(self.h, c), "set_msm_window")
 
+    def msm_accumulate_stats(self, enable):
+        """(average ms, launches) of the accumulation kernel since the last call (HIP events on its stream); then reset and
+        switch the measurement on/off"""
+        avg, cnt = ctypes.c_double(), ctypes.c_uint()
+        check(self.lib.blsgpu_msm_accumulate_stats(self.h, 1 if enable else 0, ctypes.byref(avg), ctypes.byref(cnt)), "msm_accumulate_stats")
+        return avg.value, cnt.value
+
     def set_profiling(self, on):
         check(self.lib.blsgpu_set_profiling(self.h, 1 if on else 0), "set_profiling")
 

@@ -54,6 +54,8 @@ struct blsgpu_ctx {
   int msm_c = 0;
   bool profiling = false;
   bool pipelining = false;
+  bool acc_timing = false;              // blsgpu_msm_accumulate_stats: HIP-event duration of every accumulation launch
+  double acc_ms_sum = 0.0; unsigned acc_count = 0;
   bool force_slow_sort = false;        // test hook (env BLSGPU_FORCE_SLOW_SORT at create): the global-atomic sort used beyond 2^24 points
   hipStream_t acc_stream = nullptr;     // bucket accumulation of pipelined calls (the caller's stream is never blocked)
   hipEvent_t ev[9];
@@ -67,6 +69,8 @@ struct blsgpu_ctx {
     // that they overlap the accumulation kernels of neighbouring calls.
     hipStream_t front = nullptr, tail = nullptr;
     hipEvent_t ev_in = nullptr, ev_front = nullptr, ev_acc = nullptr, ev_tail = nullptr;
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;     // around the accumulation kernel (timing enabled), see acc_stats
+    bool k_pending = false;
     bool tail_pending = false;
     bool hist_dirty = false;
     unsigned long long seq = 0;
@@ -344,6 +348,7 @@ extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
     HIPCHK(hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&sl.ev_front, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&sl.ev_acc, hipEventDisableTiming));
+    HIPCHK(hipEventCreate(&sl.ev_k0)); HIPCHK(hipEventCreate(&sl.ev_k1));
     HIPCHK(hipEventCreateWithFlags(&sl.ev_tail, hipEventDisableTiming));
   }
   *out = c;
@@ -363,6 +368,7 @@ extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
                     &sl.buckets, &sl.lvlR[0], &sl.lvlR[1], &sl.lvlT, &sl.tsum[0], &sl.tsum[1], &sl.wacc[0], &sl.wacc[1], &sl.wsums, &sl.result};
     for (auto b : sb) b->release();
     hipEventDestroy(sl.ev_in); hipEventDestroy(sl.ev_front); hipEventDestroy(sl.ev_acc); hipEventDestroy(sl.ev_tail);
+    hipEventDestroy(sl.ev_k0); hipEventDestroy(sl.ev_k1);
     hipStreamDestroy(sl.front); hipStreamDestroy(sl.tail);
   }
   for (auto& e : c->ev) hipEventDestroy(e);
@@ -381,6 +387,27 @@ extern "C" int blsgpu_synchronize(blsgpu_ctx* c) {
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipStreamSynchronize(c->acc_stream));
   for (auto& sl : c->slot) { HIPCHK(hipStreamSynchronize(sl.front)); HIPCHK(hipStreamSynchronize(sl.tail)); sl.tail_pending = false; }
+  return BLSGPU_OK;
+}
+// fold the finished accumulation timings into the running statistics (never blocks)
+static void acc_harvest(blsgpu_ctx* c, bool wait) {
+  for (auto& sl : c->slot) {
+    if (!sl.k_pending) continue;
+    if (wait) hipEventSynchronize(sl.ev_k1);
+    else if (hipEventQuery(sl.ev_k1) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, sl.ev_k0, sl.ev_k1) == hipSuccess) { c->acc_ms_sum += ms; c->acc_count++; }
+    sl.k_pending = false;
+  }
+}
+extern "C" int blsgpu_msm_accumulate_stats(blsgpu_ctx* c, int enable, double* avg_ms, unsigned* launches) {
+  if (!c) return bad("ctx is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  acc_harvest(c, true);
+  if (avg_ms) *avg_ms = c->acc_count ? c->acc_ms_sum / c->acc_count : 0.0;
+  if (launches) *launches = c->acc_count;
+  c->acc_ms_sum = 0.0; c->acc_count = 0;
+  c->acc_timing = enable != 0;
   return BLSGPU_OK;
 }
 extern "C" int blsgpu_set_pipelining(blsgpu_ctx* c, int on) { if (!c) return bad("ctx is NULL"); c->pipelining = on != 0; return BLSGPU_OK; }
@@ -668,12 +695,14 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   hipStream_t as = c->pipelining ? c->acc_stream : st;
   HIPCHK(hipStreamWaitEvent(as, sl.ev_front, 0));
   // 5. accumulate (grid covers the worst-case item count; surplus lanes exit on ctrl[2])
+  if (c->acc_timing) { acc_harvest(c, false); if (sl.k_pending) { hipEventSynchronize(sl.ev_k1); acc_harvest(c, false); } hipEventRecord(sl.ev_k0, as); }
   u32* records = sl.buckets.as<u32>();
   const u32* base_rec = (merged ? bases->table : bases->rec) + first * Store<F>::AFF_WORDS;
   if constexpr (GroupTag<F>::id == 2)
     hipLaunchKernelGGL(k_msm_accumulate_g2pair, dim3(nblk(2 * max_items, 256)), dim3(256), 0, as, base_rec, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
   else
     hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(max_items, 256)), dim3(256), 0, as, base_rec, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
+  if (c->acc_timing) { hipEventRecord(sl.ev_k1, as); sl.k_pending = true; }
   hipLaunchKernelGGL(k_msm_heavy<F>, dim3(HEAVY_SMALL_BLOCKS + 512), dim3(256), 0, as, sl.heavy.as<uint4>(), ctrl, records);
   LAUNCHCHK();
   if (prof) hipEventRecord(c->ev[5], as);

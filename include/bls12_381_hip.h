@@ -169,6 +169,11 @@ int blsgpu_mad_throughput(blsgpu_ctx* ctx, int iters, double* mads_per_second);
  * context's stream): 0 digits+hist, 1 scan, 2 scatter, 3 order, 4 accumulate, 5 reduce, 6 combine, 7 total. */
 int blsgpu_last_msm_phase_ms(blsgpu_ctx* ctx, int phase, float* ms);
 int blsgpu_set_profiling(blsgpu_ctx* ctx, int enabled);
+/* Live duration of the bucket-accumulation kernel (the dominant kernel of an MSM) measured with HIP events on the stream
+ * it is launched on, also while calls are pipelined: returns the average over the launches since the previous call and
+ * their number, then resets the statistics and switches the measurement on (enable != 0) or off.  Costs two event records
+ * per MSM while on. */
+int blsgpu_msm_accumulate_stats(blsgpu_ctx* ctx, int enable, double* avg_ms, unsigned* launches);
 
 /* ---- scalar field Fr (the producer side of the MSM's scalars) ----------------------- */
 /* A scalar is the reference's `Scalar([u64; 4])`: four little-endian u64 Montgomery limbs (R = 2^256), canonical
