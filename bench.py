@@ -196,7 +196,7 @@ def main():
         cpu = {"value": m / cdt, "unit": "scalar-muls/s", "cores": used, "kind": "port",
                "sample": f"first 2^{int(np.log2(m))} (point, scalar) pairs of the same workload: sum(P_i*s_i) by 255-step double-and-add + Sum, "
                          f"C restatement of the reference algorithm (oracle/bls_oracle.c), OpenMP over {used} threads; single thread: {one:.0f}/s",
-               "single_thread_value": one, "gpu_result_matches": same}
+               "single_thread_value": one, "parallel_speedup": (m / cdt) / one, "gpu_result_matches": same}
         if not same:
             raise SystemExit("bench: GPU MSM over the CPU sample differs from the oracle")
 
@@ -221,6 +221,24 @@ def main():
         torch.cuda.synchronize()
         pdt = (time.perf_counter() - t1) / 3
         extras["pairings_per_s"] = np_ / pdt
+        if not args.no_cpu_baseline:
+            # the reference's pairing on the host cores (C restatement, oracle/bls_oracle.c) on a bounded sample, and an exact
+            # comparison of the GPU results over that sample
+            from oracle import c_oracle
+            mp = 1 << 13
+            t1 = time.perf_counter()
+            cref, cused = c_oracle.pairing_batch(0, g1xy[:mp], g1f[:mp], g2xy[:mp], g2f[:mp], 0)
+            cpdt = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            c_oracle.pairing_batch(0, g1xy[:16], g1f[:16], g2xy[:16], g2f[:16], 1)
+            one_p = 16 / (time.perf_counter() - t1)
+            same_p = bool(np.array_equal(d_gt[:mp].cpu().numpy().view(np.uint64), cref))
+            extras["cpu_baseline_pairing"] = {"value": mp / cpdt, "unit": "pairings/s", "cores": cused, "kind": "port",
+                                              "sample": f"first 2^13 of the same pairs, C restatement of pairings.rs (Miller loop + final exponentiation), "
+                                                        f"OpenMP over {cused} threads; single thread: {one_p:.0f}/s",
+                                              "single_thread_value": one_p, "parallel_speedup": (mp / cpdt) / one_p, "gpu_result_matches": same_p}
+            if not same_p:
+                raise SystemExit("bench: GPU pairings differ from the CPU oracle on the sample")
         extras["pairing_batch"] = {"n": np_, "ms": 1e3 * pdt, "note": "2^16 independent pairing(P_i, Q_i), inputs and outputs in HBM",
                                    "frac_of_fp_mul_chain_rate": (np_ * 16000 / pdt) / fp_rate}
         # multi_miller_loop at BASELINE configs[4]'s size (2^18 terms, the 2^16 pairs tiled four times): one shared accumulator

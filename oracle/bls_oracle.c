@@ -237,3 +237,269 @@ int ora_max_threads(void) {
   return 1;
 #endif
 }
+
+/* ================================================================================================================
+ * Pairing path: Fp2 / Fp6 / Fp12 towers, the Miller loop and the final exponentiation, restating the reference
+ * (fp2.rs, fp6.rs, fp12.rs, pairings.rs; line numbers at each function).  Same purpose as above: checker and CPU
+ * baseline ("full pairing", "miller loop", "final exponentiation" of benches/groups.rs).  The three Frobenius
+ * constants come from oracle/_build/ora_consts.h, written by oracle/c_oracle.py from the tier-0 oracle's values
+ * (themselves compared with the reference's literals in tests/test_oracle_golden.py).
+ * ================================================================================================================ */
+#include "_build/ora_consts.h"      /* FROB6_C1, FROB6_C2, FROB12_C1: fp2 in Montgomery limbs */
+typedef struct { fp c0, c1; } fp2;
+typedef struct { fp2 c0, c1, c2; } fp6;
+typedef struct { fp6 c0, c1; } fp12;
+static const fp2 FP2_ZERO_C = {{{0, 0, 0, 0, 0, 0}}, {{0, 0, 0, 0, 0, 0}}};
+
+static inline fp2 fp2_add(const fp2* a, const fp2* b) { fp2 r = {fp_add(&a->c0, &b->c0), fp_add(&a->c1, &b->c1)}; return r; }   /* fp2.rs:224-229 */
+static inline fp2 fp2_sub(const fp2* a, const fp2* b) { fp2 r = {fp_sub(&a->c0, &b->c0), fp_sub(&a->c1, &b->c1)}; return r; }   /* :231-236 */
+static inline fp2 fp2_neg(const fp2* a) { fp2 r = {fp_neg(&a->c0), fp_neg(&a->c1)}; return r; }                                 /* :238-243 */
+static inline fp2 fp2_conj(const fp2* a) { fp2 r = {a->c0, fp_neg(&a->c1)}; return r; }                                         /* :148-153 */
+static inline fp2 fp2_dbl(const fp2* a) { return fp2_add(a, a); }
+static inline fp2 fp2_mul(const fp2* a, const fp2* b) {                                                                          /* :205-222 */
+  fp t0 = fp_mul(&a->c0, &b->c0), t1 = fp_mul(&a->c1, &b->c1), t2 = fp_mul(&a->c0, &b->c1), t3 = fp_mul(&a->c1, &b->c0);
+  fp2 r = {fp_sub(&t0, &t1), fp_add(&t2, &t3)};
+  return r;
+}
+static inline fp2 fp2_sqr(const fp2* a) {                                                                                       /* :182-203 */
+  fp s = fp_add(&a->c0, &a->c1), d = fp_sub(&a->c0, &a->c1), t = fp_add(&a->c0, &a->c0);
+  fp2 r = {fp_mul(&s, &d), fp_mul(&t, &a->c1)};
+  return r;
+}
+static inline fp2 fp2_mul_by_nonresidue(const fp2* a) { fp2 r = {fp_sub(&a->c0, &a->c1), fp_add(&a->c0, &a->c1)}; return r; }   /* :156-166 */
+static inline fp2 fp2_mul_fp(const fp2* a, const fp* k) { fp2 r = {fp_mul(&a->c0, k), fp_mul(&a->c1, k)}; return r; }
+static fp2 fp2_inv(const fp2* a) {                                                                                             /* :300-319 */
+  fp s0 = fp_sqr(&a->c0), s1 = fp_sqr(&a->c1), n = fp_add(&s0, &s1), t = fp_inv(&n), nt = fp_neg(&t);
+  fp2 r = {fp_mul(&a->c0, &t), fp_mul(&a->c1, &nt)};
+  return r;
+}
+static inline fp2 fp2_one(void) { fp2 r = {FP_ONE, FP_ZERO}; return r; }
+
+static inline fp6 fp6_add(const fp6* a, const fp6* b) { fp6 r = {fp2_add(&a->c0, &b->c0), fp2_add(&a->c1, &b->c1), fp2_add(&a->c2, &b->c2)}; return r; }
+static inline fp6 fp6_sub(const fp6* a, const fp6* b) { fp6 r = {fp2_sub(&a->c0, &b->c0), fp2_sub(&a->c1, &b->c1), fp2_sub(&a->c2, &b->c2)}; return r; }
+static inline fp6 fp6_neg(const fp6* a) { fp6 r = {fp2_neg(&a->c0), fp2_neg(&a->c1), fp2_neg(&a->c2)}; return r; }
+static inline fp6 fp6_mul_by_nonresidue(const fp6* a) { fp6 r = {fp2_mul_by_nonresidue(&a->c2), a->c0, a->c1}; return r; }      /* fp6.rs:139-150 */
+static fp6 fp6_mul(const fp6* a, const fp6* b) {                                                                               /* :200-274 */
+  fp2 a0b0 = fp2_mul(&a->c0, &b->c0), a1b2 = fp2_mul(&a->c1, &b->c2), a2b1 = fp2_mul(&a->c2, &b->c1);
+  fp2 a0b1 = fp2_mul(&a->c0, &b->c1), a1b0 = fp2_mul(&a->c1, &b->c0), a2b2 = fp2_mul(&a->c2, &b->c2);
+  fp2 a0b2 = fp2_mul(&a->c0, &b->c2), a1b1 = fp2_mul(&a->c1, &b->c1), a2b0 = fp2_mul(&a->c2, &b->c0);
+  fp2 s = fp2_add(&a1b2, &a2b1), ns = fp2_mul_by_nonresidue(&s), n22 = fp2_mul_by_nonresidue(&a2b2);
+  fp2 t1 = fp2_add(&a0b1, &a1b0), t2 = fp2_add(&a0b2, &a1b1);
+  fp6 r = {fp2_add(&a0b0, &ns), fp2_add(&t1, &n22), fp2_add(&t2, &a2b0)};
+  return r;
+}
+static fp6 fp6_sqr(const fp6* a) {                                                                                             /* :277-291 */
+  fp2 s0 = fp2_sqr(&a->c0), ab = fp2_mul(&a->c0, &a->c1), s1 = fp2_dbl(&ab);
+  fp2 d = fp2_sub(&a->c0, &a->c1), e = fp2_add(&d, &a->c2), s2 = fp2_sqr(&e);
+  fp2 bc = fp2_mul(&a->c1, &a->c2), s3 = fp2_dbl(&bc), s4 = fp2_sqr(&a->c2);
+  fp2 n3 = fp2_mul_by_nonresidue(&s3), n4 = fp2_mul_by_nonresidue(&s4);
+  fp2 u = fp2_add(&s1, &s2), v = fp2_add(&u, &s3), w = fp2_sub(&v, &s0);
+  fp6 r = {fp2_add(&n3, &s0), fp2_add(&n4, &s1), fp2_sub(&w, &s4)};
+  return r;
+}
+static fp6 fp6_mul_by_1(const fp6* a, const fp2* c1) {                                                                         /* :113-119 */
+  fp2 t = fp2_mul(&a->c2, c1);
+  fp6 r = {fp2_mul_by_nonresidue(&t), fp2_mul(&a->c0, c1), fp2_mul(&a->c1, c1)};
+  return r;
+}
+static fp6 fp6_mul_by_01(const fp6* a, const fp2* c0, const fp2* c1) {                                                         /* :121-136 */
+  fp2 a_a = fp2_mul(&a->c0, c0), b_b = fp2_mul(&a->c1, c1);
+  fp2 t = fp2_mul(&a->c2, c1), nt = fp2_mul_by_nonresidue(&t), t1 = fp2_add(&nt, &a_a);
+  fp2 cs = fp2_add(c0, c1), as = fp2_add(&a->c0, &a->c1), m = fp2_mul(&cs, &as), m1 = fp2_sub(&m, &a_a), t2 = fp2_sub(&m1, &b_b);
+  fp2 u = fp2_mul(&a->c2, c0), t3 = fp2_add(&u, &b_b);
+  fp6 r = {t1, t2, t3};
+  return r;
+}
+static fp6 fp6_frobenius(const fp6* a) {                                                                                       /* :154-188 */
+  fp2 c0 = fp2_conj(&a->c0), c1 = fp2_conj(&a->c1), c2 = fp2_conj(&a->c2);
+  fp6 r = {c0, fp2_mul(&c1, &FROB6_C1), fp2_mul(&c2, &FROB6_C2)};
+  return r;
+}
+static fp6 fp6_inv(const fp6* a) {                                                                                             /* :294-312 */
+  fp2 s0 = fp2_sqr(&a->c0), m12 = fp2_mul(&a->c1, &a->c2), n12 = fp2_mul_by_nonresidue(&m12), c0 = fp2_sub(&s0, &n12);
+  fp2 s2 = fp2_sqr(&a->c2), n2 = fp2_mul_by_nonresidue(&s2), m01 = fp2_mul(&a->c0, &a->c1), c1 = fp2_sub(&n2, &m01);
+  fp2 s1 = fp2_sqr(&a->c1), m02 = fp2_mul(&a->c0, &a->c2), c2 = fp2_sub(&s1, &m02);
+  fp2 x = fp2_mul(&a->c1, &c2), y = fp2_mul(&a->c2, &c1), xy = fp2_add(&x, &y), nx = fp2_mul_by_nonresidue(&xy);
+  fp2 z = fp2_mul(&a->c0, &c0), tmp = fp2_add(&nx, &z), t = fp2_inv(&tmp);
+  fp6 r = {fp2_mul(&t, &c0), fp2_mul(&t, &c1), fp2_mul(&t, &c2)};
+  return r;
+}
+static inline fp12 fp12_one(void) { fp12 r; memset(&r, 0, sizeof r); r.c0.c0.c0 = FP_ONE; return r; }
+static fp12 fp12_mul(const fp12* a, const fp12* b) {                                                                           /* fp12.rs:197-214 */
+  fp6 aa = fp6_mul(&a->c0, &b->c0), bb = fp6_mul(&a->c1, &b->c1), o = fp6_add(&b->c0, &b->c1), s = fp6_add(&a->c1, &a->c0);
+  fp6 c1 = fp6_mul(&s, &o); c1 = fp6_sub(&c1, &aa); c1 = fp6_sub(&c1, &bb);
+  fp6 nb = fp6_mul_by_nonresidue(&bb);
+  fp12 r = {fp6_add(&nb, &aa), c1};
+  return r;
+}
+static fp12 fp12_sqr(const fp12* a) {                                                                                          /* :174-185 */
+  fp6 ab = fp6_mul(&a->c0, &a->c1), c0c1 = fp6_add(&a->c0, &a->c1), n1 = fp6_mul_by_nonresidue(&a->c1), c0 = fp6_add(&n1, &a->c0);
+  c0 = fp6_mul(&c0, &c0c1); c0 = fp6_sub(&c0, &ab);
+  fp6 nab = fp6_mul_by_nonresidue(&ab);
+  fp12 r = {fp6_sub(&c0, &nab), fp6_add(&ab, &ab)};
+  return r;
+}
+static fp12 fp12_mul_by_014(const fp12* a, const fp2* c0, const fp2* c1, const fp2* c4) {                                      /* :116-128 */
+  fp6 aa = fp6_mul_by_01(&a->c0, c0, c1), bb = fp6_mul_by_1(&a->c1, c4);
+  fp2 o = fp2_add(c1, c4);
+  fp6 s = fp6_add(&a->c1, &a->c0), r1 = fp6_mul_by_01(&s, c0, &o);
+  r1 = fp6_sub(&r1, &aa); r1 = fp6_sub(&r1, &bb);
+  fp6 nb = fp6_mul_by_nonresidue(&bb);
+  fp12 r = {fp6_add(&nb, &aa), r1};
+  return r;
+}
+static inline fp12 fp12_conj(const fp12* a) { fp12 r = {a->c0, fp6_neg(&a->c1)}; return r; }                                    /* :136-141 */
+static fp12 fp12_frobenius(const fp12* a) {                                                                                    /* :145-171 */
+  fp6 c0 = fp6_frobenius(&a->c0), c1 = fp6_frobenius(&a->c1);
+  fp12 r = {c0, {fp2_mul(&c1.c0, &FROB12_C1), fp2_mul(&c1.c1, &FROB12_C1), fp2_mul(&c1.c2, &FROB12_C1)}};
+  return r;
+}
+static fp12 fp12_inv(const fp12* a) {                                                                                          /* :187-194 */
+  fp6 s0 = fp6_sqr(&a->c0), s1 = fp6_sqr(&a->c1), n1 = fp6_mul_by_nonresidue(&s1), d = fp6_sub(&s0, &n1), t = fp6_inv(&d), nt = fp6_neg(&t);
+  fp12 r = {fp6_mul(&a->c0, &t), fp6_mul(&a->c1, &nt)};
+  return r;
+}
+
+typedef struct { fp2 x, y, z; } g2r;          /* the running point of the Miller loop */
+typedef struct { fp2 a, b, c; } line3;
+static line3 doubling_step(g2r* r) {                                                                                           /* pairings.rs:709-738 */
+  fp2 tmp0 = fp2_sqr(&r->x), tmp1 = fp2_sqr(&r->y), tmp2 = fp2_sqr(&tmp1);
+  fp2 u = fp2_add(&tmp1, &r->x), u2 = fp2_sqr(&u), v = fp2_sub(&u2, &tmp0), tmp3 = fp2_sub(&v, &tmp2);
+  tmp3 = fp2_dbl(&tmp3);
+  fp2 d0 = fp2_dbl(&tmp0), tmp4 = fp2_add(&d0, &tmp0), tmp6 = fp2_add(&r->x, &tmp4), tmp5 = fp2_sqr(&tmp4), zsq = fp2_sqr(&r->z);
+  fp2 x1 = fp2_sub(&tmp5, &tmp3); r->x = fp2_sub(&x1, &tmp3);
+  fp2 zy = fp2_add(&r->z, &r->y), zy2 = fp2_sqr(&zy), z1 = fp2_sub(&zy2, &tmp1); r->z = fp2_sub(&z1, &zsq);
+  fp2 w = fp2_sub(&tmp3, &r->x); r->y = fp2_mul(&w, &tmp4);
+  tmp2 = fp2_dbl(&tmp2); tmp2 = fp2_dbl(&tmp2); tmp2 = fp2_dbl(&tmp2);
+  r->y = fp2_sub(&r->y, &tmp2);
+  tmp3 = fp2_mul(&tmp4, &zsq); tmp3 = fp2_dbl(&tmp3); tmp3 = fp2_neg(&tmp3);
+  fp2 s6 = fp2_sqr(&tmp6), s7 = fp2_sub(&s6, &tmp0); tmp6 = fp2_sub(&s7, &tmp5);
+  tmp1 = fp2_dbl(&tmp1); tmp1 = fp2_dbl(&tmp1);
+  tmp6 = fp2_sub(&tmp6, &tmp1);
+  tmp0 = fp2_mul(&r->z, &zsq); tmp0 = fp2_dbl(&tmp0);
+  line3 l = {tmp0, tmp3, tmp6};
+  return l;
+}
+static line3 addition_step(g2r* r, const fp2* qx, const fp2* qy) {                                                             /* :740-770 */
+  fp2 zsq = fp2_sqr(&r->z), ysq = fp2_sqr(qy), t0 = fp2_mul(&zsq, qx);
+  fp2 a = fp2_add(qy, &r->z), a2 = fp2_sqr(&a), b = fp2_sub(&a2, &ysq), c = fp2_sub(&b, &zsq), t1 = fp2_mul(&c, &zsq);
+  fp2 t2 = fp2_sub(&t0, &r->x), t3 = fp2_sqr(&t2), t4 = fp2_dbl(&t3); t4 = fp2_dbl(&t4);
+  fp2 t5 = fp2_mul(&t4, &t2), d = fp2_sub(&t1, &r->y), t6 = fp2_sub(&d, &r->y), t9 = fp2_mul(&t6, qx), t7 = fp2_mul(&t4, &r->x);
+  fp2 e = fp2_sqr(&t6), f = fp2_sub(&e, &t5), g = fp2_sub(&f, &t7); r->x = fp2_sub(&g, &t7);
+  fp2 h = fp2_add(&r->z, &t2), h2 = fp2_sqr(&h), i = fp2_sub(&h2, &zsq); r->z = fp2_sub(&i, &t3);
+  fp2 t10 = fp2_add(qy, &r->z), j = fp2_sub(&t7, &r->x), t8 = fp2_mul(&j, &t6);
+  t0 = fp2_mul(&r->y, &t5); t0 = fp2_dbl(&t0);
+  r->y = fp2_sub(&t8, &t0);
+  fp2 k = fp2_sqr(&t10); t10 = fp2_sub(&k, &ysq);
+  fp2 ztsq = fp2_sqr(&r->z); t10 = fp2_sub(&t10, &ztsq);
+  fp2 t9d = fp2_dbl(&t9); t9 = fp2_sub(&t9d, &t10);
+  t10 = fp2_dbl(&r->z);
+  t6 = fp2_neg(&t6); t1 = fp2_dbl(&t6);
+  line3 l = {t10, t1, t9};
+  return l;
+}
+static fp12 ell(const fp12* f, const line3* l, const fp* px, const fp* py) {                                                   /* :696-707 */
+  fp2 c0 = fp2_mul_fp(&l->a, py), c1 = fp2_mul_fp(&l->b, px);
+  return fp12_mul_by_014(f, &l->c, &c1, &c0);
+}
+static const uint64_t BLS_X_C = 0xd201000000010000ull;
+static fp12 miller_loop_c(const fp* px, const fp* py, const fp2* qx, const fp2* qy) {                                          /* :607-653, :668-694 */
+  g2r r = {*qx, *qy, fp2_one()};
+  fp12 f = fp12_one();
+  int found = 0;
+  for (int b = 63; b >= 0; b--) {
+    int i = (int)(((BLS_X_C >> 1) >> b) & 1);
+    if (!found) { found = i; continue; }
+    line3 l = doubling_step(&r); f = ell(&f, &l, px, py);
+    if (i) { l = addition_step(&r, qx, qy); f = ell(&f, &l, px, py); }
+    f = fp12_sqr(&f);
+  }
+  line3 l = doubling_step(&r); f = ell(&f, &l, px, py);
+  return fp12_conj(&f);                                  /* BLS_X_IS_NEGATIVE */
+}
+static void fp4_square(const fp2* a, const fp2* b, fp2* c0, fp2* c1) {                                                         /* :50-62 */
+  fp2 t0 = fp2_sqr(a), t1 = fp2_sqr(b), t2 = fp2_mul_by_nonresidue(&t1);
+  *c0 = fp2_add(&t2, &t0);
+  fp2 s = fp2_add(a, b); t2 = fp2_sqr(&s); t2 = fp2_sub(&t2, &t0);
+  *c1 = fp2_sub(&t2, &t1);
+}
+static fp12 cyclotomic_square(const fp12* f) {                                                                                 /* :66-112 */
+  fp2 z0 = f->c0.c0, z4 = f->c0.c1, z3 = f->c0.c2, z2 = f->c1.c0, z1 = f->c1.c1, z5 = f->c1.c2, t0, t1, t2, t3;
+  fp4_square(&z0, &z1, &t0, &t1);
+  z0 = fp2_sub(&t0, &z0); z0 = fp2_dbl(&z0); z0 = fp2_add(&z0, &t0);
+  z1 = fp2_add(&t1, &z1); z1 = fp2_dbl(&z1); z1 = fp2_add(&z1, &t1);
+  fp4_square(&z2, &z3, &t0, &t1);
+  fp4_square(&z4, &z5, &t2, &t3);
+  z4 = fp2_sub(&t0, &z4); z4 = fp2_dbl(&z4); z4 = fp2_add(&z4, &t0);
+  z5 = fp2_add(&t1, &z5); z5 = fp2_dbl(&z5); z5 = fp2_add(&z5, &t1);
+  t0 = fp2_mul_by_nonresidue(&t3);
+  z2 = fp2_add(&t0, &z2); z2 = fp2_dbl(&z2); z2 = fp2_add(&z2, &t0);
+  z3 = fp2_sub(&t2, &z3); z3 = fp2_dbl(&z3); z3 = fp2_add(&z3, &t2);
+  fp12 r = {{z0, z4, z3}, {z2, z1, z5}};
+  return r;
+}
+static fp12 cyclotomic_exp(const fp12* f) {                                                                                    /* :114-132 */
+  fp12 tmp = fp12_one();
+  int found = 0;
+  for (int b = 63; b >= 0; b--) {
+    int i = (int)((BLS_X_C >> b) & 1);
+    if (found) tmp = cyclotomic_square(&tmp); else found = i;
+    if (i) tmp = fp12_mul(&tmp, f);
+  }
+  return fp12_conj(&tmp);
+}
+static fp12 final_exponentiation_c(const fp12* fin) {                                                                          /* :134-173 */
+  fp12 t0 = *fin;
+  for (int i = 0; i < 6; i++) t0 = fp12_frobenius(&t0);
+  fp12 t1 = fp12_inv(fin), t2 = fp12_mul(&t0, &t1);
+  t1 = t2;
+  t2 = fp12_frobenius(&t2); t2 = fp12_frobenius(&t2);
+  t2 = fp12_mul(&t2, &t1);
+  fp12 cs = cyclotomic_square(&t2); t1 = fp12_conj(&cs);
+  fp12 t3 = cyclotomic_exp(&t2), t4 = cyclotomic_square(&t3), t5 = fp12_mul(&t1, &t3);
+  t1 = cyclotomic_exp(&t5);
+  t0 = cyclotomic_exp(&t1);
+  fp12 t6 = cyclotomic_exp(&t0);
+  t6 = fp12_mul(&t6, &t4);
+  t4 = cyclotomic_exp(&t6);
+  t5 = fp12_conj(&t5);
+  fp12 t52 = fp12_mul(&t5, &t2); t4 = fp12_mul(&t4, &t52);
+  t5 = fp12_conj(&t2);
+  t1 = fp12_mul(&t1, &t2);
+  t1 = fp12_frobenius(&t1); t1 = fp12_frobenius(&t1); t1 = fp12_frobenius(&t1);
+  t6 = fp12_mul(&t6, &t5);
+  t6 = fp12_frobenius(&t6);
+  t3 = fp12_mul(&t3, &t0);
+  t3 = fp12_frobenius(&t3); t3 = fp12_frobenius(&t3);
+  t3 = fp12_mul(&t3, &t1);
+  t3 = fp12_mul(&t3, &t6);
+  return fp12_mul(&t3, &t4);
+}
+/* mode 0: pairing (pairings.rs:607-653), 1: Miller loop only, 2: final exponentiation of in[i] (g1 = the 72-limb inputs).
+ * g1: n x 12 limbs, g2: n x 24 limbs (x.c0 x.c1 y.c0 y.c1), inf flags may be NULL; out: n x 72 limbs. */
+int ora_pairing_batch(int mode, const u64* g1, const uint8_t* g1inf, const u64* g2, const uint8_t* g2inf, long n, int threads, u64* out) {
+  int used = 1;
+#ifdef _OPENMP
+  if (threads <= 0) threads = omp_get_max_threads();
+  used = threads;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 4)
+#endif
+  for (long i = 0; i < n; i++) {
+    fp12 f;
+    if (mode == 2) {
+      fp12 in; memcpy(&in, g1 + 72 * i, 576);
+      f = final_exponentiation_c(&in);
+    } else if ((g1inf && g1inf[i]) || (g2inf && g2inf[i])) {
+      f = fp12_one();
+    } else {
+      fp px, py; fp2 qx, qy;
+      memcpy(&px, g1 + 12 * i, 48); memcpy(&py, g1 + 12 * i + 6, 48);
+      memcpy(&qx, g2 + 24 * i, 96); memcpy(&qy, g2 + 24 * i + 12, 96);
+      f = miller_loop_c(&px, &py, &qx, &qy);
+      if (mode == 0) f = final_exponentiation_c(&f);
+    }
+    memcpy(out + 72 * i, &f, 576);
+  }
+  (void)FP2_ZERO_C;
+  return used;
+}

@@ -893,3 +893,21 @@ def test_msm_on_public_encodings(ctx, golden_dir, group):
     bad = bytearray(raw[size:2 * size]); bad[0] |= 0x80                       # compression flag on an uncompressed encoding
     with pytest.raises(b.BlsGpuError):
         ctx.msm_bytes(group, bytes(bad), [1])
+
+
+def test_pairing_batch_exact_vs_c_oracle(ctx):
+    """2^12 pairings, raw Miller values and final results, limb for limb against the tier-1 C restatement of pairings.rs
+    (identities on either side included)"""
+    from oracle import c_oracle
+    c_oracle.build()
+    n = 1 << 12
+    ab, _ = _rand_scalars_np(n, 41)
+    bb, _ = _rand_scalars_np(n, 42)
+    g1, f1 = ctx.bases_from_scalars(1, ab).download()
+    g2, f2 = ctx.bases_from_scalars(2, bb).download()
+    f1 = f1.copy(); f2 = f2.copy(); f1[[3, 100]] = 1; f2[[100, 4000]] = 1
+    want_ml, _ = c_oracle.pairing_batch(1, g1, f1, g2, f2)
+    want, _ = c_oracle.pairing_batch(0, g1, f1, g2, f2)
+    assert np.array_equal(ctx.miller_loop_batch(g1, f1, g2, f2), want_ml)
+    assert np.array_equal(ctx.pairing_batch(g1, f1, g2, f2), want)
+    assert np.array_equal(ctx.final_exponentiation_batch(want_ml[:64]), c_oracle.pairing_batch(2, want_ml[:64], None, None, None)[0])

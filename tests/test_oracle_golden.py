@@ -387,3 +387,30 @@ def test_hash_to_curve_vectors(kats, golden_dir):
     # F_2_256 is 2^256, sgn0 is the parity of the canonical value (map_g1.rs:790-806)
     assert h._consts()["F_2_256"] == pow(2, 256, o.P)
     assert h.sgn0_fp(0) == 0 and h.sgn0_fp(1) == 1 and h.sgn0_fp(o.P - 1) == 0
+
+
+def test_c_oracle_pairing(kats):
+    """tier-1 C towers / Miller loop / final exponentiation against the RELIC constant the reference stores
+    (pairings.rs:359-475 = src/tests/mod.rs:78-231) and against the tier-0 oracle, raw Miller values included"""
+    import numpy as np
+    from oracle import c_oracle
+    c_oracle.build()
+    W = lambda v: np.array(o.fp_to_mont_limbs(v), dtype=np.uint64)
+    g1w = lambda a: np.concatenate([W(a[0]), W(a[1])])
+    g2w = lambda a: np.concatenate([W(a[0][0]), W(a[0][1]), W(a[1][0]), W(a[1][1])])
+    f12w = lambda f: np.concatenate([W(c) for c in o.fp12_flatten(f)])
+    gt, _ = c_oracle.pairing_batch(0, g1w(o.G1_GEN)[None, :], None, g2w(o.G2_GEN)[None, :], None, threads=1)
+    assert np.array_equal(gt[0], np.array(kats["consts"]["pairings.GT_GENERATOR"], dtype=np.uint64).reshape(-1))
+    r = o.SplitMix64(11)
+    ps = [o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, r.scalar())) for _ in range(3)]
+    qs = [o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, r.scalar())) for _ in range(3)]
+    G1 = np.stack([g1w(p) for p in ps]); G2 = np.stack([g2w(q) for q in qs])
+    ml, _ = c_oracle.pairing_batch(1, G1, None, G2, None)
+    full, _ = c_oracle.pairing_batch(0, G1, np.array([0, 0, 1], dtype=np.uint8), G2, None)
+    for i in range(3):
+        m = o.miller_loop(ps[i], qs[i])
+        assert np.array_equal(ml[i], f12w(m))
+        want = o.FP12_ONE if i == 2 else o.final_exponentiation(m)          # identity on the G1 side -> Gt::identity
+        assert np.array_equal(full[i], f12w(want))
+    fe, _ = c_oracle.pairing_batch(2, ml, None, None, None)
+    assert np.array_equal(fe[0], full[0])
