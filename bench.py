@@ -298,6 +298,20 @@ def main():
         ctx.join(0); torch.cuda.synchronize()
         g2dt = (time.perf_counter() - t1) / 24
         ctx.set_pipelining(False)
+        if not args.no_cpu_baseline:
+            from oracle import c_oracle
+            m2 = 1 << 12                                  # bounded sample: ~10 s of CPU work
+            xy2, inf2 = b2.download(0, m2)
+            t1 = time.perf_counter()
+            ref2, used2 = c_oracle.g2_msm(xy2, inf2, sb[:m2], 0)
+            c2dt = time.perf_counter() - t1
+            got2 = ctx.msm(b2, sb[:m2])
+            same2 = bool(np.array_equal(ctx.batch_normalize(2, got2[None, :])[0][0], c_oracle.g2_to_affine(ref2)[0]))
+            extras["cpu_baseline_g2_msm"] = {"value": m2 / c2dt, "unit": "scalar-muls/s", "cores": used2, "kind": "port",
+                                             "sample": "first 2^12 (point, scalar) pairs: sum(P_i*s_i) over G2 by 255-step double-and-add + Sum "
+                                                       f"(oracle/bls_oracle.c), OpenMP over {used2} threads", "gpu_result_matches": same2}
+            if not same2:
+                raise SystemExit("bench: GPU G2 MSM differs from the CPU oracle on the sample")
         extras["g2_msm_scalar_muls_per_s"] = n2 / g2dt
         extras["g2_msm"] = {"n": n2, "ms": 1e3 * g2dt}
         # fixed-base mode: resident window-shifted tables (13 windows of 20 bits, one bucket set, no window combine)

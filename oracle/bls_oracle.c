@@ -503,3 +503,103 @@ int ora_pairing_batch(int mode, const u64* g1, const uint8_t* g1inf, const u64* 
   (void)FP2_ZERO_C;
   return used;
 }
+
+/* ---- G2: the same complete formulas over Fp2 (g2.rs:709-738 double, :741-783 add, :825-845 multiply, :650-652 mul_by_3b) ---- */
+typedef struct { fp2 x, y, z; } g2p;
+static inline int fp2_is_zero(const fp2* a) { return fp_is_zero(&a->c0) && fp_is_zero(&a->c1); }
+static inline fp2 g2_mul_by_3b(fp2 a) {                       /* 3b' = 12 (1 + u) */
+  fp2 t = fp2_mul_by_nonresidue(&a);
+  fp2 d = fp2_dbl(&t); d = fp2_dbl(&d);                       /* 4t */
+  fp2 e = fp2_dbl(&d);                                        /* 8t */
+  return fp2_add(&e, &d);                                     /* 12t */
+}
+static g2p g2_identity(void) { g2p r; memset(&r, 0, sizeof r); r.y.c0 = FP_ONE; return r; }
+static g2p g2_double(const g2p* p) {
+  fp2 t0 = fp2_sqr(&p->y);
+  fp2 z3 = fp2_dbl(&t0); z3 = fp2_dbl(&z3); z3 = fp2_dbl(&z3);
+  fp2 t1 = fp2_mul(&p->y, &p->z);
+  fp2 t2 = fp2_sqr(&p->z); t2 = g2_mul_by_3b(t2);
+  fp2 x3 = fp2_mul(&t2, &z3);
+  fp2 y3 = fp2_add(&t0, &t2);
+  z3 = fp2_mul(&t1, &z3);
+  t1 = fp2_dbl(&t2); t2 = fp2_add(&t1, &t2);
+  t0 = fp2_sub(&t0, &t2);
+  y3 = fp2_mul(&t0, &y3); y3 = fp2_add(&x3, &y3);
+  t1 = fp2_mul(&p->x, &p->y);
+  x3 = fp2_mul(&t0, &t1); x3 = fp2_dbl(&x3);
+  g2p r = {x3, y3, z3};
+  if (fp2_is_zero(&p->z)) r = g2_identity();
+  return r;
+}
+static g2p g2_add(const g2p* p, const g2p* q) {
+  fp2 t0 = fp2_mul(&p->x, &q->x), t1 = fp2_mul(&p->y, &q->y), t2 = fp2_mul(&p->z, &q->z);
+  fp2 t3 = fp2_add(&p->x, &p->y), t4 = fp2_add(&q->x, &q->y);
+  t3 = fp2_mul(&t3, &t4); t4 = fp2_add(&t0, &t1); t3 = fp2_sub(&t3, &t4);
+  t4 = fp2_add(&p->y, &p->z);
+  fp2 x3 = fp2_add(&q->y, &q->z);
+  t4 = fp2_mul(&t4, &x3); x3 = fp2_add(&t1, &t2); t4 = fp2_sub(&t4, &x3);
+  x3 = fp2_add(&p->x, &p->z);
+  fp2 y3 = fp2_add(&q->x, &q->z);
+  x3 = fp2_mul(&x3, &y3); y3 = fp2_add(&t0, &t2); y3 = fp2_sub(&x3, &y3);
+  x3 = fp2_dbl(&t0); t0 = fp2_add(&x3, &t0);
+  t2 = g2_mul_by_3b(t2);
+  fp2 z3 = fp2_add(&t1, &t2); t1 = fp2_sub(&t1, &t2);
+  y3 = g2_mul_by_3b(y3);
+  x3 = fp2_mul(&t4, &y3); t2 = fp2_mul(&t3, &t1); x3 = fp2_sub(&t2, &x3);
+  y3 = fp2_mul(&y3, &t0); t1 = fp2_mul(&t1, &z3); y3 = fp2_add(&t1, &y3);
+  t0 = fp2_mul(&t0, &t3); z3 = fp2_mul(&z3, &t4); z3 = fp2_add(&z3, &t0);
+  g2p r = {x3, y3, z3};
+  return r;
+}
+static g2p g2_multiply(const g2p* p, const uint8_t by[32]) {
+  g2p acc = g2_identity();
+  int first = 1;
+  for (int byte = 31; byte >= 0; byte--)
+    for (int i = 7; i >= 0; i--) {
+      if (first) { first = 0; continue; }
+      acc = g2_double(&acc);
+      g2p s = g2_add(&acc, p);
+      if ((by[byte] >> i) & 1) acc = s;
+    }
+  return acc;
+}
+/* sum_i P_i * s_i over G2 (g2.rs:162-172, :626-632); xy: n x 24 limbs; out: 36 limbs projective */
+int ora_g2_msm(const u64* xy, const uint8_t* inf, const uint8_t* scalars, long n, int threads, u64* out_xyz) {
+  int used = 1;
+  g2p total = g2_identity();
+#ifdef _OPENMP
+  if (threads <= 0) threads = omp_get_max_threads();
+  if (threads > 1024) threads = 1024;
+  used = threads;
+  static g2p part[1024];
+#pragma omp parallel num_threads(threads)
+  {
+    g2p acc = g2_identity();
+#pragma omp for schedule(static)
+    for (long i = 0; i < n; i++) {
+      g2p p; memcpy(&p.x, xy + 24 * i, 96); memcpy(&p.y, xy + 24 * i + 12, 96);
+      p.z = (inf && inf[i]) ? FP2_ZERO_C : fp2_one();
+      g2p m = g2_multiply(&p, scalars + 32 * i);
+      acc = g2_add(&acc, &m);
+    }
+    part[omp_get_thread_num()] = acc;
+  }
+  for (int t = 0; t < threads; t++) total = g2_add(&total, &part[t]);
+#else
+  (void)threads;
+  for (long i = 0; i < n; i++) {
+    g2p p; memcpy(&p.x, xy + 24 * i, 96); memcpy(&p.y, xy + 24 * i + 12, 96);
+    p.z = (inf && inf[i]) ? FP2_ZERO_C : fp2_one();
+    g2p m = g2_multiply(&p, scalars + 32 * i);
+    total = g2_add(&total, &m);
+  }
+#endif
+  memcpy(out_xyz, &total, 288);
+  return used;
+}
+int ora_g2_to_affine(const u64* xyz, u64* xy) {
+  const g2p* p = (const g2p*)xyz;
+  if (fp2_is_zero(&p->z)) { memset(xy, 0, 192); memcpy(xy + 12, FP_ONE.l, 48); return 1; }
+  fp2 zi = fp2_inv(&p->z), x = fp2_mul(&p->x, &zi), y = fp2_mul(&p->y, &zi);
+  memcpy(xy, &x, 96); memcpy(xy + 12, &y, 96); return 0;
+}

@@ -414,3 +414,29 @@ def test_c_oracle_pairing(kats):
         assert np.array_equal(full[i], f12w(want))
     fe, _ = c_oracle.pairing_batch(2, ml, None, None, None)
     assert np.array_equal(fe[0], full[0])
+
+
+def test_c_oracle_g2(golden_dir):
+    """tier-1 G2 (complete formulas over Fp2, 255-step multiply, Sum) against tier 0 and the golden k*G2 records"""
+    import numpy as np
+    from oracle import c_oracle
+    c_oracle.build(True)
+    W = lambda v: np.array(o.fp_to_mont_limbs(v), dtype=np.uint64)
+    g2w = lambda a: np.concatenate([W(a[0][0]), W(a[0][1]), W(a[1][0]), W(a[1][1])])
+    raw = open(os.path.join(golden_dir, "g2_uncompressed_valid_test_vectors.dat"), "rb").read()
+    gen = g2w(o.G2_GEN)
+    for k in (1, 2, 7, 999):
+        out, _ = c_oracle.g2_msm(gen[None, :], None, np.frombuffer(k.to_bytes(32, "little"), dtype=np.uint8)[None, :], 1)
+        xy, inf = c_oracle.g2_to_affine(out)
+        a = ((o.fp_from_mont_limbs(xy[0:6]), o.fp_from_mont_limbs(xy[6:12])), (o.fp_from_mont_limbs(xy[12:18]), o.fp_from_mont_limbs(xy[18:24])), inf)
+        assert o.g2_to_uncompressed(a) == raw[192 * k:192 * k + 192]
+    r = o.SplitMix64(3)
+    ks = [r.scalar() for _ in range(5)] + [0]
+    ss = [r.scalar() for _ in range(5)] + [5]
+    pts = [o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, k)) for k in ks]
+    XY = np.stack([g2w(p) for p in pts]); INF = np.array([1 if p[2] else 0 for p in pts], dtype=np.uint8)
+    S = np.stack([np.frombuffer(s.to_bytes(32, "little"), dtype=np.uint8) for s in ss])
+    out, _ = c_oracle.g2_msm(XY, INF, S, 2)
+    xy, inf = c_oracle.g2_to_affine(out)
+    tot = sum(k * s for k, s in zip(ks, ss)) % o.R_ORDER
+    assert np.array_equal(xy, g2w(o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, tot)))) and not inf
