@@ -635,6 +635,21 @@ class G1Projective(_Group):
             return cls.identity()
         return cls(default_context().point_sum(cls.G, np.stack([p.xyz for p in pts])))
 
+    @classmethod
+    def hash_to_curve(cls, msg, dst):
+        """`<G as HashToCurve<ExpandMsgXmd<Sha256>>>::hash_to_curve(msg, dst)` (hash_to_curve/mod.rs:86-92)"""
+        return cls(default_context().hash_to_curve(cls.G, [msg], dst)[0])
+
+    @classmethod
+    def encode_to_curve(cls, msg, dst):
+        """`...::encode_to_curve(msg, dst)` (hash_to_curve/mod.rs:103-108)"""
+        return cls(default_context().hash_to_curve(cls.G, [msg], dst, encode_only=True)[0])
+
+    @classmethod
+    def hash_to_curve_batch(cls, msgs, dst, encode_only=False):
+        out = default_context().hash_to_curve(cls.G, msgs, dst, encode_only=encode_only)
+        return [cls(row) for row in out]
+
     def __eq__(self, o):
         """projective equality (g1.rs:479-496) decided on canonical affine forms"""
         return type(o) is type(self) and self.to_affine() == o.to_affine()

@@ -669,6 +669,9 @@ def test_hash_to_curve_rfc_vectors(ctx, golden_dir, group):
         sel = [t for t in vecs if t["test"].endswith("_nu") == encode]
         assert len(sel) == 5
         dst = bytes.fromhex(sel[0]["dst"])
+        G = b.G1Projective if group == 1 else b.G2Projective                     # the mirror's reference-style entry points
+        single = (G.encode_to_curve if encode else G.hash_to_curve)(bytes.fromhex(sel[1]["msg"]), dst)
+        assert single.to_affine().to_uncompressed().hex() == sel[1]["out"]
         out = ctx.hash_to_curve(group, [bytes.fromhex(t["msg"]) for t in sel], dst, encode_only=encode)
         xy, inf = ctx.batch_normalize(group, out)
         for k, t in enumerate(sel):
