@@ -67,7 +67,8 @@ struct blsgpu_ctx {
     // front: digit sort + work items (LDS/atomic bound)  ->  main stream: bucket accumulation (VALU bound)  ->
     // tail: bucket reduction + window combine (latency bound).  Front and tail run on the slot's own streams so
     // that they overlap the accumulation kernels of neighbouring calls.
-    hipStream_t front = nullptr, tail = nullptr;
+    hipStream_t front = nullptr, tail = nullptr, tail2 = nullptr;       // tail2: the T tree sums of the reduction levels (off the critical path)
+    hipEvent_t ev_lvl[8] = {}, ev_tree = nullptr;
     hipEvent_t ev_in = nullptr, ev_front = nullptr, ev_acc = nullptr, ev_tail = nullptr;
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;     // around the accumulation kernel (timing enabled), see acc_stats
     bool k_pending = false;
@@ -343,6 +344,9 @@ extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
   for (auto& sl : c->slot) {
     // the tail is a handful of wavefronts racing a chip-filling kernel: give its queue the highest priority
     HIPCHK(hipStreamCreateWithPriority(&sl.tail, hipStreamNonBlocking, prio_hi));
+    HIPCHK(hipStreamCreateWithPriority(&sl.tail2, hipStreamNonBlocking, prio_hi));
+    for (auto& e : sl.ev_lvl) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&sl.ev_tree, hipEventDisableTiming));
     if (!c->acc_stream) HIPCHK(hipStreamCreateWithFlags(&c->acc_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&sl.front, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
@@ -369,7 +373,10 @@ extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
     for (auto b : sb) b->release();
     hipEventDestroy(sl.ev_in); hipEventDestroy(sl.ev_front); hipEventDestroy(sl.ev_acc); hipEventDestroy(sl.ev_tail);
     hipEventDestroy(sl.ev_k0); hipEventDestroy(sl.ev_k1);
-    hipStreamDestroy(sl.front); hipStreamDestroy(sl.tail);
+    for (auto& e : sl.ev_lvl) hipEventDestroy(e);
+    hipEventDestroy(sl.ev_tree);
+    hipStreamSynchronize(sl.tail2);
+    hipStreamDestroy(sl.front); hipStreamDestroy(sl.tail); hipStreamDestroy(sl.tail2);
   }
   for (auto& e : c->ev) hipEventDestroy(e);
   hipStreamDestroy(c->acc_stream);
@@ -386,7 +393,7 @@ extern "C" int blsgpu_synchronize(blsgpu_ctx* c) {
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipStreamSynchronize(c->acc_stream));
-  for (auto& sl : c->slot) { HIPCHK(hipStreamSynchronize(sl.front)); HIPCHK(hipStreamSynchronize(sl.tail)); sl.tail_pending = false; }
+  for (auto& sl : c->slot) { HIPCHK(hipStreamSynchronize(sl.front)); HIPCHK(hipStreamSynchronize(sl.tail)); HIPCHK(hipStreamSynchronize(sl.tail2)); sl.tail_pending = false; }
   return BLSGPU_OK;
 }
 // fold the finished accumulation timings into the running statistics (never blocks)
@@ -615,10 +622,10 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   {
     // (re)allocation frees memory: make sure nothing of this slot is in flight
     size_t lvl = (nb / 2 + 1) * PW * 4;
-    bool grow = sl.buckets.cap < max_records * PW * 4 || sl.lvlR[0].cap < lvl || sl.wacc[0].cap < (size_t)nwin * 32 * PW * 4 || sl.wsums.cap < (size_t)nwin * PW * 4;
+    bool grow = sl.buckets.cap < max_records * PW * 4 || sl.lvlR[0].cap < lvl || sl.lvlT.cap < 2 * lvl || sl.wacc[0].cap < (size_t)nwin * 32 * PW * 4 || sl.wsums.cap < (size_t)nwin * PW * 4;
     if (grow) { HIPCHK(hipStreamSynchronize(sl.tail)); HIPCHK(hipStreamSynchronize(st)); }
     bad_alloc |= sl.buckets.reserve(max_records * PW * 4);
-    bad_alloc |= sl.lvlR[0].reserve(lvl); bad_alloc |= sl.lvlR[1].reserve(lvl); bad_alloc |= sl.lvlT.reserve(lvl);
+    bad_alloc |= sl.lvlR[0].reserve(lvl); bad_alloc |= sl.lvlR[1].reserve(lvl); bad_alloc |= sl.lvlT.reserve(2 * lvl);     // every level's T records side by side
     bad_alloc |= sl.tsum[0].reserve(lvl); bad_alloc |= sl.tsum[1].reserve(lvl);
     bad_alloc |= sl.wacc[0].reserve((size_t)nwin * 32 * PW * 4); bad_alloc |= sl.wacc[1].reserve((size_t)nwin * 32 * PW * 4);
     bad_alloc |= sl.wsums.reserve((size_t)nwin * PW * 4);
@@ -716,11 +723,15 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     int nn = (int)nbw, off = 1, cur = 0, level = 0;
     // level T sums are stored consecutively in wacc[0]: level l at offset l * nseg
     u32* tstore = sl.wacc[0].as<u32>();
+    hipStream_t t2 = sl.tail2;
+    size_t toff = 0;                                    // offset (records) of this level's T block inside lvlT
     while (nn > 1) {
       int M = nn >= 8 ? 8 : nn;
       int G = nn / M;
       u32* Rout = sl.lvlR[cur].as<u32>();
-      u32* Tout = sl.lvlT.as<u32>();
+      u32* Tout = sl.lvlT.as<u32>() + toff * PW;
+      // a level with a single group writes its T straight into the Horner table
+      if (G == 1) Tout = tstore + (size_t)level * nseg * PW;
       if ((size_t)nseg * G * TEAM <= TEAM_LANES_MAX)
         hipLaunchKernelGGL(k_wsum_level_team<F>, dim3(nblk((size_t)nseg * G * TEAM, 256)), dim3(256), TEAM_LDS(256), tt, E, Rout, Tout, nseg, nn, M, off);
       else if constexpr (GroupTag<F>::id == 2)
@@ -728,23 +739,29 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
       else
         hipLaunchKernelGGL(k_wsum_level<F>, dim3(nblk((size_t)nseg * G, 256)), dim3(256), 0, tt, E, Rout, Tout, nseg, nn, M, off);
       LAUNCHCHK();
-      // sum the G T-records of each window down to one
-      const u32* Tin = Tout; int tn = G, tc = 0;
-      while (tn > 1) {
-        int TM = tn >= 8 ? 8 : tn; int TG = (tn + TM - 1) / TM;
-        u32* o = sl.tsum[tc].as<u32>();
-        if ((size_t)nseg * TG * TEAM <= TEAM_LANES_MAX)
-          hipLaunchKernelGGL(k_tree_sum_team<F>, dim3(nblk((size_t)nseg * TG * TEAM, 256)), dim3(256), TEAM_LDS(256), tt, Tin, o, nseg, tn, TM);
-        else
-          hipLaunchKernelGGL(k_tree_sum<F>, dim3(nblk((size_t)nseg * TG, 256)), dim3(256), 0, tt, Tin, o, nseg, tn, TM);
-        LAUNCHCHK();
-        Tin = o; tn = TG; tc ^= 1;
+      // sum the G T-records of each window down to one -- on the second tail stream: the next level needs only Rout
+      if (G > 1) {
+        hipStream_t ts = level < 8 ? t2 : tt;
+        if (level < 8) { HIPCHK(hipEventRecord(sl.ev_lvl[level], tt)); HIPCHK(hipStreamWaitEvent(t2, sl.ev_lvl[level], 0)); }
+        const u32* Tin = Tout; int tn = G, tc = 0;
+        while (tn > 1) {
+          int TM = tn >= 8 ? 8 : tn; int TG = (tn + TM - 1) / TM;
+          u32* o = TG == 1 ? tstore + (size_t)level * nseg * PW : sl.tsum[tc].as<u32>();        // the last one lands in the Horner table
+          if ((size_t)nseg * TG * TEAM <= TEAM_LANES_MAX)
+            hipLaunchKernelGGL(k_tree_sum_team<F>, dim3(nblk((size_t)nseg * TG * TEAM, 256)), dim3(256), TEAM_LDS(256), ts, Tin, o, nseg, tn, TM);
+          else
+            hipLaunchKernelGGL(k_tree_sum<F>, dim3(nblk((size_t)nseg * TG, 256)), dim3(256), 0, ts, Tin, o, nseg, tn, TM);
+          LAUNCHCHK();
+          Tin = o; tn = TG; tc ^= 1;
+        }
       }
-      HIPCHK(hipMemcpyAsync(tstore + (size_t)level * nseg * PW, Tin, (size_t)nseg * PW * 4, hipMemcpyDeviceToDevice, tt));
+      toff += (size_t)nseg * G;
       Ms.push_back(M);
       E = Rout; nn = G; off = 0; cur ^= 1; level++;
       if (level >= 31) return bad("msm: reduction depth");
     }
+    HIPCHK(hipEventRecord(sl.ev_tree, t2));
+    HIPCHK(hipStreamWaitEvent(tt, sl.ev_tree, 0));
     if (level == 0) {
       // a single bucket per window (c = 1): the bucket itself is the window sum
       HIPCHK(hipMemcpyAsync(sl.wsums.p, records, (size_t)nseg * PW * 4, hipMemcpyDeviceToDevice, tt));
