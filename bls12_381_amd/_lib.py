@@ -52,6 +52,10 @@ SIGNATURES = {
     "blsgpu_g1_msm_bytes": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g2_msm_bytes": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_msm_accumulate_stats": (c_int, [c_vp, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint)]),
+    "blsgpu_g1_msm_many": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_sz, c_vp]),
+    "blsgpu_g2_msm_many": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_sz, c_vp]),
+    "blsgpu_g1_msm_many_device": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_sz, c_vp]),
+    "blsgpu_g2_msm_many_device": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_sz, c_vp]),
     "blsgpu_set_msm_window": (c_int, [c_vp, c_int]),
     "blsgpu_g1_sum": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g2_sum": (c_int, [c_vp, c_vp, c_sz, c_vp]),

@@ -199,6 +199,18 @@ class Context:
         fn = self.lib.blsgpu_g1_msm_device if bases.group == 1 else self.lib.blsgpu_g2_msm_device
         check(fn(self.h, bases.handle, first, ctypes.c_void_p(d_scalars), n, ctypes.c_void_p(d_out)), "msm_device")
 
+    def msm_many(self, bases, scalar_sets):
+        """k MSMs over the same resident bases; scalar_sets: (k, n, 32) uint8 (or a list of k scalar lists).  Returns (k, 18|36)."""
+        if isinstance(scalar_sets, np.ndarray) and scalar_sets.dtype == np.uint8:
+            s = np.ascontiguousarray(scalar_sets)
+        else:
+            s = np.stack([scalars_to_bytes(x) for x in scalar_sets])
+        k, n = s.shape[0], s.shape[1]
+        out = np.zeros((k, 18 if bases.group == 1 else 36), dtype=np.uint64)
+        fn = self.lib.blsgpu_g1_msm_many if bases.group == 1 else self.lib.blsgpu_g2_msm_many
+        check(fn(self.h, bases.handle, 0, _ptr(s), n, k, _ptr(out)), "msm_many")
+        return out
+
     def msm_bytes(self, group, bases_uncompressed, scalars):
         """MSM on the reference's public encodings: bases = n uncompressed encodings (bytes), scalars = ints / (n,32) bytes;
         returns the uncompressed encoding of the sum."""

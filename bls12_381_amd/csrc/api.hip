@@ -815,6 +815,39 @@ extern "C" int blsgpu_g1_msm(blsgpu_ctx* c, const blsgpu_bases* b, size_t first,
 extern "C" int blsgpu_g2_msm(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, uint64_t* out) { return msm_host<Fp2Policy>(c, b, first, s, n, out); }
 extern "C" int blsgpu_g1_msm_device(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const void* s, size_t n, void* out) { return msm_device<FpPolicy>(c, b, first, s, n, out); }
 extern "C" int blsgpu_g2_msm_device(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const void* s, size_t n, void* out) { return msm_device<Fp2Policy>(c, b, first, s, n, out); }
+// k MSMs over the SAME resident bases (e.g. commitments to k polynomials under one SRS): scalars of call j at
+// d_scalars + j * n * 32, result j at d_out + j * 3 * WORDS * 4.  The calls go through the pipeline slots, so the sort,
+// accumulation and tail of consecutive MSMs overlap; results are ordered on the context's stream on return.
+template <class F>
+static int msm_many_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, const void* d_scalars, size_t n, size_t k, void* d_out) {
+  if (!c || !bases || (k && (!d_out || (n && !d_scalars)))) return bad("msm_many: NULL argument");
+  const bool was = c->pipelining;
+  c->pipelining = true;
+  int rc = BLSGPU_OK;
+  for (size_t j = 0; j < k && rc == BLSGPU_OK; j++)
+    rc = msm_device<F>(c, bases, first, (const uint8_t*)d_scalars + j * n * 32, n, (uint8_t*)d_out + j * 3 * Wire<F>::WORDS * 4);
+  c->pipelining = was;
+  int rj = blsgpu_join(c);
+  return rc ? rc : rj;
+}
+extern "C" int blsgpu_g1_msm_many_device(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const void* s, size_t n, size_t k, void* out) { return msm_many_device<FpPolicy>(c, b, first, s, n, k, out); }
+extern "C" int blsgpu_g2_msm_many_device(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const void* s, size_t n, size_t k, void* out) { return msm_many_device<Fp2Policy>(c, b, first, s, n, k, out); }
+template <class F>
+static int msm_many_host(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, const uint8_t* scalars, size_t n, size_t k, uint64_t* out) {
+  if (!c || (k && (!out || (n && !scalars)))) return bad("msm_many: NULL argument");
+  if (!k) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  const size_t ob = 3 * Wire<F>::WORDS * 4;
+  if (c->io_b.reserve(n * k ? n * k * 32 : 16) || c->io_out.reserve(k * ob)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  if (n) HIPCHK(hipMemcpyAsync(c->io_b.p, scalars, n * k * 32, hipMemcpyHostToDevice, c->stream));
+  int rc = msm_many_device<F>(c, bases, first, c->io_b.p, n, k, c->io_out.p);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(out, c->io_out.p, k * ob, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_g1_msm_many(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, size_t k, uint64_t* out) { return msm_many_host<FpPolicy>(c, b, first, s, n, k, out); }
+extern "C" int blsgpu_g2_msm_many(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, size_t k, uint64_t* out) { return msm_many_host<Fp2Policy>(c, b, first, s, n, k, out); }
 template <class F>
 static int msm_oneshot(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) {
   blsgpu_bases* b = nullptr;

@@ -95,6 +95,14 @@ int blsgpu_g2_msm(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, cons
  * context's stream and the call returns without synchronising. */
 int blsgpu_g1_msm_device(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const void* d_scalars, size_t n, void* d_out_xyz);
 int blsgpu_g2_msm_device(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const void* d_scalars, size_t n, void* d_out_xyz);
+/* k MSMs over the same resident bases (k scalar vectors of n x 32 bytes back to back -> k projective results back to back),
+ * e.g. commitments to k polynomials under one SRS.  Synchronous like blsgpu_g1_msm, but the k calls run through the
+ * library's pipeline (sort / accumulation / tail of consecutive MSMs overlap): the sustained rate of the asynchronous API
+ * without managing streams. */
+int blsgpu_g1_msm_many(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const uint8_t* scalars, size_t n, size_t k, uint64_t* out_xyz);
+int blsgpu_g2_msm_many(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const uint8_t* scalars, size_t n, size_t k, uint64_t* out_xyz);
+int blsgpu_g1_msm_many_device(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const void* d_scalars, size_t n, size_t k, void* d_out_xyz);
+int blsgpu_g2_msm_many_device(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const void* d_scalars, size_t n, size_t k, void* d_out_xyz);
 /* One-shot convenience: upload, multiply, free. */
 int blsgpu_g1_msm_host(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, const uint8_t* scalars, size_t n, uint64_t out_xyz[18]);
 int blsgpu_g2_msm_host(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, const uint8_t* scalars, size_t n, uint64_t out_xyz[36]);

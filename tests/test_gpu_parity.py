@@ -914,3 +914,20 @@ def test_pairing_batch_exact_vs_c_oracle(ctx):
     assert np.array_equal(ctx.miller_loop_batch(g1, f1, g2, f2), want_ml)
     assert np.array_equal(ctx.pairing_batch(g1, f1, g2, f2), want)
     assert np.array_equal(ctx.final_exponentiation_batch(want_ml[:64]), c_oracle.pairing_batch(2, want_ml[:64], None, None, None)[0])
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_msm_many_matches_single_calls(ctx, group):
+    """`blsgpu_g{1,2}_msm_many`: k MSMs over the same bases through the internal pipeline == k synchronous calls"""
+    n, k = (1 << 15, 9) if group == 1 else (1 << 13, 6)
+    kb, _ = _rand_scalars_np(n, 50 + group)
+    bases = ctx.bases_from_scalars(group, kb)
+    rs = np.random.RandomState(60 + group)
+    S = rs.randint(0, 256, size=(k, n, 32), dtype=np.uint8); S[:, :, 31] &= 0x3F
+    S[2, :, :] = 0                                                 # one all-zero vector: identity in the middle of the batch
+    many = ctx.msm_many(bases, S)
+    for j in range(k):
+        one = ctx.msm(bases, S[j])
+        assert np.array_equal(ctx.batch_normalize(group, many[j][None, :])[0], ctx.batch_normalize(group, one[None, :])[0]), j
+    assert ctx.batch_normalize(group, many[2][None, :])[1][0] == 1
+    assert ctx.msm_many(bases, S[:0]).shape[0] == 0
