@@ -348,7 +348,7 @@ extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
     for (auto& e : sl.ev_lvl) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&sl.ev_tree, hipEventDisableTiming));
     if (!c->acc_stream) HIPCHK(hipStreamCreateWithFlags(&c->acc_stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&sl.front, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithPriority(&sl.front, hipStreamNonBlocking, prio_lo));     // sort / items fill the gaps the accumulation leaves
     HIPCHK(hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&sl.ev_front, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&sl.ev_acc, hipEventDisableTiming));
