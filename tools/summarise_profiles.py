@@ -57,7 +57,7 @@ with open(os.path.join(OUT, "r01_msm_pmc.md"), "w") as fh:
 
 Separate rocprofv3 passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, `--pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE`, each with `--kernel-trace` only) over `python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras` (tools/collect_profiles.sh); averages over the {nl} launches.
 
-* launch duration (kernel trace, stats pass): {dur/1e3:.0f} us over all {nl} launches = {dur_pipe/1e3:.0f} us for the 5 pipelined launches (warm-up + timed region, the figure `bench.py` reports as `roofline.launch_ms`) and {dur_iso/1e3:.0f} us for the 5 isolated probes that follow (`launch_ms_isolated`)
+* launch duration (kernel trace, stats pass): {dur/1e3:.0f} us over all {nl} launches = {dur_pipe/1e3:.0f} us for the 5 pipelined launches of this short traced run (1 warm-up + 4 timed; `bench.py`'s `roofline.launch_ms` is the same quantity averaged over its own timed launches, 2.6-2.8 ms over 100 steps without the tracer) and {dur_iso/1e3:.0f} us for the 5 isolated probes that follow (`launch_ms_isolated`)
 * FETCH_SIZE = {fetch_kb:.0f} KB raw -> x2 (gfx950 half-count of 16-byte-per-lane reads) = {2*fetch_kb*1024/1e9:.2f} GB;  WRITE_SIZE = {write_kb:.0f} KB = {write_kb*1024/1e9:.2f} GB
 * HBM-side traffic per launch = {hbm/1e9:.2f} GB (algorithmic: 16 windows x 2^20 gathers x (128 B record + 4 B index) + 2^19 x 176 B bucket records = {alg/1e9:.2f} GB); at {dur/1e3:.0f} us that is {hbm/dur:.2f} GB/ms = {hbm/dur/1e3:.2f} TB/s = {100*hbm/dur/1e3/8:.0f}% of the 8 TB/s HBM peak: not memory-bound (the 128 MB of resident bases also fit the 256 MB Infinity Cache).
 * SQ_INSTS_VALU = {sq.get('SQ_INSTS_VALU',0):.3e} wave-instructions, of which {mads/64:.3e} are the v_mad_u64_u32 of the 7 mul + 2 sqr + one two-product sum per mixed addition ({100*mads/64/max(sq.get('SQ_INSTS_VALU',1),1):.0f}%).
