@@ -23,14 +23,16 @@ def counters(dirpat, kernel):
     if not f: return {}
     for r in csv.DictReader(open(f)):
         if kernel in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+    out = {k: sum(v) / len(v) for k, v in acc.items()}
+    out["_launches"] = max([len(v) for v in acc.values()] or [0])
+    return out
 
 def duration(dirpat, kernel):
     f = one(dirpat + "/**/*kernel_trace.csv")
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if kernel in r["Kernel_Name"]]
     return sum(d) / len(d), len(d)
 
-stats_table(one("stats/**/*kernel_stats.csv"), "r01: rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras\n\nMI355X, 2^20-point G1 MSM per step, pipelined (4 slots); 5 bench MSMs + 5 of the roofline/phase probes = 10 launches of each per-MSM kernel.", os.path.join(OUT, "r01_msm_kernel_stats.md"))
+stats_table(one("stats/**/*kernel_stats.csv"), "r01: rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --no-extras\n\nMI355X, 2^20-point G1 MSM per step, pipelined (4 slots); 5 warm-up + 100 timed MSMs + 5 isolated roofline/phase probes = 110 launches of each per-MSM kernel.", os.path.join(OUT, "r01_msm_kernel_stats.md"))
 K = "k_msm_accumulate<bls::FpPolicy>"
 dur, nl = duration("stats", K)
 def durations_in_order(dirpat, kernel):
@@ -38,8 +40,13 @@ def durations_in_order(dirpat, kernel):
     rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(f)) if kernel in r["Kernel_Name"])
     return [d for _, d in rows]
 _d = durations_in_order("stats", K)
-dur_pipe = sum(_d[:5]) / max(1, len(_d[:5]))          # warm-up + timed steps of the bench: pipelined, overlapped with sort / tails
-dur_iso = sum(_d[5:]) / max(1, len(_d[5:]))           # the five isolated roofline / phase probes that follow
+dur_pipe = sum(_d[5:-5]) / max(1, len(_d[5:-5]))      # the timed steps of the bench (after 5 warm-up launches): pipelined, overlapped with sort / tails
+dur_iso = sum(_d[-5:]) / max(1, len(_d[-5:]))         # the five isolated roofline / phase probes at the end
+try:
+    _b = json.loads(open(os.path.join(P, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
+    bench_note = f"the bench line printed by this very run: launch_ms = {_b['roofline']['launch_ms']:.3f}, launch_ms_isolated = {_b['roofline']['launch_ms_isolated']:.3f}, frac = {_b['roofline']['frac']:.3f}"
+except Exception:
+    bench_note = "bench line of the traced run not available"
 fs, ws, sq = counters("pmc_FETCH_SIZE", K), counters("pmc_WRITE_SIZE", K), counters("pmc_SQ_INSTS_VALU", K)
 fetch_kb, write_kb = fs.get("FETCH_SIZE", 0), ws.get("WRITE_SIZE", 0)
 hbm = (2 * fetch_kb + write_kb) * 1024
@@ -49,15 +56,15 @@ mads = W * n * (7 * 406 + 2 * 315 + 602)          # 7 mul + 2 sqr + one 2-produc
 j = {"kernel": K, "workload": "2^20-point G1 MSM, c=16", "launch_avg_ns": dur, "launches": nl, "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb,
      "hbm_bytes_per_launch_corrected": hbm,
      "correction": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 16-byte-per-lane reads at half); Infinity-Cache hits are included",
-     "algorithmic_bytes_per_launch": alg, "sq": sq, "valu_wave_insts": sq.get("SQ_INSTS_VALU"), "mad_wave_insts_expected": mads / 64}
+     "algorithmic_bytes_per_launch": alg, "sq": {k: v for k, v in sq.items() if not k.startswith("_")}, "valu_wave_insts": sq.get("SQ_INSTS_VALU"), "mad_wave_insts_expected": mads / 64}
 json.dump(j, open(os.path.join(OUT, "r01_msm_pmc.json"), "w"), indent=1)
 ghz = sq.get("GRBM_GUI_ACTIVE", 0) / 8 / (dur * 1e-9) / 1e9 if dur else 0
 with open(os.path.join(OUT, "r01_msm_pmc.md"), "w") as fh:
     fh.write(f"""# r01: PMC counters of the dominant kernel ({K}, 2^20 points, c = 16)
 
-Separate rocprofv3 passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, `--pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE`, each with `--kernel-trace` only) over `python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras` (tools/collect_profiles.sh); averages over the {nl} launches.
+Separate rocprofv3 passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, `--pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE`, each with `--kernel-trace` only) over `python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras` (tools/collect_profiles.sh); counter averages over the {fs.get('_launches', 0)} launches of those passes.
 
-* launch duration (kernel trace, stats pass): {dur/1e3:.0f} us over all {nl} launches = {dur_pipe/1e3:.0f} us for the 5 pipelined launches of this short traced run (1 warm-up + 4 timed; `bench.py`'s `roofline.launch_ms` is the same quantity averaged over its own timed launches, 2.6-2.8 ms over 100 steps without the tracer) and {dur_iso/1e3:.0f} us for the 5 isolated probes that follow (`launch_ms_isolated`)
+* launch duration (kernel trace of the default bench command): {dur/1e3:.0f} us over all {nl} launches = {dur_pipe/1e3:.0f} us for the {len(_d) - 10} timed pipelined launches (what `bench.py` reports as `roofline.launch_ms`) and {dur_iso/1e3:.0f} us for the 5 isolated probes at the end (`launch_ms_isolated`); {bench_note}
 * FETCH_SIZE = {fetch_kb:.0f} KB raw -> x2 (gfx950 half-count of 16-byte-per-lane reads) = {2*fetch_kb*1024/1e9:.2f} GB;  WRITE_SIZE = {write_kb:.0f} KB = {write_kb*1024/1e9:.2f} GB
 * HBM-side traffic per launch = {hbm/1e9:.2f} GB (algorithmic: 16 windows x 2^20 gathers x (128 B record + 4 B index) + 2^19 x 176 B bucket records = {alg/1e9:.2f} GB); at {dur/1e3:.0f} us that is {hbm/dur:.2f} GB/ms = {hbm/dur/1e3:.2f} TB/s = {100*hbm/dur/1e3/8:.0f}% of the 8 TB/s HBM peak: not memory-bound (the 128 MB of resident bases also fit the 256 MB Infinity Cache).
 * SQ_INSTS_VALU = {sq.get('SQ_INSTS_VALU',0):.3e} wave-instructions, of which {mads/64:.3e} are the v_mad_u64_u32 of the 7 mul + 2 sqr + one two-product sum per mixed addition ({100*mads/64/max(sq.get('SQ_INSTS_VALU',1),1):.0f}%).
