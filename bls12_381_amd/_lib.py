@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libblsgpu.so")
+# BLSGPU_LIB_PATH: A/B experiments load an alternative build of the SAME library (tools/ab_pairing.py); never a fallback
+LIB_PATH = os.environ.get("BLSGPU_LIB_PATH") or os.path.join(_HERE, "libblsgpu.so")
 
 c_u64p = ctypes.POINTER(ctypes.c_uint64)
 c_u8p = ctypes.POINTER(ctypes.c_uint8)

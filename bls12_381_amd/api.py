@@ -61,10 +61,27 @@ def _flags(f, n):
     return f
 
 
+_R_WORDS = np.frombuffer(R_ORDER.to_bytes(32, "little"), dtype="<u8")
+
+
+def scalars_are_canonical(sb):
+    """(n,32) uint8 little-endian -> True iff every row is < r (vectorised lexicographic compare, top word first)."""
+    w = np.ascontiguousarray(sb).reshape(-1, 32).view("<u8")
+    lt = np.zeros(len(w), dtype=bool)
+    eq = np.ones(len(w), dtype=bool)
+    for k in (3, 2, 1, 0):
+        lt |= eq & (w[:, k] < _R_WORDS[k])
+        eq &= w[:, k] == _R_WORDS[k]
+    return bool(lt.all())
+
+
 def scalars_to_bytes(scalars):
     """iterable of ints / Scalars / (n,32) uint8 array -> (n,32) uint8 little-endian canonical (Scalar::to_bytes)"""
     if isinstance(scalars, np.ndarray) and scalars.dtype == np.uint8:
-        return np.ascontiguousarray(scalars).reshape(-1, 32)
+        s = np.ascontiguousarray(scalars).reshape(-1, 32)
+        if not scalars_are_canonical(s):
+            raise ValueError("scalar bytes are not canonical (>= r): Scalar::from_bytes would return None (scalar.rs:256-280)")
+        return s
     out = np.zeros((len(scalars), 32), dtype=np.uint8)
     for i, s in enumerate(scalars):
         v = s.value if isinstance(s, Scalar) else int(s) % R_ORDER
@@ -502,6 +519,9 @@ class G1Affine(_Group):
     def is_identity(self): return self.infinity
 
     def __neg__(self):
+        if self.infinity:
+            # g1.rs:121-130: conditional_select(&-y, &Fp::one(), infinity) -- the identity keeps its (0, 1, inf) limbs
+            return type(self)(self.xy.copy(), True)
         xy = self.xy.copy()
         for k in range(self.W // 6):
             off = self.W + 6 * k
@@ -570,7 +590,10 @@ class G1Affine(_Group):
 
     @classmethod
     def _decode(cls, b, compressed, checked):
-        xy, inf, ok = default_context().points_from_bytes(cls.G, bytes(b), compressed, checked)
+        b = bytes(b)
+        if len(b) != (48 if compressed else 96) * cls.G:
+            return None                  # the reference takes a fixed-size array; any other input has no decoding (CtOption none)
+        xy, inf, ok = default_context().points_from_bytes(cls.G, b, compressed, checked)
         return cls(xy[0], bool(inf[0])) if ok[0] else None
 
     @classmethod

@@ -58,7 +58,8 @@ struct blsgpu_ctx {
   double acc_ms_sum = 0.0; unsigned acc_count = 0;
   bool force_slow_sort = false;        // test hook (env BLSGPU_FORCE_SLOW_SORT at create): the global-atomic sort used beyond 2^24 points
   hipStream_t acc_stream = nullptr;     // bucket accumulation of pipelined calls (the caller's stream is never blocked)
-  hipEvent_t ev[9];
+  hipEvent_t ev[9] = {};
+  u32* d_status = nullptr;              // [0]: sticky "a scalar was not canonical (>= r)" flag, set by the digit kernels
   float phase_ms[8] = {0};
   // MSM: the chip-filling phases run on `stream`; the latency-bound tail (bucket reduction + window
   // combine, a few wavefronts) of call i runs on tail_stream[i & 1] and overlaps the next call's heavy
@@ -84,6 +85,8 @@ struct blsgpu_ctx {
   DevBuf fr_tw[2], fr_tmp, fr_ninv;     // Fr transform: twiddle tables (forward / inverse), permutation target, n^-1
   int fr_tw_log[2] = {-1, -1};
   int fr_ninv_log = -1;
+  hipEvent_t ev_fr[3] = {};             // twiddles forward / inverse, n^-1: recorded where the table was built, awaited by every user
+                                        // (the caller may have switched streams with blsgpu_set_stream in between)
 };
 
 struct blsgpu_bases {
@@ -327,6 +330,32 @@ static inline unsigned nblk(size_t n, unsigned bs) { return (unsigned)((n + bs -
 extern "C" const char* blsgpu_last_error(void) { return g_err.c_str(); }
 extern "C" int blsgpu_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
+static int ctx_init(blsgpu_ctx* c) {
+  HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+  for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
+  for (auto& e : c->ev_fr) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  int prio_lo = 0, prio_hi = 0;
+  HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+  HIPCHK(hipStreamCreateWithFlags(&c->acc_stream, hipStreamNonBlocking));
+  HIPCHK(hipMalloc((void**)&c->d_status, 16));
+  HIPCHK(hipMemset(c->d_status, 0, 16));
+  for (auto& sl : c->slot) {
+    // the tail is a handful of wavefronts racing a chip-filling kernel: give its queue the highest priority
+    HIPCHK(hipStreamCreateWithPriority(&sl.tail, hipStreamNonBlocking, prio_hi));
+    HIPCHK(hipStreamCreateWithPriority(&sl.tail2, hipStreamNonBlocking, prio_hi));
+    for (auto& e : sl.ev_lvl) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&sl.ev_tree, hipEventDisableTiming));
+    HIPCHK(hipStreamCreateWithPriority(&sl.front, hipStreamNonBlocking, prio_lo));     // sort / items fill the gaps the accumulation leaves
+    HIPCHK(hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&sl.ev_front, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&sl.ev_acc, hipEventDisableTiming));
+    HIPCHK(hipEventCreate(&sl.ev_k0)); HIPCHK(hipEventCreate(&sl.ev_k1));
+    HIPCHK(hipEventCreateWithFlags(&sl.ev_tail, hipEventDisableTiming));
+  }
+  return BLSGPU_OK;
+}
+extern "C" void blsgpu_destroy(blsgpu_ctx* c);
 extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
   if (!out) return bad("blsgpu_create: out is NULL");
   int n = 0;
@@ -336,56 +365,48 @@ extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
   blsgpu_ctx* c = new blsgpu_ctx();
   c->device = device;
   c->force_slow_sort = getenv("BLSGPU_FORCE_SLOW_SORT") != nullptr;
-  HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-  c->stream = c->own_stream;
-  for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
-  int prio_lo = 0, prio_hi = 0;
-  HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-  for (auto& sl : c->slot) {
-    // the tail is a handful of wavefronts racing a chip-filling kernel: give its queue the highest priority
-    HIPCHK(hipStreamCreateWithPriority(&sl.tail, hipStreamNonBlocking, prio_hi));
-    HIPCHK(hipStreamCreateWithPriority(&sl.tail2, hipStreamNonBlocking, prio_hi));
-    for (auto& e : sl.ev_lvl) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&sl.ev_tree, hipEventDisableTiming));
-    if (!c->acc_stream) HIPCHK(hipStreamCreateWithFlags(&c->acc_stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithPriority(&sl.front, hipStreamNonBlocking, prio_lo));     // sort / items fill the gaps the accumulation leaves
-    HIPCHK(hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&sl.ev_front, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&sl.ev_acc, hipEventDisableTiming));
-    HIPCHK(hipEventCreate(&sl.ev_k0)); HIPCHK(hipEventCreate(&sl.ev_k1));
-    HIPCHK(hipEventCreateWithFlags(&sl.ev_tail, hipEventDisableTiming));
-  }
+  int rc = ctx_init(c);
+  if (rc != BLSGPU_OK) { blsgpu_destroy(c); return rc; }       // destroy tolerates the half-built context (null handles are skipped)
   *out = c;
   return BLSGPU_OK;
 }
 extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
-  hipStreamSynchronize(c->acc_stream);
+  hipDeviceSynchronize();
+  if (c->d_status) hipFree(c->d_status);
   DevBuf* bufs[] = {&c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_out, &c->flags_a, &c->flags_b, &c->fr_tw[0], &c->fr_tw[1], &c->fr_tmp, &c->fr_ninv};
   for (auto b : bufs) b->release();
   for (auto& sl : c->slot) {
-    hipStreamSynchronize(sl.front);
-    hipStreamSynchronize(sl.tail);
     DevBuf* sb[] = {&sl.ent, &sl.sorted, &sl.hist, &sl.offs, &sl.cursor, &sl.bsum, &sl.items, &sl.heavy, &sl.ctrl,
                     &sl.buckets, &sl.lvlR[0], &sl.lvlR[1], &sl.lvlT, &sl.tsum[0], &sl.tsum[1], &sl.wacc[0], &sl.wacc[1], &sl.wsums, &sl.result};
     for (auto b : sb) b->release();
-    hipEventDestroy(sl.ev_in); hipEventDestroy(sl.ev_front); hipEventDestroy(sl.ev_acc); hipEventDestroy(sl.ev_tail);
-    hipEventDestroy(sl.ev_k0); hipEventDestroy(sl.ev_k1);
-    for (auto& e : sl.ev_lvl) hipEventDestroy(e);
-    hipEventDestroy(sl.ev_tree);
-    hipStreamSynchronize(sl.tail2);
-    hipStreamDestroy(sl.front); hipStreamDestroy(sl.tail); hipStreamDestroy(sl.tail2);
+    hipEvent_t evs[] = {sl.ev_in, sl.ev_front, sl.ev_acc, sl.ev_tail, sl.ev_k0, sl.ev_k1, sl.ev_tree};
+    for (auto e : evs) if (e) hipEventDestroy(e);
+    for (auto& e : sl.ev_lvl) if (e) hipEventDestroy(e);
+    hipStream_t sts[] = {sl.front, sl.tail, sl.tail2};
+    for (auto q : sts) if (q) hipStreamDestroy(q);
   }
-  for (auto& e : c->ev) hipEventDestroy(e);
-  hipStreamDestroy(c->acc_stream);
-  hipStreamDestroy(c->own_stream);
+  for (auto& e : c->ev) if (e) hipEventDestroy(e);
+  for (auto& e : c->ev_fr) if (e) hipEventDestroy(e);
+  if (c->acc_stream) hipStreamDestroy(c->acc_stream);
+  if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
 }
 extern "C" int blsgpu_set_stream(blsgpu_ctx* c, void* s) {
   if (!c) return bad("ctx is NULL");
   c->stream = s ? (hipStream_t)s : c->own_stream;
+  return BLSGPU_OK;
+}
+// Read and clear the sticky input-validation flags (all queued work must have finished).  Bit 0: an MSM scalar was not
+// canonical (>= r): the result of that call is unspecified, as the reference offers no such value (Scalar::from_bytes -> None).
+static int take_status(blsgpu_ctx* c) {
+  u32 st = 0;
+  HIPCHK(hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost));
+  if (st) {
+    HIPCHK(hipMemset(c->d_status, 0, 4));
+    return bad("msm: a scalar is not canonical (>= r); Scalar::to_bytes never produces such bytes (scalar.rs:284-296)");
+  }
   return BLSGPU_OK;
 }
 extern "C" int blsgpu_synchronize(blsgpu_ctx* c) {
@@ -394,7 +415,7 @@ extern "C" int blsgpu_synchronize(blsgpu_ctx* c) {
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipStreamSynchronize(c->acc_stream));
   for (auto& sl : c->slot) { HIPCHK(hipStreamSynchronize(sl.front)); HIPCHK(hipStreamSynchronize(sl.tail)); HIPCHK(hipStreamSynchronize(sl.tail2)); sl.tail_pending = false; }
-  return BLSGPU_OK;
+  return take_status(c);
 }
 // fold the finished accumulation timings into the running statistics (never blocks)
 static void acc_harvest(blsgpu_ctx* c, bool wait) {
@@ -428,7 +449,9 @@ extern "C" int blsgpu_join_lag(blsgpu_ctx* c, int lag) {
 extern "C" int blsgpu_join(blsgpu_ctx* c) { return blsgpu_join_lag(c, 0); }
 extern "C" int blsgpu_set_msm_window(blsgpu_ctx* c, int w) {
   if (!c) return bad("ctx is NULL");
-  if (w != 0 && (w < 4 || w > 20)) return bad("msm window must be 0 or in [4,20]");
+  // 16 is the widest window of the LDS counting sort (8 coarse + 7 fine key bits); wider windows exist only with
+  // resident tables (blsgpu_bases_precompute), which carry their own width
+  if (w != 0 && (w < 4 || w > 16)) return bad("msm window must be 0 or in [4,16]");
   c->msm_c = w; return BLSGPU_OK;
 }
 extern "C" int blsgpu_set_profiling(blsgpu_ctx* c, int on) { if (!c) return bad("ctx is NULL"); c->profiling = on != 0; return BLSGPU_OK; }
@@ -544,7 +567,8 @@ static int bases_download(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, si
   return BLSGPU_OK;
 }
 extern "C" int blsgpu_bases_download(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, size_t count, uint64_t* xy, uint8_t* inf) {
-  if (!c || !b || (count && !xy) || first + count > b->n) return bad("bases_download: bad argument");
+  if (!c || !b || (count && !xy) || first > b->n || count > b->n - first) return bad("bases_download: bad argument");
+  if (b->device != c->device) return bad("bases_download: bases live on another device than the context");
   HIPCHK(hipSetDevice(c->device));
   return b->group == 1 ? bases_download<FpPolicy>(c, b, first, count, xy, inf) : bases_download<Fp2Policy>(c, b, first, count, xy, inf);
 }
@@ -571,7 +595,8 @@ template <class F>
 static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, const void* d_scalars, size_t n, void* d_out_wire) {
   if (!c || !bases || !d_out_wire || (n && !d_scalars)) return bad("msm: NULL argument");
   if (bases->group != GroupTag<F>::id) return bad("msm: bases belong to the other group");
-  if (first + n > bases->n) return bad("msm: range exceeds the resident bases");
+  if (first > bases->n || n > bases->n - first) return bad("msm: range exceeds the resident bases");
+  if (bases->device != c->device) return bad("msm: bases live on another device than the context");
   if (n > ((size_t)1 << 27)) return bad("msm: n too large for one call (shard the input)");
   HIPCHK(hipSetDevice(c->device));
   hipStream_t st = c->stream;
@@ -594,6 +619,15 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   const size_t nb = (size_t)nseg * nbw;
   const size_t total = (size_t)nwin * n;
   if (total > 0xfffffff0ull) return bad("msm: n * windows exceeds 2^32 entries");
+  // the whole configuration is validated BEFORE a slot is taken or anything is enqueued
+  const bool fast_sort = merged || ((n <= ((size_t)1 << 24)) && cw <= 16 && cw >= 2 && !c->force_slow_sort);
+  const int key_bits = cw - 1;
+  const int coarse_bits = merged ? (key_bits > 7 ? key_bits - 7 : 0) : (key_bits < 8 ? key_bits : 8);
+  const int fine_bits = key_bits - coarse_bits;           // <= 7
+  const int ncoarse = 1 << coarse_bits;
+  const int nc = nseg * ncoarse;
+  if (fast_sort && nc > SORT_MAX_COUNTERS) return bad("msm: window configuration exceeds the sort's counter table");
+  if (!fast_sort && nblk(nb, 1024) > 4096) return bad("msm: too many buckets for the fallback sort (use a window <= 16)");
   int bad_alloc = 0;
   blsgpu_ctx::Slot& sl = c->slot[c->next_slot];
   c->next_slot = (c->next_slot + 1) % NSLOT;
@@ -639,22 +673,15 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   HIPCHK(hipStreamWaitEvent(ft, sl.ev_in, 0));
 
   mark(0);
-  const bool fast_sort = merged || ((n <= ((size_t)1 << 24)) && cw <= 16 && cw >= 2 && !c->force_slow_sort);
   if (fast_sort) {
     // 1'-3'. two-level counting sort (LDS atomics; see msm.cuh)
-    const int key_bits = cw - 1;
-    const int coarse_bits = merged ? (key_bits > 7 ? key_bits - 7 : 0) : (key_bits < 8 ? key_bits : 8);
-    const int fine_bits = key_bits - coarse_bits;           // <= 7
-    const int ncoarse = 1 << coarse_bits;
-    const int nc = nseg * ncoarse;
-    if (nc > SORT_MAX_COUNTERS) return bad("msm: window configuration exceeds the sort's counter table");
     // fixed layout: [MAX] counts (kept zero between calls) | [MAX+1] bases | [MAX] cursors
     u32* ghist = sl.hist.as<u32>();
     u32* gbase = ghist + SORT_MAX_COUNTERS;
     u32* gcur = gbase + SORT_MAX_COUNTERS + 1;
     if (sl.hist_dirty) { HIPCHK(hipMemsetAsync(ghist, 0, (size_t)SORT_MAX_COUNTERS * 4, ft)); sl.hist_dirty = false; }
     const unsigned tiles = nblk(n, SORT_TILE);
-    hipLaunchKernelGGL(k_sort_hist, dim3(tiles), dim3(256), (size_t)nc * 4, ft, (const u32*)d_scalars, ghist, (int)n, cw, nwin, fine_bits, ncoarse, merged ? 1 : 0);
+    hipLaunchKernelGGL(k_sort_hist, dim3(tiles), dim3(256), (size_t)nc * 4, ft, (const u32*)d_scalars, ghist, (int)n, cw, nwin, fine_bits, ncoarse, merged ? 1 : 0, c->d_status);
     LAUNCHCHK();
     mark(1);
     hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, ft, ghist, gbase, gcur, nc, sl.ctrl.as<u32>(), 4 + 2 * ITEM_BINS);
@@ -670,12 +697,11 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     sl.hist_dirty = true;
     HIPCHK(hipMemsetAsync(sl.hist.p, 0, nb * 4, ft));
     HIPCHK(hipMemsetAsync(sl.ctrl.p, 0, (4 + 2 * ITEM_BINS) * 4, ft));
-    hipLaunchKernelGGL(k_msm_digits, dim3(nblk(n, 256)), dim3(256), 0, ft, (const u32*)d_scalars, sl.ent.as<u32>(), sl.cursor.as<u32>(), sl.hist.as<u32>(), (int)n, cw, nwin);
+    hipLaunchKernelGGL(k_msm_digits, dim3(nblk(n, 256)), dim3(256), 0, ft, (const u32*)d_scalars, sl.ent.as<u32>(), sl.cursor.as<u32>(), sl.hist.as<u32>(), (int)n, cw, nwin, c->d_status);
     LAUNCHCHK();
     mark(1);
     // 2. scan
     unsigned sb = nblk(nb, 1024);
-    if (sb > 4096) return bad("msm: too many buckets");
     hipLaunchKernelGGL(k_scan_block_sums, dim3(sb), dim3(256), 0, ft, sl.hist.as<u32>(), sl.bsum.as<u32>(), (int)nb);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, ft, sl.bsum.as<u32>(), (int)sb);
     hipLaunchKernelGGL(k_scan_apply, dim3(sb), dim3(256), 0, ft, sl.hist.as<u32>(), sl.bsum.as<u32>(), sl.offs.as<u32>(), (int)nb);
@@ -809,7 +835,7 @@ static int msm_host(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, cons
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, 3 * Wire<F>::WORDS * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  return BLSGPU_OK;
+  return take_status(c);
 }
 extern "C" int blsgpu_g1_msm(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, uint64_t* out) { return msm_host<FpPolicy>(c, b, first, s, n, out); }
 extern "C" int blsgpu_g2_msm(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, uint64_t* out) { return msm_host<Fp2Policy>(c, b, first, s, n, out); }
@@ -844,7 +870,7 @@ static int msm_many_host(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first,
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, k * ob, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  return BLSGPU_OK;
+  return take_status(c);
 }
 extern "C" int blsgpu_g1_msm_many(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, size_t k, uint64_t* out) { return msm_many_host<FpPolicy>(c, b, first, s, n, k, out); }
 extern "C" int blsgpu_g2_msm_many(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, size_t k, uint64_t* out) { return msm_many_host<Fp2Policy>(c, b, first, s, n, k, out); }
@@ -1148,7 +1174,9 @@ extern "C" int blsgpu_fr_ntt_device(blsgpu_ctx* c, void* d_data, int log_n, int 
     if (log_n > 1) hipLaunchKernelGGL(k_fr_tw_levels, dim3(nblk(half, 256)), dim3(256), 0, st, c->fr_tw[dir].as<u32>(), log_n);
     LAUNCHCHK();
     c->fr_tw_log[dir] = log_n;
+    HIPCHK(hipEventRecord(c->ev_fr[dir], st));
   }
+  HIPCHK(hipStreamWaitEvent(st, c->ev_fr[dir], 0));
   u32* data = (u32*)d_data;
   u32* tmp = c->fr_tmp.as<u32>();
   const u32* tw = c->fr_tw[dir].as<u32>();
@@ -1167,7 +1195,11 @@ extern "C" int blsgpu_fr_ntt_device(blsgpu_ctx* c, void* d_data, int log_n, int 
   LAUNCHCHK();
   const u32* scale = nullptr;
   if (inverse) {
-    if (c->fr_ninv_log != log_n) { hipLaunchKernelGGL(k_fr_ninv, dim3(1), dim3(64), 0, st, c->fr_ninv.as<u32>(), log_n); c->fr_ninv_log = log_n; }
+    if (c->fr_ninv_log != log_n) {
+      hipLaunchKernelGGL(k_fr_ninv, dim3(1), dim3(64), 0, st, c->fr_ninv.as<u32>(), log_n); c->fr_ninv_log = log_n;
+      HIPCHK(hipEventRecord(c->ev_fr[2], st));
+    }
+    HIPCHK(hipStreamWaitEvent(st, c->ev_fr[2], 0));
     scale = c->fr_ninv.as<u32>();
   }
   u32* dst = src == data ? tmp : data;

@@ -122,18 +122,31 @@ DEV Proj<F> pt_add_mixed_y(const Proj<F>& p, const typename F::aff_elem& qx, con
   return r;
 }
 
+// The reference's Scalar is always canonical (Scalar::from_bytes rejects values >= r, scalar.rs:256-280), and the digit
+// recoding relies on it: scalars < r < 2^255 leave the top window a spare bit, so no carry leaves it.  A raw 32-byte input
+// that is NOT canonical is reported through a sticky device flag (blsgpu_synchronize / the synchronous MSM entry points
+// return BLSGPU_ERR_ARG) instead of silently producing s*P for some window widths and (s - 2^256)*P for others.
+DEV bool scalar_is_canonical(const u32* s) {
+  constexpr u32 r[8] = BLS_FR_MOD_W;
+  bool lt = false, eq = true;
+#pragma unroll
+  for (int i = 7; i >= 0; i--) { lt = lt || (eq && s[i] < r[i]); eq = eq && s[i] == r[i]; }
+  return lt;
+}
+
 // ---- 1. digits + histogram -------------------------------------------------------------------------
 // ent[w * n + i] = global bucket (w * nbw + |d| - 1) | sign << 31, or 0xffffffff for a zero digit;
 // rank[w * n + i] = arrival order of the entry inside its bucket (the value returned by the histogram
 // atomic), which makes the later scatter a plain permutation with no second round of atomics.
 __global__ void __launch_bounds__(256) k_msm_digits(const u32* __restrict__ scalars, u32* __restrict__ ent, u32* __restrict__ rank,
-                                                    u32* __restrict__ hist, int n, int c, int nwin) {
+                                                    u32* __restrict__ hist, int n, int c, int nwin, u32* __restrict__ status) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u32 s[9];
   const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
   uint4 a = sp[0], b = sp[1];
   s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w; s[8] = 0;
+  if (!scalar_is_canonical(s)) atomicOr(status, 1u);
   const u32 nbw = 1u << (c - 1);
   const u32 mask = (1u << c) - 1;
   u32 carry = 0;
@@ -201,6 +214,7 @@ constexpr int SORT_MAX_COUNTERS = 8192;         // nwin * ncoarse upper bound (L
 
 struct DigitIter {
   u32 s[9]; u32 carry; int c; u32 nbw, mask;
+  DEV bool canonical() const { return scalar_is_canonical(s); }
   DEV void init(const u32* scalars, size_t i, int c_) {
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
     uint4 a = sp[0], b = sp[1];
@@ -221,7 +235,7 @@ struct DigitIter {
 
 // merged != 0 (resident window-shifted tables): all windows share ONE bucket set, the window only selects the table
 __global__ void __launch_bounds__(256) k_sort_hist(const u32* __restrict__ scalars, u32* __restrict__ ghist, int n, int c, int nwin,
-                                                   int fine_bits, int ncoarse, int merged) {
+                                                   int fine_bits, int ncoarse, int merged, u32* __restrict__ status) {
   extern __shared__ u32 lh[];
   const int nc = (merged ? 1 : nwin) * ncoarse;
   for (int i = threadIdx.x; i < nc; i += 256) lh[i] = 0;
@@ -230,6 +244,7 @@ __global__ void __launch_bounds__(256) k_sort_hist(const u32* __restrict__ scala
     int i = blockIdx.x * SORT_TILE + k * 256 + threadIdx.x;
     if (i < n) {
       DigitIter d; d.init(scalars, i, c);
+      if (!d.canonical()) atomicOr(status, 1u);
       for (int w = 0; w < nwin; w++) {
         u32 mag, neg; d.next(w, mag, neg);
         if (mag) atomicAdd(&lh[(merged ? 0 : w) * ncoarse + ((mag - 1) >> fine_bits)], 1u);

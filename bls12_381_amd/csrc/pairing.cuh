@@ -77,6 +77,16 @@ constexpr int PAIRING_WAVES = BLS_PAIRING_WAVES;       // wavefronts per SIMD th
 constexpr int FP12_PROD_FAN = 8;
 
 #define S2(x) st2(x)
+// Inlining policy.  The hot loops (Miller loop, the run of compressed cyclotomic squarings) keep their state in NON-ESCAPING
+// locals and inline the tower glue around the out-of-line Fp2 products, so the register allocator owns f, R and the line (a
+// by-reference call pins them to per-lane scratch: profiles/r01_pairing_pmc.md measured ~450 KB of scratch traffic per
+// pairing that way).  Code executed a few times per pairing (final exponentiation outside the squaring runs, inversions,
+// Frobenius maps) stays out of line and by reference so that the kernels fit the instruction cache.
+#ifdef BLS_TOWER_OUTLINE
+#define HOT DEVNI
+#else
+#define HOT DEV
+#endif
 
 template <class E> DEV Fp6T<E> fp6_zero() { Fp6T<E> r; r.c0 = E2<E>::zero(); r.c1 = E2<E>::zero(); r.c2 = E2<E>::zero(); return r; }
 template <class E> DEV Fp6T<E> fp6_one() { Fp6T<E> r; r.c0 = E2<E>::one(); r.c1 = E2<E>::zero(); r.c2 = E2<E>::zero(); return r; }
@@ -175,7 +185,7 @@ template <class E> DEVNI void fp12_mul(Fp12T<E>& r, const Fp12T<E>& a, const Fp1
   r.c0 = fp6_add(fp6_mul_by_nonresidue(bb), aa);
 }
 // fp12.rs:174-185
-template <class E> DEVNI void fp12_sqr(Fp12T<E>& r, const Fp12T<E>& a) {
+template <class E> HOT void fp12_sqr_hot(Fp12T<E>& r, const Fp12T<E>& a) {
   Fp6T<E> ab, t;
   fp6_mul(ab, a.c0, a.c1);
   Fp6T<E> c0c1 = fp6_add(a.c0, a.c1);
@@ -185,8 +195,9 @@ template <class E> DEVNI void fp12_sqr(Fp12T<E>& r, const Fp12T<E>& a) {
   r.c1 = fp6_add(ab, ab);
   r.c0 = fp6_sub(t, fp6_mul_by_nonresidue(ab));
 }
+template <class E> DEVNI void fp12_sqr(Fp12T<E>& r, const Fp12T<E>& a) { fp12_sqr_hot(r, a); }
 // fp12.rs:116-128
-template <class E> DEVNI void fp12_mul_by_014(Fp12T<E>& r, const Fp12T<E>& a, const E& c0, const E& c1, const E& c4) {
+template <class E> HOT void fp12_mul_by_014(Fp12T<E>& r, const Fp12T<E>& a, const E& c0, const E& c1, const E& c4) {
   Fp6T<E> aa, bb, t;
   fp6_mul_by_01(aa, a.c0, c0, c1);
   fp6_mul_by_1(bb, a.c1, c4);
@@ -236,7 +247,7 @@ template <class E> struct G2JacT { E x, y, z; };       // the pairing's running 
 template <class E> struct LineT { E a, b, c; };        // the (Fp2, Fp2, Fp2) coefficient triple
 
 // pairings.rs:709-738 (CLN Algorithm 26)
-template <class E> DEVNI void doubling_step(G2JacT<E>& r, LineT<E>& l) {
+template <class E> HOT void doubling_step(G2JacT<E>& r, LineT<E>& l) {
   auto tmp0 = psqr(r.x);
   auto tmp1 = psqr(r.y);
   auto tmp2 = psqr(tmp1);
@@ -262,7 +273,7 @@ template <class E> DEVNI void doubling_step(G2JacT<E>& r, LineT<E>& l) {
   l.a = S2(dbl(t0)); l.b = S2(t3n); l.c = S2(t6o);
 }
 // pairings.rs:740-770 (CLN Algorithm 27)
-template <class E> DEVNI void addition_step(G2JacT<E>& r, const E& qx, const E& qy, LineT<E>& l) {
+template <class E> HOT void addition_step(G2JacT<E>& r, const E& qx, const E& qy, LineT<E>& l) {
   auto zsq = psqr(r.z);
   auto ysq = psqr(qy);
   auto t0 = pmul(zsq, qx);
@@ -292,7 +303,7 @@ template <class E> DEVNI void addition_step(G2JacT<E>& r, const E& qx, const E& 
   l.a = S2(t10d); l.b = S2(t1b); l.c = S2(t9b);
 }
 // pairings.rs:696-707
-template <class E> DEVNI void ell(Fp12T<E>& f, const LineT<E>& l, const fe1& px, const fe1& py) {
+template <class E> HOT void ell(Fp12T<E>& f, const LineT<E>& l, const fe1& px, const fe1& py) {
   E c0 = S2(mul_fp(l.a, py));
   E c1 = S2(mul_fp(l.b, px));
   fp12_mul_by_014(f, f, l.c, c1, c0);          // in place: every read of the input precedes the first write
@@ -301,22 +312,32 @@ template <class E> DEVNI void ell(Fp12T<E>& f, const LineT<E>& l, const fe1& px,
 // bits of BLS_X >> 1 below the leading one, MSB first (pairings.rs:671-685): 62 iterations, 5 set bits
 constexpr unsigned long long X_HALF = 0xd201000000010000ull >> 1;
 
-template <class E> DEVNI void miller_loop(Fp12T<E>& f, const fe1& px, const fe1& py, const E& qx, const E& qy) {
-  G2JacT<E> r; r.x = qx; r.y = qy; r.z = E2<E>::one();
-  f = fp12_one<E>();
+template <class E> DEVNI void addition_step_ell(Fp12T<E>& f, G2JacT<E>& r, const fe1& px, const fe1& py, const E& qx, const E& qy) {
   LineT<E> l;
-  for (int b = 61; b >= 0; b--) {           // bit 62 is the leading one
+  addition_step(r, qx, qy, l);
+  ell(f, l, px, py);
+}
+template <class E> DEVNI void miller_loop(Fp12T<E>& fout, const fe1& px_, const fe1& py_, const E& qx_, const E& qy_) {
+  // locals that never escape: the register allocator owns them (a reference parameter would pin them to memory across calls)
+  const fe1 px = px_, py = py_; const E qx = qx_, qy = qy_;
+  G2JacT<E> r; r.x = qx; r.y = qy; r.z = E2<E>::one();
+  Fp12T<E> f = fp12_one<E>();
+  LineT<E> l;
+  for (int b = 61; b >= -1; b--) {          // bit 62 is the leading one; b = -1: the final doubling step (pairings.rs:686-687)
     doubling_step(r, l);
     ell(f, l, px, py);
+    if (b < 0) break;
     if ((X_HALF >> b) & 1) {
-      addition_step(r, qx, qy, l);
-      ell(f, l, px, py);
+      // 5 of the 62 iterations: out of line (keeps the hot loop inside the instruction cache); the copies confine the
+      // address-taken objects to this branch
+      Fp12T<E> ft = f; G2JacT<E> rt = r;
+      addition_step_ell(ft, rt, px_, py_, qx_, qy_);
+      f = ft; r = rt;
     }
-    fp12_sqr(f, f);                         // in place
+    fp12_sqr_hot(f, f);                     // in place
   }
-  doubling_step(r, l);
-  ell(f, l, px, py);
   f.c1 = fp6_neg(f.c1);                     // conjugate: BLS_X_IS_NEGATIVE
+  fout = f;
 }
 
 // pairings.rs:554-603 as the reference schedules it: ONE accumulator for K terms -- per bit every term contributes its
@@ -325,27 +346,28 @@ template <class E> DEVNI void miller_loop(Fp12T<E>& f, const fe1& px, const fe1&
 // (:566-569).  Per-term state (P, Q in internal form and the running point R) lives in per-lane scratch.
 constexpr int MML_MAX_K = 8;
 template <class E> struct MmlTerm { fe1 px, py; E qx, qy; G2JacT<E> r; bool skip; };
-template <class E> DEVNI void multi_miller_shared(Fp12T<E>& f, MmlTerm<E>* t, int K) {
-  f = fp12_one<E>();
-  LineT<E> l;
-  for (int b = 61; b >= 0; b--) {
+template <class E> DEVNI void multi_miller_shared(Fp12T<E>& fout, MmlTerm<E>* t, int K) {
+  Fp12T<E> f = fp12_one<E>();               // non-escaping, like miller_loop's
+  for (int b = 61; b >= -1; b--) {          // b = -1: the final doubling step
     for (int k = 0; k < K; k++) {
       if (t[k].skip) continue;
-      doubling_step(t[k].r, l);
-      ell(f, l, t[k].px, t[k].py);
-      if ((X_HALF >> b) & 1) {
-        addition_step(t[k].r, t[k].qx, t[k].qy, l);
-        ell(f, l, t[k].px, t[k].py);
+      G2JacT<E> r = t[k].r;
+      const fe1 px = t[k].px, py = t[k].py;
+      LineT<E> l;
+      doubling_step(r, l);
+      ell(f, l, px, py);
+      t[k].r = r;
+      if (b >= 0 && ((X_HALF >> b) & 1)) {
+        Fp12T<E> ft = f;
+        addition_step_ell(ft, t[k].r, t[k].px, t[k].py, t[k].qx, t[k].qy);
+        f = ft;
       }
     }
-    fp12_sqr(f, f);
-  }
-  for (int k = 0; k < K; k++) {
-    if (t[k].skip) continue;
-    doubling_step(t[k].r, l);
-    ell(f, l, t[k].px, t[k].py);
+    if (b < 0) break;
+    fp12_sqr_hot(f, f);
   }
   f.c1 = fp6_neg(f.c1);
+  fout = f;
 }
 
 // ---- final exponentiation ------------------------------------------------------------------------------
@@ -394,7 +416,7 @@ template <class E> DEVNI void cyclotomic_exp_plain(Fp12T<E>& r, const Fp12T<E>& 
 // routes compute the same field element, so the result is bit-identical; `false` is returned (nothing written) in the
 // degenerate case z2 = z3 = 0 (e.g. f = 1), which the caller sends down the plain route.
 template <class E> struct CycC { E z2, z3, z4, z5; };
-template <class E> DEVNI void cyclotomic_square_compressed(CycC<E>& r, const CycC<E>& c) {
+template <class E> HOT void cyclotomic_square_compressed(CycC<E>& r, const CycC<E>& c) {
   E z2 = c.z2, z3 = c.z3, z4 = c.z4, z5 = c.z5;
   E t0, t1, t2, t3;
   fp4_square(t0, t1, z2, z3);
@@ -409,11 +431,13 @@ template <class E> DEVNI void cyclotomic_square_compressed(CycC<E>& r, const Cyc
 constexpr int CYC_NSNAP = 6;
 template <class E> DEVNI bool cyclotomic_exp_compressed(Fp12T<E>& r, const Fp12T<E>& f) {
   constexpr unsigned long long X = 0xd201000000010000ull;
-  CycC<E> c; c.z2 = f.c1.c0; c.z3 = f.c0.c2; c.z4 = f.c0.c1; c.z5 = f.c1.c2;
+  CycC<E> c; c.z2 = f.c1.c0; c.z3 = f.c0.c2; c.z4 = f.c0.c1; c.z5 = f.c1.c2;      // never escapes: lives in registers across the run
   CycC<E> snap[CYC_NSNAP];
   int ns = 0;
   for (int i = 1; i <= 63; i++) {
-    cyclotomic_square_compressed(c, c);
+    CycC<E> n;
+    cyclotomic_square_compressed(n, c);
+    c = n;
     if ((X >> i) & 1) snap[ns++] = c;
   }
   // denominators and their shared inverse (Montgomery's trick)

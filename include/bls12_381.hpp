@@ -8,6 +8,7 @@
 // CPU fallback here).
 #pragma once
 #include <array>
+#include <optional>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -39,7 +40,16 @@ class Context {
 struct Scalar {
   std::array<uint8_t, 32> bytes{};                       // little-endian canonical integer in [0, r)
   static Scalar from_u64(uint64_t v) { Scalar s; std::memcpy(s.bytes.data(), &v, 8); return s; }
-  static Scalar from_bytes(const uint8_t b[32]) { Scalar s; std::memcpy(s.bytes.data(), b, 32); return s; }
+  // scalar.rs:256-280: CtOption::none for a value >= r (here: std::nullopt)
+  static std::optional<Scalar> from_bytes(const uint8_t b[32]) {
+    static constexpr uint8_t kR[32] = {0x01, 0x00, 0x00, 0x00, 0xff, 0xff, 0xff, 0xff, 0xfe, 0x5b, 0xfe, 0xff, 0x02, 0xa4, 0xbd, 0x53,
+                                       0x05, 0xd8, 0xa1, 0x09, 0x08, 0xd8, 0x39, 0x33, 0x48, 0x7d, 0x9d, 0x29, 0x53, 0xa7, 0xed, 0x73};
+    for (int i = 31; i >= 0; i--) {
+      if (b[i] < kR[i]) { Scalar s; std::memcpy(s.bytes.data(), b, 32); return s; }
+      if (b[i] > kR[i]) return std::nullopt;
+    }
+    return std::nullopt;               // == r
+  }
   const std::array<uint8_t, 32>& to_bytes() const { return bytes; }
 };
 
