@@ -1,25 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- G1 MSM throughput (scalar-muls/s) on MI355X, the headline metric of BASELINE.json.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            (N > 1: re-executes itself under torch.distributed.run)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A step is ONE multi-scalar multiplication over this rank's shard of synthetic input that is already
-resident in HBM: 2^20 affine G1 bases (library-resident, internal form) and 2^20 32-byte scalars per GPU
-(BASELINE configs[1]; weak scaling: N GPUs compute one N*2^20-point MSM).  For N > 1 every step ends with
-the path's single exchange: an RCCL all-gather of the per-rank partial sums (144 B each) followed by the
-fold on every rank.  K steps are timed between barrier + synchronize pairs; the reported
-time is the max over ranks; `value` = total scalar-muls of all ranks / that time.
+Workloads (synthetic inputs per SURVEY.md 8d: SplitMix64 scalars uniform in [0, r), bases [k_i]G built on the device):
 
-The JSON line also carries
-  roofline      the dominant kernel (bucket accumulation) against the integer-VALU roofline: canonical
-                MAC32 per launch / HIP-event launch time, peak = v_mad_u64_u32 rate measured live
-  cpu_baseline  the C restatement of the reference's own `sum(P_i * s_i)` (oracle/bls_oracle.c) timed on the
-                host cores over a bounded sample of the same workload, and checked against the GPU result
+  N = 1   (default)   BASELINE configs[1]: a 2^20-point G1 MSM on one MI355X.  A step is ONE MSM over input that is
+                      already resident in HBM (2^20 affine bases in the library's resident form, 2^20 32-byte scalars).
+  N > 1   (default)   BASELINE configs[3]: ONE 2^24-point G1 MSM sharded N ways (2^24 / N points per GPU), ending with the
+                      path's single exchange: an RCCL all-gather of the N partial sums (144 B each) + fold on every rank
+                      (SURVEY.md 8e).  "scaling": "strong".   --weak keeps 2^--log-n points PER GPU instead.
+  --workload mixed    BASELINE configs[4]: 2^22 G1 MSM + 2^22 G2 MSM + one 2^18-term multi_miller_loop (+ its final
+                      exponentiation) per step, sharded N ways, the three jobs overlapped on separate stream sets (one
+                      library context per job type), one small all-gather each.  Prints its own JSON line.
+
+K steps are timed between barrier + synchronize pairs; the reported time is the max over ranks; `value` = scalar-muls of
+all ranks / that time.  The JSON line also carries
+  roofline        the dominant kernel (bucket accumulation) against the integer-VALU roofline: canonical MAC32 per launch /
+                  HIP-event launch time inside the timed region; peak = v_mad_u64_u32 rate measured live
+  single_call_ms / end_to_end_h2d_ms   latency of ONE non-pipelined MSM (scalars in HBM -> result in HBM) and of one MSM
+                  whose scalars start in pinned host memory and whose result ends on the host (SURVEY.md 8d protocol:
+                  3 warm-ups, median of 11)
+  cpu_baseline    the C restatement of the reference's own `sum(P_i * s_i)` (oracle/bls_oracle.c) timed on the host cores
+                  over a bounded sample of the same workload and checked against the GPU result, plus ns/op for the
+                  reference's criterion points (benches/groups.rs)
+  extras          BASELINE configs[2] (2^20 G2 MSM, 2^16 pairings), the 2^18-term multi_miller_loop, each with its
+                  canonical roofline fraction (SURVEY.md 8d work units)
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -28,70 +40,136 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-LOG_N = 20
 WINDOW_BITS = 16          # canonical c of SURVEY.md 8d; the library picks its own c
+# canonical work units: one Fp multiplication = 300 MAC32
+MAC32_G1_ADD = 11 * 300                    # one complete mixed addition per (point, window)
+MAC32_G1_MSM_2_20 = 188 * 300              # whole 2^20-point MSM, per scalar-mul
+MAC32_G2_MSM_2_20 = 666 * 300              # per scalar-mul
+MAC32_PAIRING = 16000 * 300
+MAC32_MML_TERM = 6900 * 300
 
 
-def synth_inputs(n, seed):
-    """Seeded synthetic input: k_i (base = [k_i]G1) and s_i, 254-bit uniform (top two bits cleared, so < r)."""
-    rs = np.random.RandomState(seed)
-    kb = rs.randint(0, 256, size=(n, 32), dtype=np.uint8)
-    kb[:, 31] &= 0x3F
-    sb = rs.randint(0, 256, size=(n, 32), dtype=np.uint8)
-    sb[:, 31] &= 0x3F
-    return kb, sb
-
-
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--log-n", type=int, default=LOG_N, help="log2 of points per GPU (default 20 = BASELINE configs[1])")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=["msm", "mixed"], default="msm")
+    ap.add_argument("--log-n", type=int, default=None, help="log2 of points per GPU (N=1 default 20 = BASELINE configs[1]; with --weak also for N>1)")
+    ap.add_argument("--log-total", type=int, default=24, help="N>1: log2 of the points of the ONE sharded MSM (default 24 = BASELINE configs[3])")
+    ap.add_argument("--weak", action="store_true", help="N>1: fixed 2^log-n points per GPU instead of one 2^log-total MSM split N ways")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for single-GPU plumbing tests)")
     ap.add_argument("--same-device", action="store_true", help="testing aid: all ranks use GPU 0 (needs --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (batched pairings, G2 MSM)")
-    args = ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (batched pairings, G2 MSM, latency probes)")
+    ap.add_argument("--mixed-log", type=int, nargs=3, default=[22, 22, 18], metavar=("G1", "G2", "MML"),
+                    help="--workload mixed: log2 sizes of the three jobs per node (default 22 22 18 = BASELINE configs[4])")
+    return ap.parse_args()
 
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: become the launcher (one rank per GPU)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+class Env:
+    pass
+
+
+def setup(args):
     import torch
     import torch.distributed as dist
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    if args.same_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
+    e = Env()
+    e.torch, e.dist = torch, dist
+    e.rank = int(os.environ.get("RANK", "0"))
+    e.local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
+    e.world = int(os.environ.get("WORLD_SIZE", "1"))
+    if e.world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, e.world))
+    torch.cuda.set_device(e.local_rank)
+    e.dev = torch.device("cuda", e.local_rank)
+    if e.world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=e.rank, world_size=e.world, device_id=e.dev)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
-
+            dist.init_process_group(args.backend, rank=e.rank, world_size=e.world)
+    e.xdev = e.dev if args.backend == "nccl" else torch.device("cpu")       # where the exchanged partials live
     import bls12_381_amd as bls
+    e.bls = bls
+    return e
 
-    ctx = bls.Context(local_rank)
+
+def fence(e):
+    e.torch.cuda.synchronize()
+    if e.world > 1:
+        e.dist.barrier()
+    e.torch.cuda.synchronize()
+
+
+def max_over_ranks(e, dt):
+    if e.world == 1:
+        return dt
+    t = e.torch.tensor([dt], dtype=e.torch.float64, device=e.xdev)
+    e.dist.all_reduce(t, op=e.dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def ranks_agree(e, limbs_np):
+    """every rank must hold the same value: compare through a max/min all-reduce"""
+    t = e.torch.from_numpy(limbs_np.view(np.int64).copy()).to(e.xdev)
+    hi, lo = t.clone(), t.clone()
+    e.dist.all_reduce(hi, op=e.dist.ReduceOp.MAX); e.dist.all_reduce(lo, op=e.dist.ReduceOp.MIN)
+    return bool(e.torch.equal(hi, lo))
+
+
+def median_ms(fn, sync, warm=3, reps=11):
+    for _ in range(warm):
+        fn(); sync()
+    ts = []
+    for _ in range(reps):
+        t = time.perf_counter(); fn(); sync()
+        ts.append(time.perf_counter() - t)
+    return 1e3 * float(np.median(ts))
+
+
+# =====================================================================================================================
+# workload "msm"
+# =====================================================================================================================
+def run_msm(args, e):
+    torch, dist, bls = e.torch, e.dist, e.bls
+    from bls12_381_amd import synthetic
+    from bls12_381_amd.distributed import shard_range, all_gather_rows
+    rank, world, dev = e.rank, e.world, e.dev
+    steps = args.steps if args.steps is not None else (100 if world == 1 else 20)
+    warmup = args.warmup if args.warmup is not None else 5
+    strong = world > 1 and not args.weak
+    if strong:
+        total = 1 << args.log_total
+        lo, hi = shard_range(total, rank, world)
+        n = hi - lo
+    else:
+        n = 1 << (args.log_n if args.log_n is not None else 20)
+        total = n * world
+    ctx = bls.Context(e.local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    n = 1 << args.log_n
-    kb, sb = synth_inputs(n, 0xB1512381 + rank)
-    bases = ctx.bases_from_scalars(1, kb)                       # resident bases: [k_i] G1 built on the device
+    # this rank's shard of the synthetic input: scalars uniform in [0, r) (all 255 bits in play), bases [k_i]G1
+    kb = synthetic.scalars(n, synthetic.SEED + 2 * rank + 1)
+    sb = synthetic.scalars(n, synthetic.SEED + 2 * rank)
+    bases = ctx.bases_from_scalars(1, kb)                       # resident bases, built on the device
     d_scalars = torch.from_numpy(sb).to(dev)
     d_out = [torch.zeros(18, dtype=torch.int64, device=dev) for _ in range(4)]      # up to four calls may be in flight
-    xdev = dev if args.backend == "nccl" else torch.device("cpu")       # where the exchanged partials live
-    gathered = torch.zeros((world, 18), dtype=torch.int64, device=xdev) if world > 1 else None
+    gathered = torch.zeros((world, 18), dtype=torch.int64, device=e.xdev) if world > 1 else None
     d_fold = torch.zeros(18, dtype=torch.int64, device=dev)
     ctx.set_pipelining(True)         # the latency-bound tail of MSM i overlaps the chip-filling phases of MSM i+1
     state = {"i": 0}
 
     def exchange(buf):
         """the path's single exchange step: all-gather the per-rank partial sums, fold on every rank"""
-        dist.all_gather(list(gathered.unbind(0)), buf.to(xdev))     # rows of one (world, 18) tensor
+        all_gather_rows(gathered, buf.to(e.xdev), dist)
         g = gathered if gathered.device == dev else gathered.to(dev)
         ctx.point_sum_device(1, g.data_ptr(), world, d_fold.data_ptr())     # asynchronous fold on this rank's GPU
         state["g"] = g
@@ -112,245 +190,406 @@ def main():
                 exchange(d_out[k & 3])
         state["i"] = 0
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     drain()
-    fence()
+    fence(e)
     ctx.msm_accumulate_stats(True)             # HIP events around every launch of the dominant kernel inside the timed region
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     drain()
-    fence()
+    fence(e)
     dt = time.perf_counter() - t0
     live_acc_ms, live_acc_n = ctx.msm_accumulate_stats(False)
+    dt = max_over_ranks(e, dt)
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=xdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        # every rank must hold the same folded result: compare canonical affine limbs through a max/min all-reduce
         last = d_fold.cpu().numpy().view(np.uint64)
-        aff = torch.from_numpy(ctx.batch_normalize(1, last[None, :])[0][0].view(np.int64).copy()).to(xdev)
-        hi, lo = aff.clone(), aff.clone()
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX); dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        if not bool(torch.equal(hi, lo)):
+        aff = ctx.batch_normalize(1, last[None, :])[0][0]
+        if not ranks_agree(e, aff):
             raise SystemExit("bench: ranks disagree on the folded MSM result")
     ctx.set_pipelining(False)
-    d_out = d_out[0]
+    d_out0 = d_out[0]
+    log_n = int(round(np.log2(n))) if n & (n - 1) == 0 else None
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the library's stream ----------
-    roof = None
-    phases = None
+    roof = phases = latency = None
     if rank == 0:
         peak = ctx.mad_throughput(2000)                          # v_mad_u64_u32 lane-ops/s = MAC32/s
-        fp_rate = ctx.fp_mul_throughput(2000)
         ctx.set_profiling(True)
         acc_ms, tot_ms = [], []
         for _ in range(5):
-            ctx.msm_device(bases, d_scalars.data_ptr(), n, d_out.data_ptr())
+            ctx.msm_device(bases, d_scalars.data_ptr(), n, d_out0.data_ptr())
             ph = ctx.last_msm_phase_ms()
             acc_ms.append(ph["accumulate"]); tot_ms.append(ph["total"]); phases = ph
         ctx.set_profiling(False)
         windows = (256 + WINDOW_BITS - 1) // WINDOW_BITS
-        mac32_per_launch = float(n) * windows * 11 * 300          # canonical: one complete mixed add per (point, window)
+        mac32_per_launch = float(n) * windows * MAC32_G1_ADD
         # duration of the dominant kernel: average over its launches INSIDE the timed (pipelined) region, HIP events on the
         # stream it runs on; the isolated (one MSM at a time) duration is reported next to it
         dur = (live_acc_ms if live_acc_n else float(np.mean(acc_ms))) * 1e-3
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_msm_pmc.json")
-        if args.log_n == 20 and os.path.exists(pmc_path):
+        pmc_path = os.path.join(ROOT, "profiles", "r02_msm_pmc.json")
+        if log_n == 20 and os.path.exists(pmc_path):
             # HBM-side bytes per launch of this kernel on this workload, from separate rocprofv3 --pmc passes
-            # (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); see profiles/r01_msm_pmc.md
+            # (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); see profiles/r02_msm_pmc.md
             traffic = json.load(open(pmc_path))["hbm_bytes_per_launch_corrected"]
         roof = {
             "bound": "int-valu", "kernel": "k_msm_accumulate<G1>",
             "achieved": mac32_per_launch / dur / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s",
             "frac": mac32_per_launch / dur / peak, "frac_isolated": mac32_per_launch / (float(np.mean(acc_ms)) * 1e-3) / peak, "traffic": traffic,
             "launch_ms": dur * 1e3, "launches_timed": int(live_acc_n), "launch_ms_isolated": float(np.mean(acc_ms)), "mac32_per_launch": mac32_per_launch,
-            "fp_mul_per_s_chain": fp_rate,
-            "whole_msm_frac": (float(n) * 188 * 300) / (float(np.mean(tot_ms)) * 1e-3) / peak,
+            "whole_msm_frac_pipelined": (float(n) * MAC32_G1_MSM_2_20) / (dt / steps) / peak,
+            "whole_msm_frac_single_call": (float(n) * MAC32_G1_MSM_2_20) / (float(np.mean(tot_ms)) * 1e-3) / peak,
             "note": "integer-VALU bound (no MFMA, HBM traffic ~13% of peak, see traffic): canonical 300 MAC32 per Fp mul, 11 Fp mul per mixed add, "
                     "16 windows (SURVEY.md 8d); peak = v_mad_u64_u32 issue rate measured in this run",
         }
+    # ---- latency of ONE call (SURVEY.md 8d timing protocol) ------------------------------------------------
+    if rank == 0 and world == 1 and not args.no_extras:
+        sync = torch.cuda.synchronize
+        single = median_ms(lambda: ctx.msm_device(bases, d_scalars.data_ptr(), n, d_out0.data_ptr()), sync)
+        pinned = torch.from_numpy(sb).pin_memory()
+        host_out = np.zeros(18, dtype=np.uint64)
+        import ctypes
+
+        def e2e():
+            bls._lib.check(ctx.lib.blsgpu_g1_msm(ctx.h, bases.handle, 0, ctypes.c_void_p(pinned.data_ptr()), n, ctypes.c_void_p(host_out.ctypes.data)), "g1_msm")
+        e2e_ms = median_ms(e2e, lambda: None)
+        latency = {"single_call_ms": single, "end_to_end_h2d_ms": e2e_ms,
+                   "single_call_scalar_muls_per_s": n / (single * 1e-3), "end_to_end_scalar_muls_per_s": n / (e2e_ms * 1e-3),
+                   "note": "one MSM at a time, nothing else in flight: scalars in HBM -> projective result in HBM (single_call); scalars in pinned host "
+                           "memory -> 32 MB H2D over PCIe -> MSM -> result on the host, synchronous blsgpu_g1_msm (end_to_end); 3 warm-ups, median of 11"}
 
     # ---- CPU baseline: the reference's own definition on the host cores (bounded sample) ------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import c_oracle
-        m = min(n, 1 << 15)
-        xy, inf = bases.download(0, m)
-        t1 = time.perf_counter()
-        ref, used = c_oracle.g1_msm(xy, inf, sb[:m], 0)
-        cdt = time.perf_counter() - t1
-        got = ctx.msm(bases, sb[:m])
-        same = bool(np.array_equal(ctx.batch_normalize(1, got[None, :])[0][0], c_oracle.g1_to_affine(ref)[0]))
-        t1 = time.perf_counter()
-        c_oracle.g1_msm(xy[:256], inf[:256], sb[:256], 1)
-        one = 256 / (time.perf_counter() - t1)
-        cpu = {"value": m / cdt, "unit": "scalar-muls/s", "cores": used, "kind": "port",
-               "sample": f"first 2^{int(np.log2(m))} (point, scalar) pairs of the same workload: sum(P_i*s_i) by 255-step double-and-add + Sum, "
-                         f"C restatement of the reference algorithm (oracle/bls_oracle.c), OpenMP over {used} threads; single thread: {one:.0f}/s",
-               "single_thread_value": one, "parallel_speedup": (m / cdt) / one, "gpu_result_matches": same}
-        if not same:
-            raise SystemExit("bench: GPU MSM over the CPU sample differs from the oracle")
+        cpu = cpu_baseline_g1(ctx, bases, sb, n)
 
     # ---- secondary measurements of the same path (BASELINE configs[2]); never part of `value` ---------------
     extras = None
     if rank == 0 and world == 1 and not args.no_extras:
-        extras = {}
-        np_ = 1 << 16
-        rs = np.random.RandomState(99)
-        ka = rs.randint(0, 256, size=(np_, 32), dtype=np.uint8); ka[:, 31] &= 0x3F
-        kq = rs.randint(0, 256, size=(np_, 32), dtype=np.uint8); kq[:, 31] &= 0x3F
-        g1xy, g1f = ctx.bases_from_scalars(1, ka).download()
-        g2xy, g2f = ctx.bases_from_scalars(2, kq).download()
-        d_g1 = torch.from_numpy(g1xy.view(np.int64)).to(dev); d_g2 = torch.from_numpy(g2xy.view(np.int64)).to(dev)
-        d_gt = torch.zeros((np_, 72), dtype=torch.int64, device=dev)
-        def pair():
-            bls._lib.check(ctx.lib.blsgpu_pairing_batch_device(ctx.h, d_g1.data_ptr(), None, d_g2.data_ptr(), None, np_, d_gt.data_ptr()), "pairing_batch_device")
-        pair(); torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(3):
-            pair()
-        torch.cuda.synchronize()
-        pdt = (time.perf_counter() - t1) / 3
-        extras["pairings_per_s"] = np_ / pdt
-        if not args.no_cpu_baseline:
-            # the reference's pairing on the host cores (C restatement, oracle/bls_oracle.c) on a bounded sample, and an exact
-            # comparison of the GPU results over that sample
-            from oracle import c_oracle
-            mp = 1 << 13
-            t1 = time.perf_counter()
-            cref, cused = c_oracle.pairing_batch(0, g1xy[:mp], g1f[:mp], g2xy[:mp], g2f[:mp], 0)
-            cpdt = time.perf_counter() - t1
-            t1 = time.perf_counter()
-            c_oracle.pairing_batch(0, g1xy[:16], g1f[:16], g2xy[:16], g2f[:16], 1)
-            one_p = 16 / (time.perf_counter() - t1)
-            same_p = bool(np.array_equal(d_gt[:mp].cpu().numpy().view(np.uint64), cref))
-            extras["cpu_baseline_pairing"] = {"value": mp / cpdt, "unit": "pairings/s", "cores": cused, "kind": "port",
-                                              "sample": f"first 2^13 of the same pairs, C restatement of pairings.rs (Miller loop + final exponentiation), "
-                                                        f"OpenMP over {cused} threads; single thread: {one_p:.0f}/s",
-                                              "single_thread_value": one_p, "parallel_speedup": (mp / cpdt) / one_p, "gpu_result_matches": same_p}
-            if not same_p:
-                raise SystemExit("bench: GPU pairings differ from the CPU oracle on the sample")
-        extras["pairing_batch"] = {"n": np_, "ms": 1e3 * pdt, "note": "2^16 independent pairing(P_i, Q_i), inputs and outputs in HBM",
-                                   "frac_of_fp_mul_chain_rate": (np_ * 16000 / pdt) / fp_rate}
-        # multi_miller_loop at BASELINE configs[4]'s size (2^18 terms, the 2^16 pairs tiled four times): one shared accumulator
-        # per four terms, partial products multiplied up; no final exponentiation in the timed region
-        nm = 4 * np_
-        d_g1m, d_g2m = d_g1.repeat(4, 1), d_g2.repeat(4, 1)
-        def mml():
-            bls._lib.check(ctx.lib.blsgpu_multi_miller_loop_device(ctx.h, d_g1m.data_ptr(), None, d_g2m.data_ptr(), None, nm, d_gt.data_ptr()), "multi_miller_loop_device")
-        mml(); torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(3):
-            mml()
-        torch.cuda.synchronize()
-        mdt = (time.perf_counter() - t1) / 3
-        extras["multi_miller_loop_terms_per_s"] = nm / mdt
-        extras["multi_miller_loop"] = {"n": nm, "ms": 1e3 * mdt, "note": "one product of 2^18 Miller values (no final exponentiation)"}
-        del d_g1m, d_g2m
-        # Fr transform of the MSM's scalar vector
-        d_fr = d_scalars.clone()
-        ctx.fr_ntt_device(d_fr.data_ptr(), args.log_n, False); torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(10):
-            ctx.fr_ntt_device(d_fr.data_ptr(), args.log_n, False)
-        torch.cuda.synchronize()
-        ndt = (time.perf_counter() - t1) / 10
-        extras["fr_ntt"] = {"log_n": args.log_n, "ms": 1e3 * ndt, "elements_per_s": n / ndt,
-                            "note": "radix-2 NTT over the scalar field, in place, natural order; 5 radix-4 passes over the data + one LDS pass at 2^20"}
-        del d_fr
-        # hash-to-curve in front of the pairings: 2^16 32-byte messages -> G2
-        hm = torch.from_numpy(rs.randint(0, 256, size=np_ * 32, dtype=np.uint8)).to(dev)
-        ho = torch.arange(0, (np_ + 1) * 32, 32, dtype=torch.int64, device=dev)
-        hdst = b"BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_"
-        hd = torch.from_numpy(np.frombuffer(hdst, dtype=np.uint8).copy()).to(dev)
-        hout = torch.zeros((np_, 36), dtype=torch.int64, device=dev)
-        def h2c():
-            bls._lib.check(ctx.lib.blsgpu_hash_to_curve_device(ctx.h, 2, hm.data_ptr(), ho.data_ptr(), np_, hd.data_ptr(), len(hdst), 0, hout.data_ptr()), "hash_to_curve_device")
-        h2c(); torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(3):
-            h2c()
-        torch.cuda.synchronize()
-        hdt = (time.perf_counter() - t1) / 3
-        extras["hash_to_g2"] = {"n": np_, "ms": 1e3 * hdt, "hashes_per_s": np_ / hdt, "note": "hash_to_curve (XMD:SHA-256, SSWU, RO) of 32-byte messages to G2"}
-        del hm, ho, hout
-        n2 = min(1 << 20, n)
-        k2 = rs.randint(0, 256, size=(n2, 32), dtype=np.uint8); k2[:, 31] &= 0x3F
-        b2 = ctx.bases_from_scalars(2, k2)
-        d_s2 = torch.from_numpy(sb[:n2].copy()).to(dev)
-        d_o2 = [torch.zeros(36, dtype=torch.int64, device=dev) for _ in range(4)]
-        ctx.set_pipelining(True)
-        for i in range(2):
-            ctx.msm_device(b2, d_s2.data_ptr(), n2, d_o2[i].data_ptr())
-        ctx.join(0); torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(24):
-            ctx.msm_device(b2, d_s2.data_ptr(), n2, d_o2[i & 3].data_ptr())
-        ctx.join(0); torch.cuda.synchronize()
-        g2dt = (time.perf_counter() - t1) / 24
-        ctx.set_pipelining(False)
-        if not args.no_cpu_baseline:
-            from oracle import c_oracle
-            m2 = 1 << 12                                  # bounded sample: ~10 s of CPU work
-            xy2, inf2 = b2.download(0, m2)
-            t1 = time.perf_counter()
-            ref2, used2 = c_oracle.g2_msm(xy2, inf2, sb[:m2], 0)
-            c2dt = time.perf_counter() - t1
-            got2 = ctx.msm(b2, sb[:m2])
-            same2 = bool(np.array_equal(ctx.batch_normalize(2, got2[None, :])[0][0], c_oracle.g2_to_affine(ref2)[0]))
-            extras["cpu_baseline_g2_msm"] = {"value": m2 / c2dt, "unit": "scalar-muls/s", "cores": used2, "kind": "port",
-                                             "sample": "first 2^12 (point, scalar) pairs: sum(P_i*s_i) over G2 by 255-step double-and-add + Sum "
-                                                       f"(oracle/bls_oracle.c), OpenMP over {used2} threads", "gpu_result_matches": same2}
-            if not same2:
-                raise SystemExit("bench: GPU G2 MSM differs from the CPU oracle on the sample")
-        extras["g2_msm_scalar_muls_per_s"] = n2 / g2dt
-        extras["g2_msm"] = {"n": n2, "ms": 1e3 * g2dt}
-        # fixed-base mode: resident window-shifted tables (13 windows of 20 bits, one bucket set, no window combine)
-        t1 = time.perf_counter()
-        bases.precompute(0)
-        pre_s = time.perf_counter() - t1
-        d_o1 = [torch.zeros(18, dtype=torch.int64, device=dev) for _ in range(4)]
-        ctx.set_pipelining(True)
-        for i in range(3):
-            ctx.msm_device(bases, d_scalars.data_ptr(), n, d_o1[i].data_ptr())
-        ctx.join(0); torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(20):
-            ctx.msm_device(bases, d_scalars.data_ptr(), n, d_o1[i & 3].data_ptr())
-        ctx.join(0); torch.cuda.synchronize()
-        pdt2 = (time.perf_counter() - t1) / 20
-        ctx.set_pipelining(False)
-        same = bool(np.array_equal(ctx.batch_normalize(1, d_o1[3].cpu().numpy().view(np.uint64)[None, :])[0],
-                                   ctx.batch_normalize(1, d_out.cpu().numpy().view(np.uint64)[None, :])[0]))
-        extras["g1_msm_precomputed_tables"] = {"scalar_muls_per_s": n / pdt2, "ms": 1e3 * pdt2, "table_build_s": pre_s, "window_bits": 20,
-                                               "resident_bytes": 13 * n * 128, "matches_plain_path": same,
-                                               "note": "optional mode for reused bases (blsgpu_bases_precompute); NOT the headline value"}
+        extras = run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out0)
 
     if rank == 0:
-        total = float(n) * world * args.steps
+        if strong:
+            workload = ("ONE 2^%d-point G1 MSM sharded over %d MI355X (%d points per GPU), bases and scalars resident in HBM; one result per step: "
+                        "RCCL all-gather of the %d partial sums (144 B each) + fold on every rank" % (args.log_total, world, n, world))
+        else:
+            workload = ("2^%d-point G1 MSM per MI355X, bases resident in HBM, scalars in HBM; one result per step%s"
+                        % (log_n, "" if world == 1 else " (RCCL all-gather of N partial sums + fold)"))
         line = {
-            "metric": "G1 MSM throughput (scalar-muls/sec) at 2^%d points per GPU" % args.log_n,
-            "value": total / dt, "unit": "scalar-muls/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "G1 MSM throughput (scalar-muls/sec) at 2^%d points" % (args.log_total if strong else log_n) + ("" if strong or world == 1 else " per GPU"),
+            "value": float(total) * steps / dt, "unit": "scalar-muls/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u32 (14x28-bit limbs, 64-bit accumulators)", "data": "synthetic",
-            "config": {"workload": "2^%d-point G1 MSM per MI355X, bases resident in HBM, scalars in HBM; one result per step "
-                                   "(N>1: RCCL all-gather of N partial sums + fold)" % args.log_n,
-                       "points_per_gpu": n, "total_points": n * world, "parallelism": "shard%d" % world},
-            "roofline": roof, "cpu_baseline": cpu, "msm_phase_ms": phases, "extras": extras,
+            "config": {"workload": workload, "points_per_gpu": n, "total_points": total, "parallelism": "shard%d" % world,
+                       "scalars": "SplitMix64(0xB1512381 + 2*rank), uniform in [0, r) by rejection (SURVEY.md 8d)"},
+            "roofline": roof, "cpu_baseline": cpu, "latency": latency, "msm_phase_ms": phases, "extras": extras,
+        }
+        if latency:
+            line["single_call_ms"] = latency["single_call_ms"]; line["end_to_end_h2d_ms"] = latency["end_to_end_h2d_ms"]
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline_g1(ctx, bases, sb, n):
+    """oracle/bls_oracle.c (kind "port") on the host cores; also the per-op table of the reference's criterion points."""
+    from oracle import c_oracle
+    per_op = {}
+    # single-thread figures from >= ~1 s samples after a warm-up
+    xy1, inf1 = bases.download(0, 4096)
+    c_oracle.g1_msm(xy1[:64], inf1[:64], sb[:64], 1)
+    t1 = time.perf_counter(); c_oracle.g1_msm(xy1, inf1, sb[:4096], 1); one = 4096 / (time.perf_counter() - t1)
+    per_op["g1_scalar_mul_ns"] = 1e9 / one
+    # all cores: warm the thread pool, then a sample large enough that every thread gets hundreds of terms
+    m = min(n, 1 << 17)
+    xy, inf = bases.download(0, m)
+    c_oracle.g1_msm(xy[:4096], inf[:4096], sb[:4096], 0)
+    t1 = time.perf_counter()
+    ref, used = c_oracle.g1_msm(xy, inf, sb[:m], 0)
+    cdt = time.perf_counter() - t1
+    got = ctx.msm(bases, sb[:m])
+    same = bool(np.array_equal(ctx.batch_normalize(1, got[None, :])[0][0], c_oracle.g1_to_affine(ref)[0]))
+    if not same:
+        raise SystemExit("bench: GPU MSM over the CPU sample differs from the oracle")
+    return {"value": m / cdt, "unit": "scalar-muls/s", "cores": used, "kind": "port",
+            "sample": f"first 2^{int(np.log2(m))} (point, scalar) pairs of the same workload: sum(P_i*s_i) by 255-step double-and-add + Sum, "
+                      f"C restatement of the reference algorithm (oracle/bls_oracle.c), OpenMP dynamic schedule over {used} threads after a warm-up; "
+                      f"single thread (4096-pair sample): {one:.0f}/s",
+            "single_thread_value": one, "parallel_speedup": (m / cdt) / one, "gpu_result_matches": same, "per_op_ns": per_op}
+
+
+def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
+    torch, bls, dev = e.torch, e.bls, e.dev
+    from bls12_381_amd import synthetic
+    extras = {}
+    np_ = 1 << 16
+    ka = synthetic.scalars(np_, 99)
+    kq = synthetic.scalars(np_, 100)
+    g1xy, g1f = ctx.bases_from_scalars(1, ka).download()
+    g2xy, g2f = ctx.bases_from_scalars(2, kq).download()
+    d_g1 = torch.from_numpy(g1xy.view(np.int64)).to(dev); d_g2 = torch.from_numpy(g2xy.view(np.int64)).to(dev)
+    d_gt = torch.zeros((np_, 72), dtype=torch.int64, device=dev)
+    sync = torch.cuda.synchronize
+    pms = median_ms(lambda: ctx.pairing_batch_device(d_g1.data_ptr(), d_g2.data_ptr(), np_, d_gt.data_ptr()), sync, warm=1, reps=5)
+    pdt = pms * 1e-3
+    extras["pairings_per_s"] = np_ / pdt
+    extras["pairing_batch"] = {"n": np_, "ms": pms, "note": "2^16 independent pairing(P_i, Q_i), inputs and outputs in HBM",
+                               "roofline": {"bound": "int-valu", "kernel": "k_pairing", "mac32_per_unit": MAC32_PAIRING, "achieved": np_ * MAC32_PAIRING / pdt / 1e12,
+                                            "peak": peak / 1e12, "unit": "TMAC32/s", "frac": np_ * MAC32_PAIRING / pdt / peak}}
+    if not args.no_cpu_baseline:
+        from oracle import c_oracle
+        per_op = {}
+        c_oracle.pairing_batch(0, g1xy[:8], g1f[:8], g2xy[:8], g2f[:8], 1)
+        for mode, name, cnt in ((0, "full_pairing_ns", 512), (1, "miller_loop_ns", 1024), (2, "final_exponentiation_ns", 1024)):
+            src = d_gt[:cnt].cpu().numpy().view(np.uint64) if mode == 2 else g1xy[:cnt]
+            t1 = time.perf_counter()
+            c_oracle.pairing_batch(mode, src, g1f[:cnt], g2xy[:cnt], g2f[:cnt], 1)
+            per_op[name] = 1e9 * (time.perf_counter() - t1) / cnt
+        mp = 1 << 14
+        c_oracle.pairing_batch(0, g1xy[:1024], g1f[:1024], g2xy[:1024], g2f[:1024], 0)           # thread-pool warm-up
+        t1 = time.perf_counter()
+        cref, cused = c_oracle.pairing_batch(0, g1xy[:mp], g1f[:mp], g2xy[:mp], g2f[:mp], 0)
+        cpdt = time.perf_counter() - t1
+        same_p = bool(np.array_equal(d_gt[:mp].cpu().numpy().view(np.uint64), cref))
+        one_p = 1e9 / per_op["full_pairing_ns"]
+        extras["cpu_baseline_pairing"] = {"value": mp / cpdt, "unit": "pairings/s", "cores": cused, "kind": "port",
+                                          "sample": f"first 2^14 of the same pairs, C restatement of pairings.rs (Miller loop + final exponentiation), "
+                                                    f"OpenMP over {cused} threads after a warm-up; single thread (512-pair sample): {one_p:.0f}/s",
+                                          "single_thread_value": one_p, "parallel_speedup": (mp / cpdt) / one_p, "gpu_result_matches": same_p, "per_op_ns": per_op}
+        if not same_p:
+            raise SystemExit("bench: GPU pairings differ from the CPU oracle on the sample")
+    # multi_miller_loop at BASELINE configs[4]'s size (2^18 terms, the 2^16 pairs tiled four times): one shared accumulator
+    # per four terms, partial products multiplied up; no final exponentiation in the timed region
+    nm = 4 * np_
+    d_g1m, d_g2m = d_g1.repeat(4, 1), d_g2.repeat(4, 1)
+    mms = median_ms(lambda: ctx.multi_miller_loop_device(d_g1m.data_ptr(), d_g2m.data_ptr(), nm, d_gt.data_ptr()), sync, warm=1, reps=5)
+    mdt = mms * 1e-3
+    extras["multi_miller_loop_terms_per_s"] = nm / mdt
+    extras["multi_miller_loop"] = {"n": nm, "ms": mms, "note": "one product of 2^18 Miller values (no final exponentiation)",
+                                   "roofline": {"bound": "int-valu", "kernel": "k_multi_miller_shared", "mac32_per_unit": MAC32_MML_TERM, "achieved": nm * MAC32_MML_TERM / mdt / 1e12,
+                                                "peak": peak / 1e12, "unit": "TMAC32/s", "frac": nm * MAC32_MML_TERM / mdt / peak}}
+    del d_g1m, d_g2m
+    # Fr transform of the MSM's scalar vector (SURVEY.md 8(f) rank 3)
+    if n & (n - 1) == 0:
+        log_n = int(np.log2(n))
+        d_fr = d_scalars.clone()
+        nms = median_ms(lambda: ctx.fr_ntt_device(d_fr.data_ptr(), log_n, False), sync, warm=1, reps=10)
+        extras["fr_ntt"] = {"log_n": log_n, "ms": nms, "elements_per_s": n / (nms * 1e-3),
+                            "note": "radix-2 NTT over the scalar field, in place, natural order; 5 radix-4 passes over the data + one LDS pass at 2^20"}
+        del d_fr
+    # hash-to-curve in front of the pairings (SURVEY.md 8(f) rank 4): 2^16 32-byte messages -> G2
+    rs = np.random.RandomState(99)
+    hm = torch.from_numpy(rs.randint(0, 256, size=np_ * 32, dtype=np.uint8)).to(dev)
+    ho = torch.arange(0, (np_ + 1) * 32, 32, dtype=torch.int64, device=dev)
+    hdst = b"BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_"
+    hd = torch.from_numpy(np.frombuffer(hdst, dtype=np.uint8).copy()).to(dev)
+    hout = torch.zeros((np_, 36), dtype=torch.int64, device=dev)
+
+    def h2c():
+        bls._lib.check(ctx.lib.blsgpu_hash_to_curve_device(ctx.h, 2, hm.data_ptr(), ho.data_ptr(), np_, hd.data_ptr(), len(hdst), 0, hout.data_ptr()), "hash_to_curve_device")
+    hms = median_ms(h2c, sync, warm=1, reps=3)
+    extras["hash_to_g2"] = {"n": np_, "ms": hms, "hashes_per_s": np_ / (hms * 1e-3), "note": "hash_to_curve (XMD:SHA-256, SSWU, RO) of 32-byte messages to G2"}
+    del hm, ho, hout
+    # 2^20-point G2 MSM (BASELINE configs[2]), pipelined like the headline
+    n2 = min(1 << 20, n)
+    k2 = synthetic.scalars(n2, 101)
+    b2 = ctx.bases_from_scalars(2, k2)
+    d_s2 = torch.from_numpy(sb[:n2].copy()).to(dev)
+    d_o2 = [torch.zeros(36, dtype=torch.int64, device=dev) for _ in range(4)]
+    ctx.set_pipelining(True)
+    for i in range(2):
+        ctx.msm_device(b2, d_s2.data_ptr(), n2, d_o2[i].data_ptr())
+    ctx.join(0); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(24):
+        ctx.msm_device(b2, d_s2.data_ptr(), n2, d_o2[i & 3].data_ptr())
+    ctx.join(0); torch.cuda.synchronize()
+    g2dt = (time.perf_counter() - t1) / 24
+    ctx.set_pipelining(False)
+    g2single = median_ms(lambda: ctx.msm_device(b2, d_s2.data_ptr(), n2, d_o2[0].data_ptr()), sync, warm=1, reps=5)
+    if not args.no_cpu_baseline:
+        from oracle import c_oracle
+        m2 = 1 << 13                                  # bounded sample: a few seconds of CPU work
+        xy2, inf2 = b2.download(0, m2)
+        c_oracle.g2_msm(xy2[:512], inf2[:512], sb[:512], 0)
+        t1 = time.perf_counter()
+        ref2, used2 = c_oracle.g2_msm(xy2, inf2, sb[:m2], 0)
+        c2dt = time.perf_counter() - t1
+        t1 = time.perf_counter(); c_oracle.g2_msm(xy2[:1024], inf2[:1024], sb[:1024], 1); one2 = 1024 / (time.perf_counter() - t1)
+        got2 = ctx.msm(b2, sb[:m2])
+        same2 = bool(np.array_equal(ctx.batch_normalize(2, got2[None, :])[0][0], c_oracle.g2_to_affine(ref2)[0]))
+        extras["cpu_baseline_g2_msm"] = {"value": m2 / c2dt, "unit": "scalar-muls/s", "cores": used2, "kind": "port",
+                                         "sample": "first 2^13 (point, scalar) pairs: sum(P_i*s_i) over G2 by 255-step double-and-add + Sum "
+                                                   f"(oracle/bls_oracle.c), OpenMP over {used2} threads after a warm-up; single thread (1024-pair sample): {one2:.0f}/s",
+                                         "single_thread_value": one2, "parallel_speedup": (m2 / c2dt) / one2, "gpu_result_matches": same2,
+                                         "per_op_ns": {"g2_scalar_mul_ns": 1e9 / one2}}
+        if not same2:
+            raise SystemExit("bench: GPU G2 MSM differs from the CPU oracle on the sample")
+    extras["g2_msm_scalar_muls_per_s"] = n2 / g2dt
+    extras["g2_msm"] = {"n": n2, "ms": 1e3 * g2dt, "single_call_ms": g2single,
+                        "roofline": {"bound": "int-valu", "kernel": "whole G2 MSM (k_msm_accumulate_g2pair dominant)", "mac32_per_unit": MAC32_G2_MSM_2_20,
+                                     "achieved": n2 * MAC32_G2_MSM_2_20 / g2dt / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s", "frac": n2 * MAC32_G2_MSM_2_20 / g2dt / peak}}
+    # fixed-base mode: resident window-shifted tables (13 windows of 20 bits, one bucket set, no window combine)
+    t1 = time.perf_counter()
+    bases.precompute(0)
+    pre_s = time.perf_counter() - t1
+    d_o1 = [torch.zeros(18, dtype=torch.int64, device=dev) for _ in range(4)]
+    ctx.set_pipelining(True)
+    for i in range(3):
+        ctx.msm_device(bases, d_scalars.data_ptr(), n, d_o1[i].data_ptr())
+    ctx.join(0); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(20):
+        ctx.msm_device(bases, d_scalars.data_ptr(), n, d_o1[i & 3].data_ptr())
+    ctx.join(0); torch.cuda.synchronize()
+    pdt2 = (time.perf_counter() - t1) / 20
+    ctx.set_pipelining(False)
+    same = bool(np.array_equal(ctx.batch_normalize(1, d_o1[3].cpu().numpy().view(np.uint64)[None, :])[0],
+                               ctx.batch_normalize(1, d_out.cpu().numpy().view(np.uint64)[None, :])[0]))
+    extras["g1_msm_precomputed_tables"] = {"scalar_muls_per_s": n / pdt2, "ms": 1e3 * pdt2, "table_build_s": pre_s, "window_bits": 20,
+                                           "resident_bytes": 13 * n * 128, "matches_plain_path": same,
+                                           "note": "optional mode for reused bases (blsgpu_bases_precompute); NOT the headline value"}
+    return extras
+
+
+# =====================================================================================================================
+# workload "mixed" (BASELINE configs[4])
+# =====================================================================================================================
+class MixedJobs:
+    """The three jobs of BASELINE configs[4] on ONE rank's shard, each on its own library context (own stream set), so the
+    G1 MSM, the G2 MSM and the multi-Miller loop overlap on the GPU.  Also used by the single-GPU logical-rank test."""
+
+    def __init__(self, bls, torch, device_index, sizes, rank, world, seed_base=None):
+        from bls12_381_amd import synthetic
+        from bls12_381_amd.distributed import shard_range
+        self.bls, self.torch = bls, torch
+        dev = torch.device("cuda", device_index)
+        seed = synthetic.SEED if seed_base is None else seed_base
+        self.ctx = [bls.Context(device_index) for _ in range(3)]
+        for c in self.ctx:
+            c.set_pipelining(True)
+        n1 = shard_range(1 << sizes[0], rank, world); n2 = shard_range(1 << sizes[1], rank, world); nm = shard_range(1 << sizes[2], rank, world)
+        self.n = (n1[1] - n1[0], n2[1] - n2[0], nm[1] - nm[0])
+        self.kb1 = synthetic.scalars(self.n[0], seed + 100 + rank); self.sb1 = synthetic.scalars(self.n[0], seed + 200 + rank)
+        self.kb2 = synthetic.scalars(self.n[1], seed + 300 + rank); self.sb2 = synthetic.scalars(self.n[1], seed + 400 + rank)
+        self.ka = synthetic.scalars(self.n[2], seed + 500 + rank); self.kq = synthetic.scalars(self.n[2], seed + 600 + rank)
+        self.b1 = self.ctx[0].bases_from_scalars(1, self.kb1)
+        self.b2 = self.ctx[1].bases_from_scalars(2, self.kb2)
+        g1xy, _ = self.ctx[2].bases_from_scalars(1, self.ka).download()
+        g2xy, _ = self.ctx[2].bases_from_scalars(2, self.kq).download()
+        self.d_s1 = torch.from_numpy(self.sb1).to(dev); self.d_s2 = torch.from_numpy(self.sb2).to(dev)
+        self.d_g1 = torch.from_numpy(g1xy.view(np.int64)).to(dev); self.d_g2 = torch.from_numpy(g2xy.view(np.int64)).to(dev)
+        self.o1 = torch.zeros(18, dtype=torch.int64, device=dev)
+        self.o2 = torch.zeros(36, dtype=torch.int64, device=dev)
+        self.om = torch.zeros(72, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+
+    def launch(self, which=(0, 1, 2)):
+        """enqueue the rank-local part of the selected jobs; returns immediately (each context has its own streams)"""
+        if 0 in which:
+            self.ctx[0].msm_device(self.b1, self.d_s1.data_ptr(), self.n[0], self.o1.data_ptr())
+        if 1 in which:
+            self.ctx[1].msm_device(self.b2, self.d_s2.data_ptr(), self.n[1], self.o2.data_ptr())
+        if 2 in which:
+            self.ctx[2].multi_miller_loop_device(self.d_g1.data_ptr(), self.d_g2.data_ptr(), self.n[2], self.om.data_ptr())
+
+    def join(self):
+        for c in self.ctx[:2]:
+            c.join(0)
+
+    def sync(self):
+        for c in self.ctx:
+            c.synchronize()
+
+    def partials(self):
+        self.sync()
+        return [t.cpu().numpy().view(np.uint64).copy() for t in (self.o1, self.o2, self.om)]
+
+    def expected_scalars(self):
+        """discrete-log side of the three identities, this rank's share: (sum s k over G1, over G2, sum a b)"""
+        from bls12_381_amd import synthetic
+        return (synthetic.dot_mod_r(self.kb1, self.sb1), synthetic.dot_mod_r(self.kb2, self.sb2), synthetic.dot_mod_r(self.ka, self.kq))
+
+
+def run_mixed(args, e):
+    torch, dist, bls = e.torch, e.dist, e.bls
+    from bls12_381_amd.distributed import all_gather_rows
+    rank, world, dev = e.rank, e.world, e.dev
+    steps = args.steps if args.steps is not None else 5
+    warmup = args.warmup if args.warmup is not None else 1
+    jobs = MixedJobs(bls, torch, e.local_rank, args.mixed_log, rank, world)
+    fold_ctx = jobs.ctx[2]
+    gath = [torch.zeros((world, w), dtype=torch.int64, device=e.xdev) for w in (18, 36, 72)] if world > 1 else None
+    f1 = torch.zeros(18, dtype=torch.int64, device=dev); f2 = torch.zeros(36, dtype=torch.int64, device=dev)
+    fm = torch.zeros(72, dtype=torch.int64, device=dev); gt = torch.zeros(72, dtype=torch.int64, device=dev)
+
+    def step(which=(0, 1, 2)):
+        jobs.launch(which)
+        jobs.sync()                        # the three rank-local results (one element each) are ready
+        srcm = jobs.om
+        if world > 1:
+            # the three tiny exchanges (144 B, 288 B, 576 B per rank) + folds on every rank
+            for k, (buf, g, out, grp) in enumerate(((jobs.o1, gath[0], f1, 1), (jobs.o2, gath[1], f2, 2))):
+                if k in which:
+                    all_gather_rows(g, buf.to(e.xdev), dist)
+                    gg = g if g.device == dev else g.to(dev)
+                    fold_ctx.point_sum_device(grp, gg.data_ptr(), world, out.data_ptr())
+            if 2 in which:
+                all_gather_rows(gath[2], jobs.om.to(e.xdev), dist)
+                gg = gath[2] if gath[2].device == dev else gath[2].to(dev)
+                fold_ctx.fp12_product_device(gg.data_ptr(), world, fm.data_ptr())
+                srcm = fm
+        if 2 in which:
+            fold_ctx.final_exponentiation_device(srcm.data_ptr(), 1, gt.data_ptr())     # ONE final exponentiation per product
+        fold_ctx.synchronize()
+
+    def timed(which, k):
+        fence(e)
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step(which)
+        fence(e)
+        return max_over_ranks(e, (time.perf_counter() - t0) / k)
+
+    for _ in range(warmup):
+        step()
+    dt = timed((0, 1, 2), steps)
+    alone = [timed((k,), max(1, steps // 2)) for k in range(3)]
+    ok = True
+    if world > 1:
+        ok = ranks_agree(e, gt.cpu().numpy().view(np.uint64)) and ranks_agree(e, f1.cpu().numpy().view(np.uint64))
+    if rank == 0:
+        s = [1 << x for x in args.mixed_log]
+        line = {
+            "metric": "mixed workload wall time per instance (BASELINE configs[4])", "value": 1e3 * dt, "unit": "ms", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * dt, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u32 (14x28-bit limbs, 64-bit accumulators)", "data": "synthetic",
+            "config": {"workload": "2^%d-point G1 MSM + 2^%d-point G2 MSM + 2^%d-term multi_miller_loop with its final exponentiation, sharded over %d MI355X, "
+                                   "the three jobs overlapped on separate stream sets, one all-gather (144 / 288 / 576 B per rank) + fold each"
+                                   % (args.mixed_log[0], args.mixed_log[1], args.mixed_log[2], world), "parallelism": "shard%d" % world},
+            "jobs_alone_ms": {"g1_msm": 1e3 * alone[0], "g2_msm": 1e3 * alone[1], "multi_miller_loop+final_exp": 1e3 * alone[2]},
+            "sum_of_jobs_alone_ms": 1e3 * sum(alone), "overlap_gain": sum(alone) / dt,
+            "rates_overlapped": {"g1_scalar_muls_per_s": s[0] / dt, "g2_scalar_muls_per_s": s[1] / dt, "miller_terms_per_s": s[2] / dt},
+            "ranks_agree": ok,
         }
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    e = setup(args)
+    if args.workload == "mixed":
+        run_mixed(args, e)
+    else:
+        run_msm(args, e)
 
 
 if __name__ == "__main__":

@@ -75,6 +75,9 @@ SIGNATURES = {
     "blsgpu_fp12_product": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_pairing_batch_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_multi_miller_loop_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_miller_loop_batch_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_final_exponentiation_device": (c_int, [c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_fp12_product_device": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_fp_op": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_fp2_op": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_fp12_op": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp]),

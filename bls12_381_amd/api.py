@@ -421,6 +421,25 @@ class Context:
         check(self.lib.blsgpu_gt_mul_scalar_batch(self.h, _ptr(gt), _ptr(sb), gt.shape[0], _ptr(out)), "gt_mul_scalar_batch")
         return out
 
+    # device-pointer variants (asynchronous on the context's stream); pointers are plain ints (e.g. tensor.data_ptr())
+    def pairing_batch_device(self, d_g1, d_g2, n, d_out, d_g1_inf=None, d_g2_inf=None):
+        check(self.lib.blsgpu_pairing_batch_device(self.h, ctypes.c_void_p(d_g1), ctypes.c_void_p(d_g1_inf), ctypes.c_void_p(d_g2), ctypes.c_void_p(d_g2_inf), n,
+                                                   ctypes.c_void_p(d_out)), "pairing_batch_device")
+
+    def miller_loop_batch_device(self, d_g1, d_g2, n, d_out, d_g1_inf=None, d_g2_inf=None):
+        check(self.lib.blsgpu_miller_loop_batch_device(self.h, ctypes.c_void_p(d_g1), ctypes.c_void_p(d_g1_inf), ctypes.c_void_p(d_g2), ctypes.c_void_p(d_g2_inf), n,
+                                                       ctypes.c_void_p(d_out)), "miller_loop_batch_device")
+
+    def multi_miller_loop_device(self, d_g1, d_g2, n, d_out, d_g1_inf=None, d_g2_inf=None):
+        check(self.lib.blsgpu_multi_miller_loop_device(self.h, ctypes.c_void_p(d_g1), ctypes.c_void_p(d_g1_inf), ctypes.c_void_p(d_g2), ctypes.c_void_p(d_g2_inf), n,
+                                                       ctypes.c_void_p(d_out)), "multi_miller_loop_device")
+
+    def final_exponentiation_device(self, d_in, n, d_out):
+        check(self.lib.blsgpu_final_exponentiation_device(self.h, ctypes.c_void_p(d_in), n, ctypes.c_void_p(d_out)), "final_exponentiation_device")
+
+    def fp12_product_device(self, d_in, n, d_out):
+        check(self.lib.blsgpu_fp12_product_device(self.h, ctypes.c_void_p(d_in), n, ctypes.c_void_p(d_out)), "fp12_product_device")
+
     def fp12_product(self, f):
         f = _u64(f, (-1, 72))
         out = np.zeros(72, dtype=np.uint64)

@@ -1260,6 +1260,21 @@ extern "C" int blsgpu_pairing_batch_device(blsgpu_ctx* c, const void* g1, const 
   return pairing_launch(c, 0, g1, g1inf, g2, g2inf, n, out);
 }
 
+extern "C" int blsgpu_miller_loop_batch_device(blsgpu_ctx* c, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) {
+  if (!c || (n && (!g1 || !g2 || !out))) return bad("miller_loop: NULL argument");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  return pairing_launch(c, 1, g1, g1inf, g2, g2inf, n, out);
+}
+extern "C" int blsgpu_final_exponentiation_device(blsgpu_ctx* c, const void* in, size_t n, void* out) {
+  if (!c || (n && (!in || !out))) return bad("final_exponentiation: NULL argument");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_final_exp, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)in, (u32*)out, n);
+  LAUNCHCHK();
+  return BLSGPU_OK;
+}
+
 // product of n Fp12 wire values already in device memory (d_in) -> one wire value (d_out); tree of k_fp12_prod
 static int fp12_product_device(blsgpu_ctx* c, const u32* d_in, size_t n, u32* d_out) {
   if (c->io_c.reserve((n / 2 + 1) * 576) || c->io_d.reserve((n / 4 + 1) * 576)) { g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP; }
@@ -1278,6 +1293,11 @@ static int fp12_product_device(blsgpu_ctx* c, const u32* d_in, size_t n, u32* d_
   }
   if (in != d_out) HIPCHK(hipMemcpyAsync(d_out, in, 576, hipMemcpyDeviceToDevice, c->stream));
   return BLSGPU_OK;
+}
+extern "C" int blsgpu_fp12_product_device(blsgpu_ctx* c, const void* in, size_t n, void* out) {
+  if (!c || !out || (n && !in)) return bad("fp12_product: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  return fp12_product_device(c, (const u32*)in, n, (u32*)out);
 }
 extern "C" int blsgpu_multi_miller_loop_device(blsgpu_ctx* c, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) {
   if (!c || !out || (n && (!g1 || !g2))) return bad("multi_miller_loop: NULL argument");

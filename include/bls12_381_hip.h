@@ -158,6 +158,12 @@ int blsgpu_gt_mul_scalar_batch(blsgpu_ctx* ctx, const uint64_t* gt, const uint8_
 /* Device-pointer variants (inputs/outputs in device memory, asynchronous on the context's stream). */
 int blsgpu_pairing_batch_device(blsgpu_ctx* ctx, const void* d_g1_xy, const void* d_g1_inf, const void* d_g2_xy, const void* d_g2_inf, size_t n, void* d_out_gt);
 int blsgpu_multi_miller_loop_device(blsgpu_ctx* ctx, const void* d_g1_xy, const void* d_g1_inf, const void* d_g2_xy, const void* d_g2_inf, size_t n, void* d_out_f);
+/* raw Miller values of n pairs, final exponentiation of n values and the product of n values, device to device: the pieces a
+ * sharded `multi_miller_loop` needs around its single exchange (rank-local product -> all-gather -> fold -> ONE final
+ * exponentiation; src/pairings.rs:179-186, :48-176) and that a sharded batch of independent pairings keeps on the device. */
+int blsgpu_miller_loop_batch_device(blsgpu_ctx* ctx, const void* d_g1_xy, const void* d_g1_inf, const void* d_g2_xy, const void* d_g2_inf, size_t n, void* d_out_f);
+int blsgpu_final_exponentiation_device(blsgpu_ctx* ctx, const void* d_in_f, size_t n, void* d_out_gt);
+int blsgpu_fp12_product_device(blsgpu_ctx* ctx, const void* d_in_f, size_t n, void* d_out_f);
 
 /* ---- field self-test hooks (parity tests of the arithmetic core against the oracle) ---------------------- */
 /* out[i] = a[i] op b[i] over n Fp elements in wire format; op: 0 mul, 1 add, 2 sub, 3 square(a), 4 invert(a), 5 neg(a). */

@@ -208,7 +208,7 @@ int ora_g1_msm(const u64* xy, const uint8_t* inf, const uint8_t* scalars, long n
   {
     int t = omp_get_thread_num();
     g1p acc = G1_IDENTITY;
-#pragma omp for schedule(static)
+#pragma omp for schedule(dynamic, 16)
     for (long i = 0; i < n; i++) {
       g1p p; memcpy(&p.x, xy + 12 * i, 48); memcpy(&p.y, xy + 12 * i + 6, 48); p.z = (inf && inf[i]) ? FP_ZERO : FP_ONE;
       g1p m = g1_multiply(&p, scalars + 32 * i);
@@ -575,7 +575,7 @@ int ora_g2_msm(const u64* xy, const uint8_t* inf, const uint8_t* scalars, long n
 #pragma omp parallel num_threads(threads)
   {
     g2p acc = g2_identity();
-#pragma omp for schedule(static)
+#pragma omp for schedule(dynamic, 16)
     for (long i = 0; i < n; i++) {
       g2p p; memcpy(&p.x, xy + 24 * i, 96); memcpy(&p.y, xy + 24 * i + 12, 96);
       p.z = (inf && inf[i]) ? FP2_ZERO_C : fp2_one();

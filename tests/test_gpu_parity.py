@@ -931,3 +931,197 @@ def test_msm_many_matches_single_calls(ctx, group):
         assert np.array_equal(ctx.batch_normalize(group, many[j][None, :])[0], ctx.batch_normalize(group, one[None, :])[0]), j
     assert ctx.batch_normalize(group, many[2][None, :])[1][0] == 1
     assert ctx.msm_many(bases, S[:0]).shape[0] == 0
+
+
+# ---- round 2: the north-star sizes with the survey's input distribution (uniform in [0, r): top bits and the top-window carry) ----
+def _g1_point_bytes(ctx, xyz):
+    import bls12_381_amd as b
+    xy, inf = ctx.batch_normalize(1, np.asarray(xyz)[None, :])
+    return b.G1Affine(xy[0], bool(inf[0])).to_uncompressed()
+
+
+def _expected_g1(tot):
+    """[tot] G1 as uncompressed bytes, by the tier-1 C oracle (one 255-step double-and-add of the generator)"""
+    from oracle import c_oracle
+    gx = np.concatenate([fpw(o.G1_GEN[0]), fpw(o.G1_GEN[1])])
+    xyz = c_oracle.g1_affine_mul(gx, False, np.frombuffer(int(tot).to_bytes(32, "little"), dtype=np.uint8))
+    xy, inf = c_oracle.g1_to_affine(xyz)
+    import bls12_381_amd as b
+    return b.G1Affine(xy, inf).to_uncompressed()
+
+
+def test_msm_north_star_sizes_2_21_2_24_and_beyond(ctx):
+    """2^21 points (the per-GPU share of BASELINE configs[3]), 2^24 points (the whole of it on one GPU) and 2^24 + 3 points (the
+    first size on the fallback sort), scalars uniform in [0, r) from the survey's SplitMix64 stream, through the discrete-log
+    identity MSM(s, [k_i]G) = [sum s_i k_i]G on uncompressed bytes; the three calls share one resident base set"""
+    from bls12_381_amd import synthetic as sy
+    n = (1 << 24) + 3
+    kb = sy.scalars(n, sy.SEED + 11)
+    sb = sy.scalars(n, sy.SEED + 12)
+    assert (sb[:, 31] >> 6).max() == 1                       # bit 254 is in play
+    bases = ctx.bases_from_scalars(1, kb)
+    # spot-check the device-built bases against the reference definition (tier-1 C): first / last / a few in between
+    from oracle import c_oracle
+    gx = np.concatenate([fpw(o.G1_GEN[0]), fpw(o.G1_GEN[1])])
+    for i in (0, 1, 12345, (1 << 21) - 1, 1 << 24, n - 1):
+        xy, inf = bases.download(i, 1)
+        want = c_oracle.g1_to_affine(c_oracle.g1_affine_mul(gx, False, kb[i]))
+        assert np.array_equal(xy[0], want[0]) and bool(inf[0]) == want[1], i
+    tot = 0
+    prev = 0
+    for m in (1 << 21, 1 << 24, n):
+        tot = (tot + sy.dot_mod_r(kb[prev:m], sb[prev:m])) % o.R_ORDER
+        prev = m
+        got = ctx.msm(bases, sb[:m])
+        assert _g1_point_bytes(ctx, got) == _expected_g1(tot), m
+    bases.free()
+
+
+def test_msm_2_15_exact_vs_tier1_reference_definition(ctx):
+    """2^15 (point, scalar) pairs: the GPU result equals sum(P_i * s_i) evaluated by the tier-1 C restatement of the reference's
+    own multiply + Sum (g1.rs:754-774, :161-171), for G1 and (2^12) for G2; uniform scalars incl. the top bits"""
+    from bls12_381_amd import synthetic as sy
+    from oracle import c_oracle
+    for group, m in ((1, 1 << 15), (2, 1 << 12)):
+        kb = sy.scalars(m, 900 + group); sb = sy.scalars(m, 950 + group)
+        bases = ctx.bases_from_scalars(group, kb)
+        xy, inf = bases.download()
+        got = ctx.msm(bases, sb)
+        if group == 1:
+            ref, _ = c_oracle.g1_msm(xy, inf, sb, 0)
+            assert np.array_equal(ctx.batch_normalize(1, got[None, :])[0][0], c_oracle.g1_to_affine(ref)[0])
+        else:
+            ref, _ = c_oracle.g2_msm(xy, inf, sb, 0)
+            assert np.array_equal(ctx.batch_normalize(2, got[None, :])[0][0], c_oracle.g2_to_affine(ref)[0])
+
+
+def test_noncanonical_scalars_are_reported_not_miscomputed(ctx):
+    """a raw 32-byte scalar >= r has no `Scalar` value in the reference (from_bytes -> None, scalar.rs:256-280): the library
+    reports BLSGPU_ERR_ARG for it -- at every window width -- instead of returning (s - 2^256) P for the widths that divide 256"""
+    import ctypes
+    import bls12_381_amd as b
+    r = o.SplitMix64(77)
+    n = 64
+    ks = [r.scalar() for _ in range(n)]
+    bases = ctx.bases_from_scalars(1, ks)
+    sb = np.stack([np.frombuffer(r.scalar().to_bytes(32, "little"), dtype=np.uint8) for _ in range(n)]).copy()
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    out = np.zeros(18, dtype=np.uint64)
+    for bad in (o.R_ORDER, (1 << 255) + 5, (1 << 256) - 1):
+        s2 = sb.copy(); s2[17] = np.frombuffer(bad.to_bytes(32, "little"), dtype=np.uint8)
+        for w in (0, 8, 13, 16):
+            ctx.set_msm_window(w)
+            assert ctx.lib.blsgpu_g1_msm(ctx.h, bases.handle, 0, P(s2), n, P(out)) == -2, (hex(bad), w)
+            assert b"canonical" in ctx.lib.blsgpu_last_error()
+            assert ctx.lib.blsgpu_g1_msm(ctx.h, bases.handle, 0, P(sb), n, P(out)) == 0          # the flag does not stick to the next call
+        with pytest.raises(ValueError):
+            ctx.msm(bases, s2)                                                                      # the Python mirror rejects before the call
+    ctx.set_msm_window(0)
+    # r - 1 is canonical and exact
+    _msm_case(ctx, 1, ks[:3], [o.R_ORDER - 1, o.R_ORDER - 2, 1])
+
+
+def test_two_contexts_on_two_host_threads(ctx):
+    """the ABI is re-entrant per context: two contexts driven from two host threads at the same time (G1 MSMs on one, pairings and
+    a G2 MSM on the other) give the same results as the same calls made alone"""
+    import threading
+    import bls12_381_amd as b
+    from bls12_381_amd import synthetic as sy
+    n = 1 << 14
+    kb, sb = sy.scalars(n, 31), sy.scalars(n, 32)
+    ka, kq = sy.scalars(256, 33), sy.scalars(256, 34)
+    c1, c2 = b.Context(0), b.Context(0)
+    b1 = c1.bases_from_scalars(1, kb); b2 = c2.bases_from_scalars(2, kb[:4096])
+    g1, f1 = c2.bases_from_scalars(1, ka).download(); g2, f2 = c2.bases_from_scalars(2, kq).download()
+    want1 = c1.msm(b1, sb); want2 = c2.msm(b2, sb[:4096]); wantp = c2.pairing_batch(g1, f1, g2, f2)
+    res, errs = {}, []
+
+    def t1():
+        try:
+            res["a"] = [c1.msm(b1, sb) for _ in range(6)]
+        except Exception as ex:      # noqa: BLE001
+            errs.append(ex)
+
+    def t2():
+        try:
+            res["b"] = [(c2.pairing_batch(g1, f1, g2, f2), c2.msm(b2, sb[:4096])) for _ in range(3)]
+        except Exception as ex:      # noqa: BLE001
+            errs.append(ex)
+    th = [threading.Thread(target=t1), threading.Thread(target=t2)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+    n1 = lambda x: c1.batch_normalize(1, x[None, :])[0]
+    n2 = lambda x: c2.batch_normalize(2, x[None, :])[0]
+    assert all(np.array_equal(n1(x), n1(want1)) for x in res["a"])
+    assert all(np.array_equal(p, wantp) and np.array_equal(n2(m), n2(want2)) for p, m in res["b"])
+    c1.close(); c2.close()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_logical_ranks_sharded_pairings_and_mixed_workload(ctx, world):
+    """BASELINE configs[4] as `world` logical ranks on one GPU (SURVEY.md 8e caveat), reduced sizes: every rank runs its shard of
+    the G1 MSM, the G2 MSM and the multi_miller_loop concurrently on three contexts (bench.MixedJobs, the code `bench.py
+    --workload mixed` runs), the partials are gathered and folded as the RCCL path does, and the folded results satisfy the
+    discrete-log identities; plus N independent pairings sharded by index slices with no exchange (pairings.rs:607-653)"""
+    import torch
+    import bench
+    import bls12_381_amd as b
+    from bls12_381_amd.distributed import LogicalRanks, sharded_pairings, shard_range
+    sizes = (12, 11, 9)
+    lr = LogicalRanks(world)
+    exp = [0, 0, 0]
+    for rank in range(world):
+        jobs = bench.MixedJobs(b, torch, 0, sizes, rank, world, seed_base=4242)
+        jobs.launch()                                   # three jobs in flight at once on this logical rank
+        p1, p2, pm = jobs.partials()
+        for k, v in enumerate((p1, p2, pm)):
+            lr.contribute(("part", k), rank, v)
+        e = jobs.expected_scalars()
+        exp = [(a + c) % o.R_ORDER for a, c in zip(exp, e)]
+        for c in jobs.ctx:
+            c.close()
+    g1sum = ctx.point_sum(1, lr.collect(("part", 0)))
+    g2sum = ctx.point_sum(2, lr.collect(("part", 1)))
+    fsum = ctx.fp12_product(lr.collect(("part", 2)))
+    assert _g1_point_bytes(ctx, g1sum) == _expected_g1(exp[0])
+    xy, inf = ctx.batch_normalize(2, g2sum[None, :])
+    assert b.G2Affine(xy[0], bool(inf[0])).to_uncompressed() == o.g2_to_uncompressed(o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, exp[1])))
+    gt = ctx.final_exponentiation_batch(fsum[None, :])[0]
+    assert np.array_equal(gt, fp12w(o.gt_mul_scalar(o.pairing(o.G1_GEN, o.G2_GEN), exp[2])))
+    # independent pairings: rank r computes only its slice; concatenating the slices gives the unsharded batch
+    r = o.SplitMix64(99 + world)
+    n = 37
+    a = [r.scalar() for _ in range(n)]; q = [r.scalar() for _ in range(n)]
+    g1, f1 = ctx.bases_from_scalars(1, a).download(); g2, f2 = ctx.bases_from_scalars(2, q).download()
+    f1[5] = 1
+    whole = ctx.pairing_batch(g1, f1, g2, f2)
+    seen = np.zeros((n, 72), dtype=np.uint64)
+    for rank in range(world):
+        (lo, hi), mine = sharded_pairings(lambda lo, hi: ctx.pairing_batch(g1[lo:hi], f1[lo:hi], g2[lo:hi], f2[lo:hi]) if hi > lo else np.zeros((0, 72), dtype=np.uint64),
+                                          n, world, rank)
+        assert (lo, hi) == shard_range(n, rank, world)
+        seen[lo:hi] = mine
+    assert np.array_equal(seen, whole)
+    gen = o.pairing(o.G1_GEN, o.G2_GEN)
+    assert np.array_equal(whole[7], fp12w(o.gt_mul_scalar(gen, a[7] * q[7] % o.R_ORDER))) and np.array_equal(whole[5], fp12w(o.FP12_ONE))
+
+
+def test_device_variants_of_miller_final_exp_product(ctx):
+    """the device-pointer entry points a sharded multi_miller_loop is built from agree with their host-pointer twins"""
+    import torch
+    r = o.SplitMix64(555)
+    n = 33
+    a = [r.scalar() for _ in range(n)]; q = [r.scalar() for _ in range(n)]
+    g1, f1 = ctx.bases_from_scalars(1, a).download(); g2, f2 = ctx.bases_from_scalars(2, q).download()
+    dev = torch.device("cuda", 0)
+    d1 = torch.from_numpy(g1.view(np.int64)).to(dev); d2 = torch.from_numpy(g2.view(np.int64)).to(dev)
+    dml = torch.zeros((n, 72), dtype=torch.int64, device=dev); dgt = torch.zeros((n, 72), dtype=torch.int64, device=dev)
+    dpr = torch.zeros(72, dtype=torch.int64, device=dev)
+    ctx.miller_loop_batch_device(d1.data_ptr(), d2.data_ptr(), n, dml.data_ptr())
+    ctx.final_exponentiation_device(dml.data_ptr(), n, dgt.data_ptr())
+    ctx.fp12_product_device(dml.data_ptr(), n, dpr.data_ptr())
+    ctx.synchronize()
+    ml = ctx.miller_loop_batch(g1, None, g2, None)
+    assert np.array_equal(dml.cpu().numpy().view(np.uint64), ml)
+    assert np.array_equal(dgt.cpu().numpy().view(np.uint64), ctx.pairing_batch(g1, None, g2, None))
+    assert np.array_equal(dpr.cpu().numpy().view(np.uint64), ctx.multi_miller_loop(g1, None, g2, None))

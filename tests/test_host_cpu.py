@@ -114,6 +114,24 @@ def local_product(lo, hi): return F(functools.reduce(o.fp12_mul, vals[lo:hi], o.
 def fold12(parts): return F(functools.reduce(o.fp12_mul, [UF(p) for p in parts], o.FP12_ONE))
 got = sharded_product(local_product, fold12, 4, world, rank, dist)
 assert UF(got) == functools.reduce(o.fp12_mul, vals, o.FP12_ONE)
+# independent pairings: index slices, no collective unless the caller asks for the gather (pairings.rs:607-653)
+from bls12_381_amd.distributed import sharded_pairings, all_gather_rows
+gts = [F(o.final_exponentiation(v)) for v in vals]
+def local_pairings(lo, hi): return np.stack(gts[lo:hi]) if hi > lo else np.zeros((0, 72), dtype=np.uint64)
+(lo, hi), mine = sharded_pairings(local_pairings, 3, world, rank)
+assert mine.shape == (hi - lo, 72) and all(np.array_equal(mine[i], gts[lo + i]) for i in range(hi - lo))
+(lo, hi), allv = sharded_pairings(local_pairings, 3, world, rank, gather=True, dist=dist)
+assert (lo, hi) == (0, 3) and all(np.array_equal(allv[i], gts[i]) for i in range(3))
+# the tensor plumbing of bench.py's RCCL branch, exactly: ONE (world, words) int64 tensor whose unbound rows receive the
+# per-rank partials in place, then handed on as one contiguous buffer
+import torch
+for words in (18, 36, 72):
+    gathered = torch.zeros((world, words), dtype=torch.int64)
+    row = torch.arange(words, dtype=torch.int64) + 1000 * (rank + 1)
+    g = all_gather_rows(gathered, row, dist)
+    assert g.data_ptr() == gathered.data_ptr() and g.is_contiguous()
+    for rk in range(world):
+        assert torch.equal(g[rk], torch.arange(words, dtype=torch.int64) + 1000 * (rk + 1))
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
@@ -142,3 +160,64 @@ def test_header_is_plain_c():
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr])
     text = open(hdr).read()
     assert "#include <torch" not in text and "at::" not in text and "std::" not in text
+
+
+def test_synthetic_scalars_match_the_oracle_stream():
+    """the vectorised generator of bench.py / the full-size tests is the SAME SplitMix64 stream as the oracle's scalar-at-a-time
+    sampler (32 random bytes, top bit cleared, reject >= r): uniform in [0, r), top bits included"""
+    from bls12_381_amd import synthetic as sy
+    r = o.SplitMix64(sy.SEED)
+    want = [r.scalar() for _ in range(2500)]
+    assert sy.to_ints(sy.scalars(2500)) == want
+    for n in (0, 1, 2, 1023, 1024, 1025):
+        assert sy.to_ints(sy.scalars(n)) == want[:n]
+    big = sy.scalars(1 << 16, 7)
+    assert all(v < o.R_ORDER for v in sy.to_ints(big[:2000]))
+    top = big[:, 31] >> 6                    # bit 254 must occur (r / 2^255 = 0.906: about 45% of the scalars have it set)
+    assert 0.40 < float((top == 1).mean()) < 0.50
+    a, b = sy.scalars(300, 1), sy.scalars(300, 2)
+    assert sy.dot_mod_r(a, b) == sum(x * y for x, y in zip(sy.to_ints(a), sy.to_ints(b))) % o.R_ORDER
+    from bls12_381_amd.api import scalars_are_canonical
+    assert scalars_are_canonical(big)
+    bad = big[:4].copy(); bad[2] = np.frombuffer(o.R_ORDER.to_bytes(32, "little"), dtype=np.uint8)
+    assert not scalars_are_canonical(bad)
+
+
+def test_product_constants_match_reference_literals(kats):
+    """bls12_381_amd/csrc/h2c_constants.json (what the library is built from) holds the same numbers as the literals extracted
+    from the reference's map_g1.rs / map_g2.rs (tests/golden/ref_kats.json): the product owns its constants, the fixture pins them"""
+    import json
+    prod = json.load(open(os.path.join(ROOT, "bls12_381_amd", "csrc", "h2c_constants.json")))
+    kc = kats["consts"]
+    rinv = pow(1 << 384, -1, o.P)
+    val = lambda l6: sum(int(v) << (64 * i) for i, v in enumerate(l6)) * rinv % o.P
+    for name in ("ISO11_XNUM", "ISO11_XDEN", "ISO11_YNUM", "ISO11_YDEN"):
+        assert [int(v, 16) for v in prod["g1"][name]] == [val(v) for v in kc["h2c_g1." + name]], name
+    for name in ("SSWU_ELLP_A", "SSWU_ELLP_B", "SSWU_XI", "SQRT_M_XI_CUBED"):
+        assert int(prod["g1"][name], 16) == val(kc["h2c_g1." + name][0]), name
+    for name in ("ISO3_XNUM", "ISO3_XDEN", "ISO3_YNUM", "ISO3_YDEN", "SSWU_ELLP_A", "SSWU_ELLP_B", "SSWU_XI", "SSWU_RV1", "SSWU_ETAS"):
+        flat = [int(c, 16) for v in prod["g2"][name] for c in v]
+        assert flat == [val(v) for v in kc["h2c_g2." + name]], name
+    gen = open(os.path.join(ROOT, "tools", "gen_consts.py")).read()
+    assert "ref_kats" not in gen and "tests\", \"golden" not in gen, "the constants generator must not read anything under tests/"
+
+
+def test_bench_launch_contract():
+    """`python bench.py --gpus N` launched plainly re-executes itself under torch.distributed.run (one rank per GPU) and, for N > 1,
+    defaults to ONE 2^24-point MSM sharded N ways (BASELINE configs[3]); checked on the argument logic, no GPU needed"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "torch.distributed.run" in src and "os.execv" in src and '"WORLD_SIZE" not in os.environ' in src
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    old = sys.argv
+    try:
+        sys.argv = ["bench.py", "--gpus", "8"]
+        a = bench.parse()
+        assert a.log_total == 24 and not a.weak and a.workload == "msm"
+        sys.argv = ["bench.py", "--workload", "mixed"]
+        assert bench.parse().mixed_log == [22, 22, 18]
+    finally:
+        sys.argv = old
+    from bls12_381_amd.distributed import shard_range
+    assert [shard_range(1 << 24, r, 8)[1] - shard_range(1 << 24, r, 8)[0] for r in range(8)] == [1 << 21] * 8
