@@ -56,6 +56,7 @@ struct blsgpu_ctx {
   bool pipelining = false;
   bool acc_timing = false;              // blsgpu_msm_accumulate_stats: HIP-event duration of every accumulation launch
   double acc_ms_sum = 0.0; unsigned acc_count = 0;
+  bool no_glv = false;                 // A/B hook (env BLSGPU_NO_GLV at create): plain 256-bit windows for G1
   bool force_slow_sort = false;        // test hook (env BLSGPU_FORCE_SLOW_SORT at create): the global-atomic sort used beyond 2^24 points
   hipStream_t acc_stream = nullptr;     // bucket accumulation of pipelined calls (the caller's stream is never blocked)
   hipEvent_t ev[9] = {};
@@ -76,7 +77,7 @@ struct blsgpu_ctx {
     bool tail_pending = false;
     bool hist_dirty = false;
     unsigned long long seq = 0;
-    DevBuf ent, sorted, hist, offs, cursor, bsum, items, heavy, ctrl;
+    DevBuf ent, sorted, hist, offs, cursor, bsum, items, heavy, ctrl, glv;
     DevBuf buckets, lvlR[2], lvlT, tsum[2], wacc[2], wsums, result;
   } slot[NSLOT];
   int next_slot = 0;
@@ -91,6 +92,7 @@ struct blsgpu_ctx {
 
 struct blsgpu_bases {
   int group = 1; size_t n = 0; int device = 0; u32* rec = nullptr;   // AFF_WORDS per point
+  u32* endo = nullptr;               // G1 only: the images (BETA x, y) of the records under the GLV endomorphism (msm.cuh)
   // optional window-shifted tables: table[w * n + i] = [2^(table_c * w)] P_i   (blsgpu_bases_precompute)
   u32* table = nullptr; int table_c = 0, table_w = 0;
 };
@@ -365,6 +367,7 @@ extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
   blsgpu_ctx* c = new blsgpu_ctx();
   c->device = device;
   c->force_slow_sort = getenv("BLSGPU_FORCE_SLOW_SORT") != nullptr;
+  c->no_glv = getenv("BLSGPU_NO_GLV") != nullptr;
   int rc = ctx_init(c);
   if (rc != BLSGPU_OK) { blsgpu_destroy(c); return rc; }       // destroy tolerates the half-built context (null handles are skipped)
   *out = c;
@@ -378,7 +381,7 @@ extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
   DevBuf* bufs[] = {&c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_out, &c->flags_a, &c->flags_b, &c->fr_tw[0], &c->fr_tw[1], &c->fr_tmp, &c->fr_ninv};
   for (auto b : bufs) b->release();
   for (auto& sl : c->slot) {
-    DevBuf* sb[] = {&sl.ent, &sl.sorted, &sl.hist, &sl.offs, &sl.cursor, &sl.bsum, &sl.items, &sl.heavy, &sl.ctrl,
+    DevBuf* sb[] = {&sl.ent, &sl.sorted, &sl.hist, &sl.offs, &sl.cursor, &sl.bsum, &sl.items, &sl.heavy, &sl.ctrl, &sl.glv,
                     &sl.buckets, &sl.lvlR[0], &sl.lvlR[1], &sl.lvlT, &sl.tsum[0], &sl.tsum[1], &sl.wacc[0], &sl.wacc[1], &sl.wsums, &sl.result};
     for (auto b : sb) b->release();
     hipEvent_t evs[] = {sl.ev_in, sl.ev_front, sl.ev_acc, sl.ev_tail, sl.ev_k0, sl.ev_k1, sl.ev_tree};
@@ -463,6 +466,14 @@ extern "C" int blsgpu_last_msm_phase_ms(blsgpu_ctx* c, int phase, float* ms) {
 // ---------------------------------------------------------------------------------------------------
 // bases
 // ---------------------------------------------------------------------------------------------------
+// G1 bases also keep their images under the GLV endomorphism next to them (2x the resident memory; see k_glv_decompose)
+static int bases_make_endo(blsgpu_ctx* c, blsgpu_bases* b) {
+  if (b->group != 1 || !b->n) return BLSGPU_OK;
+  if (hipMalloc((void**)&b->endo, b->n * Store<FpPolicy>::AFF_WORDS * 4) != hipSuccess) { g_err = "hipMalloc(bases endo) failed"; return BLSGPU_ERR_HIP; }
+  hipLaunchKernelGGL(k_bases_endo, dim3(nblk(b->n, 256)), dim3(256), 0, c->stream, b->rec, b->endo, b->n);
+  LAUNCHCHK();
+  return BLSGPU_OK;
+}
 template <class F>
 static int bases_import(blsgpu_ctx* c, const void* d_xy, const void* d_inf, size_t n, blsgpu_bases** out) {
   blsgpu_bases* b = new blsgpu_bases();
@@ -474,6 +485,7 @@ static int bases_import(blsgpu_ctx* c, const void* d_xy, const void* d_inf, size
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { hipFree(b->rec); delete b; return fail("k_bases_import", e, __LINE__); }
   }
+  if (int rc = bases_make_endo(c, b)) { hipFree(b->rec); delete b; return rc; }
   *out = b;
   return BLSGPU_OK;
 }
@@ -517,6 +529,7 @@ extern "C" int blsgpu_bases_from_scalars(blsgpu_ctx* c, int group, const uint8_t
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { hipFree(b->rec); delete b; return fail("k_bases_from_scalars", e, __LINE__); }
   }
+  if (int rc = bases_make_endo(c, b)) { hipFree(b->rec); delete b; return rc; }
   HIPCHK(hipStreamSynchronize(c->stream));
   *out = b;
   return BLSGPU_OK;
@@ -527,6 +540,7 @@ extern "C" void blsgpu_bases_free(blsgpu_bases* b) {
   hipSetDevice(b->device);
   hipDeviceSynchronize();                  // an asynchronous MSM may still be reading the records
   if (b->rec) hipFree(b->rec);
+  if (b->endo) hipFree(b->endo);
   if (b->table) hipFree(b->table);
   delete b;
 }
@@ -576,11 +590,11 @@ extern "C" int blsgpu_bases_download(blsgpu_ctx* c, const blsgpu_bases* b, size_
 // ---------------------------------------------------------------------------------------------------
 // MSM
 // ---------------------------------------------------------------------------------------------------
-static int pick_window(size_t n) {
-  // minimise  n*W (mixed adds) + 2*W*2^(c-1)*1.2 (bucket reduction), W = ceil(256/c)
+static int pick_window(size_t n, int bits) {
+  // minimise  n*W (mixed adds) + 2*W*2^(c-1)*1.2 (bucket reduction), W = ceil(bits/c); n = scalars of `bits` bits
   int best = 8; double bc = 1e300;
   for (int c = 6; c <= 16; c++) {
-    int W = (256 + c - 1) / c;
+    int W = (bits + c - 1) / c;
     double cost = (double)n * W + 2.4 * W * (double)(1u << (c - 1));
     if (cost < bc) { bc = cost; best = c; }
   }
@@ -612,15 +626,19 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   }
   // resident window-shifted tables (blsgpu_bases_precompute): all windows share one bucket set
   const bool merged = bases->table != nullptr;
-  const int cw = merged ? bases->table_c : (c->msm_c ? c->msm_c : pick_window(n));
-  const int nwin = (256 + cw - 1) / cw;                 // digit windows per scalar
+  // GLV (G1): 2n points (the bases and their images under the endomorphism) with balanced 127-bit scalars -> half the windows
+  const bool glv = GroupTag<F>::id == 1 && !merged && bases->endo && !c->no_glv && !c->force_slow_sort && 2 * n <= ((size_t)1 << 24);
+  const size_t ns = glv ? 2 * n : n;                    // scalars the sort sees
+  const int sbits = glv ? 128 : 256;                    // ... and their width (incl. the spare bit of the signed recoding)
+  const int cw = merged ? bases->table_c : (c->msm_c ? c->msm_c : pick_window(ns, sbits));
+  const int nwin = (sbits + cw - 1) / cw;               // digit windows per scalar
   const int nseg = merged ? 1 : nwin;                   // independent bucket sets
   const u32 nbw = 1u << (cw - 1);
   const size_t nb = (size_t)nseg * nbw;
-  const size_t total = (size_t)nwin * n;
+  const size_t total = (size_t)nwin * ns;
   if (total > 0xfffffff0ull) return bad("msm: n * windows exceeds 2^32 entries");
   // the whole configuration is validated BEFORE a slot is taken or anything is enqueued
-  const bool fast_sort = merged || ((n <= ((size_t)1 << 24)) && cw <= 16 && cw >= 2 && !c->force_slow_sort);
+  const bool fast_sort = merged || ((ns <= ((size_t)1 << 24)) && cw <= 16 && cw >= 2 && !c->force_slow_sort);
   const int key_bits = cw - 1;
   const int coarse_bits = merged ? (key_bits > 7 ? key_bits - 7 : 0) : (key_bits < 8 ? key_bits : 8);
   const int fine_bits = key_bits - coarse_bits;           // <= 7
@@ -642,12 +660,13 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     bad_alloc |= sl.hist.reserve(hb);
     if (fresh && !bad_alloc) HIPCHK(hipMemsetAsync(sl.hist.p, 0, sl.hist.cap, ft));      // the sort keeps its counters zeroed between calls
   }
-  bad_alloc |= sl.cursor.reserve(total * 4);      // per-entry rank inside its bucket
+  if (!fast_sort) bad_alloc |= sl.cursor.reserve(total * 4);      // per-entry rank inside its bucket (fallback sort only)
+  if (glv) bad_alloc |= sl.glv.reserve(ns * 16);
   bad_alloc |= sl.offs.reserve((nb + 1) * 4);
   bad_alloc |= sl.bsum.reserve(4096 * 4);
   // item cap: ~4x the mean bucket load, so that with uniform scalars (almost) no bucket is cut
   u32 cap = 128;
-  while (cap < ITEM_CAP_MAX && (size_t)cap * nbw < 4 * n) cap *= 2;
+  while (cap < ITEM_CAP_MAX && (size_t)cap * nbw < 4 * ns) cap *= 2;
   const size_t max_items = total / cap + nb + 1;                // every bucket has >= 1 item
   const size_t max_records = nb + max_items;                    // bucket sums + partial sums of heavy buckets
   bad_alloc |= sl.items.reserve(max_items * sizeof(ItemDesc));
@@ -680,15 +699,25 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     u32* gbase = ghist + SORT_MAX_COUNTERS;
     u32* gcur = gbase + SORT_MAX_COUNTERS + 1;
     if (sl.hist_dirty) { HIPCHK(hipMemsetAsync(ghist, 0, (size_t)SORT_MAX_COUNTERS * 4, ft)); sl.hist_dirty = false; }
-    const unsigned tiles = nblk(n, SORT_TILE);
-    hipLaunchKernelGGL(k_sort_hist, dim3(tiles), dim3(256), (size_t)nc * 4, ft, (const u32*)d_scalars, ghist, (int)n, cw, nwin, fine_bits, ncoarse, merged ? 1 : 0, c->d_status);
+    const unsigned tiles = nblk(ns, SORT_TILE);
+    const u32* sort_in = (const u32*)d_scalars;
+    if (glv) {
+      hipLaunchKernelGGL(k_glv_decompose, dim3(nblk(n, 256)), dim3(256), 0, ft, (const u32*)d_scalars, sl.glv.as<u32>(), (int)n, c->d_status);
+      sort_in = sl.glv.as<u32>();
+      hipLaunchKernelGGL(k_sort_hist<4>, dim3(tiles), dim3(256), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, 0, c->d_status);
+    } else {
+      hipLaunchKernelGGL(k_sort_hist<8>, dim3(tiles), dim3(256), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, merged ? 1 : 0, c->d_status);
+    }
     LAUNCHCHK();
     mark(1);
     hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, ft, ghist, gbase, gcur, nc, sl.ctrl.as<u32>(), 4 + 2 * ITEM_BINS);
     LAUNCHCHK();
     mark(2);
-    hipLaunchKernelGGL(k_sort_scatter, dim3(tiles), dim3(256), (size_t)nc * 8, ft, (const u32*)d_scalars, gbase, gcur, sl.ent.as<u32>(), (int)n, cw, nwin,
-                       fine_bits, ncoarse, merged ? 1 : 0, (u32)bases->n);
+    if (glv)
+      hipLaunchKernelGGL(k_sort_scatter<4>, dim3(tiles), dim3(256), (size_t)nc * 8, ft, sort_in, gbase, gcur, sl.ent.as<u32>(), (int)ns, cw, nwin, fine_bits, ncoarse, 0, (u32)0);
+    else
+      hipLaunchKernelGGL(k_sort_scatter<8>, dim3(tiles), dim3(256), (size_t)nc * 8, ft, sort_in, gbase, gcur, sl.ent.as<u32>(), (int)ns, cw, nwin,
+                         fine_bits, ncoarse, merged ? 1 : 0, (u32)bases->n);
     hipLaunchKernelGGL(k_sort_fine, dim3(nc), dim3(256), 0, ft, sl.ent.as<u32>(), gbase, sl.sorted.as<u32>(), sl.offs.as<u32>(), fine_bits, nc);
     LAUNCHCHK();
     mark(3);
@@ -734,7 +763,8 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   if constexpr (GroupTag<F>::id == 2)
     hipLaunchKernelGGL(k_msm_accumulate_g2pair, dim3(nblk(2 * max_items, 256)), dim3(256), 0, as, base_rec, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
   else
-    hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(max_items, 256)), dim3(256), 0, as, base_rec, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
+    hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(max_items, 256)), dim3(256), 0, as, base_rec, glv ? bases->endo + first * Store<F>::AFF_WORDS : (const u32*)nullptr,
+                       glv ? (u32)n : 0xffffffffu, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
   if (c->acc_timing) { hipEventRecord(sl.ev_k1, as); sl.k_pending = true; }
   hipLaunchKernelGGL(k_msm_heavy<F>, dim3(HEAVY_SMALL_BLOCKS + 512), dim3(256), 0, as, sl.heavy.as<uint4>(), ctrl, records);
   LAUNCHCHK();

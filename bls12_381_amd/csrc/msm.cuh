@@ -212,28 +212,113 @@ __global__ void __launch_bounds__(256) k_bases_precompute(const u32* __restrict_
 constexpr int SORT_TILE = 2048;                 // scalars per block in k_sort_hist / k_sort_scatter
 constexpr int SORT_MAX_COUNTERS = 8192;         // nwin * ncoarse upper bound (LDS: 32 KB)
 
-struct DigitIter {
-  u32 s[9]; u32 carry; int c; u32 nbw, mask;
-  DEV bool canonical() const { return scalar_is_canonical(s); }
-  DEV void init(const u32* scalars, size_t i, int c_) {
-    const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
-    uint4 a = sp[0], b = sp[1];
-    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w; s[8] = 0;
+// Signed c-bit digits of a scalar, lowest window first.  WORDS = 8: a canonical 32-byte scalar.  WORDS = 4: one half of a GLV
+// decomposition (k_glv_decompose below): a 127-bit magnitude with the sign of its contribution in bit 127.  The scalar is kept
+// as a shift register (funnel shifts with static register indices), so the iterator lives entirely in VGPRs.
+template <int WORDS> struct DigitIter {
+  u32 s[WORDS]; u32 carry, sign; int c; u32 nbw, mask;
+  DEV void init(const u32* src, size_t i, int c_) {
+    const uint4* sp = reinterpret_cast<const uint4*>(src + i * WORDS);
+    uint4 a = sp[0];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
+    if constexpr (WORDS == 8) { uint4 b = sp[1]; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w; sign = 0; }
+    else { sign = s[3] >> 31; s[3] &= 0x7fffffffu; }
     carry = 0; c = c_; nbw = 1u << (c - 1); mask = (1u << c) - 1;
   }
-  // signed digit of window w (must be called for w = 0, 1, 2, ... in order): magnitude (0 = skip) and sign
-  DEV void next(int w, u32& mag, u32& neg) {
-    int bit = w * c, lo = bit >> 5, sh = bit & 31;
-    u32 raw = 0;
-    if (lo < 8) raw = (u32)((((u64)s[lo + 1] << 32) | s[lo]) >> sh) & mask;
-    raw += carry;
-    neg = raw > nbw;
-    mag = neg ? ((1u << c) - raw) : raw;
-    carry = neg;
+  DEV bool canonical() const { if constexpr (WORDS == 8) return scalar_is_canonical(s); else return true; }
+  // next window (call once per window, in order): magnitude (0 = no entry) and the sign of the entry
+  DEV void next(u32& mag, u32& neg) {
+    u32 raw = (s[0] & mask) + carry;
+#pragma unroll
+    for (int j = 0; j < WORDS - 1; j++) s[j] = (s[j] >> c) | (s[j + 1] << (32 - c));
+    s[WORDS - 1] >>= c;
+    u32 over = raw > nbw;
+    mag = over ? ((1u << c) - raw) : raw;
+    carry = over;
+    neg = over ^ sign;
   }
 };
 
+// ---- GLV decomposition (G1) --------------------------------------------------------------------------------------------
+// phi(x, y) = (BETA x, y) is the endomorphism of g1.rs:421-437; the reference's subgroup check (:396-405) states
+// phi(P) = -[z^2] P.  With L = z^2 (128 bits; r = L^2 - L + 1) a scalar k < r splits as k = k1 + k2 L and, using L^2 = L - 1
+// (mod r), into BALANCED halves |k1|, |k2| <= L/2 + 1 < 2^126.5:
+//     k P = k1 P + k2 [L] P = sign(k1) |k1| P  -  sign(k2) |k2| phi(P).
+// The MSM then runs over 2n points (the resident bases and their images under phi, stored next to them) with 127-bit
+// scalars: the same number of bucket additions, but HALF the windows -- half the buckets to reduce and half the doublings
+// in the window combine.  out[i] = |k1|, out[n + i] = |k2| as four words each; bit 127 = 1 if the term is SUBTRACTED.
+typedef unsigned __int128 u128;
+__global__ void __launch_bounds__(256) k_glv_decompose(const u32* __restrict__ scalars, u32* __restrict__ out, int n, u32* __restrict__ status) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr u32 Lw[4] = BLS_GLV_L_W, Mw[5] = BLS_GLV_M_W, Hw[4] = BLS_GLV_H_W;
+  u32 k[8];
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+  uint4 a = sp[0], b = sp[1];
+  k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
+  if (!scalar_is_canonical(k)) atomicOr(status, 1u);
+  // q = floor(k M / 2^256) in {floor(k / L) - 1, floor(k / L)}   (M = floor(2^256 / L))
+  u32 q[5];
+  u128 acc = 0;
+#pragma unroll
+  for (int col = 0; col < 13; col++) {
+#pragma unroll
+    for (int x = 0; x < 8; x++) { int y = col - x; if (y >= 0 && y < 5) acc += (u64)k[x] * Mw[y]; }
+    if (col >= 8) q[col - 8] = (u32)acc;
+    acc >>= 32;
+  }
+  // k1 = k - q L  (five words are enough: k1 < 2L)
+  u32 t[5];
+  acc = 0;
+#pragma unroll
+  for (int col = 0; col < 5; col++) {
+#pragma unroll
+    for (int x = 0; x < 4; x++) { int y = col - x; if (y >= 0 && y < 4) acc += (u64)q[x] * Lw[y]; }
+    t[col] = (u32)acc;
+    acc >>= 32;
+  }
+  u32 k1[5];
+  {
+    int64_t br = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) { int64_t d = (int64_t)k[j] - (int64_t)t[j] + br; k1[j] = (u32)d; br = d >> 32; }
+  }
+  auto ge4 = [](const u32* x, const u32* y) { bool gt = false, eq = true; for (int j = 3; j >= 0; j--) { gt = gt || (eq && x[j] > y[j]); eq = eq && x[j] == y[j]; } return gt || eq; };
+  auto gt4 = [](const u32* x, const u32* y) { bool gt = false, eq = true; for (int j = 3; j >= 0; j--) { gt = gt || (eq && x[j] > y[j]); eq = eq && x[j] == y[j]; } return gt; };
+  auto sub4 = [](u32* r, const u32* x, const u32* y) { int64_t br = 0; for (int j = 0; j < 4; j++) { int64_t d = (int64_t)x[j] - (int64_t)y[j] + br; r[j] = (u32)d; br = d >> 32; } };
+  auto addsmall4 = [](u32* x, int v) { int64_t cy = v; for (int j = 0; j < 4; j++) { int64_t d = (int64_t)x[j] + cy; x[j] = (u32)d; cy = d >> 32; } };
+  u32 k2[4] = {q[0], q[1], q[2], q[3]};
+  if (k1[4] != 0 || ge4(k1, Lw)) { sub4(k1, k1, Lw); addsmall4(k2, 1); }          // the Barrett estimate was one short
+  // balance: k1 in (-L/2 - 1, L/2], k2 in (-L/2, L/2]
+  u32 neg1 = 0, neg2 = 0;
+  if (gt4(k1, Hw)) { sub4(k1, Lw, k1); neg1 = 1; addsmall4(k2, 1); }              // k1 - L, carried into k2
+  if (gt4(k2, Hw)) {
+    u32 lm1[4] = {Lw[0], Lw[1], Lw[2], Lw[3]}; addsmall4(lm1, -1);
+    sub4(k2, lm1, k2); neg2 = 1;                                                  // k2 L = (k2 - L + 1) L - 1  (mod r)
+    bool z1 = (k1[0] | k1[1] | k1[2] | k1[3]) == 0;
+    if (neg1) addsmall4(k1, 1); else if (z1) { k1[0] = 1; neg1 = 1; } else addsmall4(k1, -1);
+  }
+  // k P = (neg1 ? -1 : 1) |k1| P  +  k2 (-phi(P)):  the phi term is subtracted when k2 > 0
+  u32 sub2 = neg2 ? 0u : 1u;
+  uint4* o = reinterpret_cast<uint4*>(out);
+  o[i] = make_uint4(k1[0], k1[1], k1[2], k1[3] | (neg1 << 31));
+  o[(size_t)n + i] = make_uint4(k2[0], k2[1], k2[2], k2[3] | (sub2 << 31));
+}
+// the images under phi of resident G1 bases: (BETA x, y), same flag
+__global__ void __launch_bounds__(256) k_bases_endo(const u32* __restrict__ rec, u32* __restrict__ endo, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int AW = Store<FpPolicy>::AFF_WORDS;
+  constexpr PLimbs kb = {BLS_BETA};
+  const u32* r = rec + i * AW; u32* e = endo + i * AW;
+  fe1 x; Store<FpPolicy>::ld(r, x);
+  fe1 bx = canon(mul(x, fe1_const(kb)));
+  Store<FpPolicy>::st(e, bx);
+  for (int j = NL; j < AW; j++) e[j] = r[j];
+}
+
 // merged != 0 (resident window-shifted tables): all windows share ONE bucket set, the window only selects the table
+template <int WORDS>
 __global__ void __launch_bounds__(256) k_sort_hist(const u32* __restrict__ scalars, u32* __restrict__ ghist, int n, int c, int nwin,
                                                    int fine_bits, int ncoarse, int merged, u32* __restrict__ status) {
   extern __shared__ u32 lh[];
@@ -243,10 +328,10 @@ __global__ void __launch_bounds__(256) k_sort_hist(const u32* __restrict__ scala
   for (int k = 0; k < SORT_TILE / 256; k++) {
     int i = blockIdx.x * SORT_TILE + k * 256 + threadIdx.x;
     if (i < n) {
-      DigitIter d; d.init(scalars, i, c);
+      DigitIter<WORDS> d; d.init(scalars, i, c);
       if (!d.canonical()) atomicOr(status, 1u);
       for (int w = 0; w < nwin; w++) {
-        u32 mag, neg; d.next(w, mag, neg);
+        u32 mag, neg; d.next(mag, neg);
         if (mag) atomicAdd(&lh[(merged ? 0 : w) * ncoarse + ((mag - 1) >> fine_bits)], 1u);
       }
     }
@@ -277,6 +362,7 @@ __global__ void __launch_bounds__(1024) k_sort_scan(u32* __restrict__ ghist, u32
   if (threadIdx.x == 1023) gbase[nc] = part[1023];
   for (int i = threadIdx.x; i < nctrl; i += 1024) ctrl[i] = 0;
 }
+template <int WORDS>
 __global__ void __launch_bounds__(256) k_sort_scatter(const u32* __restrict__ scalars, const u32* __restrict__ gbase, u32* __restrict__ gcur,
                                                       u32* __restrict__ coarse_out, int n, int c, int nwin, int fine_bits, int ncoarse,
                                                       int merged, u32 stride) {
@@ -288,9 +374,9 @@ __global__ void __launch_bounds__(256) k_sort_scatter(const u32* __restrict__ sc
   for (int k = 0; k < SORT_TILE / 256; k++) {
     int i = blockIdx.x * SORT_TILE + k * 256 + threadIdx.x;
     if (i < n) {
-      DigitIter d; d.init(scalars, i, c);
+      DigitIter<WORDS> d; d.init(scalars, i, c);
       for (int w = 0; w < nwin; w++) {
-        u32 mag, neg; d.next(w, mag, neg);
+        u32 mag, neg; d.next(mag, neg);
         if (mag) atomicAdd(&lh[(merged ? 0 : w) * ncoarse + ((mag - 1) >> fine_bits)], 1u);
       }
     }
@@ -306,9 +392,9 @@ __global__ void __launch_bounds__(256) k_sort_scatter(const u32* __restrict__ sc
   for (int k = 0; k < SORT_TILE / 256; k++) {
     int i = blockIdx.x * SORT_TILE + k * 256 + threadIdx.x;
     if (i < n) {
-      DigitIter d; d.init(scalars, i, c);
+      DigitIter<WORDS> d; d.init(scalars, i, c);
       for (int w = 0; w < nwin; w++) {
-        u32 mag, neg; d.next(w, mag, neg);
+        u32 mag, neg; d.next(mag, neg);
         if (mag) {
           int ci = (merged ? 0 : w) * ncoarse + ((mag - 1) >> fine_bits);
           u32 r = atomicAdd(&lh[ci], 1u);
@@ -492,13 +578,20 @@ __global__ void __launch_bounds__(256) k_item_fill(const u32* __restrict__ offs,
 }
 
 // ---- 5. bucket accumulation ---------------------------------------------------------------------------
+// Point index e (31 bits): records [0, nsplit) live in `bases`, records [nsplit, ...) in `bases2` (the images under the GLV
+// endomorphism; nsplit = 0xffffffff when there is no second array).
 template <class F>
-__global__ void __launch_bounds__(256) k_msm_accumulate(const u32* __restrict__ bases, const u32* __restrict__ sorted,
+__global__ void __launch_bounds__(256) k_msm_accumulate(const u32* __restrict__ bases, const u32* __restrict__ bases2, u32 nsplit,
+                                                        const u32* __restrict__ sorted,
                                                         const ItemDesc* __restrict__ items, const u32* __restrict__ ctrl,
                                                         u32* __restrict__ records) {
   u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ctrl[2]) return;
   ItemDesc d = items[t];
+  auto rec_of = [&](u32 e) -> const u32* {
+    u32 idx = e & 0x7fffffffu;
+    return idx < nsplit ? bases + (size_t)idx * Store<F>::AFF_WORDS : bases2 + (size_t)(idx - nsplit) * Store<F>::AFF_WORDS;
+  };
   Xyzz<F> acc;
   acc.x = F::zero(); acc.y = F::zero(); acc.zz = F::zero(); acc.zzz = F::zero();
   bool acc_inf = true;
@@ -508,11 +601,11 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const u32* __restrict__ 
   u32 e = d.len ? sorted[d.start] : 0;
   u32 e_next = d.len > 1 ? sorted[d.start + 1] : 0;
   Aff<F> q; bool inf;
-  load_aff<F>(bases + (size_t)(e & 0x7fffffffu) * Store<F>::AFF_WORDS, q, inf);
+  load_aff<F>(rec_of(e), q, inf);
   for (u32 j = d.start; j < end; j++) {
     Aff<F> qn = q; bool infn = true;
     u32 e_next2 = 0;
-    if (j + 1 < end) load_aff<F>(bases + (size_t)(e_next & 0x7fffffffu) * Store<F>::AFF_WORDS, qn, infn);
+    if (j + 1 < end) load_aff<F>(rec_of(e_next), qn, infn);
     if (j + 2 < end) e_next2 = sorted[j + 2];
     if (!inf) {                                             // identity base: contributes nothing
       auto qy = cond_neg(q.y, (e >> 31) != 0);
