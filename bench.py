@@ -294,6 +294,18 @@ def run_msm(args, e):
         dist.destroy_process_group()
 
 
+def host_cpu_allotment():
+    """what this process may really use: affinity mask and cgroup CPU quota (a container can see 256 hardware threads and be
+    allowed a dozen) -- reported next to the thread count so that the CPU baseline can be read correctly"""
+    info = {"hw_threads_visible": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        info["cgroup_cpu_max"] = None if q[0] == "max" else float(q[0]) / float(q[1])
+    except Exception:
+        info["cgroup_cpu_max"] = None
+    return info
+
+
 def cpu_baseline_g1(ctx, bases, sb, n):
     """oracle/bls_oracle.c (kind "port") on the host cores; also the per-op table of the reference's criterion points."""
     from oracle import c_oracle
@@ -318,7 +330,8 @@ def cpu_baseline_g1(ctx, bases, sb, n):
             "sample": f"first 2^{int(np.log2(m))} (point, scalar) pairs of the same workload: sum(P_i*s_i) by 255-step double-and-add + Sum, "
                       f"C restatement of the reference algorithm (oracle/bls_oracle.c), OpenMP dynamic schedule over {used} threads after a warm-up; "
                       f"single thread (4096-pair sample): {one:.0f}/s",
-            "single_thread_value": one, "parallel_speedup": (m / cdt) / one, "gpu_result_matches": same, "per_op_ns": per_op}
+            "single_thread_value": one, "parallel_speedup": (m / cdt) / one, "gpu_result_matches": same, "per_op_ns": per_op,
+            "host": host_cpu_allotment()}
 
 
 def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):

@@ -1,6 +1,6 @@
 // api.hip -- host side of libblsgpu.so: the C ABI declared in include/bls12_381_hip.h.
 // One context = one device + one stream + grow-only scratch.  All heavy lifting is in the kernels of
-// msm.cuh / pairing.cuh; this file only sequences launches and moves bytes.
+// msm.hip.h / pairing.hip.h; this file only sequences launches and moves bytes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -10,11 +10,11 @@
 #include <vector>
 
 #include "../../include/bls12_381_hip.h"
-#include "msm.cuh"
-#include "pairing.cuh"
-#include "fr.cuh"
-#include "h2c.cuh"
-#include "codec.cuh"
+#include "msm.hip.h"
+#include "pairing.hip.h"
+#include "fr.hip.h"
+#include "h2c.hip.h"
+#include "codec.hip.h"
 
 using namespace bls;
 
@@ -92,7 +92,7 @@ struct blsgpu_ctx {
 
 struct blsgpu_bases {
   int group = 1; size_t n = 0; int device = 0; u32* rec = nullptr;   // AFF_WORDS per point
-  u32* endo = nullptr;               // G1 only: the images (BETA x, y) of the records under the GLV endomorphism (msm.cuh)
+  u32* endo = nullptr;               // G1 only: the images (BETA x, y) of the records under the GLV endomorphism (msm.hip.h)
   // optional window-shifted tables: table[w * n + i] = [2^(table_c * w)] P_i   (blsgpu_bases_precompute)
   u32* table = nullptr; int table_c = 0, table_w = 0;
 };
@@ -693,7 +693,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
 
   mark(0);
   if (fast_sort) {
-    // 1'-3'. two-level counting sort (LDS atomics; see msm.cuh)
+    // 1'-3'. two-level counting sort (LDS atomics; see msm.hip.h)
     // fixed layout: [MAX] counts (kept zero between calls) | [MAX+1] bases | [MAX] cursors
     u32* ghist = sl.hist.as<u32>();
     u32* gbase = ghist + SORT_MAX_COUNTERS;
@@ -1091,7 +1091,7 @@ extern "C" int blsgpu_g1_msm_bytes(blsgpu_ctx* c, const uint8_t* bases, const ui
 extern "C" int blsgpu_g2_msm_bytes(blsgpu_ctx* c, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[192]) { return msm_bytes<2>(c, bases, scalars, n, out); }
 
 // ---------------------------------------------------------------------------------------------------
-// hash-to-curve (h2c.cuh)
+// hash-to-curve (h2c.hip.h)
 // ---------------------------------------------------------------------------------------------------
 template <class F>
 static int h2c_host(blsgpu_ctx* c, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst, size_t dst_len, int encode_only,
@@ -1125,7 +1125,7 @@ static int h2c_host(blsgpu_ctx* c, const uint8_t* msgs, const uint64_t* offsets,
   if constexpr (GroupTag<F>::id == 1)
     hipLaunchKernelGGL(k_hash_to_curve<FpPolicy>, dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->io_a.as<uint8_t>(), (const unsigned long long*)c->io_b.p, n,
                        c->io_c.as<uint8_t>(), dlen, encode_only ? 1 : 0, c->io_out.as<u32>());
-  else                                               // G2: one message per lane pair (pairlane.cuh)
+  else                                               // G2: one message per lane pair (pairlane.hip.h)
     hipLaunchKernelGGL(k_hash_to_curve<Fp2PairPolicy>, dim3(nblk(n * 2, 256)), dim3(256), 0, c->stream, c->io_a.as<uint8_t>(), (const unsigned long long*)c->io_b.p, n,
                        c->io_c.as<uint8_t>(), dlen, encode_only ? 1 : 0, c->io_out.as<u32>());
   LAUNCHCHK();
@@ -1160,7 +1160,7 @@ extern "C" int blsgpu_hash_to_curve_device(blsgpu_ctx* c, int group, const void*
 }
 
 // ---------------------------------------------------------------------------------------------------
-// scalar field Fr: element-wise vector operations and the radix-2 transform (fr.cuh)
+// scalar field Fr: element-wise vector operations and the radix-2 transform (fr.hip.h)
 // ---------------------------------------------------------------------------------------------------
 extern "C" int blsgpu_fr_op_device(blsgpu_ctx* c, int op, const void* a, const void* b, size_t n, void* out, void* nonzero_flags) {
   if (!c || (n && (!a || !out))) return bad("fr_op: NULL argument");
@@ -1402,7 +1402,7 @@ extern "C" int blsgpu_fp12_product(blsgpu_ctx* c, const uint64_t* in, size_t n, 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// batched point (de)serialisation + validation  (codec.cuh)
+// batched point (de)serialisation + validation  (codec.hip.h)
 // ---------------------------------------------------------------------------------------------------
 template <class F>
 static int point_decode(blsgpu_ctx* c, const uint8_t* bytes, size_t n, int compressed, int checked, uint64_t* xy, uint8_t* inf, uint8_t* ok) {

@@ -1,4 +1,4 @@
-// codec.cuh -- batched point (de)serialisation and validation: the step in FRONT of the hot path
+// codec.hip.h -- batched point (de)serialisation and validation: the step in FRONT of the hot path
 // (SURVEY.md 8f rank 1).  Real MSM / pairing inputs arrive as compressed bytes; decompression (a square
 // root per point) and the subgroup check (a scalar multiplication by the curve parameter per point) are
 // themselves data-parallel, one point per lane.
@@ -12,7 +12,7 @@
 // Outputs are the reference's values: a decoded point is returned in wire limbs with its infinity flag and
 // an `ok` byte that is 1 exactly where the reference returns `CtOption::some`.
 #pragma once
-#include "convert.cuh"
+#include "convert.hip.h"
 
 namespace bls {
 

@@ -1,12 +1,12 @@
-// convert.cuh -- wire format <-> internal form.
+// convert.hip.h -- wire format <-> internal form.
 //
 // Wire format = the reference's in-memory value layout: an Fp is six little-endian u64 limbs of the
 // canonical representative of x * 2^384 mod p (src/fp.rs:11-15, R at :83-90) -- read here as twelve
-// u32 words.  Internal form = x * 2^392 mod p on 14 x 28-bit limbs (fe.cuh).  One Montgomery
+// u32 words.  Internal form = x * 2^392 mod p on 14 x 28-bit limbs (fe.hip.h).  One Montgomery
 // multiplication by a constant converts in either direction; outputs are fully reduced, so the bytes
 // handed back are exactly the reference's limbs.
 #pragma once
-#include "curve.cuh"
+#include "curve.hip.h"
 
 namespace bls {
 

@@ -1,4 +1,4 @@
-// curve.cuh -- G1 / G2 point arithmetic: the reference's complete RCB15 formulas (a = 0) written once
+// curve.hip.h -- G1 / G2 point arithmetic: the reference's complete RCB15 formulas (a = 0) written once
 // over a field policy (Fp for G1, Fp2 for G2).
 //
 // Reference: /root/reference/src/g1.rs  double :638-667 (Alg. 9), add :670-712 (Alg. 7),
@@ -8,7 +8,7 @@
 // (P+P, P-P, identity operands), which is what keeps Pippenger's bucket accumulation free of
 // divergence on a 64-wide wavefront.  Bounds of the lazy field arithmetic are proven by the types.
 #pragma once
-#include "fp2.cuh"
+#include "fp2.hip.h"
 
 namespace bls {
 

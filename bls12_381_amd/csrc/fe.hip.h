@@ -1,4 +1,4 @@
-// fe.cuh -- base field Fp of BLS12-381 on the gfx950 integer VALU.
+// fe.hip.h -- base field Fp of BLS12-381 on the gfx950 integer VALU.
 //
 // Reference semantics: /root/reference/src/fp.rs (add :382-394, sub :421-423, neg :397-418,
 // mul :565-609, square :613-660, invert :346-358).  The reference keeps 6x64-bit *saturated* limbs in
@@ -21,7 +21,7 @@
 // non-negative.  A formula that could overflow does not compile.
 //
 // The library converts between the reference's wire format (canonical 6x64 limbs, R = 2^384) and this
-// form at the C-ABI boundary only (convert.cuh); results are canonical and bit-identical to the
+// form at the C-ABI boundary only (convert.hip.h); results are canonical and bit-identical to the
 // reference because Fp elements are compared/serialised only after full reduction.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -80,7 +80,7 @@ struct Fe {
 
 // Storage forms used in structs/arrays (limbs normalised):
 //   fe1  canonical inputs (value < p);   fe  working values (value < 12p; every point formula in
-//   curve.cuh maps coordinates < 12p to coordinates < 12p without a value reduction -- build with
+//   curve.hip.h maps coordinates < 12p to coordinates < 12p without a value reduction -- build with
 //   -DBLS_STRICT_STORE to have the compiler prove it);   fe2p  output of a mul with small inputs.
 constexpr int VS = 12;
 typedef Fe<1, VS> fe;
@@ -260,7 +260,7 @@ DEV Fe<1, sop2_v(V00, V01, V10, V11)> sop2_inl(const Fe<A00, V00>& a0, const Fe<
 }
 
 // Fp2 product core: c0 = a0 b0 - a1 b1, c1 = a0 b1 + a1 b0, two reductions in total.
-// Contract (checked by the typed wrapper in fp2.cuh): every operand has limbs <= 2*(2^28-1) and
+// Contract (checked by the typed wrapper in fp2.hip.h): every operand has limbs <= 2*(2^28-1) and
 // value < FE2_IN_V * p.  -a1 is formed against the fixed multiple (FE2_IN_V+1)*p.
 constexpr int FE2_IN_A = 2;
 constexpr int FE2_IN_V = 128;

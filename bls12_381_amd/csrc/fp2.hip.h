@@ -1,11 +1,11 @@
-// fp2.cuh -- Fp2 = Fp[u]/(u^2+1) on the lazy 14x28 representation.
+// fp2.hip.h -- Fp2 = Fp[u]/(u^2+1) on the lazy 14x28 representation.
 //
 // Reference: /root/reference/src/fp2.rs  mul :205-222, square :182-203, add/sub/neg :224-243,
 // mul_by_nonresidue :156-166, conjugate :148-153, invert :300-319.  The reference computes the two
 // coefficients of a product as interleaved sums of products; mathematically the same field elements
 // are produced here with 3 base-field multiplications (Karatsuba) whose subtractions are carry-free.
 #pragma once
-#include "fe.cuh"
+#include "fe.hip.h"
 
 namespace bls {
 

@@ -1,4 +1,4 @@
-// fr.cuh -- the scalar field Fr of BLS12-381 and a radix-2 number-theoretic transform over it.
+// fr.hip.h -- the scalar field Fr of BLS12-381 and a radix-2 number-theoretic transform over it.
 //
 // Reference: /root/reference/src/scalar.rs -- `Scalar([u64; 4])` in Montgomery form with R = 2^256 (:23-27,
 // :155-165), add :435-449, sub :420-432, neg :552-568, mul :452-503 + montgomery_reduce :506-550, square
@@ -17,7 +17,7 @@
 // the inverse uses w^-1 and scales by n^-1.  The reference crate has no transform; oracle/bls12_381_ref.py
 // fr_ntt states the definition the kernels are tested against.
 #pragma once
-#include "fe.cuh"
+#include "fe.hip.h"
 
 namespace bls {
 

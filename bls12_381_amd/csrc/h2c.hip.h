@@ -1,4 +1,4 @@
-// h2c.cuh -- batched hash-to-curve: what stands in front of `multi_miller_loop` when BLS
+// h2c.hip.h -- batched hash-to-curve: what stands in front of `multi_miller_loop` when BLS
 // signatures are verified in bulk.  One message per lane: expand_message_xmd(SHA-256) -> hash_to_field ->
 // simplified SWU onto the isogenous curve -> isogeny -> (sum of the two points) -> cofactor clearing.
 //
@@ -10,7 +10,7 @@
 // fixed addition chains (chain.rs) are replaced by windowed exponentiation with the same exponents.
 // Only the XMD/SHA-256 expander (the BLS-signature suites) is provided.
 #pragma once
-#include "codec.cuh"
+#include "codec.hip.h"
 
 namespace bls {
 
@@ -165,7 +165,7 @@ template <> struct H2c2<Fp2PairPolicy> {
 
 // ---- exponentiations ---------------------------------------------------------------------------------------------
 // a^((p-3)/4)  (chain_pm3div4): (p-3)/4 = (p+1)/4 - 1, i.e. the square-root exponent with the last multiplication left out;
-// computed directly with the generic windowed power (codec.cuh, exponent selector 2)
+// computed directly with the generic windowed power (codec.hip.h, exponent selector 2)
 DEV fe h2c_pow_pm3div4(const fe& a) { return (fe)from_v16<2>(fe_pow_raw(to_v16(a), 2)); }
 // a^((p^2-9)/16) in Fp2 (chain_p2m9div16): 4-bit fixed windows over the 762-bit exponent
 template <class F2> DEVNI void h2c_pow_p2m9div16(typename F2::elem& r, const typename F2::elem& a) {

@@ -1,4 +1,4 @@
-// msm.cuh -- Pippenger multi-scalar multiplication  sum_i s_i * P_i  for G1 and G2 (templated on the
+// msm.hip.h -- Pippenger multi-scalar multiplication  sum_i s_i * P_i  for G1 and G2 (templated on the
 // field policy).
 //
 // The reference has no MSM routine; it defines the result as  points.zip(scalars).map(|(p,s)| p*s).sum()
@@ -12,7 +12,7 @@
 //   4. items       buckets cut into work items of <= 128 entries, sorted by length (descending) so that
 //                  the 64 lanes of a wavefront walk items of equal length and no lane walks a long bucket
 //   5. accumulate  one lane per item: gathers its points (128 B / 256 B records) and adds them with the
-//                  exception-free mixed addition of curve.cuh -- this is >90% of the arithmetic; partial
+//                  exception-free mixed addition of curve.hip.h -- this is >90% of the arithmetic; partial
 //                  sums of buckets that were cut are folded by a block-level tree
 //   6. reduce      sum_k k * B_k per window by chunked running sums (log-depth recursion)
 //   7. combine     Horner over the windows (c doublings + 1 addition each)
@@ -23,9 +23,9 @@
 // temporaries (4 B per (point, window) and 176 / 336 B per bucket).
 #pragma once
 #include <type_traits>
-#include "convert.cuh"
-#include "team.cuh"
-#include "pairlane.cuh"
+#include "convert.hip.h"
+#include "team.hip.h"
+#include "pairlane.hip.h"
 
 namespace bls {
 
@@ -618,7 +618,7 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const u32* __restrict__ 
   }
   store_proj<F>(records + (size_t)d.dest * Store<F>::PROJ_WORDS, xyzz_to_proj<F>(acc, acc_inf));
 }
-// G2 accumulation with every Fp2 value spread over a lane pair (pairlane.cuh): lane 2k works on the c0 coefficients
+// G2 accumulation with every Fp2 value spread over a lane pair (pairlane.hip.h): lane 2k works on the c0 coefficients
 // and lane 2k+1 on the c1 coefficients of chain k.  Same items, same records, same formula.
 __global__ void __launch_bounds__(256, 2) k_msm_accumulate_g2pair(const u32* __restrict__ bases, const u32* __restrict__ sorted,
                                                                const ItemDesc* __restrict__ items, const u32* __restrict__ ctrl,
@@ -729,7 +729,7 @@ __global__ void __launch_bounds__(256) k_wsum_level(const u32* __restrict__ E, u
   store_proj<F>(Rout + (size_t)t * Store<F>::PROJ_WORDS, run);
   store_proj<F>(Tout + (size_t)t * Store<F>::PROJ_WORDS, tot);
 }
-// G2 bottom level over lane pairs (pairlane.cuh): chain t on lanes 2t / 2t+1, c0 / c1 coefficients; same records, same sums.
+// G2 bottom level over lane pairs (pairlane.hip.h): chain t on lanes 2t / 2t+1, c0 / c1 coefficients; same records, same sums.
 // Half the registers of the one-lane form, and twice the lanes: the 2^16 chains of a 2^20-point MSM fill two wavefronts per SIMD.
 DEV void load_proj_pair(const u32* rec, u32 par, Proj<Fp2PairPolicy>& p) {
 #pragma unroll

@@ -1,4 +1,4 @@
-// pairing.cuh -- Fp6 / Fp12 towers, Miller loop and final exponentiation.
+// pairing.hip.h -- Fp6 / Fp12 towers, Miller loop and final exponentiation.
 //
 // Reference: /root/reference/src/fp6.rs (mul :200-274, square :277-291, mul_by_1 :113-119, mul_by_01
 // :121-136, mul_by_nonresidue :139-150, frobenius_map :154-188, invert :294-312), src/fp12.rs (mul
@@ -17,13 +17,13 @@
 // The loop schedule is a compile-time constant, so all 64 lanes of a wavefront stay converged.  The code is
 // generic over the Fp2 element type E:
 //   E = fe2          one pairing per lane (Fp2 = two Fe in one lane; Fp12 = 168 registers),
-//   E = fp2p         one pairing per PAIR of lanes (pairlane.cuh: lane 2k holds every c0 coefficient, lane 2k+1
+//   E = fp2p         one pairing per PAIR of lanes (pairlane.hip.h: lane 2k holds every c0 coefficient, lane 2k+1
 //                    every c1; Fp12 = 84 registers per lane), the form the kernels use.
 // Tower elements live in the storage form (limbs normalised, value < 32p); the out-of-line helpers take them by
 // reference, i.e. operands are staged in per-lane scratch and streamed through the VGPRs.
 #pragma once
-#include "convert.cuh"
-#include "pairlane.cuh"
+#include "convert.hip.h"
+#include "pairlane.hip.h"
 
 namespace bls {
 

@@ -1,4 +1,4 @@
-// pairlane.cuh -- Fp2 arithmetic with one element spread over a PAIR of adjacent lanes.
+// pairlane.hip.h -- Fp2 arithmetic with one element spread over a PAIR of adjacent lanes.
 //
 // A G2 bucket accumulator in XYZZ form is 4 Fp2 = 112 registers per lane, and the out-of-line Fp2 product
 // needs another ~120: the one-lane-per-chain G2 accumulation kernel needs 444 registers, i.e. one wavefront
@@ -7,9 +7,9 @@
 // lane-local; a product c0 = a0 b0 - a1 b1, c1 = a0 b1 + a1 b0 (src/fp2.rs:205-222) becomes ONE sum of two
 // products per lane after swapping operands with the partner lane (v_mov_b32 dpp quad_perm:[1,0,3,2]), a
 // square (src/fp2.rs:182-203) one multiplication per lane.  Register use drops to that of the G1 kernel, two
-// wavefronts fit a SIMD, and the formulas (curve.cuh, generic over the field policy) are reused unchanged.
+// wavefronts fit a SIMD, and the formulas (curve.hip.h, generic over the field policy) are reused unchanged.
 #pragma once
-#include "curve.cuh"
+#include "curve.hip.h"
 
 namespace bls {
 
@@ -87,7 +87,7 @@ template <int A, int V> DEV bool is_zero_fast(const FeP<A, V>& a) {
 }
 
 
-// ---- operations of the pairing code (pairing.cuh) ---------------------------------------------------------
+// ---- operations of the pairing code (pairing.hip.h) ---------------------------------------------------------
 // out-of-line product / square with fixed operand bounds (limbs <= 2 (2^28-1), value < 160 p): the pairing code
 // has hundreds of call sites
 constexpr int FEP_IN_A = 2, FEP_IN_V = 160;

@@ -1,4 +1,4 @@
-// team.cuh -- lane-cooperative point arithmetic for the latency-bound tails.
+// team.hip.h -- lane-cooperative point arithmetic for the latency-bound tails.
 //
 // The last phases of an MSM (upper levels of the bucket reduction, the Horner combine over the windows, the
 // cross-rank fold) are dependent chains of a few hundred point operations with almost no parallelism across
@@ -7,9 +7,9 @@
 // independent products (6 + 6 for an addition, 4 + 4 for a doubling), so a TEAM of 8 adjacent lanes keeps the
 // operands replicated in registers, lets lane k compute product k of the layer, and exchanges the results
 // through an LDS mailbox: 2 multiplication latencies per point operation instead of 8-12.
-// Same formulas as curve.cuh (g1.rs:638-667, :670-712), hence the same projective triples.
+// Same formulas as curve.hip.h (g1.rs:638-667, :670-712), hence the same projective triples.
 #pragma once
-#include "curve.cuh"
+#include "curve.hip.h"
 
 namespace bls {
 

@@ -1,0 +1,208 @@
+//! `src/hip.rs` for a fork of zkcrypto/bls12_381 v0.8.0 -- the limb-level MI355X back end behind the crate's own types.
+//!
+//! Add `mod hip;` (behind a `hip` cargo feature) to src/lib.rs and copy `../src/ffi.rs` next to this file as `src/hip_ffi.rs`.
+//! The crate denies `unsafe_code` (src/lib.rs:17); a `deny` lint may be lifted per module, which the first line below does.
+//! Values cross the C ABI in the crate's own in-memory format -- `Fp([u64; 6])` canonical Montgomery limbs (src/fp.rs:15),
+//! struct order for Fp2 / Fp6 / Fp12 (src/fp2.rs:11-14, src/fp6.rs:12-16, src/fp12.rs:13-16), `Scalar::to_bytes` for scalars
+//! (src/scalar.rs:284-296), (X : Y : Z) with identity (0 : 1 : 0) for projective points (src/g1.rs:605-611) -- so the binding
+//! is copies of limbs plus an explicit infinity byte (the `Choice` field of the affine types is not `repr(C)`, src/g1.rs:28-32).
+//!
+//! What is forwarded (see in-tree/README.md for the four call sites that change):
+//!   `impl Engine for Bls12 { fn pairing }`                    src/pairings.rs:795-806   -> hip::pairing
+//!   `impl MultiMillerLoop for Bls12 { fn multi_miller_loop }` src/pairings.rs:817-824   -> hip::multi_miller_loop
+//!   `impl pairing::MillerLoopResult { fn final_exponentiation }` :808-814               -> hip::final_exponentiation
+//!   slice-level `G1Projective::msm` / `G2Projective::msm`       (new; the element-wise `Mul` src/g1.rs:556-594 and `Sum`
+//!                                                               :161-171 keep their CPU meaning for single elements)
+//!   `G1Projective::batch_normalize` for n >= 4096              src/g1.rs:806-839         -> hip::batch_normalize_g1
+#![allow(unsafe_code)]
+
+use crate::fp::Fp;
+use crate::fp2::Fp2;
+use crate::fp6::Fp6;
+use crate::fp12::Fp12;
+use crate::hip_ffi as ffi;
+use crate::{G1Affine, G1Projective, G2Affine, G2Projective, Gt, MillerLoopResult, Scalar};
+use alloc::vec::Vec;
+use core::ffi::c_int;
+
+/// With the `hip` feature `G2Prepared` (opaque: private fields, src/pairings.rs:498-501) holds the affine point; the GPU
+/// recomputes the 68 line-coefficient triples on the fly instead of reading 19 584 B per point from memory.
+#[derive(Clone, Debug)]
+pub struct G2PreparedHip { pub(crate) q: G2Affine }
+impl From<G2Affine> for G2PreparedHip { fn from(q: G2Affine) -> Self { G2PreparedHip { q } } }
+
+/// Process-wide context (one device).  `None` = no GPU / creation failed: every caller below then falls back to the CPU path,
+/// which keeps the infallible signatures of the reference.
+struct Ctx(*mut ffi::BlsgpuCtx);
+unsafe impl Send for Ctx {}
+static CTX: spin::Mutex<Option<Ctx>> = spin::Mutex::new(None);     // any lock works; the context is single-stream
+
+fn with_ctx<R>(f: impl FnOnce(*mut ffi::BlsgpuCtx) -> Option<R>) -> Option<R> {
+    let mut g = CTX.lock();
+    if g.is_none() {
+        let mut h = core::ptr::null_mut();
+        if unsafe { ffi::blsgpu_create(0, &mut h) } != ffi::BLSGPU_OK { return None; }
+        *g = Some(Ctx(h));
+    }
+    f(g.as_ref().unwrap().0)
+}
+fn ok(rc: c_int) -> Option<()> { (rc == ffi::BLSGPU_OK).then_some(()) }
+
+// ---- limbs <-> crate types ---------------------------------------------------------------------------------------------
+fn fp(l: &[u64]) -> Fp { Fp::from_raw_unchecked([l[0], l[1], l[2], l[3], l[4], l[5]]) }       // src/fp.rs:302
+fn fp2(l: &[u64]) -> Fp2 { Fp2 { c0: fp(&l[0..6]), c1: fp(&l[6..12]) } }
+fn fp6(l: &[u64]) -> Fp6 { Fp6 { c0: fp2(&l[0..12]), c1: fp2(&l[12..24]), c2: fp2(&l[24..36]) } }
+fn fp12(l: &[u64]) -> Fp12 { Fp12 { c0: fp6(&l[0..36]), c1: fp6(&l[36..72]) } }
+fn put_fp(out: &mut Vec<u64>, a: &Fp) { out.extend_from_slice(&a.0); }
+fn put_fp2(out: &mut Vec<u64>, a: &Fp2) { put_fp(out, &a.c0); put_fp(out, &a.c1); }
+fn put_fp12(out: &mut Vec<u64>, a: &Fp12) {
+    for c6 in [&a.c0, &a.c1] { for c2 in [&c6.c0, &c6.c1, &c6.c2] { put_fp2(out, c2); } }
+}
+fn g1_wire(points: &[G1Affine]) -> (Vec<u64>, Vec<u8>) {
+    let (mut xy, mut inf) = (Vec::with_capacity(points.len() * 12), Vec::with_capacity(points.len()));
+    for p in points { put_fp(&mut xy, &p.x); put_fp(&mut xy, &p.y); inf.push(bool::from(p.is_identity()) as u8); }
+    (xy, inf)
+}
+fn g2_wire(points: &[G2Affine]) -> (Vec<u64>, Vec<u8>) {
+    let (mut xy, mut inf) = (Vec::with_capacity(points.len() * 24), Vec::with_capacity(points.len()));
+    for p in points { put_fp2(&mut xy, &p.x); put_fp2(&mut xy, &p.y); inf.push(bool::from(p.is_identity()) as u8); }
+    (xy, inf)
+}
+fn scalar_bytes(scalars: &[Scalar]) -> Vec<u8> {
+    let mut s = Vec::with_capacity(scalars.len() * 32);
+    for k in scalars { s.extend_from_slice(&k.to_bytes()); }
+    s
+}
+
+// ---- MSM ----------------------------------------------------------------------------------------------------------------
+/// `bases.iter().zip(scalars).map(|(p, s)| p * s).sum::<G1Projective>()`  (src/g1.rs:573-579, 754-774, 161-171)
+pub fn msm_g1(bases: &[G1Affine], scalars: &[Scalar]) -> G1Projective {
+    assert_eq!(bases.len(), scalars.len());
+    let gpu = with_ctx(|ctx| {
+        let ((xy, inf), s) = (g1_wire(bases), scalar_bytes(scalars));
+        let mut out = [0u64; 18];
+        ok(unsafe { ffi::blsgpu_g1_msm_host(ctx, xy.as_ptr(), inf.as_ptr(), s.as_ptr(), bases.len(), out.as_mut_ptr()) })?;
+        Some(G1Projective { x: fp(&out[0..6]), y: fp(&out[6..12]), z: fp(&out[12..18]) })
+    });
+    gpu.unwrap_or_else(|| bases.iter().zip(scalars).map(|(p, s)| p * s).sum())
+}
+/// the same over G2 (src/g2.rs:626-632, 825-845, 162-172)
+pub fn msm_g2(bases: &[G2Affine], scalars: &[Scalar]) -> G2Projective {
+    assert_eq!(bases.len(), scalars.len());
+    let gpu = with_ctx(|ctx| {
+        let ((xy, inf), s) = (g2_wire(bases), scalar_bytes(scalars));
+        let mut out = [0u64; 36];
+        ok(unsafe { ffi::blsgpu_g2_msm_host(ctx, xy.as_ptr(), inf.as_ptr(), s.as_ptr(), bases.len(), out.as_mut_ptr()) })?;
+        Some(G2Projective { x: fp2(&out[0..12]), y: fp2(&out[12..24]), z: fp2(&out[24..36]) })
+    });
+    gpu.unwrap_or_else(|| bases.iter().zip(scalars).map(|(p, s)| p * s).sum())
+}
+/// `Sum` over a slice of projective points (src/g1.rs:161-171) on the device (used to fold per-GPU partial sums)
+pub fn sum_g1(points: &[G1Projective]) -> G1Projective {
+    let gpu = with_ctx(|ctx| {
+        let mut xyz = Vec::with_capacity(points.len() * 18);
+        for p in points { put_fp(&mut xyz, &p.x); put_fp(&mut xyz, &p.y); put_fp(&mut xyz, &p.z); }
+        let mut out = [0u64; 18];
+        ok(unsafe { ffi::blsgpu_g1_sum(ctx, xyz.as_ptr(), points.len(), out.as_mut_ptr()) })?;
+        Some(G1Projective { x: fp(&out[0..6]), y: fp(&out[6..12]), z: fp(&out[12..18]) })
+    });
+    gpu.unwrap_or_else(|| points.iter().sum())
+}
+/// `G1Projective::batch_normalize` (src/g1.rs:806-839): Montgomery's trick on the GPU; `q.len()` must equal `p.len()`
+pub fn batch_normalize_g1(p: &[G1Projective], q: &mut [G1Affine]) {
+    assert_eq!(p.len(), q.len());
+    let done = with_ctx(|ctx| {
+        let mut xyz = Vec::with_capacity(p.len() * 18);
+        for a in p { put_fp(&mut xyz, &a.x); put_fp(&mut xyz, &a.y); put_fp(&mut xyz, &a.z); }
+        let (mut xy, mut inf) = (alloc::vec![0u64; p.len() * 12], alloc::vec![0u8; p.len()]);
+        ok(unsafe { ffi::blsgpu_g1_batch_normalize(ctx, xyz.as_ptr(), p.len(), xy.as_mut_ptr(), inf.as_mut_ptr()) })?;
+        for (i, out) in q.iter_mut().enumerate() {
+            *out = if inf[i] != 0 { G1Affine::identity() } else {
+                G1Affine { x: fp(&xy[12 * i..12 * i + 6]), y: fp(&xy[12 * i + 6..12 * i + 12]), infinity: subtle::Choice::from(0u8) }
+            };
+        }
+        Some(())
+    });
+    if done.is_none() { G1Projective::batch_normalize_cpu(p, q); }     // the existing body of src/g1.rs:806-839, renamed
+}
+
+// ---- pairings -----------------------------------------------------------------------------------------------------------
+/// Batched `pairing` (src/pairings.rs:607-653): out[i] = e(p[i], q[i]); identities give `Gt::identity()` as in :636-651.
+pub fn pairing_batch(p: &[G1Affine], q: &[G2Affine]) -> Vec<Gt> {
+    assert_eq!(p.len(), q.len());
+    let gpu = with_ctx(|ctx| {
+        let ((g1, f1), (g2, f2)) = (g1_wire(p), g2_wire(q));
+        let mut out = alloc::vec![0u64; p.len() * 72];
+        ok(unsafe { ffi::blsgpu_pairing_batch(ctx, g1.as_ptr(), f1.as_ptr(), g2.as_ptr(), f2.as_ptr(), p.len(), out.as_mut_ptr()) })?;
+        Some(out.chunks_exact(72).map(|c| Gt(fp12(c))).collect::<Vec<_>>())
+    });
+    gpu.unwrap_or_else(|| p.iter().zip(q).map(|(a, b)| crate::pairings::pairing_cpu(a, b)).collect())
+}
+/// `pairing` for one pair (what `Engine::pairing` forwards to; one pair keeps a GPU idle -- batch where possible)
+pub fn pairing(p: &G1Affine, q: &G2Affine) -> Gt { pairing_batch(core::slice::from_ref(p), core::slice::from_ref(q)).pop().unwrap() }
+
+/// `multi_miller_loop` (src/pairings.rs:554-603); terms with an identity are skipped (:566-569); no terms give `default()`.
+pub fn multi_miller_loop(terms: &[(&G1Affine, &G2PreparedHip)]) -> MillerLoopResult {
+    let gpu = with_ctx(|ctx| {
+        let p: Vec<G1Affine> = terms.iter().map(|t| *t.0).collect();
+        let q: Vec<G2Affine> = terms.iter().map(|t| t.1.q).collect();
+        let ((g1, f1), (g2, f2)) = (g1_wire(&p), g2_wire(&q));
+        let mut out = [0u64; 72];
+        ok(unsafe { ffi::blsgpu_multi_miller_loop(ctx, g1.as_ptr(), f1.as_ptr(), g2.as_ptr(), f2.as_ptr(), terms.len(), out.as_mut_ptr()) })?;
+        Some(MillerLoopResult(fp12(&out)))
+    });
+    gpu.unwrap_or_else(|| crate::pairings::multi_miller_loop_cpu(terms))
+}
+/// `MillerLoopResult::final_exponentiation` (src/pairings.rs:48-176)
+pub fn final_exponentiation(f: &MillerLoopResult) -> Gt {
+    let gpu = with_ctx(|ctx| {
+        let mut inp = Vec::with_capacity(72);
+        put_fp12(&mut inp, &f.0);
+        let mut out = [0u64; 72];
+        ok(unsafe { ffi::blsgpu_final_exponentiation_batch(ctx, inp.as_ptr(), 1, out.as_mut_ptr()) })?;
+        Some(Gt(fp12(&out)))
+    });
+    gpu.unwrap_or_else(|| f.final_exponentiation_cpu())
+}
+/// `MillerLoopResult + MillerLoopResult` over a slice (src/pairings.rs:179-186): fold of per-GPU partial products
+pub fn miller_product(parts: &[MillerLoopResult]) -> MillerLoopResult {
+    let gpu = with_ctx(|ctx| {
+        let mut inp = Vec::with_capacity(parts.len() * 72);
+        for p in parts { put_fp12(&mut inp, &p.0); }
+        let mut out = [0u64; 72];
+        ok(unsafe { ffi::blsgpu_fp12_product(ctx, inp.as_ptr(), parts.len(), out.as_mut_ptr()) })?;
+        Some(MillerLoopResult(fp12(&out)))
+    });
+    gpu.unwrap_or_else(|| parts.iter().fold(MillerLoopResult::default(), |a, b| a + b))
+}
+
+// ---- trait forwarding (replaces the bodies at src/pairings.rs:795-824) --------------------------------------------------
+#[cfg(feature = "hip")]
+impl pairing::Engine for crate::Bls12 {
+    type Fr = Scalar;
+    type G1 = G1Projective;
+    type G1Affine = G1Affine;
+    type G2 = G2Projective;
+    type G2Affine = G2Affine;
+    type Gt = Gt;
+    fn pairing(p: &Self::G1Affine, q: &Self::G2Affine) -> Self::Gt { pairing(p, q) }
+}
+#[cfg(feature = "hip")]
+impl pairing::MillerLoopResult for MillerLoopResult {
+    type Gt = Gt;
+    fn final_exponentiation(&self) -> Self::Gt { final_exponentiation(self) }
+}
+#[cfg(feature = "hip")]
+impl pairing::MultiMillerLoop for crate::Bls12 {
+    type G2Prepared = G2PreparedHip;
+    type Result = MillerLoopResult;
+    fn multi_miller_loop(terms: &[(&Self::G1Affine, &Self::G2Prepared)]) -> Self::Result { multi_miller_loop(terms) }
+}
+/// slice-level helpers next to the element-wise operators (`Mul<&Scalar>` src/g1.rs:556-594 and `Sum` :161-171 are unchanged)
+impl G1Projective {
+    pub fn msm(bases: &[G1Affine], scalars: &[Scalar]) -> G1Projective { msm_g1(bases, scalars) }
+    pub fn sum_slice(points: &[G1Projective]) -> G1Projective { sum_g1(points) }
+}
+impl G2Projective {
+    pub fn msm(bases: &[G2Affine], scalars: &[Scalar]) -> G2Projective { msm_g2(bases, scalars) }
+}

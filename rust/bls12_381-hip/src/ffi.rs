@@ -1,0 +1,83 @@
+//! `extern "C"` declarations of libblsgpu.so -- GENERATED from include/bls12_381_hip.h by tools/gen_rust_ffi.py; do not edit.
+//! One entry per symbol of the C ABI; the header documents each one and cites the reference lines it replaces.
+#![allow(non_camel_case_types, dead_code)]
+use core::ffi::{c_char, c_int, c_uint, c_void};
+
+/// opaque: one device + its streams and scratch (blsgpu_create / blsgpu_destroy)
+#[repr(C)] pub struct BlsgpuCtx { _private: [u8; 0] }
+/// opaque: bases resident in HBM (blsgpu_g1_bases_upload & co. / blsgpu_bases_free)
+#[repr(C)] pub struct BlsgpuBases { _private: [u8; 0] }
+
+pub const BLSGPU_OK: c_int = 0;
+
+#[link(name = "blsgpu")]
+extern "C" {
+    pub fn blsgpu_create(device: c_int, out: *mut *mut BlsgpuCtx) -> c_int;
+    pub fn blsgpu_destroy(ctx: *mut BlsgpuCtx);
+    pub fn blsgpu_last_error() -> *const c_char;
+    pub fn blsgpu_device_count() -> c_int;
+    pub fn blsgpu_set_stream(ctx: *mut BlsgpuCtx, hip_stream: *mut c_void) -> c_int;
+    pub fn blsgpu_synchronize(ctx: *mut BlsgpuCtx) -> c_int;
+    pub fn blsgpu_set_pipelining(ctx: *mut BlsgpuCtx, enabled: c_int) -> c_int;
+    pub fn blsgpu_join(ctx: *mut BlsgpuCtx) -> c_int;
+    pub fn blsgpu_join_lag(ctx: *mut BlsgpuCtx, lag: c_int) -> c_int;
+    pub fn blsgpu_g1_bases_upload(ctx: *mut BlsgpuCtx, xy: *const u64, infinity: *const u8, n: usize, out: *mut *mut BlsgpuBases) -> c_int;
+    pub fn blsgpu_g2_bases_upload(ctx: *mut BlsgpuCtx, xy: *const u64, infinity: *const u8, n: usize, out: *mut *mut BlsgpuBases) -> c_int;
+    pub fn blsgpu_g1_bases_from_device(ctx: *mut BlsgpuCtx, d_xy: *const c_void, d_infinity: *const c_void, n: usize, out: *mut *mut BlsgpuBases) -> c_int;
+    pub fn blsgpu_g2_bases_from_device(ctx: *mut BlsgpuCtx, d_xy: *const c_void, d_infinity: *const c_void, n: usize, out: *mut *mut BlsgpuBases) -> c_int;
+    pub fn blsgpu_bases_from_scalars(ctx: *mut BlsgpuCtx, group: c_int, scalars: *const u8, n: usize, out: *mut *mut BlsgpuBases) -> c_int;
+    pub fn blsgpu_bases_precompute(ctx: *mut BlsgpuCtx, b: *mut BlsgpuBases, window_bits: c_int) -> c_int;
+    pub fn blsgpu_bases_len(b: *const BlsgpuBases) -> usize;
+    pub fn blsgpu_bases_download(ctx: *mut BlsgpuCtx, b: *const BlsgpuBases, first: usize, count: usize, xy: *mut u64, infinity: *mut u8) -> c_int;
+    pub fn blsgpu_bases_free(b: *mut BlsgpuBases);
+    pub fn blsgpu_g1_msm(ctx: *mut BlsgpuCtx, bases: *const BlsgpuBases, first: usize, scalars: *const u8, n: usize, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_g2_msm(ctx: *mut BlsgpuCtx, bases: *const BlsgpuBases, first: usize, scalars: *const u8, n: usize, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_g1_msm_device(ctx: *mut BlsgpuCtx, bases: *const BlsgpuBases, first: usize, d_scalars: *const c_void, n: usize, d_out_xyz: *mut c_void) -> c_int;
+    pub fn blsgpu_g2_msm_device(ctx: *mut BlsgpuCtx, bases: *const BlsgpuBases, first: usize, d_scalars: *const c_void, n: usize, d_out_xyz: *mut c_void) -> c_int;
+    pub fn blsgpu_g1_msm_many(ctx: *mut BlsgpuCtx, bases: *const BlsgpuBases, first: usize, scalars: *const u8, n: usize, k: usize, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_g2_msm_many(ctx: *mut BlsgpuCtx, bases: *const BlsgpuBases, first: usize, scalars: *const u8, n: usize, k: usize, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_g1_msm_many_device(ctx: *mut BlsgpuCtx, bases: *const BlsgpuBases, first: usize, d_scalars: *const c_void, n: usize, k: usize, d_out_xyz: *mut c_void) -> c_int;
+    pub fn blsgpu_g2_msm_many_device(ctx: *mut BlsgpuCtx, bases: *const BlsgpuBases, first: usize, d_scalars: *const c_void, n: usize, k: usize, d_out_xyz: *mut c_void) -> c_int;
+    pub fn blsgpu_g1_msm_host(ctx: *mut BlsgpuCtx, xy: *const u64, infinity: *const u8, scalars: *const u8, n: usize, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_g2_msm_host(ctx: *mut BlsgpuCtx, xy: *const u64, infinity: *const u8, scalars: *const u8, n: usize, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_g1_msm_bytes(ctx: *mut BlsgpuCtx, bases_uncompressed: *const u8, scalars: *const u8, n: usize, out: *mut u8) -> c_int;
+    pub fn blsgpu_g2_msm_bytes(ctx: *mut BlsgpuCtx, bases_uncompressed: *const u8, scalars: *const u8, n: usize, out: *mut u8) -> c_int;
+    pub fn blsgpu_set_msm_window(ctx: *mut BlsgpuCtx, c: c_int) -> c_int;
+    pub fn blsgpu_g1_sum(ctx: *mut BlsgpuCtx, xyz: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_g2_sum(ctx: *mut BlsgpuCtx, xyz: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_g1_sum_device(ctx: *mut BlsgpuCtx, d_xyz: *const c_void, n: usize, d_out_xyz: *mut c_void) -> c_int;
+    pub fn blsgpu_g2_sum_device(ctx: *mut BlsgpuCtx, d_xyz: *const c_void, n: usize, d_out_xyz: *mut c_void) -> c_int;
+    pub fn blsgpu_g1_batch_normalize(ctx: *mut BlsgpuCtx, xyz: *const u64, n: usize, xy: *mut u64, infinity: *mut u8) -> c_int;
+    pub fn blsgpu_g2_batch_normalize(ctx: *mut BlsgpuCtx, xyz: *const u64, n: usize, xy: *mut u64, infinity: *mut u8) -> c_int;
+    pub fn blsgpu_g1_from_bytes_batch(ctx: *mut BlsgpuCtx, bytes: *const u8, n: usize, compressed: c_int, checked: c_int, xy: *mut u64, infinity: *mut u8, ok: *mut u8) -> c_int;
+    pub fn blsgpu_g2_from_bytes_batch(ctx: *mut BlsgpuCtx, bytes: *const u8, n: usize, compressed: c_int, checked: c_int, xy: *mut u64, infinity: *mut u8, ok: *mut u8) -> c_int;
+    pub fn blsgpu_g1_to_bytes_batch(ctx: *mut BlsgpuCtx, xy: *const u64, infinity: *const u8, n: usize, compressed: c_int, out: *mut u8) -> c_int;
+    pub fn blsgpu_g2_to_bytes_batch(ctx: *mut BlsgpuCtx, xy: *const u64, infinity: *const u8, n: usize, compressed: c_int, out: *mut u8) -> c_int;
+    pub fn blsgpu_pairing_batch(ctx: *mut BlsgpuCtx, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, n: usize, out_gt: *mut u64) -> c_int;
+    pub fn blsgpu_miller_loop_batch(ctx: *mut BlsgpuCtx, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, n: usize, out_f: *mut u64) -> c_int;
+    pub fn blsgpu_multi_miller_loop(ctx: *mut BlsgpuCtx, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, n: usize, out_f: *mut u64) -> c_int;
+    pub fn blsgpu_final_exponentiation_batch(ctx: *mut BlsgpuCtx, in_f: *const u64, n: usize, out_gt: *mut u64) -> c_int;
+    pub fn blsgpu_fp12_product(ctx: *mut BlsgpuCtx, in_f: *const u64, n: usize, out_f: *mut u64) -> c_int;
+    pub fn blsgpu_gt_mul_scalar_batch(ctx: *mut BlsgpuCtx, gt: *const u64, scalars: *const u8, n: usize, out: *mut u64) -> c_int;
+    pub fn blsgpu_pairing_batch_device(ctx: *mut BlsgpuCtx, d_g1_xy: *const c_void, d_g1_inf: *const c_void, d_g2_xy: *const c_void, d_g2_inf: *const c_void, n: usize, d_out_gt: *mut c_void) -> c_int;
+    pub fn blsgpu_multi_miller_loop_device(ctx: *mut BlsgpuCtx, d_g1_xy: *const c_void, d_g1_inf: *const c_void, d_g2_xy: *const c_void, d_g2_inf: *const c_void, n: usize, d_out_f: *mut c_void) -> c_int;
+    pub fn blsgpu_miller_loop_batch_device(ctx: *mut BlsgpuCtx, d_g1_xy: *const c_void, d_g1_inf: *const c_void, d_g2_xy: *const c_void, d_g2_inf: *const c_void, n: usize, d_out_f: *mut c_void) -> c_int;
+    pub fn blsgpu_final_exponentiation_device(ctx: *mut BlsgpuCtx, d_in_f: *const c_void, n: usize, d_out_gt: *mut c_void) -> c_int;
+    pub fn blsgpu_fp12_product_device(ctx: *mut BlsgpuCtx, d_in_f: *const c_void, n: usize, d_out_f: *mut c_void) -> c_int;
+    pub fn blsgpu_fp_op(ctx: *mut BlsgpuCtx, op: c_int, a: *const u64, b: *const u64, n: usize, out: *mut u64) -> c_int;
+    pub fn blsgpu_fp2_op(ctx: *mut BlsgpuCtx, op: c_int, a: *const u64, b: *const u64, n: usize, out: *mut u64) -> c_int;
+    pub fn blsgpu_fp12_op(ctx: *mut BlsgpuCtx, op: c_int, a: *const u64, b: *const u64, n: usize, out: *mut u64) -> c_int;
+    pub fn blsgpu_point_op(ctx: *mut BlsgpuCtx, group: c_int, op: c_int, a: *const u64, b: *const u64, b_inf: *const u8, n: usize, out: *mut u64) -> c_int;
+    pub fn blsgpu_fp_mul_throughput(ctx: *mut BlsgpuCtx, iters: c_int, muls_per_second: *mut f64) -> c_int;
+    pub fn blsgpu_mad_throughput(ctx: *mut BlsgpuCtx, iters: c_int, mads_per_second: *mut f64) -> c_int;
+    pub fn blsgpu_last_msm_phase_ms(ctx: *mut BlsgpuCtx, phase: c_int, ms: *mut f32) -> c_int;
+    pub fn blsgpu_set_profiling(ctx: *mut BlsgpuCtx, enabled: c_int) -> c_int;
+    pub fn blsgpu_msm_accumulate_stats(ctx: *mut BlsgpuCtx, enable: c_int, avg_ms: *mut f64, launches: *mut c_uint) -> c_int;
+    pub fn blsgpu_fr_op(ctx: *mut BlsgpuCtx, op: c_int, a: *const u64, b: *const u64, n: usize, out: *mut u64, nonzero_flags: *mut u8) -> c_int;
+    pub fn blsgpu_fr_op_device(ctx: *mut BlsgpuCtx, op: c_int, d_a: *const c_void, d_b: *const c_void, n: usize, d_out: *mut c_void, d_nonzero_flags: *mut c_void) -> c_int;
+    pub fn blsgpu_fr_ntt(ctx: *mut BlsgpuCtx, data: *mut u64, log_n: c_int, inverse: c_int) -> c_int;
+    pub fn blsgpu_fr_ntt_device(ctx: *mut BlsgpuCtx, d_data: *mut c_void, log_n: c_int, inverse: c_int) -> c_int;
+    pub fn blsgpu_g1_hash_to_curve_batch(ctx: *mut BlsgpuCtx, msgs: *const u8, offsets: *const u64, n: usize, dst: *const u8, dst_len: usize, encode_only: c_int, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_g2_hash_to_curve_batch(ctx: *mut BlsgpuCtx, msgs: *const u8, offsets: *const u64, n: usize, dst: *const u8, dst_len: usize, encode_only: c_int, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_hash_to_curve_device(ctx: *mut BlsgpuCtx, group: c_int, d_msgs: *const c_void, d_offsets: *const c_void, n: usize, d_dst: *const c_void, dst_len: usize, encode_only: c_int, d_out_xyz: *mut c_void) -> c_int;
+}

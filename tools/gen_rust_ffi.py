@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""include/bls12_381_hip.h -> rust/bls12_381-hip/src/ffi.rs (the `extern "C"` block of the Rust binding).
+
+    python tools/gen_rust_ffi.py            # prints the Rust source
+    python tools/gen_rust_ffi.py --write    # rewrites rust/bls12_381-hip/src/ffi.rs
+
+tests/test_host_cpu.py::test_rust_ffi_matches_header re-parses BOTH files independently and compares every signature, so a
+hand edit of either side that drifts from the other fails the CPU suite."""
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "bls12_381_hip.h")
+OUT = os.path.join(ROOT, "rust", "bls12_381-hip", "src", "ffi.rs")
+
+C_TO_RUST = {
+    "int": "c_int", "size_t": "usize", "void": "()", "unsigned": "c_uint",
+    "blsgpu_ctx*": "*mut BlsgpuCtx", "blsgpu_ctx**": "*mut *mut BlsgpuCtx",
+    "blsgpu_bases*": "*mut BlsgpuBases", "const blsgpu_bases*": "*const BlsgpuBases", "blsgpu_bases**": "*mut *mut BlsgpuBases",
+    "const uint64_t*": "*const u64", "uint64_t*": "*mut u64", "const uint8_t*": "*const u8", "uint8_t*": "*mut u8",
+    "const void*": "*const c_void", "void*": "*mut c_void", "double*": "*mut f64", "float*": "*mut f32", "unsigned*": "*mut c_uint",
+    "const char*": "*const c_char",
+}
+
+
+def strip_comments(text):
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    return re.sub(r"//[^\n]*", " ", text)
+
+
+def parse_header(path=HEADER):
+    """-> list of (name, return C type, [(C type, param name)])"""
+    text = strip_comments(open(path).read())
+    out = []
+    for m in re.finditer(r"\b((?:const\s+)?[A-Za-z_][\w]*\s*\**)\s*\b(blsgpu_\w+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, params = m.group(1), m.group(2), m.group(3)
+        ret = re.sub(r"\s+", " ", ret).replace(" *", "*").strip()
+        ps = []
+        params = params.strip()
+        if params and params != "void":
+            for p in params.split(","):
+                p = re.sub(r"\s+", " ", p).strip()
+                arr = re.match(r"^(.*?)(\w+)\s*\[\s*\d+\s*\]$", p)
+                if arr:                                   # `uint64_t out[18]` decays to a pointer
+                    ctype, pname = arr.group(1).strip() + "*", arr.group(2)
+                else:
+                    mm = re.match(r"^(.*?)(\w+)$", p)
+                    ctype, pname = mm.group(1).strip(), mm.group(2)
+                ctype = ctype.replace(" *", "*").replace("* ", "*")
+                ps.append((ctype, pname))
+        out.append((name, ret, ps))
+    return out
+
+
+def rust_source():
+    decls = parse_header()
+    lines = ["//! `extern \"C\"` declarations of libblsgpu.so -- GENERATED from include/bls12_381_hip.h by tools/gen_rust_ffi.py; do not edit.",
+             "//! One entry per symbol of the C ABI; the header documents each one and cites the reference lines it replaces.",
+             "#![allow(non_camel_case_types, dead_code)]",
+             "use core::ffi::{c_char, c_int, c_uint, c_void};",
+             "",
+             "/// opaque: one device + its streams and scratch (blsgpu_create / blsgpu_destroy)",
+             "#[repr(C)] pub struct BlsgpuCtx { _private: [u8; 0] }",
+             "/// opaque: bases resident in HBM (blsgpu_g1_bases_upload & co. / blsgpu_bases_free)",
+             "#[repr(C)] pub struct BlsgpuBases { _private: [u8; 0] }",
+             "",
+             "pub const BLSGPU_OK: c_int = 0;",
+             "",
+             "#[link(name = \"blsgpu\")]",
+             "extern \"C\" {"]
+    for name, ret, ps in decls:
+        args = ", ".join("%s: %s" % ("r#type" if n == "type" else n, C_TO_RUST[t]) for t, n in ps)
+        r = "" if ret == "void" else " -> " + C_TO_RUST[ret]
+        lines.append("    pub fn %s(%s)%s;" % (name, args, r))
+    lines.append("}")
+    return "\n".join(lines) + "\n"
+
+
+if __name__ == "__main__":
+    src = rust_source()
+    if "--write" in sys.argv:
+        os.makedirs(os.path.dirname(OUT), exist_ok=True)
+        open(OUT, "w").write(src)
+        print("wrote", OUT)
+    else:
+        sys.stdout.write(src)
