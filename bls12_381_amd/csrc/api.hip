@@ -56,6 +56,7 @@ struct blsgpu_ctx {
   bool pipelining = false;
   bool acc_timing = false;              // blsgpu_msm_accumulate_stats: HIP-event duration of every accumulation launch
   double acc_ms_sum = 0.0; unsigned acc_count = 0;
+  bool g1_single = false;              // A/B hook (env BLSGPU_G1_SINGLE at create): one lane per G1 bucket chain instead of a lane pair
   bool no_glv = false;                 // A/B hook (env BLSGPU_NO_GLV at create): plain 256-bit windows for G1
   bool force_slow_sort = false;        // test hook (env BLSGPU_FORCE_SLOW_SORT at create): the global-atomic sort used beyond 2^24 points
   hipStream_t acc_stream = nullptr;     // bucket accumulation of pipelined calls (the caller's stream is never blocked)
@@ -368,6 +369,7 @@ extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
   c->device = device;
   c->force_slow_sort = getenv("BLSGPU_FORCE_SLOW_SORT") != nullptr;
   c->no_glv = getenv("BLSGPU_NO_GLV") != nullptr;
+  c->g1_single = getenv("BLSGPU_G1_SINGLE") != nullptr;
   int rc = ctx_init(c);
   if (rc != BLSGPU_OK) { blsgpu_destroy(c); return rc; }       // destroy tolerates the half-built context (null handles are skipped)
   *out = c;
@@ -762,6 +764,9 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   const u32* base_rec = (merged ? bases->table : bases->rec) + first * Store<F>::AFF_WORDS;
   if constexpr (GroupTag<F>::id == 2)
     hipLaunchKernelGGL(k_msm_accumulate_g2pair, dim3(nblk(2 * max_items, 256)), dim3(256), 0, as, base_rec, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
+  else if (!c->g1_single)
+    hipLaunchKernelGGL(k_msm_accumulate_g1pair, dim3(nblk(2 * max_items, 256)), dim3(256), 0, as, base_rec, glv ? bases->endo + first * Store<F>::AFF_WORDS : (const u32*)nullptr,
+                       glv ? (u32)n : 0xffffffffu, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
   else
     hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(max_items, 256)), dim3(256), 0, as, base_rec, glv ? bases->endo + first * Store<F>::AFF_WORDS : (const u32*)nullptr,
                        glv ? (u32)n : 0xffffffffu, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);

@@ -653,6 +653,106 @@ __global__ void __launch_bounds__(256, 2) k_msm_accumulate_g2pair(const u32* __r
   for (int i = 0; i < NL; i++) { o[i] = pr.x.v.l[i]; o[2 * NL + i] = pr.y.v.l[i]; o[4 * NL + i] = pr.z.v.l[i]; }
 }
 
+// G1 accumulation over LANE PAIRS.  One lane per bucket chain needs 241 registers (two wavefronts per SIMD), and with two
+// wavefronts the VALU issue port idles ~37% of the time (profiles/r02_msm_pmc.md: a wavefront can issue a multiply-add only
+// every other slot, so any bubble in one wavefront is lost).  Here lane 2k (the "x lane") owns X and ZZ of chain k's extended
+// Jacobian accumulator and lane 2k+1 (the "y lane") owns Y and ZZZ; madd-2008-s splits into FIVE multiplications per lane
+// executed in lock step, operands exchanged with the partner by DPP (quad_perm [1,0,3,2]):
+//     step      x lane                       y lane
+//     1 mul     U2 = X2 ZZ,   P = U2 - X     S2 = Y2 ZZZ,  R = S2 - Y
+//     2 sqr     PP = P^2                     RR = R^2                          exchange: PP <-> RR, X <-> Y
+//     3 mul     PPP = P PP                   Q = X PP                          exchange: PPP <-> Q
+//     4 mul     ZZ' = ZZ PP                  ZZZ' = ZZZ PPP                    both: X3 = RR - PPP - 2Q
+//     5 mul     T = Y PPP                    W = R (Q - X3)                    exchange: T -> y lane;  Y' = W - T,  X' = X3
+// 4 x 406 + 315 multiply-adds per lane (3 878 per addition against 4 074 for the one-lane form), half the registers, three
+// wavefronts per SIMD.  Same items, same records, same exceptional-case handling (both lanes of a pair take every branch together).
+#ifndef BLS_G1PAIR_WAVES
+#define BLS_G1PAIR_WAVES 3
+#endif
+__global__ void __launch_bounds__(256, BLS_G1PAIR_WAVES) k_msm_accumulate_g1pair(const u32* __restrict__ bases, const u32* __restrict__ bases2, u32 nsplit,
+                                                                                const u32* __restrict__ sorted, const ItemDesc* __restrict__ items,
+                                                                                const u32* __restrict__ ctrl, u32* __restrict__ records) {
+  typedef FpPolicy F;
+  constexpr int AW = Store<F>::AFF_WORDS, PW = Store<F>::PROJ_WORDS;
+  u32 t = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  if (t >= ctrl[2]) return;                     // both lanes of a pair leave together
+  const bool isA = (threadIdx.x & 1) == 0;
+  ItemDesc d = items[t];
+  fe c0 = fe_zero(), z = fe_zero();             // x lane: X, ZZ      y lane: Y, ZZZ
+  bool acc_inf = true;
+  const u32 end = d.start + d.len;
+  u32 e_next = d.len ? sorted[d.start] : 0;
+  for (u32 j = d.start; j < end; j++) {
+    const u32 e = e_next;
+    if (j + 1 < end) e_next = sorted[j + 1];
+    const u32 idx = e & 0x7fffffffu;
+    const u32* rec = idx < nsplit ? bases + (size_t)idx * AW : bases2 + (size_t)(idx - nsplit) * AW;
+    fe1 q;                                      // x lane: x2      y lane: y2
+    {
+      const uint2* p = reinterpret_cast<const uint2*>(rec + (isA ? 0 : NL));      // 56-byte halves of the 128-byte record
+#pragma unroll
+      for (int i = 0; i < NL / 2; i++) { uint2 v = p[i]; q.l[2 * i] = v.x; q.l[2 * i + 1] = v.y; }
+    }
+    if (rec[2 * NL] != 0) continue;             // identity base (same decision in both lanes)
+    const bool ng = (e >> 31) != 0;
+    Fe<2, 2> q2 = select(ng && !isA, neg(q), (Fe<2, 2>)q);
+    if (acc_inf) { c0 = F::st(q2); z = fe_one(); acc_inf = false; continue; }
+    auto m = mul_inl(q2, z);                    // U2 | S2
+    auto dd = sub(m, c0);                       // P | R        (limbs <= 3 * 2^28: inside the multiplier's column bound)
+    {
+      bool mz = maybe_zero(dd);
+      bool pmz = partner_flag(mz);
+      if (isA ? mz : pmz) {                     // P may be zero: same x -- doubling or cancellation (never on random input)
+        bool ez = is_zero(dd);
+        bool pez = partner_flag(ez);
+        const bool p_zero = isA ? ez : pez, r_zero = isA ? pez : ez;
+        if (p_zero) {
+          if (r_zero) {
+            auto pq = partner((Fe<2, 2>)q2);
+            fe1 qx = isA ? q : canon(pq);
+            Fe<2, 2> qy = select(isA, (Fe<2, 2>)norm(pq), q2);
+            Xyzz<F> r2 = xyzz_double_affine<F>(qx, qy);
+            c0 = select(isA, r2.x, r2.y); z = select(isA, r2.zz, r2.zzz);
+          } else {
+            acc_inf = true;
+          }
+          continue;
+        }
+      }
+    }
+    auto ee = sqr_inl(dd);                      // PP | RR                                   Fe<1,2>
+    auto pe = partner(ee);                      // RR | PP
+    auto pc0 = partner(c0);                     // Y  | X
+    typedef Fe<3, 15> W1;
+    auto f = mul_inl(select(isA, (W1)dd, (W1)pc0), select(isA, ee, pe));        // PPP | Q    Fe<1,2>
+    auto pf = partner(f);                       // Q | PPP
+    auto zn = mul_inl(z, select(isA, ee, pf));  // ZZ PP | ZZZ PPP
+    auto rr = select(isA, pe, ee), ppp = select(isA, f, pf), qq = select(isA, pf, f);
+    auto x3 = norm(sub(rr, add(ppp, dbl(qq))));                                 // Fe<1,9> in both lanes
+    typedef Fe<1, 12> W2;
+    auto g = mul_inl(select(isA, (W1)pc0, (W1)dd), select(isA, (W2)ppp, (W2)norm(sub(qq, x3))));      // Y PPP | R (Q - X3)
+    auto npg = partner(neg(g));                 // the y lane needs W - T: the x lane sends -T (never subtract an exchanged value)
+    typedef Fe<3, 9> W3;
+    c0 = F::st(select(isA, (W3)x3, (W3)add(g, npg)));
+    z = F::st(zn);
+  }
+  // XYZZ -> (X ZZZ : Y ZZ : ZZ ZZZ); identity -> (0 : 1 : 0)
+  u32* o = records + (size_t)d.dest * PW;
+  fe cx, cz;
+  if (acc_inf) {
+    cx = isA ? fe_zero() : fe_one(); cz = fe_zero();
+  } else {
+    auto pz = partner(z);
+    cx = F::st(mul(c0, pz)); cz = F::st(mul(z, pz));
+  }
+#pragma unroll
+  for (int i = 0; i < NL; i++) o[(isA ? 0 : NL) + i] = cx.l[i];
+  if (isA) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) o[2 * NL + i] = cz.l[i];
+  }
+}
+
 // fold the partial sums of the heavy buckets: one lane per bucket when it has few partials ...
 constexpr int HEAVY_SMALL_BLOCKS = 256;      // blocks [0, 256) of k_msm_heavy run the per-lane path, the rest the per-block path
 template <class F>

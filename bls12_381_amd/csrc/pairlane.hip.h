@@ -18,6 +18,15 @@ template <int A, int V> struct FeP { Fe<A, V> v; static constexpr int kA = A, kV
 
 DEV bool lane_is_c1() { return (threadIdx.x & 1) != 0; }
 DEV u32 dpp_swap1(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false); }
+// RULE: never subtract an exchanged value -- exchange the negation and add.  The compiler's DPP-combine pass folds
+// `b - dpp(a)` into `v_subrev_u32_dpp d, a, b`, and on this toolchain / gfx950 the *rev* forms do not compute what LLVM assumes:
+// measured with inline assembly, `v_subrev_u32_dpp d, x, y quad_perm:[1,0,3,2]` returns dpp(y) - x (v_lshlrev_b32_dpp is off
+// in the same way; v_mov / v_add / v_sub / v_and / v_xor with DPP behave as documented).  Whether a subtraction was folded
+// depended on register allocation, so any unrelated edit of a kernel could silently change results (round-2 notes in
+// DESIGN.md).  `a + partner(neg(a))` costs the same instructions as the folded subtraction, keeps the same static bounds and
+// can only fold into v_add_u32_dpp; __graft_entry__.check_isa() rejects a library containing a v_subrev_*_dpp.
+// Also: every exchange must be executed by BOTH lanes of a pair -- never inside a lane-dependent conditional expression
+// (a DPP read of a lane that is masked off returns 0).
 template <int A, int V> DEV Fe<A, V> partner(const Fe<A, V>& a) {
   Fe<A, V> r;
 #pragma unroll
@@ -41,7 +50,7 @@ template <int A, int V> DEV auto mul_by_nonresidue(const FeP<A, V>& a) {
   auto o = partner(a.v);
   FeP<2 * A + 1, 2 * V + 1> r;
   // c0 lane: a_me - a_other ; c1 lane: a_other + a_me
-  auto m = sub(a.v, o);
+  auto m = add(a.v, partner(neg(a.v)));
   auto p = add(a.v, o);
   r.v = select(lane_is_c1(), (Fe<2 * A + 1, 2 * V + 1>)p, m);
   return r;
@@ -57,7 +66,7 @@ DEV FeP<1, pair_mul_v(V1, V2)> mul_inl(const FeP<A1, V1>& a, const FeP<A2, V2>& 
   const bool c1 = lane_is_c1();
   auto ao = partner(a.v); auto bo = partner(b.v);
   auto x0 = select(c1, ao, a.v);
-  Fe<A1 + 1, V1 + 1> x1 = select(c1, (Fe<A1 + 1, V1 + 1>)a.v, neg(ao));
+  Fe<A1 + 1, V1 + 1> x1 = select(c1, (Fe<A1 + 1, V1 + 1>)a.v, partner(neg(a.v)));
   FeP<1, pair_mul_v(V1, V2)> r;
   r.v = from_v16<pair_mul_v(V1, V2)>(fe_sop2_body(to_v16(x0), to_v16(b.v), to_v16(x1), to_v16(bo)));
   return r;
@@ -71,7 +80,7 @@ DEV auto sqr_inl(const FeP<A, V>& a) {
   typedef Fe<2 * A, 2 * V> XT;
   typedef Fe<2 * A + 1, 2 * V + 1> YT;
   XT x = add(ao, select(c1, ao, a.v));               // c1 lane: 2 a0 ; c0 lane: a0 + a1
-  YT y = select(c1, (YT)a.v, sub(a.v, ao));
+  YT y = select(c1, (YT)a.v, add(a.v, partner(neg(a.v))));
   FeP<1, mul_v(2 * V, 2 * V + 1)> r;
   r.v = mul_inl(x, y);
   return r;
@@ -97,10 +106,12 @@ DEVNI v16 fep_mul_raw(v16 a, v16 b) {
   v16 x0, x1, bo;
 #pragma unroll
   for (int i = 0; i < NL; i++) {
-    u32 ao = dpp_swap1(a[i]);
+    // both lanes execute every exchange; the c0 lane needs -a' and receives it as the partner's (bias - a): no subtraction
+    // of an exchanged value (see the rule at dpp_swap1)
+    const u32 ao = dpp_swap1(a[i]), nao = dpp_swap1(bias.l[i] - a[i]);
     bo[i] = dpp_swap1(b[i]);
     x0[i] = c1 ? ao : a[i];
-    x1[i] = c1 ? a[i] : bias.l[i] - ao;
+    x1[i] = c1 ? a[i] : nao;
   }
   x0[14] = x0[15] = x1[14] = x1[15] = bo[14] = bo[15] = 0;
   return fe_sop2_body(x0, b, x1, bo);
@@ -121,7 +132,7 @@ DEV auto sqr_ni(const FeP<A, V>& a) {
   typedef Fe<2 * A, 2 * V> XT;
   typedef Fe<2 * A + 1, 2 * V + 1> YT;
   XT x = add(ao, select(c1, ao, a.v));               // c1 lane: 2 a0 ; c0 lane: a0 + a1
-  YT y = select(c1, (YT)a.v, sub(a.v, ao));
+  YT y = select(c1, (YT)a.v, add(a.v, partner(neg(a.v))));
   auto p = mulx(x, y);
   FeP<1, decltype(p)::kV> r; r.v = p;
   return r;
@@ -142,7 +153,7 @@ template <int A, int V> DEV auto conj(const FeP<A, V>& a) {
 // (a0 + a1 u) u = -a1 + a0 u
 template <int A, int V> DEV auto mul_by_u(const FeP<A, V>& a) {
   auto o = partner(a.v);
-  FeP<A + 1, V + 1> r; r.v = select(lane_is_c1(), (Fe<A + 1, V + 1>)o, neg(o)); return r;
+  FeP<A + 1, V + 1> r; r.v = select(lane_is_c1(), (Fe<A + 1, V + 1>)o, partner(neg(a.v))); return r;
 }
 // Fp2 x Fp (k identical in both lanes)
 template <int A1, int V1, int A2, int V2> DEV auto mul_fp(const FeP<A1, V1>& a, const Fe<A2, V2>& k) {

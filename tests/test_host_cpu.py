@@ -282,3 +282,12 @@ def test_rust_sources_are_complete():
                    "pub fn sum_g1", "impl From<G2Affine> for G2PreparedHip"):
         assert needle in hip, needle
     assert os.path.exists(os.path.join(base, "Cargo.toml")) and os.path.exists(os.path.join(base, "build.rs"))
+
+
+def test_device_code_has_no_folded_subrev_dpp():
+    """the shipped library's gfx950 code must not contain `v_subrev_*_dpp` (it miscomputes on this toolchain; see
+    pairlane.hip.h::dpp_swap1_sub and __graft_entry__.check_isa)"""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    import bls12_381_amd as b
+    g.check_isa(b.LIB_PATH)

@@ -1,22 +1,16 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence quoted in DESIGN.md / bench.py (run on the GPU box through gpurun):
-#   gpurun_out/prof/stats      kernel trace + stats of the default bench workload
-#   gpurun_out/prof/pmc_*      separate PMC passes (kernel-trace only, as the MI355X guide prescribes)
-# tools/summarise_profiles.py turns them into profiles/r01_*.md / .json.
-cd /tmp && export TMPDIR=/tmp
-cd "${GRAFT_REPO_ROOT:-/root/repo}"
-B="python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras"
-rm -rf gpurun_out/prof; mkdir -p gpurun_out/prof
-# the stats pass traces the default timed region (100 steps + 5 warm-up) and prints the bench line of that very run
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/stats -- python bench.py --no-cpu-baseline --no-extras > gpurun_out/prof/bench_under_rocprof.json 2> /dev/null
-for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
-  d=gpurun_out/prof/pmc_$(echo $c | cut -d" " -f1)
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -- $B > /dev/null 2>&1
-done
-# pairing kernel
-for c in "" "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
-  if [ -z "$c" ]; then rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/pair_stats -- python tools/quick_pair3.py > /dev/null 2>&1
-  else rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/prof/pair_pmc_$(echo $c | cut -d" " -f1) -- python tools/quick_pair3.py > /dev/null 2>&1; fi
-done
-find gpurun_out/prof -name "*agent_info.csv" -delete
-ls gpurun_out/prof
+#   gpurun_out/prof_msm        kernel trace + stats of the default bench timed region, then PMC passes (tools/pmc.sh)
+#   gpurun_out/prof_pair       the same for 2^16 pairings (tools/run_pairing.py)
+#   gpurun_out/prof_mml        ... and for a 2^18-term multi_miller_loop
+# tools/summarise_profiles.py <round> turns them into profiles/<round>_*.md / .json.
+R="${GRAFT_REPO_ROOT:-$PWD}"; cd "$R"
+tools/pmc.sh prof_msm python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras
+# the stats pass of prof_msm is replaced by one over the DEFAULT command, whose bench line is kept next to it
+cd /tmp && export TMPDIR=/tmp && cd "$R"
+rm -rf gpurun_out/prof_msm/stats
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_msm/stats -- python bench.py --no-cpu-baseline --no-extras > gpurun_out/prof_msm/bench_under_rocprof.json 2> /dev/null
+tools/pmc.sh prof_pair python tools/run_pairing.py pairing 16 3
+tools/pmc.sh prof_mml python tools/run_pairing.py mml 18 3
+find gpurun_out/prof_msm gpurun_out/prof_pair gpurun_out/prof_mml -name "*agent_info.csv" -delete
+du -sh gpurun_out/prof_*

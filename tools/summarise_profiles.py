@@ -1,13 +1,25 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof (tools/collect_profiles.sh) -> profiles/r01_msm_kernel_stats.md, r01_msm_pmc.{md,json}, r01_pairing_pmc.md"""
-import csv, glob, json, collections, os, sys
+"""gpurun_out/prof_{msm,pair,mml} (tools/collect_profiles.sh) -> profiles/<round>_*.md / .json
+
+    python tools/summarise_profiles.py r02
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = os.path.join(ROOT, "gpurun_out", "prof")
+G = os.path.join(ROOT, "gpurun_out")
 OUT = os.path.join(ROOT, "profiles")
+RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+
 
 def one(pattern):
-    f = glob.glob(os.path.join(P, pattern), recursive=True)
+    f = glob.glob(os.path.join(G, pattern), recursive=True)
     return f[0] if f else None
+
 
 def stats_table(path, title, out):
     rows = list(csv.DictReader(open(path)))
@@ -17,72 +29,101 @@ def stats_table(path, title, out):
         for r in rows:
             fh.write(f"| `{r['Name'][:100]}` | {r['Calls']} | {int(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.1f} | {int(r['MinNs'])/1e3:.1f} | {int(r['MaxNs'])/1e3:.1f} | {100*int(r['TotalDurationNs'])/tot:.1f} |\n")
 
-def counters(dirpat, kernel):
-    acc = collections.defaultdict(list)
-    f = one(dirpat + "/**/*counter_collection.csv")
-    if not f: return {}
-    for r in csv.DictReader(open(f)):
-        if kernel in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    out = {k: sum(v) / len(v) for k, v in acc.items()}
-    out["_launches"] = max([len(v) for v in acc.values()] or [0])
-    return out
 
-def duration(dirpat, kernel):
-    f = one(dirpat + "/**/*kernel_trace.csv")
-    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if kernel in r["Kernel_Name"]]
-    return sum(d) / len(d), len(d)
+def counters(d, kernel):
+    """averages per launch of every counter collected for `kernel` under gpurun_out/<d>/pmc_*"""
+    res = {}
+    for f in sorted(glob.glob(os.path.join(G, d, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            res[k] = sum(v) / len(v)
+            res["_launches"] = max(res.get("_launches", 0), len(v))
+    return res
 
-stats_table(one("stats/**/*kernel_stats.csv"), "r01: rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --no-extras\n\nMI355X, 2^20-point G1 MSM per step, pipelined (4 slots); 5 warm-up + 100 timed MSMs + 5 isolated roofline/phase probes = 110 launches of each per-MSM kernel.", os.path.join(OUT, "r01_msm_kernel_stats.md"))
-K = "k_msm_accumulate<bls::FpPolicy>"
-dur, nl = duration("stats", K)
-def durations_in_order(dirpat, kernel):
-    f = one(dirpat + "/**/*kernel_trace.csv")
-    rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(f)) if kernel in r["Kernel_Name"])
-    return [d for _, d in rows]
-_d = durations_in_order("stats", K)
-dur_pipe = sum(_d[5:-5]) / max(1, len(_d[5:-5]))      # the timed steps of the bench (after 5 warm-up launches): pipelined, overlapped with sort / tails
-dur_iso = sum(_d[-5:]) / max(1, len(_d[-5:]))         # the five isolated roofline / phase probes at the end
-try:
-    _b = json.loads(open(os.path.join(P, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
-    bench_note = f"the bench line printed by this very run: launch_ms = {_b['roofline']['launch_ms']:.3f}, launch_ms_isolated = {_b['roofline']['launch_ms_isolated']:.3f}, frac = {_b['roofline']['frac']:.3f}"
-except Exception:
-    bench_note = "bench line of the traced run not available"
-fs, ws, sq = counters("pmc_FETCH_SIZE", K), counters("pmc_WRITE_SIZE", K), counters("pmc_SQ_INSTS_VALU", K)
-fetch_kb, write_kb = fs.get("FETCH_SIZE", 0), ws.get("WRITE_SIZE", 0)
-hbm = (2 * fetch_kb + write_kb) * 1024
-n, W = 1 << 20, 16
-alg = W * n * (128 + 4) + (1 << 19) * 176
-mads = W * n * (7 * 406 + 2 * 315 + 602)          # 7 mul + 2 sqr + one 2-product sum per mixed addition
-j = {"kernel": K, "workload": "2^20-point G1 MSM, c=16", "launch_avg_ns": dur, "launches": nl, "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb,
-     "hbm_bytes_per_launch_corrected": hbm,
-     "correction": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 16-byte-per-lane reads at half); Infinity-Cache hits are included",
-     "algorithmic_bytes_per_launch": alg, "sq": {k: v for k, v in sq.items() if not k.startswith("_")}, "valu_wave_insts": sq.get("SQ_INSTS_VALU"), "mad_wave_insts_expected": mads / 64}
-json.dump(j, open(os.path.join(OUT, "r01_msm_pmc.json"), "w"), indent=1)
-ghz = sq.get("GRBM_GUI_ACTIVE", 0) / 8 / (dur * 1e-9) / 1e9 if dur else 0
-with open(os.path.join(OUT, "r01_msm_pmc.md"), "w") as fh:
-    fh.write(f"""# r01: PMC counters of the dominant kernel ({K}, 2^20 points, c = 16)
 
-Separate rocprofv3 passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, `--pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE`, each with `--kernel-trace` only) over `python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras` (tools/collect_profiles.sh); counter averages over the {fs.get('_launches', 0)} launches of those passes.
+def durations(d, kernel):
+    f = one(d + "/stats/**/*kernel_trace.csv")
+    rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r) for r in csv.DictReader(open(f)) if kernel in r["Kernel_Name"])
+    return [x[1] for x in rows], (rows[0][2] if rows else {})
 
-* launch duration (kernel trace of the default bench command): {dur/1e3:.0f} us over all {nl} launches = {dur_pipe/1e3:.0f} us for the {len(_d) - 10} timed pipelined launches (what `bench.py` reports as `roofline.launch_ms`) and {dur_iso/1e3:.0f} us for the 5 isolated probes at the end (`launch_ms_isolated`); {bench_note}
+
+def msm():
+    K = "k_msm_accumulate<bls::FpPolicy>"
+    stats_table(one("prof_msm/stats/**/*kernel_stats.csv"),
+                f"{RND}: rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --no-extras\n\nMI355X, 2^20-point G1 MSM per step (GLV: 2^21 half-width terms, 8 windows of 16 bits), pipelined (4 slots); 5 warm-up + 100 timed MSMs + 5 isolated roofline/phase probes.",
+                os.path.join(OUT, f"{RND}_msm_kernel_stats.md"))
+    d, row = durations("prof_msm", K)
+    pipe = d[5:-5] if len(d) > 20 else d
+    iso = d[-5:]
+    dur = sum(d) / len(d)
+    try:
+        b = json.loads(open(os.path.join(G, "prof_msm", "bench_under_rocprof.json")).read().strip().splitlines()[-1])
+        note = f"the bench line printed by this very run: value = {b['value']:.4g} scalar-muls/s, ms_per_step = {b['ms_per_step']:.3f}, roofline.launch_ms = {b['roofline']['launch_ms']:.3f}, launch_ms_isolated = {b['roofline']['launch_ms_isolated']:.3f}, frac = {b['roofline']['frac']:.3f}"
+    except Exception:
+        note = "bench line of the traced run not available"
+    c = counters("prof_msm", K)
+    fetch_kb, write_kb = c.get("FETCH_SIZE", 0), c.get("WRITE_SIZE", 0)
+    hbm = (2 * fetch_kb + write_kb) * 1024
+    n, W = 1 << 20, 16
+    alg = W * n * (128 + 4) + (1 << 18) * 176
+    mads = W * n * (7 * 406 + 2 * 315 + 602)
+    j = {"kernel": K, "workload": "2^20-point G1 MSM (GLV: 2^21 terms x 8 windows, c=16)", "launch_avg_ns": dur, "launches": len(d),
+         "launch_pipelined_avg_ns": sum(pipe) / max(1, len(pipe)), "launch_isolated_avg_ns": sum(iso) / max(1, len(iso)),
+         "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb, "hbm_bytes_per_launch_corrected": hbm,
+         "correction": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 16-byte-per-lane reads at half); Infinity-Cache hits are included",
+         "algorithmic_bytes_per_launch": alg, "counters": {k: v for k, v in c.items() if not k.startswith("_")},
+         "mad_wave_insts_expected": mads / 64, "vgpr": row.get("VGPR_Count"), "scratch": row.get("Scratch_Size")}
+    json.dump(j, open(os.path.join(OUT, f"{RND}_msm_pmc.json"), "w"), indent=1)
+    ghz = c.get("GRBM_GUI_ACTIVE", 0) / 8 / (dur * 1e-9) / 1e9 if dur else 0
+    wc = c.get("SQ_WAVE_CYCLES", 1)
+    with open(os.path.join(OUT, f"{RND}_msm_pmc.md"), "w") as fh:
+        fh.write(f"""# {RND}: PMC counters of the dominant kernel ({K}, 2^20 points, GLV, c = 16)
+
+Separate rocprofv3 passes (one `--pmc` group each, `--kernel-trace` only; tools/pmc.sh, tools/collect_profiles.sh) over `python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras`; counter averages over the {c.get('_launches', 0)} launches of a pass.
+
+* launch duration (kernel trace of the DEFAULT bench command): {dur/1e3:.0f} us over all {len(d)} launches = {sum(pipe)/max(1,len(pipe))/1e3:.0f} us for the timed pipelined launches (what `bench.py` reports as `roofline.launch_ms`) and {sum(iso)/max(1,len(iso))/1e3:.0f} us for the 5 isolated probes at the end (`launch_ms_isolated`); {note}
+* registers / scratch per lane: {row.get('VGPR_Count')} VGPR, {row.get('Scratch_Size')} B scratch
 * FETCH_SIZE = {fetch_kb:.0f} KB raw -> x2 (gfx950 half-count of 16-byte-per-lane reads) = {2*fetch_kb*1024/1e9:.2f} GB;  WRITE_SIZE = {write_kb:.0f} KB = {write_kb*1024/1e9:.2f} GB
-* HBM-side traffic per launch = {hbm/1e9:.2f} GB (algorithmic: 16 windows x 2^20 gathers x (128 B record + 4 B index) + 2^19 x 176 B bucket records = {alg/1e9:.2f} GB); at {dur/1e3:.0f} us that is {hbm/dur:.2f} GB/ms = {hbm/dur/1e3:.2f} TB/s = {100*hbm/dur/1e3/8:.0f}% of the 8 TB/s HBM peak: not memory-bound (the 128 MB of resident bases also fit the 256 MB Infinity Cache).
-* SQ_INSTS_VALU = {sq.get('SQ_INSTS_VALU',0):.3e} wave-instructions, of which {mads/64:.3e} are the v_mad_u64_u32 of the 7 mul + 2 sqr + one two-product sum per mixed addition ({100*mads/64/max(sq.get('SQ_INSTS_VALU',1),1):.0f}%).
-* GRBM_GUI_ACTIVE = {sq.get('GRBM_GUI_ACTIVE',0):.3e} (summed over 8 XCDs) -> {ghz:.2f} GHz effective clock under profiling.
+* HBM-side traffic per launch = {hbm/1e9:.2f} GB (algorithmic: 8 windows x 2^21 gathers x (128 B record + 4 B index) + 2^18 x 176 B bucket records = {alg/1e9:.2f} GB); at {dur/1e3:.0f} us that is {hbm/dur/1e3:.2f} TB/s = {100*hbm/dur/1e3/8:.0f}% of the 8 TB/s HBM peak: not memory-bound.  With GLV the gathers range over 256 MB (bases + their endomorphism images), the size of the Infinity Cache.
+* SQ_INSTS_VALU = {c.get('SQ_INSTS_VALU',0):.3e} wave-instructions, of which {mads/64:.3e} are the v_mad_u64_u32 of the 7 mul + 2 sqr + one two-product sum per mixed addition ({100*mads/64/max(c.get('SQ_INSTS_VALU',1),1):.0f}%).
+* wave-cycle split: SQ_ACTIVE_INST_ANY {100*c.get('SQ_ACTIVE_INST_ANY',0)/wc:.0f}%, SQ_WAIT_INST_ANY (issue stalls) {100*c.get('SQ_WAIT_INST_ANY',0)/wc:.0f}%, SQ_WAIT_ANY (s_waitcnt) {100*c.get('SQ_WAIT_ANY',0)/wc:.0f}% of SQ_WAVE_CYCLES = {wc:.3e}
+* instruction cache: {c.get('SQC_ICACHE_MISSES',0):.3e} misses of {c.get('SQC_ICACHE_REQ',0):.3e} requests
+* GRBM_GUI_ACTIVE = {c.get('GRBM_GUI_ACTIVE',0):.3e} (summed over 8 XCDs) -> {ghz:.2f} GHz effective clock under profiling.
 """)
-# pairing
-KP = "k_pairing"
-pd, pn = duration("pair_stats", KP)
-pf, pw, ps = counters("pair_pmc_FETCH_SIZE", KP), counters("pair_pmc_WRITE_SIZE", KP), counters("pair_pmc_SQ_INSTS_VALU", KP)
-stats_table(one("pair_stats/**/*kernel_stats.csv"), "r01: rocprofv3 --kernel-trace --stats -- python tools/quick_pair3.py  (3 launches of 2^16 pairings)", os.path.join(OUT, "r01_pairing_kernel_stats.md"))
-with open(os.path.join(OUT, "r01_pairing_pmc.md"), "w") as fh:
-    fh.write(f"""# r01: PMC counters of k_pairing (2^16 pairings per launch, lane-pair layout, 2 wavefronts/SIMD)
 
-`tools/quick_pair3.py` under rocprofv3 (`--kernel-trace` + one `--pmc` group per pass; tools/collect_profiles.sh); averages over {pn} launches.
 
-* launch duration: {pd/1e6:.2f} ms -> {65536/(pd*1e-9):.3e} pairings/s
-* FETCH_SIZE = {pf.get('FETCH_SIZE',0)/1e6:.2f} GB raw (x2 if counted as 16-byte reads: {2*pf.get('FETCH_SIZE',0)*1024/1e9:.1f} GB), WRITE_SIZE = {pw.get('WRITE_SIZE',0)*1024/1e9:.1f} GB: the per-lane scratch traffic of the out-of-line Fp12 routines ({(2*pf.get('FETCH_SIZE',0)+pw.get('WRITE_SIZE',0))*1024/pd/1e3:.2f} TB/s).
-* SQ_INSTS_VALU = {ps.get('SQ_INSTS_VALU',0):.3e} wave-instructions = {ps.get('SQ_INSTS_VALU',0)/2048:.3e} per wavefront; ~2.97e6 of them are v_mad_u64_u32 (16 k field multiplications per pairing over two lanes).
-* SQ_WAVE_CYCLES = {ps.get('SQ_WAVE_CYCLES',0):.3e}, SQ_BUSY_CYCLES = {ps.get('SQ_BUSY_CYCLES',0):.3e}, GRBM_GUI_ACTIVE = {ps.get('GRBM_GUI_ACTIVE',0):.3e}
+def pairing(d, K, units, unit_name, mac32, tag, what):
+    dd, row = durations(d, K)
+    if not dd:
+        return
+    dur = sum(dd) / len(dd)
+    c = counters(d, K)
+    stats_table(one(d + "/stats/**/*kernel_stats.csv"), f"{RND}: rocprofv3 --kernel-trace --stats -- python tools/run_pairing.py {what}", os.path.join(OUT, f"{RND}_{tag}_kernel_stats.md"))
+    lanes = units * 2 if tag == "pairing" else None
+    wc = c.get("SQ_WAVE_CYCLES", 1)
+    with open(os.path.join(OUT, f"{RND}_{tag}_pmc.md"), "w") as fh:
+        fh.write(f"""# {RND}: PMC counters of {K} ({units} {unit_name} per launch, lane-pair layout, 2 wavefronts/SIMD)
+
+`tools/run_pairing.py {what}` under rocprofv3 (`--kernel-trace` + one `--pmc` group per pass; tools/pmc.sh); averages over {len(dd)} launches.
+
+* launch duration: {dur/1e6:.2f} ms -> {units/(dur*1e-9):.3e} {unit_name}/s; canonical work {mac32/1e6:.2f} M MAC32 per unit (SURVEY.md 8d) -> {units*mac32/(dur*1e-9)/1e12:.2f} TMAC32/s
+* registers / scratch per lane: {row.get('VGPR_Count')} VGPR, {row.get('Scratch_Size')} B of scratch frame (the deepest call path; the Miller loop touches ~1.7 KB of it)
+* FETCH_SIZE = {c.get('FETCH_SIZE',0)/1e6:.2f} GB raw (x2 if counted as 16-byte reads: {2*c.get('FETCH_SIZE',0)*1024/1e9:.1f} GB), WRITE_SIZE = {c.get('WRITE_SIZE',0)*1024/1e9:.1f} GB per launch: per-lane scratch (spills around the out-of-line Fp2 products, by-reference Fp12 operands of the final exponentiation); r01 measured 13.1 / 31.2 GB
+* SQ_INSTS_VALU = {c.get('SQ_INSTS_VALU',0):.3e} wave-instructions; SQ_INSTS_VMEM_RD / WR = {c.get('SQ_INSTS_VMEM_RD',0):.3e} / {c.get('SQ_INSTS_VMEM_WR',0):.3e}
+* wave-cycle split: SQ_ACTIVE_INST_ANY {100*c.get('SQ_ACTIVE_INST_ANY',0)/wc:.0f}%, SQ_WAIT_INST_ANY (issue stalls) {100*c.get('SQ_WAIT_INST_ANY',0)/wc:.0f}%, SQ_WAIT_ANY (s_waitcnt) {100*c.get('SQ_WAIT_ANY',0)/wc:.0f}% of SQ_WAVE_CYCLES = {wc:.3e}
+* instruction cache: {c.get('SQC_ICACHE_MISSES',0):.3e} misses of {c.get('SQC_ICACHE_REQ',0):.3e} requests (the 64 KB hot loop of the inlined Miller loop does not thrash it)
+* GRBM_GUI_ACTIVE = {c.get('GRBM_GUI_ACTIVE',0):.3e} (8 XCDs) -> {c.get('GRBM_GUI_ACTIVE',0)/8/(dur*1e-9)/1e9:.2f} GHz under profiling
 """)
-print("profiles written")
+
+
+os.makedirs(OUT, exist_ok=True)
+if one("prof_msm/stats/**/*kernel_stats.csv"):
+    msm()
+if one("prof_pair/stats/**/*kernel_trace.csv"):
+    pairing("prof_pair", "k_pairing", 65536, "pairings", 4.8e6, "pairing", "pairing 16 3")
+if one("prof_mml/stats/**/*kernel_trace.csv"):
+    pairing("prof_mml", "k_multi_miller_shared", 262144, "terms", 2.07e6, "mml", "mml 18 3")
+print("profiles written for", RND)
