@@ -56,7 +56,8 @@ struct blsgpu_ctx {
   bool pipelining = false;
   bool acc_timing = false;              // blsgpu_msm_accumulate_stats: HIP-event duration of every accumulation launch
   double acc_ms_sum = 0.0; unsigned acc_count = 0;
-  bool g1_single = false;              // A/B hook (env BLSGPU_G1_SINGLE at create): one lane per G1 bucket chain instead of a lane pair
+  bool g1_single = true;               // one lane per G1 bucket chain (default); env BLSGPU_G1_PAIR at create selects the lane-pair
+                                       // kernel (k_msm_accumulate_g1pair: 161 VGPRs, three wavefronts per SIMD -- measured 12% slower)
   bool no_glv = false;                 // A/B hook (env BLSGPU_NO_GLV at create): plain 256-bit windows for G1
   bool force_slow_sort = false;        // test hook (env BLSGPU_FORCE_SLOW_SORT at create): the global-atomic sort used beyond 2^24 points
   hipStream_t acc_stream = nullptr;     // bucket accumulation of pipelined calls (the caller's stream is never blocked)
@@ -369,7 +370,7 @@ extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
   c->device = device;
   c->force_slow_sort = getenv("BLSGPU_FORCE_SLOW_SORT") != nullptr;
   c->no_glv = getenv("BLSGPU_NO_GLV") != nullptr;
-  c->g1_single = getenv("BLSGPU_G1_SINGLE") != nullptr;
+  c->g1_single = getenv("BLSGPU_G1_PAIR") == nullptr;
   int rc = ctx_init(c);
   if (rc != BLSGPU_OK) { blsgpu_destroy(c); return rc; }       // destroy tolerates the half-built context (null handles are skipped)
   *out = c;

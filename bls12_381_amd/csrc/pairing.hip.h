@@ -335,22 +335,50 @@ template <class E> DEVNI void addition_step_ell(Fp12T<E>& f, G2JacT<E>& r, const
   addition_step(r, qx, qy, l);
   ell(f, l, px, py);
 }
-template <class E> DEVNI void miller_loop(Fp12T<E>& fout, const fe1& px_, const fe1& py_, const E& qx_, const E& qy_) {
-  // locals that never escape: the register allocator owns them (a reference parameter would pin them to memory across calls)
-  const fe1 px = px_, py = py_; const E qx = qx_, qy = qy_;
-  G2JacT<E> r; r.x = qx; r.y = qy; r.z = E2<E>::one();
-  Fp12T<E> f = fp12_one<E>();
-  LineT<E> l;
+// LDS parking lot: while the accumulator f (84 registers per lane) is being squared or multiplied by a line, the running point
+// R (42) and P (28) are not needed, and vice versa -- but the register allocator sees them all live across the whole loop and
+// spills whatever does not fit to per-lane scratch, whose hot footprint (512 lanes x ~2 KB per CU) misses the 4 MB L2.  The 70
+// words are parked in LDS instead (160 KB / 8 wavefronts = 320 B per lane; word w of lane t at [w * PAIRING_BLOCK + t]:
+// conflict-free), which takes them out of the allocator's hands.  The loop is inlined into its single caller, which owns the
+// LDS array, so `park` is an LDS address by construction (ds_read / ds_write, not flat).
+constexpr int PARK_WORDS = 5 * NL;          // R.x R.y R.z (one coefficient per lane of the pair) + px py
+template <int V> DEV void park_put(u32* park, int slot, const Fe<1, V>& a) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) park[(slot * NL + i) * PAIRING_BLOCK] = a.l[i];
+}
+template <int V> DEV void park_get(const u32* park, int slot, Fe<1, V>& a) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) a.l[i] = park[(slot * NL + i) * PAIRING_BLOCK];
+}
+template <class E> DEV void miller_loop(Fp12T<E>& fout, const fe1& px_, const fe1& py_, const E& qx_, const E& qy_, u32* park) {
+  {
+    const E one = E2<E>::one();
+    park_put(park, 0, qx_.v); park_put(park, 1, qy_.v); park_put(park, 2, one.v);
+    park_put(park, 3, px_); park_put(park, 4, py_);
+  }
+  Fp12T<E> f = fp12_one<E>();               // never escapes: the register allocator owns it
   for (int b = 61; b >= -1; b--) {          // bit 62 is the leading one; b = -1: the final doubling step (pairings.rs:686-687)
-    doubling_step(r, l);
-    ell(f, l, px, py);
+    LineT<E> l;
+    {
+      G2JacT<E> r;
+      park_get(park, 0, r.x.v); park_get(park, 1, r.y.v); park_get(park, 2, r.z.v);
+      doubling_step(r, l);
+      park_put(park, 0, r.x.v); park_put(park, 1, r.y.v); park_put(park, 2, r.z.v);
+    }
+    {
+      fe1 px, py;
+      park_get(park, 3, px); park_get(park, 4, py);
+      ell(f, l, px, py);
+    }
     if (b < 0) break;
     if ((X_HALF >> b) & 1) {
       // 5 of the 62 iterations: out of line (keeps the hot loop inside the instruction cache); the copies confine the
       // address-taken objects to this branch
-      Fp12T<E> ft = f; G2JacT<E> rt = r;
+      Fp12T<E> ft = f; G2JacT<E> rt;
+      park_get(park, 0, rt.x.v); park_get(park, 1, rt.y.v); park_get(park, 2, rt.z.v);
       addition_step_ell(ft, rt, px_, py_, qx_, qy_);
-      f = ft; r = rt;
+      f = ft;
+      park_put(park, 0, rt.x.v); park_put(park, 1, rt.y.v); park_put(park, 2, rt.z.v);
     }
     fp12_sqr_hot(f, f);                     // in place
   }
@@ -538,6 +566,7 @@ constexpr int PL = E2<PE>::LANES;
 // Identity on either side -> Fp12::one() (pairings.rs:636-651; multi_miller_loop skips such terms :566-569).
 PAIR_KERNEL k_pairing(int mode, const u32* __restrict__ g1, const uint8_t* __restrict__ g1inf, const u32* __restrict__ g2,
                       const uint8_t* __restrict__ g2inf, u32* __restrict__ out, size_t n) {
+  __shared__ u32 park_lds[PARK_WORDS * PAIRING_BLOCK];          // 70 KB per 256-thread workgroup: see miller_loop
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / PL;
   if (i >= n) return;
   bool ident = (g1inf && g1inf[i]) || (g2inf && g2inf[i]);
@@ -547,7 +576,7 @@ PAIR_KERNEL k_pairing(int mode, const u32* __restrict__ g1, const uint8_t* __res
   } else {
     fe1 px = fe_from_ref(g1 + i * 24), py = fe_from_ref(g1 + i * 24 + 12);
     PE qx = E2<PE>::load(g2 + i * 48), qy = E2<PE>::load(g2 + i * 48 + 24);
-    miller_loop(f, px, py, qx, qy);
+    miller_loop(f, px, py, qx, qy, park_lds + threadIdx.x);
     if (mode == 0) { Fp12T<PE> g; final_exponentiation(g, f); f = g; }
   }
   fp12_save(f, out + i * 144);
