@@ -306,21 +306,32 @@ def host_cpu_allotment():
     return info
 
 
+def host_threads():
+    """threads for the CPU baseline: what the cgroup quota / affinity mask really grants (oversubscribing a 16-CPU quota with
+    256 threads only adds scheduler noise); 0 = let OpenMP decide"""
+    h = host_cpu_allotment()
+    k = h["affinity"]
+    if h.get("cgroup_cpu_max"):
+        k = min(k, max(1, int(h["cgroup_cpu_max"])))
+    return int(k)
+
+
 def cpu_baseline_g1(ctx, bases, sb, n):
     """oracle/bls_oracle.c (kind "port") on the host cores; also the per-op table of the reference's criterion points."""
     from oracle import c_oracle
     per_op = {}
+    threads = host_threads()
     # single-thread figures from >= ~1 s samples after a warm-up
     xy1, inf1 = bases.download(0, 4096)
     c_oracle.g1_msm(xy1[:64], inf1[:64], sb[:64], 1)
     t1 = time.perf_counter(); c_oracle.g1_msm(xy1, inf1, sb[:4096], 1); one = 4096 / (time.perf_counter() - t1)
     per_op["g1_scalar_mul_ns"] = 1e9 / one
     # all cores: warm the thread pool, then a sample large enough that every thread gets hundreds of terms
-    m = min(n, 1 << 17)
+    m = min(n, 1 << 16)
     xy, inf = bases.download(0, m)
-    c_oracle.g1_msm(xy[:4096], inf[:4096], sb[:4096], 0)
+    c_oracle.g1_msm(xy[:4096], inf[:4096], sb[:4096], threads)
     t1 = time.perf_counter()
-    ref, used = c_oracle.g1_msm(xy, inf, sb[:m], 0)
+    ref, used = c_oracle.g1_msm(xy, inf, sb[:m], threads)
     cdt = time.perf_counter() - t1
     got = ctx.msm(bases, sb[:m])
     same = bool(np.array_equal(ctx.batch_normalize(1, got[None, :])[0][0], c_oracle.g1_to_affine(ref)[0]))
@@ -328,7 +339,7 @@ def cpu_baseline_g1(ctx, bases, sb, n):
         raise SystemExit("bench: GPU MSM over the CPU sample differs from the oracle")
     return {"value": m / cdt, "unit": "scalar-muls/s", "cores": used, "kind": "port",
             "sample": f"first 2^{int(np.log2(m))} (point, scalar) pairs of the same workload: sum(P_i*s_i) by 255-step double-and-add + Sum, "
-                      f"C restatement of the reference algorithm (oracle/bls_oracle.c), OpenMP dynamic schedule over {used} threads after a warm-up; "
+                      f"C restatement of the reference algorithm (oracle/bls_oracle.c), OpenMP dynamic schedule over {used} threads (= the CPUs the cgroup quota / affinity grants this process) after a warm-up; "
                       f"single thread (4096-pair sample): {one:.0f}/s",
             "single_thread_value": one, "parallel_speedup": (m / cdt) / one, "gpu_result_matches": same, "per_op_ns": per_op,
             "host": host_cpu_allotment()}
@@ -362,9 +373,9 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
             c_oracle.pairing_batch(mode, src, g1f[:cnt], g2xy[:cnt], g2f[:cnt], 1)
             per_op[name] = 1e9 * (time.perf_counter() - t1) / cnt
         mp = 1 << 14
-        c_oracle.pairing_batch(0, g1xy[:1024], g1f[:1024], g2xy[:1024], g2f[:1024], 0)           # thread-pool warm-up
+        c_oracle.pairing_batch(0, g1xy[:1024], g1f[:1024], g2xy[:1024], g2f[:1024], host_threads())           # thread-pool warm-up
         t1 = time.perf_counter()
-        cref, cused = c_oracle.pairing_batch(0, g1xy[:mp], g1f[:mp], g2xy[:mp], g2f[:mp], 0)
+        cref, cused = c_oracle.pairing_batch(0, g1xy[:mp], g1f[:mp], g2xy[:mp], g2f[:mp], host_threads())
         cpdt = time.perf_counter() - t1
         same_p = bool(np.array_equal(d_gt[:mp].cpu().numpy().view(np.uint64), cref))
         one_p = 1e9 / per_op["full_pairing_ns"]
@@ -427,9 +438,9 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
         from oracle import c_oracle
         m2 = 1 << 13                                  # bounded sample: a few seconds of CPU work
         xy2, inf2 = b2.download(0, m2)
-        c_oracle.g2_msm(xy2[:512], inf2[:512], sb[:512], 0)
+        c_oracle.g2_msm(xy2[:512], inf2[:512], sb[:512], host_threads())
         t1 = time.perf_counter()
-        ref2, used2 = c_oracle.g2_msm(xy2, inf2, sb[:m2], 0)
+        ref2, used2 = c_oracle.g2_msm(xy2, inf2, sb[:m2], host_threads())
         c2dt = time.perf_counter() - t1
         t1 = time.perf_counter(); c_oracle.g2_msm(xy2[:1024], inf2[:1024], sb[:1024], 1); one2 = 1024 / (time.perf_counter() - t1)
         got2 = ctx.msm(b2, sb[:m2])
