@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--weak", action="store_true", help="N>1: fixed 2^log-n points per GPU instead of one 2^log-total MSM split N ways")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for single-GPU plumbing tests)")
     ap.add_argument("--same-device", action="store_true", help="testing aid: all ranks use GPU 0 (needs --backend gloo)")
+    ap.add_argument("--dist-single", action="store_true", help="testing aid: run the N>1 code path (process group over RCCL, all-gather of the partial "
+                    "sums, fold, rank agreement) with ONE rank -- the only way to execute that path on a one-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (batched pairings, G2 MSM, latency probes)")
     ap.add_argument("--mixed-log", type=int, nargs=3, default=[22, 22, 18], metavar=("G1", "G2", "MML"),
@@ -91,8 +93,11 @@ def setup(args):
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, e.world))
     torch.cuda.set_device(e.local_rank)
     e.dev = torch.device("cuda", e.local_rank)
-    if e.world > 1:
+    e.multi = e.world > 1 or args.dist_single          # the distributed code path (exchange + fold) is active
+    if e.multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if e.world == 1:
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); os.environ.setdefault("MASTER_PORT", str(s.getsockname()[1])); s.close()
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=e.rank, world_size=e.world, device_id=e.dev)
         else:
@@ -105,13 +110,13 @@ def setup(args):
 
 def fence(e):
     e.torch.cuda.synchronize()
-    if e.world > 1:
+    if e.multi:
         e.dist.barrier()
     e.torch.cuda.synchronize()
 
 
 def max_over_ranks(e, dt):
-    if e.world == 1:
+    if not e.multi:
         return dt
     t = e.torch.tensor([dt], dtype=e.torch.float64, device=e.xdev)
     e.dist.all_reduce(t, op=e.dist.ReduceOp.MAX)
@@ -144,9 +149,10 @@ def run_msm(args, e):
     from bls12_381_amd import synthetic
     from bls12_381_amd.distributed import shard_range, all_gather_rows
     rank, world, dev = e.rank, e.world, e.dev
-    steps = args.steps if args.steps is not None else (100 if world == 1 else 20)
+    multi = e.multi
+    steps = args.steps if args.steps is not None else (100 if not multi else 20)
     warmup = args.warmup if args.warmup is not None else 5
-    strong = world > 1 and not args.weak
+    strong = multi and not args.weak
     if strong:
         total = 1 << args.log_total
         lo, hi = shard_range(total, rank, world)
@@ -162,7 +168,7 @@ def run_msm(args, e):
     bases = ctx.bases_from_scalars(1, kb)                       # resident bases, built on the device
     d_scalars = torch.from_numpy(sb).to(dev)
     d_out = [torch.zeros(18, dtype=torch.int64, device=dev) for _ in range(4)]      # up to four calls may be in flight
-    gathered = torch.zeros((world, 18), dtype=torch.int64, device=e.xdev) if world > 1 else None
+    gathered = torch.zeros((world, 18), dtype=torch.int64, device=e.xdev) if multi else None
     d_fold = torch.zeros(18, dtype=torch.int64, device=dev)
     ctx.set_pipelining(True)         # the latency-bound tail of MSM i overlaps the chip-filling phases of MSM i+1
     state = {"i": 0}
@@ -177,7 +183,7 @@ def run_msm(args, e):
     def step():
         i = state["i"]; state["i"] = i + 1
         ctx.msm_device(bases, d_scalars.data_ptr(), n, d_out[i & 3].data_ptr())
-        if world > 1 and i >= 2:
+        if multi and i >= 2:
             # consume result i-2: by now its tail has long finished, so the wait (and the exchange queued behind it on this
             # stream) does not hold back the front of MSM i+1, whose dependency on this stream is recorded at its launch
             ctx.join(2)
@@ -185,7 +191,7 @@ def run_msm(args, e):
 
     def drain():
         ctx.join(0)
-        if world > 1:
+        if multi:
             for k in range(max(0, state["i"] - 2), state["i"]):
                 exchange(d_out[k & 3])
         state["i"] = 0
@@ -203,7 +209,7 @@ def run_msm(args, e):
     dt = time.perf_counter() - t0
     live_acc_ms, live_acc_n = ctx.msm_accumulate_stats(False)
     dt = max_over_ranks(e, dt)
-    if world > 1:
+    if multi:
         last = d_fold.cpu().numpy().view(np.uint64)
         aff = ctx.batch_normalize(1, last[None, :])[0][0]
         if not ranks_agree(e, aff):
@@ -245,7 +251,7 @@ def run_msm(args, e):
                     "16 windows (SURVEY.md 8d); peak = v_mad_u64_u32 issue rate measured in this run",
         }
     # ---- latency of ONE call (SURVEY.md 8d timing protocol) ------------------------------------------------
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and not multi and not args.no_extras:
         sync = torch.cuda.synchronize
         single = median_ms(lambda: ctx.msm_device(bases, d_scalars.data_ptr(), n, d_out0.data_ptr()), sync)
         pinned = torch.from_numpy(sb).pin_memory()
@@ -262,12 +268,12 @@ def run_msm(args, e):
 
     # ---- CPU baseline: the reference's own definition on the host cores (bounded sample) ------------------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not multi and not args.no_cpu_baseline:
         cpu = cpu_baseline_g1(ctx, bases, sb, n)
 
     # ---- secondary measurements of the same path (BASELINE configs[2]); never part of `value` ---------------
     extras = None
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and not multi and not args.no_extras:
         extras = run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out0)
 
     if rank == 0:
@@ -276,9 +282,9 @@ def run_msm(args, e):
                         "RCCL all-gather of the %d partial sums (144 B each) + fold on every rank" % (args.log_total, world, n, world))
         else:
             workload = ("2^%d-point G1 MSM per MI355X, bases resident in HBM, scalars in HBM; one result per step%s"
-                        % (log_n, "" if world == 1 else " (RCCL all-gather of N partial sums + fold)"))
+                        % (log_n, "" if not multi else " (RCCL all-gather of N partial sums + fold)"))
         line = {
-            "metric": "G1 MSM throughput (scalar-muls/sec) at 2^%d points" % (args.log_total if strong else log_n) + ("" if strong or world == 1 else " per GPU"),
+            "metric": "G1 MSM throughput (scalar-muls/sec) at 2^%d points" % (args.log_total if strong else log_n) + ("" if strong or not multi else " per GPU"),
             "value": float(total) * steps / dt, "unit": "scalar-muls/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u32 (14x28-bit limbs, 64-bit accumulators)", "data": "synthetic",
@@ -289,7 +295,7 @@ def run_msm(args, e):
         if latency:
             line["single_call_ms"] = latency["single_call_ms"]; line["end_to_end_h2d_ms"] = latency["end_to_end_h2d_ms"]
         print(json.dumps(line))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -542,11 +548,12 @@ def run_mixed(args, e):
     torch, dist, bls = e.torch, e.dist, e.bls
     from bls12_381_amd.distributed import all_gather_rows
     rank, world, dev = e.rank, e.world, e.dev
+    multi = e.multi
     steps = args.steps if args.steps is not None else 5
     warmup = args.warmup if args.warmup is not None else 1
     jobs = MixedJobs(bls, torch, e.local_rank, args.mixed_log, rank, world)
     fold_ctx = jobs.ctx[2]
-    gath = [torch.zeros((world, w), dtype=torch.int64, device=e.xdev) for w in (18, 36, 72)] if world > 1 else None
+    gath = [torch.zeros((world, w), dtype=torch.int64, device=e.xdev) for w in (18, 36, 72)] if multi else None
     f1 = torch.zeros(18, dtype=torch.int64, device=dev); f2 = torch.zeros(36, dtype=torch.int64, device=dev)
     fm = torch.zeros(72, dtype=torch.int64, device=dev); gt = torch.zeros(72, dtype=torch.int64, device=dev)
 
@@ -554,7 +561,7 @@ def run_mixed(args, e):
         jobs.launch(which)
         jobs.sync()                        # the three rank-local results (one element each) are ready
         srcm = jobs.om
-        if world > 1:
+        if multi:
             # the three tiny exchanges (144 B, 288 B, 576 B per rank) + folds on every rank
             for k, (buf, g, out, grp) in enumerate(((jobs.o1, gath[0], f1, 1), (jobs.o2, gath[1], f2, 2))):
                 if k in which:
@@ -583,7 +590,7 @@ def run_mixed(args, e):
     dt = timed((0, 1, 2), steps)
     alone = [timed((k,), max(1, steps // 2)) for k in range(3)]
     ok = True
-    if world > 1:
+    if multi:
         ok = ranks_agree(e, gt.cpu().numpy().view(np.uint64)) and ranks_agree(e, f1.cpu().numpy().view(np.uint64))
     if rank == 0:
         s = [1 << x for x in args.mixed_log]
@@ -600,7 +607,7 @@ def run_mixed(args, e):
             "ranks_agree": ok,
         }
         print(json.dumps(line))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -56,8 +56,9 @@ struct blsgpu_ctx {
   bool pipelining = false;
   bool acc_timing = false;              // blsgpu_msm_accumulate_stats: HIP-event duration of every accumulation launch
   double acc_ms_sum = 0.0; unsigned acc_count = 0;
-  bool g1_single = true;               // one lane per G1 bucket chain (default); env BLSGPU_G1_PAIR at create selects the lane-pair
-                                       // kernel (k_msm_accumulate_g1pair: 161 VGPRs, three wavefronts per SIMD -- measured 12% slower)
+  int g1_kernel = 1;                    // G1 bucket accumulation: 1 = k_msm_accumulate<FpPolicy> (one lane per chain, 241 VGPRs, two wavefronts per SIMD;
+                                        // default), 0 = k_msm_accumulate_g1 (three wavefronts per SIMD, LDS-DMA prefetch; env BLSGPU_G1_SPLIT: measured 7% slower),
+                                        // 2 = lane-pair kernel (env BLSGPU_G1_PAIR: measured 12% slower)
   bool no_glv = false;                 // A/B hook (env BLSGPU_NO_GLV at create): plain 256-bit windows for G1
   bool force_slow_sort = false;        // test hook (env BLSGPU_FORCE_SLOW_SORT at create): the global-atomic sort used beyond 2^24 points
   hipStream_t acc_stream = nullptr;     // bucket accumulation of pipelined calls (the caller's stream is never blocked)
@@ -370,7 +371,7 @@ extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
   c->device = device;
   c->force_slow_sort = getenv("BLSGPU_FORCE_SLOW_SORT") != nullptr;
   c->no_glv = getenv("BLSGPU_NO_GLV") != nullptr;
-  c->g1_single = getenv("BLSGPU_G1_PAIR") == nullptr;
+  c->g1_kernel = getenv("BLSGPU_G1_PAIR") ? 2 : getenv("BLSGPU_G1_SPLIT") ? 0 : 1;
   int rc = ctx_init(c);
   if (rc != BLSGPU_OK) { blsgpu_destroy(c); return rc; }       // destroy tolerates the half-built context (null handles are skipped)
   *out = c;
@@ -765,7 +766,10 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   const u32* base_rec = (merged ? bases->table : bases->rec) + first * Store<F>::AFF_WORDS;
   if constexpr (GroupTag<F>::id == 2)
     hipLaunchKernelGGL(k_msm_accumulate_g2pair, dim3(nblk(2 * max_items, 256)), dim3(256), 0, as, base_rec, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
-  else if (!c->g1_single)
+  else if (c->g1_kernel == 0)
+    hipLaunchKernelGGL(k_msm_accumulate_g1, dim3(nblk(max_items, 256)), dim3(256), 0, as, base_rec, glv ? bases->endo + first * Store<F>::AFF_WORDS : (const u32*)nullptr,
+                       glv ? (u32)n : 0xffffffffu, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
+  else if (c->g1_kernel == 2)
     hipLaunchKernelGGL(k_msm_accumulate_g1pair, dim3(nblk(2 * max_items, 256)), dim3(256), 0, as, base_rec, glv ? bases->endo + first * Store<F>::AFF_WORDS : (const u32*)nullptr,
                        glv ? (u32)n : 0xffffffffu, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
   else

@@ -618,6 +618,117 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const u32* __restrict__ 
   }
   store_proj<F>(records + (size_t)d.dest * Store<F>::PROJ_WORDS, xyzz_to_proj<F>(acc, acc_inf));
 }
+// G1 accumulation, round-2 form: THREE wavefronts per SIMD.
+//
+// What kept k_msm_accumulate<FpPolicy> at 241 registers (two wavefronts per SIMD, where a wavefront can start a multiply-add
+// only every other issue slot and ~37% of the issue cycles are lost, profiles/r02_msm_pmc.md) was not the addition formula but
+// (a) the exceptional cases of madd-2008-s -- doubling / cancellation code with out-of-line calls in the middle of the loop
+// body, whose live ranges and call-clobbered registers the allocator had to plan for on the hot path -- and (b) the next
+// base record prefetched into 28 registers.  Here
+//   * the fast loop handles only the generic case; when the one-limb filter says P = U2 - X MAY be zero (probability
+//     ~15 / 2^28 per addition on random input, certain for duplicates and +-pairs) the lane leaves the loop and finishes its
+//     chain with the reference's complete mixed addition (RCB15 Alg. 8, g1.rs:715-752) -- same group element;
+//   * the next record is prefetched by the LDS-DMA path of gfx950 (global_load_lds_dwordx4: HBM -> LDS without passing
+//     through registers), 8 x 16 B per lane into a per-wavefront staging area, and read back with ds_read_b128 at the top
+//     of the next iteration.
+// Hot loop: 168 registers, no scratch, 32 KB LDS per 256-lane block (three blocks per CU).
+#ifndef BLS_ACC_WAVES
+#define BLS_ACC_WAVES 3
+#endif
+#ifndef BLS_ACC_PREFETCH
+#define BLS_ACC_PREFETCH 1          // 1: LDS-DMA staging of the next record; 2: next record prefetched into registers; 0: index prefetch only
+#endif
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_cvoid_t;
+__global__ void __launch_bounds__(256, BLS_ACC_WAVES) k_msm_accumulate_g1(const u32* __restrict__ bases, const u32* __restrict__ bases2, u32 nsplit,
+                                                                           const u32* __restrict__ sorted, const ItemDesc* __restrict__ items,
+                                                                           const u32* __restrict__ ctrl, u32* __restrict__ records) {
+  typedef FpPolicy F;
+  constexpr int AW = Store<F>::AFF_WORDS;
+#if BLS_ACC_PREFETCH == 1
+  __shared__ uint4 stage[4][AW / 4][64];          // [wavefront][16-byte chunk of the record][lane]
+  const u32 wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+#endif
+  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ctrl[2]) return;
+  ItemDesc d = items[t];
+  auto rec_of = [&](u32 e) -> const u32* {
+    u32 idx = e & 0x7fffffffu;
+    return idx < nsplit ? bases + (size_t)idx * AW : bases2 + (size_t)(idx - nsplit) * AW;
+  };
+#if BLS_ACC_PREFETCH == 1
+  auto fetch = [&](u32 e) {
+    const u32* r = rec_of(e);
+#pragma unroll
+    for (int c = 0; c < AW / 4; c++)
+      __builtin_amdgcn_global_load_lds((glb_cvoid_t*)(r + 4 * c), (lds_void_t*)&stage[wv][c][0], 16, 0, 0);
+  };
+#endif
+  fe X = fe_zero(), Y = fe_zero(), ZZ = fe_zero(), ZZZ = fe_zero();
+  bool acc_inf = true, slow = false;
+  const u32 end = d.start + d.len;
+  u32 j = d.start;
+  u32 e = d.len ? sorted[d.start] : 0;
+  u32 e_next = d.len > 1 ? sorted[d.start + 1] : 0;
+#if BLS_ACC_PREFETCH == 1
+  if (d.len) fetch(e);
+#elif BLS_ACC_PREFETCH == 2
+  Aff<F> qn; bool infn = true;
+  if (d.len) load_aff<F>(rec_of(e), qn, infn);
+#endif
+  for (; j < end; j++) {
+    Aff<F> q; bool inf;
+#if BLS_ACC_PREFETCH == 1
+    {
+      u32 w[AW];
+#pragma unroll
+      for (int c = 0; c < AW / 4; c++) { uint4 v = stage[wv][c][ln]; w[4 * c] = v.x; w[4 * c + 1] = v.y; w[4 * c + 2] = v.z; w[4 * c + 3] = v.w; }
+      Store<F>::ld(w, q.x); Store<F>::ld(w + NL, q.y); inf = w[2 * NL] != 0;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): the staging area has been read before the DMA overwrites it
+#elif BLS_ACC_PREFETCH == 2
+    q = qn; inf = infn;
+#else
+    load_aff<F>(rec_of(e), q, inf);
+#endif
+    const u32 e_cur = e;
+    u32 e_next2 = 0;
+#if BLS_ACC_PREFETCH == 1
+    if (j + 1 < end) fetch(e_next);
+#elif BLS_ACC_PREFETCH == 2
+    if (j + 1 < end) load_aff<F>(rec_of(e_next), qn, infn);
+#endif
+    if (j + 2 < end) e_next2 = sorted[j + 2];
+    e = e_next; e_next = e_next2;
+    if (inf) continue;                            // identity base: contributes nothing
+    auto qy = cond_neg(q.y, (e_cur >> 31) != 0);
+    if (acc_inf) { acc_inf = false; X = F::st(q.x); Y = F::st(qy); ZZ = fe_one(); ZZZ = fe_one(); continue; }
+    auto P = sub(mul_inl(q.x, ZZ), X);            // limbs <= 3 * 2^28: still inside the multiplier's column bound
+    auto R = sub(mul_inl(qy, ZZZ), Y);
+    if (maybe_zero(P)) { slow = true; e = e_cur; break; }      // entry j is NOT consumed
+    auto PP = sqr_inl(P);
+    auto PPP = mul_inl(P, PP);
+    auto Q = mul_inl(X, PP);
+    auto X3 = norm(sub(sqr_inl(R), add(PPP, dbl(Q))));
+    auto Y3 = sop2_inl(R, norm(sub(Q, X3)), neg(Y), PPP);      // R (Q - X3) - Y1 PPP with one reduction
+    ZZ = F::st(mul_inl(ZZ, PP));
+    ZZZ = F::st(mul_inl(ZZZ, PPP));
+    X = F::st(X3); Y = F::st(Y3);
+  }
+  Xyzz<F> acc; acc.x = X; acc.y = Y; acc.zz = ZZ; acc.zzz = ZZZ;
+  Proj<F> pr = xyzz_to_proj<F>(acc, acc_inf);
+  if (slow) {
+    for (; j < end; j++) {
+      u32 e2 = sorted[j];
+      Aff<F> q; bool inf;
+      load_aff<F>(rec_of(e2), q, inf);
+      if (inf) continue;
+      pr = pt_add_mixed_y<F>(pr, q.x, cond_neg(q.y, (e2 >> 31) != 0));
+    }
+  }
+  store_proj<F>(records + (size_t)d.dest * Store<F>::PROJ_WORDS, pr);
+}
+
 // G2 accumulation with every Fp2 value spread over a lane pair (pairlane.hip.h): lane 2k works on the c0 coefficients
 // and lane 2k+1 on the c1 coefficients of chain k.  Same items, same records, same formula.
 __global__ void __launch_bounds__(256, 2) k_msm_accumulate_g2pair(const u32* __restrict__ bases, const u32* __restrict__ sorted,

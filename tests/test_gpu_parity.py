@@ -1125,3 +1125,56 @@ def test_device_variants_of_miller_final_exp_product(ctx):
     assert np.array_equal(dml.cpu().numpy().view(np.uint64), ml)
     assert np.array_equal(dgt.cpu().numpy().view(np.uint64), ctx.pairing_batch(g1, None, g2, None))
     assert np.array_equal(dpr.cpu().numpy().view(np.uint64), ctx.multi_miller_loop(g1, None, g2, None))
+
+
+@pytest.mark.parametrize("workload", ["msm", "mixed"])
+def test_bench_distributed_branch_over_rccl_with_one_rank(workload):
+    """bench.py's N > 1 code path -- process group on backend "nccl" (= RCCL) bound to the device, the (world, words) int64
+    all-gather of the partial sums on the GPU, the device-side fold, the max / min all-reduces of the timing and agreement
+    checks -- executed for real with a single rank (`--dist-single`): a one-GPU box cannot run two RCCL ranks, but every
+    call of the branch goes through RCCL exactly as it does with eight."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dist-single", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extras"]
+    if workload == "msm":
+        cmd += ["--log-total", "18"]
+    else:
+        cmd += ["--workload", "mixed", "--mixed-log", "14", "12", "10"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("MASTER_PORT", None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    if workload == "msm":
+        assert line["scaling"] == "strong" and line["config"]["total_points"] == 1 << 18
+        assert "RCCL all-gather" in line["config"]["workload"]
+    else:
+        assert line["ranks_agree"] is True
+
+
+def test_msm_split_accumulation_kernel(monkeypatch):
+    """the experimental G1 accumulation kernel (k_msm_accumulate_g1: generic-case fast loop at three wavefronts per SIMD with the
+    next record staged by the gfx950 LDS-DMA path, exceptional cases finished by the reference's complete mixed addition;
+    BLSGPU_G1_SPLIT) must give the same group elements as the default kernel: duplicates, +-pairs, identities, one bucket
+    holding everything, every window width, and a medium random case"""
+    import bls12_381_amd as b
+    monkeypatch.setenv("BLSGPU_G1_SPLIT", "1")
+    c = b.Context(0)
+    monkeypatch.delenv("BLSGPU_G1_SPLIT")
+    r = o.SplitMix64(777)
+    rr = o.R_ORDER
+    ks = [1, 2, 3, 0, 5, 5, 5, rr - 5, 7, rr - 7, 0, 11] + [r.scalar() for _ in range(20)]
+    ss = [0, 1, rr - 1, 12345, 9, 9, rr - 9, 9, (1 << 254), (1 << 254), 0, (1 << 16) - 1] + \
+         [(1 << (16 * i)) - 1 for i in range(1, 11)] + [(1 << 15) + (1 << (16 * i + 15)) for i in range(10)]
+    for w in (0, 4, 7, 13, 16):
+        _msm_case(c, 1, ks, ss, window=w)
+    _msm_case(c, 1, [3] * 300, [1] * 300)
+    _msm_case(c, 1, [3] * 3000, [7] * 3000)
+    _msm_case(c, 1, [4, rr - 4], [77, 77])
+    _msm_case(c, 1, [4, 4, rr - 4, 4, 0, 4], [77, 77, 77, 77, 5, 77])
+    n = 1 << 14
+    _msm_case(c, 1, [r.scalar() for _ in range(n)], [r.scalar() for _ in range(n)])
