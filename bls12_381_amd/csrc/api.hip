@@ -59,7 +59,7 @@ struct blsgpu_ctx {
   int g1_kernel = 1;                    // G1 bucket accumulation: 1 = k_msm_accumulate<FpPolicy> (one lane per chain, 241 VGPRs, two wavefronts per SIMD;
                                         // default), 0 = k_msm_accumulate_g1 (three wavefronts per SIMD, LDS-DMA prefetch; env BLSGPU_G1_SPLIT: measured 7% slower),
                                         // 2 = lane-pair kernel (env BLSGPU_G1_PAIR: measured 12% slower)
-  bool no_glv = false;                 // A/B hook (env BLSGPU_NO_GLV at create): plain 256-bit windows for G1
+  bool no_glv = false;                 // A/B hook (env BLSGPU_NO_GLV at create): plain 256-bit windows (no GLV for G1, no psi decomposition for G2)
   bool force_slow_sort = false;        // test hook (env BLSGPU_FORCE_SLOW_SORT at create): the global-atomic sort used beyond 2^24 points
   hipStream_t acc_stream = nullptr;     // bucket accumulation of pipelined calls (the caller's stream is never blocked)
   hipEvent_t ev[9] = {};
@@ -95,7 +95,8 @@ struct blsgpu_ctx {
 
 struct blsgpu_bases {
   int group = 1; size_t n = 0; int device = 0; u32* rec = nullptr;   // AFF_WORDS per point
-  u32* endo = nullptr;               // G1 only: the images (BETA x, y) of the records under the GLV endomorphism (msm.hip.h)
+  u32* endo = nullptr;               // G1: the images (BETA x, y) of the records under the GLV endomorphism, same order as rec;
+                                     // G2: the four images psi^j(P), j = 0..3, interleaved (record 4 i + j) -- msm.hip.h
   // optional window-shifted tables: table[w * n + i] = [2^(table_c * w)] P_i   (blsgpu_bases_precompute)
   u32* table = nullptr; int table_c = 0, table_w = 0;
 };
@@ -470,11 +471,18 @@ extern "C" int blsgpu_last_msm_phase_ms(blsgpu_ctx* c, int phase, float* ms) {
 // ---------------------------------------------------------------------------------------------------
 // bases
 // ---------------------------------------------------------------------------------------------------
-// G1 bases also keep their images under the GLV endomorphism next to them (2x the resident memory; see k_glv_decompose)
+// G1 bases also keep their images under the GLV endomorphism next to them (2x the resident memory; see k_glv_decompose);
+// G2 bases keep P, psi(P), psi^2(P), psi^3(P) interleaved in a second array (5x the resident memory; see k_gls_decompose)
 static int bases_make_endo(blsgpu_ctx* c, blsgpu_bases* b) {
-  if (b->group != 1 || !b->n) return BLSGPU_OK;
-  if (hipMalloc((void**)&b->endo, b->n * Store<FpPolicy>::AFF_WORDS * 4) != hipSuccess) { g_err = "hipMalloc(bases endo) failed"; return BLSGPU_ERR_HIP; }
-  hipLaunchKernelGGL(k_bases_endo, dim3(nblk(b->n, 256)), dim3(256), 0, c->stream, b->rec, b->endo, b->n);
+  if (!b->n) return BLSGPU_OK;
+  if (b->group == 1) {
+    if (hipMalloc((void**)&b->endo, b->n * Store<FpPolicy>::AFF_WORDS * 4) != hipSuccess) { g_err = "hipMalloc(bases endo) failed"; return BLSGPU_ERR_HIP; }
+    hipLaunchKernelGGL(k_bases_endo, dim3(nblk(b->n, 256)), dim3(256), 0, c->stream, b->rec, b->endo, b->n);
+  } else {
+    if (b->n > ((size_t)1 << 22)) return BLSGPU_OK;          // 4 n must fit the sort's 24-bit indices: larger sets use plain windows
+    if (hipMalloc((void**)&b->endo, 4 * b->n * Store<Fp2Policy>::AFF_WORDS * 4) != hipSuccess) { g_err = "hipMalloc(bases endo) failed"; return BLSGPU_ERR_HIP; }
+    hipLaunchKernelGGL(k_bases_endo_g2, dim3(nblk(b->n, 256)), dim3(256), 0, c->stream, b->rec, b->endo, b->n);
+  }
   LAUNCHCHK();
   return BLSGPU_OK;
 }
@@ -632,8 +640,10 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   const bool merged = bases->table != nullptr;
   // GLV (G1): 2n points (the bases and their images under the endomorphism) with balanced 127-bit scalars -> half the windows
   const bool glv = GroupTag<F>::id == 1 && !merged && bases->endo && !c->no_glv && !c->force_slow_sort && 2 * n <= ((size_t)1 << 24);
-  const size_t ns = glv ? 2 * n : n;                    // scalars the sort sees
-  const int sbits = glv ? 128 : 256;                    // ... and their width (incl. the spare bit of the signed recoding)
+  // four-dimensional decomposition (G2): 4n points (every base with its images under psi, psi^2, psi^3) with 63-bit scalars -> a quarter of the windows
+  const bool gls = GroupTag<F>::id == 2 && !merged && bases->endo && !c->no_glv && !c->force_slow_sort && 4 * n <= ((size_t)1 << 24);
+  const size_t ns = glv ? 2 * n : gls ? 4 * n : n;      // scalars the sort sees
+  const int sbits = glv ? 128 : gls ? 64 : 256;         // ... and their width (incl. the spare bit of the signed recoding)
   const int cw = merged ? bases->table_c : (c->msm_c ? c->msm_c : pick_window(ns, sbits));
   const int nwin = (sbits + cw - 1) / cw;               // digit windows per scalar
   const int nseg = merged ? 1 : nwin;                   // independent bucket sets
@@ -666,6 +676,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   }
   if (!fast_sort) bad_alloc |= sl.cursor.reserve(total * 4);      // per-entry rank inside its bucket (fallback sort only)
   if (glv) bad_alloc |= sl.glv.reserve(ns * 16);
+  if (gls) bad_alloc |= sl.glv.reserve(ns * 8);
   bad_alloc |= sl.offs.reserve((nb + 1) * 4);
   bad_alloc |= sl.bsum.reserve(4096 * 4);
   // item cap: ~4x the mean bucket load, so that with uniform scalars (almost) no bucket is cut
@@ -709,6 +720,10 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
       hipLaunchKernelGGL(k_glv_decompose, dim3(nblk(n, 256)), dim3(256), 0, ft, (const u32*)d_scalars, sl.glv.as<u32>(), (int)n, c->d_status);
       sort_in = sl.glv.as<u32>();
       hipLaunchKernelGGL(k_sort_hist<4>, dim3(tiles), dim3(256), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, 0, c->d_status);
+    } else if (gls) {
+      hipLaunchKernelGGL(k_gls_decompose, dim3(nblk(n, 256)), dim3(256), 0, ft, (const u32*)d_scalars, sl.glv.as<u32>(), (int)n, c->d_status);
+      sort_in = sl.glv.as<u32>();
+      hipLaunchKernelGGL(k_sort_hist<2>, dim3(tiles), dim3(256), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, 0, c->d_status);
     } else {
       hipLaunchKernelGGL(k_sort_hist<8>, dim3(tiles), dim3(256), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, merged ? 1 : 0, c->d_status);
     }
@@ -719,6 +734,8 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     mark(2);
     if (glv)
       hipLaunchKernelGGL(k_sort_scatter<4>, dim3(tiles), dim3(256), (size_t)nc * 8, ft, sort_in, gbase, gcur, sl.ent.as<u32>(), (int)ns, cw, nwin, fine_bits, ncoarse, 0, (u32)0);
+    else if (gls)
+      hipLaunchKernelGGL(k_sort_scatter<2>, dim3(tiles), dim3(256), (size_t)nc * 8, ft, sort_in, gbase, gcur, sl.ent.as<u32>(), (int)ns, cw, nwin, fine_bits, ncoarse, 0, (u32)0);
     else
       hipLaunchKernelGGL(k_sort_scatter<8>, dim3(tiles), dim3(256), (size_t)nc * 8, ft, sort_in, gbase, gcur, sl.ent.as<u32>(), (int)ns, cw, nwin,
                          fine_bits, ncoarse, merged ? 1 : 0, (u32)bases->n);
@@ -765,7 +782,8 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   u32* records = sl.buckets.as<u32>();
   const u32* base_rec = (merged ? bases->table : bases->rec) + first * Store<F>::AFF_WORDS;
   if constexpr (GroupTag<F>::id == 2)
-    hipLaunchKernelGGL(k_msm_accumulate_g2pair, dim3(nblk(2 * max_items, 256)), dim3(256), 0, as, base_rec, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
+    hipLaunchKernelGGL(k_msm_accumulate_g2pair, dim3(nblk(2 * max_items, 256)), dim3(256), 0, as, gls ? bases->endo + 4 * first * Store<F>::AFF_WORDS : base_rec,
+                       sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
   else if (c->g1_kernel == 0)
     hipLaunchKernelGGL(k_msm_accumulate_g1, dim3(nblk(max_items, 256)), dim3(256), 0, as, base_rec, glv ? bases->endo + first * Store<F>::AFF_WORDS : (const u32*)nullptr,
                        glv ? (u32)n : 0xffffffffu, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);

@@ -213,16 +213,22 @@ constexpr int SORT_TILE = 2048;                 // scalars per block in k_sort_h
 constexpr int SORT_MAX_COUNTERS = 8192;         // nwin * ncoarse upper bound (LDS: 32 KB)
 
 // Signed c-bit digits of a scalar, lowest window first.  WORDS = 8: a canonical 32-byte scalar.  WORDS = 4: one half of a GLV
-// decomposition (k_glv_decompose below): a 127-bit magnitude with the sign of its contribution in bit 127.  The scalar is kept
+// decomposition (k_glv_decompose below): a 127-bit magnitude with the sign of its contribution in bit 127.  WORDS = 2: one of the
+// four 63-bit digits of the G2 decomposition (k_gls_decompose), sign in bit 63.  The scalar is kept
 // as a shift register (funnel shifts with static register indices), so the iterator lives entirely in VGPRs.
 template <int WORDS> struct DigitIter {
   u32 s[WORDS]; u32 carry, sign; int c; u32 nbw, mask;
   DEV void init(const u32* src, size_t i, int c_) {
-    const uint4* sp = reinterpret_cast<const uint4*>(src + i * WORDS);
-    uint4 a = sp[0];
-    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
-    if constexpr (WORDS == 8) { uint4 b = sp[1]; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w; sign = 0; }
-    else { sign = s[3] >> 31; s[3] &= 0x7fffffffu; }
+    if constexpr (WORDS == 2) {
+      uint2 a = *reinterpret_cast<const uint2*>(src + i * 2);
+      s[0] = a.x; s[1] = a.y; sign = s[1] >> 31; s[1] &= 0x7fffffffu;
+    } else {
+      const uint4* sp = reinterpret_cast<const uint4*>(src + i * WORDS);
+      uint4 a = sp[0];
+      s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
+      if constexpr (WORDS == 8) { uint4 b = sp[1]; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w; sign = 0; }
+      else { sign = s[3] >> 31; s[3] &= 0x7fffffffu; }
+    }
     carry = 0; c = c_; nbw = 1u << (c - 1); mask = (1u << c) - 1;
   }
   DEV bool canonical() const { if constexpr (WORDS == 8) return scalar_is_canonical(s); else return true; }
@@ -315,6 +321,106 @@ __global__ void __launch_bounds__(256) k_bases_endo(const u32* __restrict__ rec,
   fe1 bx = canon(mul(x, fe1_const(kb)));
   Store<FpPolicy>::st(e, bx);
   for (int j = NL; j < AW; j++) e[j] = r[j];
+}
+
+// ---- four-dimensional decomposition (G2) ------------------------------------------------------------------------------
+// psi (g2.rs:847-890: the untwist-Frobenius-twist endomorphism) acts on the order-r subgroup of the twist as multiplication by
+// the curve parameter x = -X, X = 0xd201000000010000 -- that is the reference's own subgroup test psi(P) == [x] P
+// (g2.rs:475-482) -- and r = x^4 - x^2 + 1.  A scalar k < r < X^4 has four base-X digits k = d0 + d1 X + d2 X^2 + d3 X^3, so
+//     k P = d0 P  -  d1 psi(P)  +  d2 psi^2(P)  -  d3 psi^3(P).
+// Digits are balanced into (-X/2, X/2] (a carry out of d3 is folded back with x^4 = x^2 - 1 (mod r): d2 += 1, d0 -= 1), which
+// leaves |d_i| <= X/2 + 1 < 2^63: the top 16-bit window never exceeds 0x6901, so the signed recoding needs no extra window.
+// The MSM then runs over 4n points (every base with its three images, interleaved in one resident array) with 63-bit scalars:
+// the same 16 n bucket additions, but FOUR windows instead of sixteen -- a quarter of the buckets to reduce and 48 instead of
+// 240 doublings in the window combine.  out[4 i + j] = |d_j| (two words), bit 63 = 1 if the term is SUBTRACTED.
+// Division by X: Knuth's algorithm D on 32-bit digits (X is normalised: its top bit is set), two corrections at most.
+DEV void gls_divmod_x(u32* u, int m, u32* q) {        // u: m + 2 words (top word 0 on entry), q: m words; remainder left in u[0..1]
+  constexpr u64 X = 0xd201000000010000ull;
+  constexpr u32 v1 = (u32)(X >> 32);
+  for (int j = m - 1; j >= 0; j--) {
+    u64 hi = ((u64)u[j + 2] << 32) | u[j + 1];
+    u64 qh = hi / v1;
+    if (qh > 0xffffffffull) qh = 0xffffffffull;
+    // t = u[j+2 : j] - qh * X as a signed 128-bit value
+    __int128 t = ((__int128)(((unsigned __int128)u[j + 2] << 64) | ((unsigned __int128)u[j + 1] << 32) | u[j])) - (__int128)((unsigned __int128)qh * X);
+    while (t < 0) { t += (__int128)X; qh--; }
+    q[j] = (u32)qh;
+    u[j] = (u32)(u64)t; u[j + 1] = (u32)((u64)t >> 32); u[j + 2] = 0;
+  }
+}
+__global__ void __launch_bounds__(256) k_gls_decompose(const u32* __restrict__ scalars, u32* __restrict__ out, int n, u32* __restrict__ status) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr u64 X = 0xd201000000010000ull, H = X >> 1;
+  u32 k[10];
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+  uint4 a = sp[0], b = sp[1];
+  k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w; k[8] = 0; k[9] = 0;
+  if (!scalar_is_canonical(k)) atomicOr(status, 1u);
+  u64 d[5];
+  u32 q0[8], q1[6];
+  gls_divmod_x(k, 7, q0);                       // k = q0 X + d0,  q0 < 2^192
+  d[0] = ((u64)k[1] << 32) | k[0];
+  u32 w[8];
+#pragma unroll
+  for (int j = 0; j < 6; j++) w[j] = q0[j];
+  w[6] = 0; w[7] = 0;
+  gls_divmod_x(w, 5, q1);                       // q0 = q1 X + d1,  q1 < 2^128
+  d[1] = ((u64)w[1] << 32) | w[0];
+  u32 z[6];
+#pragma unroll
+  for (int j = 0; j < 4; j++) z[j] = q1[j];
+  z[4] = 0; z[5] = 0;
+  u32 q2[4];
+  gls_divmod_x(z, 3, q2);                       // q1 = d3 X + d2,  d3 < X
+  d[2] = ((u64)z[1] << 32) | z[0];
+  d[3] = ((u64)q2[1] << 32) | q2[0];
+  // balance (digits as signed 65-bit values: magnitude + sign)
+  u32 neg[4];
+  u64 carry = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    u64 v = d[j] + carry;                       // <= X: no wrap
+    if (v > H) { d[j] = X - v; neg[j] = 1; carry = 1; } else { d[j] = v; neg[j] = 0; carry = 0; }
+  }
+  if (carry) {                                  // X^4 = x^4 = x^2 - 1 (mod r):  d2 += 1, d0 -= 1   (signed)
+    if (neg[2]) { if (d[2] == 0) { d[2] = 1; neg[2] = 0; } else d[2] -= 1; } else d[2] += 1;
+    if (neg[0]) d[0] += 1; else if (d[0] == 0) { d[0] = 1; neg[0] = 1; } else d[0] -= 1;
+  }
+  // k P = d0 P - d1 psi(P) + d2 psi^2(P) - d3 psi^3(P):  odd terms are subtracted when their digit is positive
+  uint4* o = reinterpret_cast<uint4*>(out + (size_t)i * 8);
+  u32 s0 = neg[0], s1 = neg[1] ^ 1u, s2 = neg[2], s3 = neg[3] ^ 1u;
+  o[0] = make_uint4((u32)d[0], (u32)(d[0] >> 32) | (s0 << 31), (u32)d[1], (u32)(d[1] >> 32) | (s1 << 31));
+  o[1] = make_uint4((u32)d[2], (u32)(d[2] >> 32) | (s2 << 31), (u32)d[3], (u32)(d[3] >> 32) | (s3 << 31));
+}
+// the images psi^j(P), j = 0..3, of resident G2 bases, interleaved (four 256-byte records per point):
+// psi(x, y) = (conj(x) cx, conj(y) cy) (g2.rs:847-890), psi^2(x, y) = (x k2, -y) (:891-912), psi^3 = psi o psi^2
+__global__ void __launch_bounds__(256) k_bases_endo_g2(const u32* __restrict__ rec, u32* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int AW = Store<Fp2Policy>::AFF_WORDS, EL = Store<Fp2Policy>::EL;
+  constexpr PLimbs zero = {{0}}, px1 = {BLS_PSI_X_1}, py0 = {BLS_PSI_Y_0}, py1 = {BLS_PSI_Y_1}, k2 = {BLS_PSI2_X};
+  fe2_1 cx, cy;
+  cx.c0 = fe1_const(zero); cx.c1 = fe1_const(px1); cy.c0 = fe1_const(py0); cy.c1 = fe1_const(py1);
+  const u32* r = rec + i * AW;
+  u32* o = out + 4 * i * AW;
+  fe2_1 x, y; Store<Fp2Policy>::ld(r, x); Store<Fp2Policy>::ld(r + EL, y);
+  const u32 flag = r[2 * EL];
+  auto put = [&](int j, const fe2_1& px, const fe2_1& py) {
+    u32* e = o + j * AW;
+    Store<Fp2Policy>::st(e, px); Store<Fp2Policy>::st(e + EL, py);
+    e[2 * EL] = flag;
+    for (int t = 2 * EL + 1; t < AW; t++) e[t] = 0;
+  };
+  auto canon2 = [](const auto& v) { fe2_1 c; c.c0 = canon(v.c0); c.c1 = canon(v.c1); return c; };
+  auto psi = [&](const fe2_1& px, const fe2_1& py, fe2_1& ox, fe2_1& oy) {
+    ox = canon2(mul(conj(px), cx)); oy = canon2(mul(conj(py), cy));
+  };
+  put(0, x, y);
+  fe2_1 x1, y1; psi(x, y, x1, y1); put(1, x1, y1);
+  fe2_1 x2 = canon2(mul_fp(x, fe1_const(k2))), y2 = canon2(neg(y));
+  put(2, x2, y2);
+  fe2_1 x3, y3; psi(x2, y2, x3, y3); put(3, x3, y3);
 }
 
 // merged != 0 (resident window-shifted tables): all windows share ONE bucket set, the window only selects the table
@@ -740,25 +846,70 @@ __global__ void __launch_bounds__(256, 2) k_msm_accumulate_g2pair(const u32* __r
   if (t >= ctrl[2]) return;                     // both lanes of a pair leave together
   const u32 par = threadIdx.x & 1;
   ItemDesc d = items[t];
-  Xyzz<F> acc;
-  acc.x = F::zero(); acc.y = F::zero(); acc.zz = F::zero(); acc.zzz = F::zero();
-  bool acc_inf = true;
-  for (u32 j = d.start; j < d.start + d.len; j++) {
-    u32 e = sorted[j];
+  // this lane's halves of a record: x coefficient `par`, y coefficient `par`, and the identity flag
+  auto load_half = [&](u32 e, FeP<1, 1>& qx, FeP<1, 1>& qy, u32& flag) {
     const u32* rec = bases + (size_t)(e & 0x7fffffffu) * AW;
-    if (rec[4 * NL] != 0) continue;             // identity base (same decision in both lanes)
-    FeP<1, 1> qx, qy1;
     const uint2* px = reinterpret_cast<const uint2*>(rec + par * NL);
     const uint2* py = reinterpret_cast<const uint2*>(rec + 2 * NL + par * NL);
 #pragma unroll
     for (int i = 0; i < NL / 2; i++) {
       uint2 a = px[i], b = py[i];
-      qx.v.l[2 * i] = a.x; qx.v.l[2 * i + 1] = a.y; qy1.v.l[2 * i] = b.x; qy1.v.l[2 * i + 1] = b.y;
+      qx.v.l[2 * i] = a.x; qx.v.l[2 * i + 1] = a.y; qy.v.l[2 * i] = b.x; qy.v.l[2 * i + 1] = b.y;
     }
-    FeP<2, 2> qy = select((e >> 31) != 0, neg(qy1), (FeP<2, 2>)qy1);
-    acc = xyzz_add_mixed<F>(acc, acc_inf, qx, qy);
+    flag = rec[4 * NL];
+  };
+  Xyzz<F> acc;
+  acc.x = F::zero(); acc.y = F::zero(); acc.zz = F::zero(); acc.zzz = F::zero();
+  bool acc_inf = true, slow = false;
+  // software pipeline as in the G1 kernel: while addition j runs, the record of entry j+1 and the index of entry j+2 are in
+  // flight (with the four images of every base resident the gathers range over 1 GB -- past the Infinity Cache)
+  const u32 end = d.start + d.len;
+  u32 j = d.start;
+  u32 e = d.len ? sorted[d.start] : 0;
+  u32 e_next = d.len > 1 ? sorted[d.start + 1] : 0;
+  FeP<1, 1> qxn, qyn; u32 flagn = 1;
+  if (d.len) load_half(e, qxn, qyn, flagn);
+  for (; j < end; j++) {
+    const FeP<1, 1> qx = qxn, qy1 = qyn;
+    const u32 flag = flagn, e_cur = e;
+    u32 e_next2 = 0;
+    if (j + 1 < end) load_half(e_next, qxn, qyn, flagn);
+    if (j + 2 < end) e_next2 = sorted[j + 2];
+    e = e_next; e_next = e_next2;
+    if (flag != 0) continue;                    // identity base (same decision in both lanes)
+    FeP<2, 2> qy = select((e_cur >> 31) != 0, neg(qy1), (FeP<2, 2>)qy1);
+    if (acc_inf) { acc_inf = false; acc = xyzz_from_affine<F>(qx, qy); continue; }
+    // madd-2008-s, generic case only; when P = U2 - X MAY be zero (one-limb filter on both coefficients, decided identically
+    // in both lanes) the pair leaves the loop and finishes the chain with the complete mixed addition
+    auto U2 = mul(qx, acc.zz);
+    auto S2 = mul(qy, acc.zzz);
+    auto P = norm(sub(U2, acc.x));
+    auto R = norm(sub(S2, acc.y));
+    {
+      bool m = maybe_zero(P.v);
+      bool pm = partner_flag(m);
+      if (m && pm) { slow = true; e = e_cur; break; }          // entry j is NOT consumed
+    }
+    auto PP = sqr(P);
+    auto PPP = mul(P, PP);
+    auto Q = mul(acc.x, PP);
+    auto X3 = norm(sub(sqr(R), add(PPP, dbl(Q))));
+    auto Y3 = sub(mul(R, norm(sub(Q, X3))), mul(acc.y, PPP));
+    auto ZZ3 = mul(acc.zz, PP);
+    auto ZZZ3 = mul(acc.zzz, PPP);
+    acc.x = F::st(X3); acc.y = F::st(Y3); acc.zz = F::st(ZZ3); acc.zzz = F::st(ZZZ3);
   }
   Proj<F> pr = xyzz_to_proj<F>(acc, acc_inf);
+  if (slow) {
+    for (; j < end; j++) {
+      u32 e2 = sorted[j];
+      FeP<1, 1> qx, qy1; u32 flag;
+      load_half(e2, qx, qy1, flag);
+      if (flag != 0) continue;
+      FeP<2, 2> qy = select((e2 >> 31) != 0, neg(qy1), (FeP<2, 2>)qy1);
+      pr = pt_add_mixed_y<F>(pr, qx, qy);
+    }
+  }
   u32* o = records + (size_t)d.dest * PW + par * NL;
 #pragma unroll
   for (int i = 0; i < NL; i++) { o[i] = pr.x.v.l[i]; o[2 * NL + i] = pr.y.v.l[i]; o[4 * NL + i] = pr.z.v.l[i]; }

@@ -1178,3 +1178,35 @@ def test_msm_split_accumulation_kernel(monkeypatch):
     _msm_case(c, 1, [4, 4, rr - 4, 4, 0, 4], [77, 77, 77, 77, 5, 77])
     n = 1 << 14
     _msm_case(c, 1, [r.scalar() for _ in range(n)], [r.scalar() for _ in range(n)])
+
+
+def test_msm_g2_psi_decomposition_boundaries(ctx, monkeypatch):
+    """G2 MSMs split every scalar into four signed base-|x| digits (psi acts as [x] on the subgroup, g2.rs:475-482 / :847-890).
+    Scalars at the digit boundaries -- multiples of X, X^2, X^3 and their neighbours, the balancing threshold X/2, the carry
+    out of the top digit (folded back with x^4 = x^2 - 1 mod r), 0, 1, r - 1 -- against the oracle, on the default path and
+    with the decomposition switched off."""
+    import bls12_381_amd as b
+    X = 0xd201000000010000
+    H = X // 2
+    rr = o.R_ORDER
+    cand = [0, 1, 2, rr - 1, rr - 2, H, H + 1, H - 1, X - 1, X, X + 1]
+    for pw in (2, 3):
+        for m in (1, 2, H, H + 1, X - 1):
+            for dlt in (-1, 0, 1):
+                cand.append(m * X ** pw + dlt)
+                cand.append(m * X ** pw + H + dlt)
+    cand += [X ** 3 * (X - 1) + X ** 2 * (X - 1), (H + 1) * (1 + X + X ** 2 + X ** 3), H * (1 + X + X ** 2 + X ** 3)]
+    ss = sorted({c % rr for c in cand if c >= 0})
+    r = o.SplitMix64(4040)
+    ks = [r.scalar() for _ in ss]
+    _msm_case(ctx, 2, ks, ss)
+    _msm_case(ctx, 2, ks, ss, window=13)
+    _msm_case(ctx, 2, [5] * len(ss), ss)                      # one base, every term lands on the same four images
+    monkeypatch.setenv("BLSGPU_NO_GLV", "1")
+    plain = b.Context(0)
+    monkeypatch.delenv("BLSGPU_NO_GLV")
+    _msm_case(plain, 2, ks, ss)
+    n = 1 << 12
+    ks2 = [r.scalar() for _ in range(n)]; ss2 = [r.scalar() for _ in range(n)]
+    _msm_case(plain, 2, ks2, ss2)
+    _msm_case(ctx, 2, ks2, ss2)
