@@ -59,6 +59,7 @@ struct blsgpu_ctx {
   int g1_kernel = 1;                    // G1 bucket accumulation: 1 = k_msm_accumulate<FpPolicy> (one lane per chain, 241 VGPRs, two wavefronts per SIMD;
                                         // default), 0 = k_msm_accumulate_g1 (three wavefronts per SIMD, LDS-DMA prefetch; env BLSGPU_G1_SPLIT: measured 7% slower),
                                         // 2 = lane-pair kernel (env BLSGPU_G1_PAIR: measured 12% slower)
+  u32 item_cap = 0;                    // A/B hook (env BLSGPU_ITEM_CAP at create): entries per work item of the accumulation (0 = automatic)
   bool no_glv = false;                 // A/B hook (env BLSGPU_NO_GLV at create): plain 256-bit windows (no GLV for G1, no psi decomposition for G2)
   bool force_slow_sort = false;        // test hook (env BLSGPU_FORCE_SLOW_SORT at create): the global-atomic sort used beyond 2^24 points
   hipStream_t acc_stream = nullptr;     // bucket accumulation of pipelined calls (the caller's stream is never blocked)
@@ -372,6 +373,7 @@ extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
   c->device = device;
   c->force_slow_sort = getenv("BLSGPU_FORCE_SLOW_SORT") != nullptr;
   c->no_glv = getenv("BLSGPU_NO_GLV") != nullptr;
+  if (const char* v = getenv("BLSGPU_ITEM_CAP")) { long k = atol(v); if (k >= 8 && k <= ITEM_CAP_MAX) c->item_cap = (u32)k; }
   c->g1_kernel = getenv("BLSGPU_G1_PAIR") ? 2 : getenv("BLSGPU_G1_SPLIT") ? 0 : 1;
   int rc = ctx_init(c);
   if (rc != BLSGPU_OK) { blsgpu_destroy(c); return rc; }       // destroy tolerates the half-built context (null handles are skipped)
@@ -682,6 +684,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   // item cap: ~4x the mean bucket load, so that with uniform scalars (almost) no bucket is cut
   u32 cap = 128;
   while (cap < ITEM_CAP_MAX && (size_t)cap * nbw < 4 * ns) cap *= 2;
+  if (c->item_cap) cap = c->item_cap;
   const size_t max_items = total / cap + nb + 1;                // every bucket has >= 1 item
   const size_t max_records = nb + max_items;                    // bucket sums + partial sums of heavy buckets
   bad_alloc |= sl.items.reserve(max_items * sizeof(ItemDesc));
