@@ -722,13 +722,13 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     if (glv) {
       hipLaunchKernelGGL(k_glv_decompose, dim3(nblk(n, 256)), dim3(256), 0, ft, (const u32*)d_scalars, sl.glv.as<u32>(), (int)n, c->d_status);
       sort_in = sl.glv.as<u32>();
-      hipLaunchKernelGGL(k_sort_hist<4>, dim3(tiles), dim3(256), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, 0, c->d_status);
+      hipLaunchKernelGGL(k_sort_hist<4>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, 0, c->d_status);
     } else if (gls) {
       hipLaunchKernelGGL(k_gls_decompose, dim3(nblk(n, 256)), dim3(256), 0, ft, (const u32*)d_scalars, sl.glv.as<u32>(), (int)n, c->d_status);
       sort_in = sl.glv.as<u32>();
-      hipLaunchKernelGGL(k_sort_hist<2>, dim3(tiles), dim3(256), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, 0, c->d_status);
+      hipLaunchKernelGGL(k_sort_hist<2>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, 0, c->d_status);
     } else {
-      hipLaunchKernelGGL(k_sort_hist<8>, dim3(tiles), dim3(256), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, merged ? 1 : 0, c->d_status);
+      hipLaunchKernelGGL(k_sort_hist<8>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, merged ? 1 : 0, c->d_status);
     }
     LAUNCHCHK();
     mark(1);
@@ -736,11 +736,11 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     LAUNCHCHK();
     mark(2);
     if (glv)
-      hipLaunchKernelGGL(k_sort_scatter<4>, dim3(tiles), dim3(256), (size_t)nc * 8, ft, sort_in, gbase, gcur, sl.ent.as<u32>(), (int)ns, cw, nwin, fine_bits, ncoarse, 0, (u32)0);
+      hipLaunchKernelGGL(k_sort_scatter<4>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 8, ft, sort_in, gbase, gcur, sl.ent.as<u32>(), (int)ns, cw, nwin, fine_bits, ncoarse, 0, (u32)0);
     else if (gls)
-      hipLaunchKernelGGL(k_sort_scatter<2>, dim3(tiles), dim3(256), (size_t)nc * 8, ft, sort_in, gbase, gcur, sl.ent.as<u32>(), (int)ns, cw, nwin, fine_bits, ncoarse, 0, (u32)0);
+      hipLaunchKernelGGL(k_sort_scatter<2>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 8, ft, sort_in, gbase, gcur, sl.ent.as<u32>(), (int)ns, cw, nwin, fine_bits, ncoarse, 0, (u32)0);
     else
-      hipLaunchKernelGGL(k_sort_scatter<8>, dim3(tiles), dim3(256), (size_t)nc * 8, ft, sort_in, gbase, gcur, sl.ent.as<u32>(), (int)ns, cw, nwin,
+      hipLaunchKernelGGL(k_sort_scatter<8>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 8, ft, sort_in, gbase, gcur, sl.ent.as<u32>(), (int)ns, cw, nwin,
                          fine_bits, ncoarse, merged ? 1 : 0, (u32)bases->n);
     hipLaunchKernelGGL(k_sort_fine, dim3(nc), dim3(256), 0, ft, sl.ent.as<u32>(), gbase, sl.sorted.as<u32>(), sl.offs.as<u32>(), fine_bits, nc);
     LAUNCHCHK();

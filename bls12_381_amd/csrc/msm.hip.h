@@ -209,7 +209,17 @@ __global__ void __launch_bounds__(256) k_bases_precompute(const u32* __restrict_
 //                   `sorted` grouped by bucket and the bucket offsets `offs` (no global scan over the buckets)
 // Compared with one global atomic + one random 4-byte gather/scatter per entry, almost all atomics are LDS
 // atomics and the random traffic stays inside a 16 KB region.
-constexpr int SORT_TILE = 2048;                 // scalars per block in k_sort_hist / k_sort_scatter
+// tile / block size of the coarse sort passes: every tile costs one global atomic per non-empty (window, coarse) counter in
+// each pass, so larger tiles mean fewer of them and longer runs per region (measured at 2^21 half-scalars: 2048/256 -> 0.40 ms for
+// hist + scan + scatter, 4096/512 -> 0.29 ms, 8192/1024 -> 0.30 ms, 16384/1024 -> 0.37 ms)
+#ifndef BLS_SORT_TILE
+#define BLS_SORT_TILE 4096
+#endif
+#ifndef BLS_SORT_THREADS
+#define BLS_SORT_THREADS 512
+#endif
+constexpr int SORT_TILE = BLS_SORT_TILE;         // scalars per block in k_sort_hist / k_sort_scatter
+constexpr int SORT_THREADS = BLS_SORT_THREADS;   // threads per block of those two kernels
 constexpr int SORT_MAX_COUNTERS = 8192;         // nwin * ncoarse upper bound (LDS: 32 KB)
 
 // Signed c-bit digits of a scalar, lowest window first.  WORDS = 8: a canonical 32-byte scalar.  WORDS = 4: one half of a GLV
@@ -425,14 +435,14 @@ __global__ void __launch_bounds__(256) k_bases_endo_g2(const u32* __restrict__ r
 
 // merged != 0 (resident window-shifted tables): all windows share ONE bucket set, the window only selects the table
 template <int WORDS>
-__global__ void __launch_bounds__(256) k_sort_hist(const u32* __restrict__ scalars, u32* __restrict__ ghist, int n, int c, int nwin,
+__global__ void __launch_bounds__(SORT_THREADS) k_sort_hist(const u32* __restrict__ scalars, u32* __restrict__ ghist, int n, int c, int nwin,
                                                    int fine_bits, int ncoarse, int merged, u32* __restrict__ status) {
   extern __shared__ u32 lh[];
   const int nc = (merged ? 1 : nwin) * ncoarse;
-  for (int i = threadIdx.x; i < nc; i += 256) lh[i] = 0;
+  for (int i = threadIdx.x; i < nc; i += SORT_THREADS) lh[i] = 0;
   __syncthreads();
-  for (int k = 0; k < SORT_TILE / 256; k++) {
-    int i = blockIdx.x * SORT_TILE + k * 256 + threadIdx.x;
+  for (int k = 0; k < SORT_TILE / SORT_THREADS; k++) {
+    int i = blockIdx.x * SORT_TILE + k * SORT_THREADS + threadIdx.x;
     if (i < n) {
       DigitIter<WORDS> d; d.init(scalars, i, c);
       if (!d.canonical()) atomicOr(status, 1u);
@@ -443,7 +453,7 @@ __global__ void __launch_bounds__(256) k_sort_hist(const u32* __restrict__ scala
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < nc; i += 256) if (lh[i]) atomicAdd(&ghist[i], lh[i]);
+  for (int i = threadIdx.x; i < nc; i += SORT_THREADS) if (lh[i]) atomicAdd(&ghist[i], lh[i]);
 }
 // exclusive scan of nc <= 8192 counters; gbase[nc] = total.  Also does the per-call zeroing that would
 // otherwise be separate memset launches: the reservation cursors, the item-control words, and the counters
@@ -469,16 +479,16 @@ __global__ void __launch_bounds__(1024) k_sort_scan(u32* __restrict__ ghist, u32
   for (int i = threadIdx.x; i < nctrl; i += 1024) ctrl[i] = 0;
 }
 template <int WORDS>
-__global__ void __launch_bounds__(256) k_sort_scatter(const u32* __restrict__ scalars, const u32* __restrict__ gbase, u32* __restrict__ gcur,
+__global__ void __launch_bounds__(SORT_THREADS) k_sort_scatter(const u32* __restrict__ scalars, const u32* __restrict__ gbase, u32* __restrict__ gcur,
                                                       u32* __restrict__ coarse_out, int n, int c, int nwin, int fine_bits, int ncoarse,
                                                       int merged, u32 stride) {
   extern __shared__ u32 lh[];          // [nc] counts, then reused as running local ranks; [nc] bases
   const int nc = (merged ? 1 : nwin) * ncoarse;
   u32* lbase = lh + nc;
-  for (int i = threadIdx.x; i < nc; i += 256) lh[i] = 0;
+  for (int i = threadIdx.x; i < nc; i += SORT_THREADS) lh[i] = 0;
   __syncthreads();
-  for (int k = 0; k < SORT_TILE / 256; k++) {
-    int i = blockIdx.x * SORT_TILE + k * 256 + threadIdx.x;
+  for (int k = 0; k < SORT_TILE / SORT_THREADS; k++) {
+    int i = blockIdx.x * SORT_TILE + k * SORT_THREADS + threadIdx.x;
     if (i < n) {
       DigitIter<WORDS> d; d.init(scalars, i, c);
       for (int w = 0; w < nwin; w++) {
@@ -488,15 +498,15 @@ __global__ void __launch_bounds__(256) k_sort_scatter(const u32* __restrict__ sc
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < nc; i += 256) {
+  for (int i = threadIdx.x; i < nc; i += SORT_THREADS) {
     u32 cnt = lh[i];
     lbase[i] = cnt ? gbase[i] + atomicAdd(&gcur[i], cnt) : 0;
     lh[i] = 0;
   }
   __syncthreads();
   const u32 fmask = (1u << fine_bits) - 1;
-  for (int k = 0; k < SORT_TILE / 256; k++) {
-    int i = blockIdx.x * SORT_TILE + k * 256 + threadIdx.x;
+  for (int k = 0; k < SORT_TILE / SORT_THREADS; k++) {
+    int i = blockIdx.x * SORT_TILE + k * SORT_THREADS + threadIdx.x;
     if (i < n) {
       DigitIter<WORDS> d; d.init(scalars, i, c);
       for (int w = 0; w < nwin; w++) {
