@@ -665,7 +665,11 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   int bad_alloc = 0;
   blsgpu_ctx::Slot& sl = c->slot[c->next_slot];
   c->next_slot = (c->next_slot + 1) % NSLOT;
-  hipStream_t ft = sl.front, tt = sl.tail;
+  // One call at a time (no pipelining): front, accumulation and tail run on the caller's stream -- every cross-stream
+  // dependency costs a barrier packet and 20-90 us of idle time between the phases (kernel trace of a single call), and there is
+  // nothing to overlap with.  Only the T tree sums keep their side stream.  Pipelined calls use the slot's own streams.
+  const bool single = !c->pipelining;
+  hipStream_t ft = single ? st : sl.front, tt = single ? st : sl.tail;
   // every buffer of this slot may still be in use by the call that used it last (NSLOT calls ago)
   if (sl.tail_pending) { HIPCHK(hipStreamWaitEvent(ft, sl.ev_tail, 0)); HIPCHK(hipStreamWaitEvent(st, sl.ev_tail, 0)); }
   bad_alloc |= sl.ent.reserve(total * 4);
@@ -706,8 +710,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   const bool prof = c->profiling;
   auto mark = [&](int i) { if (prof) hipEventRecord(c->ev[i], ft); };
   // the front stream starts after whatever produced the scalars on the caller's stream
-  HIPCHK(hipEventRecord(sl.ev_in, st));
-  HIPCHK(hipStreamWaitEvent(ft, sl.ev_in, 0));
+  if (ft != st) { HIPCHK(hipEventRecord(sl.ev_in, st)); HIPCHK(hipStreamWaitEvent(ft, sl.ev_in, 0)); }
 
   mark(0);
   if (fast_sort) {
@@ -770,16 +773,15 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   u32* ctrl = sl.ctrl.as<u32>();
   u32* bins = ctrl + 4;
   u32* bcur = ctrl + 4 + ITEM_BINS;
-  hipLaunchKernelGGL(k_item_count, dim3(nblk(nb, 256)), dim3(256), 0, ft, sl.offs.as<u32>(), bins, ctrl, (int)nb, cap);
+  hipLaunchKernelGGL(k_item_count, dim3(nblk(nb, ITEM_BLOCK_BUCKETS)), dim3(256), 0, ft, sl.offs.as<u32>(), bins, ctrl, (int)nb, cap);
   hipLaunchKernelGGL(k_item_scan, dim3(1), dim3(256), 0, ft, bins, ctrl, cap);
-  hipLaunchKernelGGL(k_item_fill, dim3(nblk(nb, 256)), dim3(256), 0, ft, sl.offs.as<u32>(), bins, bcur, ctrl, sl.items.as<ItemDesc>(),
+  hipLaunchKernelGGL(k_item_fill, dim3(nblk(nb, ITEM_BLOCK_BUCKETS)), dim3(256), 0, ft, sl.offs.as<u32>(), bins, bcur, ctrl, sl.items.as<ItemDesc>(),
                      sl.heavy.as<uint4>(), (int)nb, cap);
   LAUNCHCHK();
   mark(4);
-  HIPCHK(hipEventRecord(sl.ev_front, ft));
   // pipelined calls accumulate on the library's own stream: front(i+1) must not queue behind accumulate(i)
   hipStream_t as = c->pipelining ? c->acc_stream : st;
-  HIPCHK(hipStreamWaitEvent(as, sl.ev_front, 0));
+  if (as != ft) { HIPCHK(hipEventRecord(sl.ev_front, ft)); HIPCHK(hipStreamWaitEvent(as, sl.ev_front, 0)); }
   // 5. accumulate (grid covers the worst-case item count; surplus lanes exit on ctrl[2])
   if (c->acc_timing) { acc_harvest(c, false); if (sl.k_pending) { hipEventSynchronize(sl.ev_k1); acc_harvest(c, false); } hipEventRecord(sl.ev_k0, as); }
   u32* records = sl.buckets.as<u32>();
@@ -801,8 +803,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   LAUNCHCHK();
   if (prof) hipEventRecord(c->ev[5], as);
   // ---- tail on the slot's own stream ---------------------------------------------------------------
-  HIPCHK(hipEventRecord(sl.ev_acc, as));
-  HIPCHK(hipStreamWaitEvent(tt, sl.ev_acc, 0));
+  if (tt != as) { HIPCHK(hipEventRecord(sl.ev_acc, as)); HIPCHK(hipStreamWaitEvent(tt, sl.ev_acc, 0)); }
   // 6. per-window weighted sums:  wsum = sum_g T_g + M * wsum0(R)
   {
     std::vector<int> Ms;
@@ -812,6 +813,27 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     u32* tstore = sl.wacc[0].as<u32>();
     hipStream_t t2 = sl.tail2;
     size_t toff = 0;                                    // offset (records) of this level's T block inside lvlT
+    struct Tree { const u32* in; int n, pp, level; size_t off; };
+    std::vector<Tree> trees;                            // T trees with passes left
+    // one pass of every unfinished tree: a single multi-job launch when all of them fit the team form
+    auto tree_step = [&]() -> int {
+      TreeJobs J; J.njobs = 0; J.nseg = nseg; J.first_team[0] = 0;
+      for (auto& tr : trees) {
+        if (tr.n <= 1) continue;
+        int TM = tr.n >= 8 ? 8 : tr.n, TG = (tr.n + TM - 1) / TM;
+        u32* o = TG == 1 ? tstore + (size_t)tr.level * nseg * PW : sl.tsum[tr.pp].template as<u32>() + tr.off * PW;   // the last pass lands in the Horner table
+        if ((size_t)nseg * TG * TEAM <= TEAM_LANES_MAX && J.njobs < TREE_JOBS_MAX) {
+          int j = J.njobs++;
+          J.in[j] = tr.in; J.out[j] = o; J.n[j] = tr.n; J.M[j] = TM; J.G[j] = TG; J.first_team[j + 1] = J.first_team[j] + nseg * TG;
+        } else {
+          hipLaunchKernelGGL(k_tree_sum<F>, dim3(nblk((size_t)nseg * TG, 256)), dim3(256), 0, t2, tr.in, o, nseg, tr.n, TM);
+        }
+        tr.in = o; tr.n = TG; tr.pp ^= 1;
+      }
+      if (J.njobs) hipLaunchKernelGGL(k_tree_sum_team_multi<F>, dim3(nblk((size_t)J.first_team[J.njobs] * TEAM, 256)), dim3(256), TEAM_LDS(256), t2, J);
+      LAUNCHCHK();
+      return BLSGPU_OK;
+    };
     while (nn > 1) {
       int M = nn >= 8 ? 8 : nn;
       int G = nn / M;
@@ -826,29 +848,37 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
       else
         hipLaunchKernelGGL(k_wsum_level<F>, dim3(nblk((size_t)nseg * G, 256)), dim3(256), 0, tt, E, Rout, Tout, nseg, nn, M, off);
       LAUNCHCHK();
-      // sum the G T-records of each window down to one -- on the second tail stream: the next level needs only Rout
+      // sum the G T-records of each window down to one -- on the second tail stream: the next level needs only Rout.  Level l
+      // needs log8(G_l) passes; after every level ONE launch carries the next pass of every tree that still has one (the T
+      // trees of different levels are independent), so the trees finish while the R chain is still running.
       if (G > 1) {
-        hipStream_t ts = level < 8 ? t2 : tt;
-        if (level < 8) { HIPCHK(hipEventRecord(sl.ev_lvl[level], tt)); HIPCHK(hipStreamWaitEvent(t2, sl.ev_lvl[level], 0)); }
-        const u32* Tin = Tout; int tn = G, tc = 0;
-        while (tn > 1) {
-          int TM = tn >= 8 ? 8 : tn; int TG = (tn + TM - 1) / TM;
-          u32* o = TG == 1 ? tstore + (size_t)level * nseg * PW : sl.tsum[tc].as<u32>();        // the last one lands in the Horner table
-          if ((size_t)nseg * TG * TEAM <= TEAM_LANES_MAX)
-            hipLaunchKernelGGL(k_tree_sum_team<F>, dim3(nblk((size_t)nseg * TG * TEAM, 256)), dim3(256), TEAM_LDS(256), ts, Tin, o, nseg, tn, TM);
-          else
-            hipLaunchKernelGGL(k_tree_sum<F>, dim3(nblk((size_t)nseg * TG, 256)), dim3(256), 0, ts, Tin, o, nseg, tn, TM);
-          LAUNCHCHK();
-          Tin = o; tn = TG; tc ^= 1;
+        if (level < 8) {
+          if (t2 != tt) { HIPCHK(hipEventRecord(sl.ev_lvl[level], tt)); HIPCHK(hipStreamWaitEvent(t2, sl.ev_lvl[level], 0)); }
+          trees.push_back({Tout, G, 0, level, toff});
+        } else {
+          // (never reached with windows <= 16 bits: more than eight levels)  plain sequential tree on the tail stream
+          const u32* Tin = Tout; int tn = G, tc = 0;
+          while (tn > 1) {
+            int TM = tn >= 8 ? 8 : tn; int TG = (tn + TM - 1) / TM;
+            u32* o = TG == 1 ? tstore + (size_t)level * nseg * PW : sl.tsum[tc].as<u32>() + toff * PW;
+            hipLaunchKernelGGL(k_tree_sum<F>, dim3(nblk((size_t)nseg * TG, 256)), dim3(256), 0, tt, Tin, o, nseg, tn, TM);
+            LAUNCHCHK();
+            Tin = o; tn = TG; tc ^= 1;
+          }
         }
       }
+      tree_step();
       toff += (size_t)nseg * G;
       Ms.push_back(M);
       E = Rout; nn = G; off = 0; cur ^= 1; level++;
       if (level >= 31) return bad("msm: reduction depth");
     }
-    HIPCHK(hipEventRecord(sl.ev_tree, t2));
-    HIPCHK(hipStreamWaitEvent(tt, sl.ev_tree, 0));
+    for (bool more = true; more;) {                    // passes that are left when the last level has run
+      more = false;
+      for (auto& tr : trees) more |= tr.n > 1;
+      if (more) tree_step();
+    }
+    if (t2 != tt) { HIPCHK(hipEventRecord(sl.ev_tree, t2)); HIPCHK(hipStreamWaitEvent(tt, sl.ev_tree, 0)); }
     if (level == 0) {
       // a single bucket per window (c = 1): the bucket itself is the window sum
       HIPCHK(hipMemcpyAsync(sl.wsums.p, records, (size_t)nseg * PW * 4, hipMemcpyDeviceToDevice, tt));
@@ -874,7 +904,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   HIPCHK(hipEventRecord(sl.ev_tail, tt));
   sl.tail_pending = true;
   sl.seq = ++c->msm_calls;
-  if (!c->pipelining) HIPCHK(hipStreamWaitEvent(st, sl.ev_tail, 0));    // in-order semantics on the caller's stream
+  if (!c->pipelining && tt != st) HIPCHK(hipStreamWaitEvent(st, sl.ev_tail, 0));    // in-order semantics on the caller's stream
   if (prof) {
     HIPCHK(hipStreamSynchronize(tt));
     HIPCHK(hipStreamSynchronize(st));

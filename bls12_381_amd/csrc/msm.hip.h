@@ -628,16 +628,24 @@ constexpr int ITEM_BINS = ITEM_CAP_MAX + 1;       // bin = cap - len  (bin 0 = l
 constexpr int HEAVY_SMALL = 16;                   // heavy buckets with <= this many partials are folded by one lane
 struct ItemDesc { u32 start, len, dest; };        // entries [start, start+len) of `sorted`; dest = record index
 // ctrl[0] = #partial records handed out, ctrl[1] = #heavy buckets, ctrl[2] = #items
+// Each block handles ITEM_BLOCK_BUCKETS buckets: the per-block LDS histograms are flushed with one global atomic per
+// non-empty bin, and all blocks hit the same few dozen bins (lengths cluster around the mean load), so fewer, fatter blocks
+// mean proportionally fewer contended atomics (256 buckets per block: 55 + 48 us for 2^18 buckets; 2048: see DESIGN.md).
+constexpr int ITEM_PER_THREAD = 8;
+constexpr int ITEM_BLOCK_BUCKETS = 256 * ITEM_PER_THREAD;
 __global__ void __launch_bounds__(256) k_item_count(const u32* __restrict__ offs, u32* __restrict__ bins, u32* __restrict__ ctrl, int nb, u32 cap) {
   __shared__ u32 cnt[ITEM_BINS];
   for (u32 i = threadIdx.x; i <= cap; i += 256) cnt[i] = 0;
   __syncthreads();
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < nb) {
-    u32 load = offs[b + 1] - offs[b];
-    u32 full = load / cap, rem = load - full * cap;
-    if (full) atomicAdd(&cnt[0], full);
-    if (rem || !full) atomicAdd(&cnt[cap - rem], 1u);
+#pragma unroll
+  for (int k = 0; k < ITEM_PER_THREAD; k++) {
+    int b = blockIdx.x * ITEM_BLOCK_BUCKETS + k * 256 + threadIdx.x;
+    if (b < nb) {
+      u32 load = offs[b + 1] - offs[b];
+      u32 full = load / cap, rem = load - full * cap;
+      if (full) atomicAdd(&cnt[0], full);
+      if (rem || !full) atomicAdd(&cnt[cap - rem], 1u);
+    }
   }
   __syncthreads();
   for (u32 i = threadIdx.x; i <= cap; i += 256) if (cnt[i]) atomicAdd(&bins[i], cnt[i]);
@@ -661,34 +669,41 @@ __global__ void __launch_bounds__(256) k_item_fill(const u32* __restrict__ offs,
   const u32 ITEM_CAP = cap;
   for (u32 i = threadIdx.x; i <= cap; i += 256) cnt[i] = 0;
   __syncthreads();
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  u32 beg = 0, load = 0, full = 0, rem = 0, r_full = 0, r_rem = 0;
-  bool has_rem = false;
-  if (b < nb) {
-    beg = offs[b]; load = offs[b + 1] - beg;
-    full = load / ITEM_CAP; rem = load - full * ITEM_CAP;
-    has_rem = rem || !full;
-    if (full) r_full = atomicAdd(&cnt[0], full);
-    if (has_rem) r_rem = atomicAdd(&cnt[ITEM_CAP - rem], 1u);
+  u32 beg[ITEM_PER_THREAD], full[ITEM_PER_THREAD], rem[ITEM_PER_THREAD], r_full[ITEM_PER_THREAD], r_rem[ITEM_PER_THREAD];
+#pragma unroll
+  for (int k = 0; k < ITEM_PER_THREAD; k++) {
+    int b = blockIdx.x * ITEM_BLOCK_BUCKETS + k * 256 + threadIdx.x;
+    beg[k] = 0; full[k] = 0; rem[k] = 0; r_full[k] = 0; r_rem[k] = 0;
+    if (b < nb) {
+      beg[k] = offs[b]; u32 load = offs[b + 1] - beg[k];
+      full[k] = load / ITEM_CAP; rem[k] = load - full[k] * ITEM_CAP;
+      if (full[k]) r_full[k] = atomicAdd(&cnt[0], full[k]);
+      if (rem[k] || !full[k]) r_rem[k] = atomicAdd(&cnt[ITEM_CAP - rem[k]], 1u);
+    }
   }
   __syncthreads();
   for (u32 i = threadIdx.x; i <= cap; i += 256) base[i] = cnt[i] ? bins[i] + atomicAdd(&bcur[i], cnt[i]) : 0;
   __syncthreads();
-  if (b < nb) {
-    u32 nitems = full + (has_rem ? 1u : 0u);
-    u32 dest0 = (u32)b;
-    if (nitems > 1) {
-      dest0 = (u32)nb + atomicAdd(&ctrl[0], nitems);
-      u32 h = atomicAdd(&ctrl[1], 1u);
-      heavy[h] = make_uint4((u32)b, dest0, nitems, 0);
-    }
-    for (u32 j = 0; j < full; j++) {
-      ItemDesc d; d.start = beg + j * ITEM_CAP; d.len = ITEM_CAP; d.dest = dest0 + j;
-      items[base[0] + r_full + j] = d;
-    }
-    if (has_rem) {
-      ItemDesc d; d.start = beg + full * ITEM_CAP; d.len = rem; d.dest = dest0 + full;
-      items[base[ITEM_CAP - rem] + r_rem] = d;
+#pragma unroll
+  for (int k = 0; k < ITEM_PER_THREAD; k++) {
+    int b = blockIdx.x * ITEM_BLOCK_BUCKETS + k * 256 + threadIdx.x;
+    if (b < nb) {
+      const bool has_rem = rem[k] || !full[k];
+      u32 nitems = full[k] + (has_rem ? 1u : 0u);
+      u32 dest0 = (u32)b;
+      if (nitems > 1) {
+        dest0 = (u32)nb + atomicAdd(&ctrl[0], nitems);
+        u32 h = atomicAdd(&ctrl[1], 1u);
+        heavy[h] = make_uint4((u32)b, dest0, nitems, 0);
+      }
+      for (u32 j = 0; j < full[k]; j++) {
+        ItemDesc d; d.start = beg[k] + j * ITEM_CAP; d.len = ITEM_CAP; d.dest = dest0 + j;
+        items[base[0] + r_full[k] + j] = d;
+      }
+      if (has_rem) {
+        ItemDesc d; d.start = beg[k] + full[k] * ITEM_CAP; d.len = rem[k]; d.dest = dest0 + full[k];
+        items[base[ITEM_CAP - rem[k]] + r_rem[k]] = d;
+      }
     }
   }
 }
@@ -1193,6 +1208,42 @@ __global__ void __launch_bounds__(256) k_tree_sum_team(const u32* __restrict__ E
     acc = pt_add_team<F>(acc, e, mbox, tl);
   }
   if (live && tl == 0) store_proj<F>(out + (size_t)t * Store<F>::PROJ_WORDS, acc);
+}
+// Several independent tree-sum passes in ONE launch (the T sums of different reduction levels: level l's records become
+// available when level l has run, and every level needs log8(G_l) passes -- one launch per step carries the next pass of
+// every level that still has one, so the whole T tree finishes while the R chain is still running).
+constexpr int TREE_JOBS_MAX = 8;
+struct TreeJobs {
+  const u32* in[TREE_JOBS_MAX]; u32* out[TREE_JOBS_MAX];
+  int n[TREE_JOBS_MAX], M[TREE_JOBS_MAX], G[TREE_JOBS_MAX];
+  int first_team[TREE_JOBS_MAX + 1];          // teams of job j: [first_team[j], first_team[j + 1])
+  int njobs, nseg;
+};
+template <class F>
+__global__ void __launch_bounds__(256) k_tree_sum_team_multi(TreeJobs J) {
+  extern __shared__ u32 team_lds[];
+  __builtin_amdgcn_s_setprio(3);
+  const int tl = threadIdx.x & (TEAM - 1);
+  u32* mbox = team_lds + (threadIdx.x / TEAM) * TEAM_SLOTS * TeamTraits<F>::WORDS;
+  const int total = J.first_team[J.njobs];
+  int t = (blockIdx.x * blockDim.x + threadIdx.x) / TEAM;
+  bool live = t < total;
+  if (!live) t = total - 1;
+  int j = 0;
+#pragma unroll
+  for (int k = 1; k < TREE_JOBS_MAX; k++) if (k < J.njobs && t >= J.first_team[k]) j = k;
+  const int local = t - J.first_team[j];
+  const int G = J.G[j], n = J.n[j], M = J.M[j];
+  const int seg = local / G, g = local - seg * G;
+  const u32* E = J.in[j];
+  Proj<F> acc = pt_identity<F>();
+  for (int k = 0; k < M; k++) {
+    int i = g * M + k;
+    Proj<F> e = pt_identity<F>();
+    if (i < n) load_proj<F>(E + ((size_t)seg * n + i) * Store<F>::PROJ_WORDS, e);
+    acc = pt_add_team<F>(acc, e, mbox, tl);
+  }
+  if (live && tl == 0) store_proj<F>(J.out[j] + (size_t)local * Store<F>::PROJ_WORDS, acc);
 }
 template <class F>
 __global__ void __launch_bounds__(256) k_shift_add_team(const u32* __restrict__ x, const u32* __restrict__ y, u32* __restrict__ out, int nseg, int k) {
