@@ -59,6 +59,7 @@ struct blsgpu_ctx {
   int g1_kernel = 1;                    // G1 bucket accumulation: 1 = k_msm_accumulate<FpPolicy> (one lane per chain, 241 VGPRs, two wavefronts per SIMD;
                                         // default), 0 = k_msm_accumulate_g1 (three wavefronts per SIMD, LDS-DMA prefetch; env BLSGPU_G1_SPLIT: measured 7% slower),
                                         // 2 = lane-pair kernel (env BLSGPU_G1_PAIR: measured 12% slower)
+  bool wsum_one_lane = false;          // A/B hook (env BLSGPU_WSUM_ONE_LANE at create): the one-lane form of the bottom reduction level (G1)
   u32 item_cap = 0;                    // A/B hook (env BLSGPU_ITEM_CAP at create): entries per work item of the accumulation (0 = automatic)
   bool no_glv = false;                 // A/B hook (env BLSGPU_NO_GLV at create): plain 256-bit windows (no GLV for G1, no psi decomposition for G2)
   bool force_slow_sort = false;        // test hook (env BLSGPU_FORCE_SLOW_SORT at create): the global-atomic sort used beyond 2^24 points
@@ -373,6 +374,7 @@ extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
   c->device = device;
   c->force_slow_sort = getenv("BLSGPU_FORCE_SLOW_SORT") != nullptr;
   c->no_glv = getenv("BLSGPU_NO_GLV") != nullptr;
+  c->wsum_one_lane = getenv("BLSGPU_WSUM_ONE_LANE") != nullptr;
   if (const char* v = getenv("BLSGPU_ITEM_CAP")) { long k = atol(v); if (k >= 8 && k <= ITEM_CAP_MAX) c->item_cap = (u32)k; }
   c->g1_kernel = getenv("BLSGPU_G1_PAIR") ? 2 : getenv("BLSGPU_G1_SPLIT") ? 0 : 1;
   int rc = ctx_init(c);
@@ -841,10 +843,17 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
       u32* Tout = sl.lvlT.as<u32>() + toff * PW;
       // a level with a single group writes its T straight into the Horner table
       if (G == 1) Tout = tstore + (size_t)level * nseg * PW;
-      if ((size_t)nseg * G * TEAM <= TEAM_LANES_MAX)
+      // the two running sums of a chain (R and T) advance on two teams / two lanes, T one step behind R: M + 1 dependent
+      // additions per level instead of 2 M
+      if ((size_t)nseg * G * 2 * TEAM <= TEAM_LANES_MAX)
+        hipLaunchKernelGGL(k_wsum_level_team2<F>, dim3(nblk((size_t)nseg * G * 2 * TEAM, 256)), dim3(256),
+                           TEAM_LDS(256) + (size_t)(256 / TEAM / 2) * 3 * TeamTraits<F>::WORDS * 4, tt, E, Rout, Tout, nseg, nn, M, off);
+      else if ((size_t)nseg * G * TEAM <= TEAM_LANES_MAX)
         hipLaunchKernelGGL(k_wsum_level_team<F>, dim3(nblk((size_t)nseg * G * TEAM, 256)), dim3(256), TEAM_LDS(256), tt, E, Rout, Tout, nseg, nn, M, off);
       else if constexpr (GroupTag<F>::id == 2)
         hipLaunchKernelGGL(k_wsum_level_g2pair, dim3(nblk((size_t)nseg * G * 2, 256)), dim3(256), 0, tt, E, Rout, Tout, nseg, nn, M, off);
+      else if (!c->wsum_one_lane)
+        hipLaunchKernelGGL(k_wsum_level_pair, dim3(nblk((size_t)nseg * G * 2, 256)), dim3(256), 0, tt, E, Rout, Tout, nseg, nn, M, off);
       else
         hipLaunchKernelGGL(k_wsum_level<F>, dim3(nblk((size_t)nseg * G, 256)), dim3(256), 0, tt, E, Rout, Tout, nseg, nn, M, off);
       LAUNCHCHK();

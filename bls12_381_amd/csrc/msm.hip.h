@@ -1116,6 +1116,33 @@ __global__ void __launch_bounds__(256) k_wsum_level(const u32* __restrict__ E, u
   store_proj<F>(Rout + (size_t)t * Store<F>::PROJ_WORDS, run);
   store_proj<F>(Tout + (size_t)t * Store<F>::PROJ_WORDS, tot);
 }
+// G1 bottom level with the two running sums of a chain on TWO lanes: lane 2t keeps R (run += E_i), lane 2t+1 keeps T
+// (tot += run), one step behind -- the value of `run` travels to the partner lane by DPP.  M + 1 dependent additions per chain
+// instead of 2 M (the level is latency-bound: 2^15 chains of 16 complete additions on a chip with 2^16 wavefront slots' worth
+// of lanes).  Same group elements; the projective representatives differ from the one-lane form only by additions of the identity.
+__global__ void __launch_bounds__(256) k_wsum_level_pair(const u32* __restrict__ E, u32* __restrict__ Rout, u32* __restrict__ Tout,
+                                                         int nseg, int n, int M, int off) {
+  typedef FpPolicy F;
+  constexpr int PW = Store<F>::PROJ_WORDS;
+  __builtin_amdgcn_s_setprio(3);
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  int t = gid >> 1;
+  const bool isT = (gid & 1) != 0;
+  int G = n / M;
+  if (t >= nseg * G) return;                       // both lanes of a pair leave together
+  int seg = t / G, g = t - seg * G;
+  const u32* base = E + ((size_t)seg * n + (size_t)g * M) * PW;
+  Proj<F> acc = pt_identity<F>();
+  for (int s = 0; s <= M; s++) {
+    Proj<F> prev;                                  // the partner's sum after step s - 1 (both lanes execute the exchange)
+    prev.x = partner(acc.x); prev.y = partner(acc.y); prev.z = partner(acc.z);
+    Proj<F> e = pt_identity<F>();
+    if (!isT) { if (s < M) load_proj<F>(base + (size_t)(M - 1 - s) * PW, e); }
+    else if (s >= 1 && ((M - s) > 0 || off)) e = prev;
+    acc = pt_add<F>(acc, e);
+  }
+  store_proj<F>((isT ? Tout : Rout) + (size_t)t * PW, acc);
+}
 // G2 bottom level over lane pairs (pairlane.hip.h): chain t on lanes 2t / 2t+1, c0 / c1 coefficients; same records, same sums.
 // Half the registers of the one-lane form, and twice the lanes: the 2^16 chains of a 2^20-point MSM fill two wavefronts per SIMD.
 DEV void load_proj_pair(const u32* rec, u32 par, Proj<Fp2PairPolicy>& p) {
@@ -1188,6 +1215,36 @@ __global__ void __launch_bounds__(256) k_wsum_level_team(const u32* __restrict__
     store_proj<F>(Rout + (size_t)t * Store<F>::PROJ_WORDS, run);
     store_proj<F>(Tout + (size_t)t * Store<F>::PROJ_WORDS, tot);
   }
+}
+// the same split for the team form: teams 2t (R) and 2t+1 (T) of a block share a chain; R's running sum is handed over
+// through LDS after every step.  M + 1 team additions per chain instead of 2 M.
+template <class F>
+__global__ void __launch_bounds__(256) k_wsum_level_team2(const u32* __restrict__ E, u32* __restrict__ Rout, u32* __restrict__ Tout,
+                                                          int nseg, int n, int M, int off) {
+  extern __shared__ u32 team_lds[];
+  __builtin_amdgcn_s_setprio(3);
+  constexpr int PW = Store<F>::PROJ_WORDS, W = TeamTraits<F>::WORDS;
+  const int tl = threadIdx.x & (TEAM - 1);
+  const int team = threadIdx.x / TEAM;
+  const bool isT = (team & 1) != 0;
+  u32* mbox = team_lds + team * TEAM_SLOTS * W;
+  u32* xch = team_lds + (blockDim.x / TEAM) * TEAM_SLOTS * W + (team >> 1) * 3 * W;       // R's sum, written by team 2t, read by team 2t+1
+  int G = n / M, total = nseg * G;
+  int t = (blockIdx.x * blockDim.x + threadIdx.x) / (2 * TEAM);
+  bool live = t < total;
+  if (!live) t = total - 1;
+  int seg = t / G, g = t - seg * G;
+  const u32* base = E + ((size_t)seg * n + (size_t)g * M) * PW;
+  Proj<F> acc = pt_identity<F>();
+  for (int s = 0; s <= M; s++) {
+    Proj<F> e = pt_identity<F>();
+    if (!isT) { if (s < M) load_proj<F>(base + (size_t)(M - 1 - s) * PW, e); }
+    else if (s >= 1 && ((M - s) > 0 || off)) { TeamTraits<F>::get(xch, e.x); TeamTraits<F>::get(xch + W, e.y); TeamTraits<F>::get(xch + 2 * W, e.z); }
+    acc = pt_add_team<F>(acc, e, mbox, tl);        // (block barriers inside: every read of xch above precedes the write below)
+    if (!isT && tl == 0) { TeamTraits<F>::put(xch, acc.x); TeamTraits<F>::put(xch + W, acc.y); TeamTraits<F>::put(xch + 2 * W, acc.z); }
+    __syncthreads();
+  }
+  if (live && tl == 0) store_proj<F>((isT ? Tout : Rout) + (size_t)t * PW, acc);
 }
 template <class F>
 __global__ void __launch_bounds__(256) k_tree_sum_team(const u32* __restrict__ E, u32* __restrict__ out, int nseg, int n, int M) {
