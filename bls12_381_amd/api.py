@@ -162,9 +162,9 @@ class Context:
 
     def msm_accumulate_stats(self, enable):
         """(average ms, launches) of the accumulation kernel since the last call (HIP events on its stream); then reset and
-        switch the measurement on/off"""
+        switch the measurement off (False / 0) or on (True / 1: every launch; N: every N-th launch)"""
         avg, cnt = ctypes.c_double(), ctypes.c_uint()
-        check(self.lib.blsgpu_msm_accumulate_stats(self.h, 1 if enable else 0, ctypes.byref(avg), ctypes.byref(cnt)), "msm_accumulate_stats")
+        check(self.lib.blsgpu_msm_accumulate_stats(self.h, int(enable), ctypes.byref(avg), ctypes.byref(cnt)), "msm_accumulate_stats")
         return avg.value, cnt.value
 
     def set_profiling(self, on):

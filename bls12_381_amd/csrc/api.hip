@@ -54,7 +54,8 @@ struct blsgpu_ctx {
   int msm_c = 0;
   bool profiling = false;
   bool pipelining = false;
-  bool acc_timing = false;              // blsgpu_msm_accumulate_stats: HIP-event duration of every accumulation launch
+  int acc_timing = 0;                   // blsgpu_msm_accumulate_stats: HIP-event duration of every acc_timing-th accumulation launch (0 = off)
+  unsigned acc_tick = 0;
   double acc_ms_sum = 0.0; unsigned acc_count = 0;
   int g1_kernel = 1;                    // G1 bucket accumulation: 1 = k_msm_accumulate<FpPolicy> (one lane per chain, 241 VGPRs, two wavefronts per SIMD;
                                         // default), 0 = k_msm_accumulate_g1 (three wavefronts per SIMD, LDS-DMA prefetch; env BLSGPU_G1_SPLIT: measured 7% slower),
@@ -447,7 +448,7 @@ extern "C" int blsgpu_msm_accumulate_stats(blsgpu_ctx* c, int enable, double* av
   if (avg_ms) *avg_ms = c->acc_count ? c->acc_ms_sum / c->acc_count : 0.0;
   if (launches) *launches = c->acc_count;
   c->acc_ms_sum = 0.0; c->acc_count = 0;
-  c->acc_timing = enable != 0;
+  c->acc_timing = enable < 0 ? 0 : enable; c->acc_tick = 0;
   return BLSGPU_OK;
 }
 extern "C" int blsgpu_set_pipelining(blsgpu_ctx* c, int on) { if (!c) return bad("ctx is NULL"); c->pipelining = on != 0; return BLSGPU_OK; }
@@ -785,7 +786,9 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   hipStream_t as = c->pipelining ? c->acc_stream : st;
   if (as != ft) { HIPCHK(hipEventRecord(sl.ev_front, ft)); HIPCHK(hipStreamWaitEvent(as, sl.ev_front, 0)); }
   // 5. accumulate (grid covers the worst-case item count; surplus lanes exit on ctrl[2])
-  if (c->acc_timing) { acc_harvest(c, false); if (sl.k_pending) { hipEventSynchronize(sl.ev_k1); acc_harvest(c, false); } hipEventRecord(sl.ev_k0, as); }
+  // timing events are not free in a pipelined run (two records cost ~0.05-0.1 ms of queue time per MSM): sample every N-th launch
+  const bool time_this = c->acc_timing && (c->acc_tick++ % (unsigned)c->acc_timing) == 0;
+  if (time_this) { acc_harvest(c, false); if (sl.k_pending) { hipEventSynchronize(sl.ev_k1); acc_harvest(c, false); } hipEventRecord(sl.ev_k0, as); }
   u32* records = sl.buckets.as<u32>();
   const u32* base_rec = (merged ? bases->table : bases->rec) + first * Store<F>::AFF_WORDS;
   if constexpr (GroupTag<F>::id == 2)
@@ -800,12 +803,14 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   else
     hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(max_items, 256)), dim3(256), 0, as, base_rec, glv ? bases->endo + first * Store<F>::AFF_WORDS : (const u32*)nullptr,
                        glv ? (u32)n : 0xffffffffu, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
-  if (c->acc_timing) { hipEventRecord(sl.ev_k1, as); sl.k_pending = true; }
-  hipLaunchKernelGGL(k_msm_heavy<F>, dim3(HEAVY_SMALL_BLOCKS + 512), dim3(256), 0, as, sl.heavy.as<uint4>(), ctrl, records);
-  LAUNCHCHK();
+  if (time_this) { hipEventRecord(sl.ev_k1, as); sl.k_pending = true; }
   if (prof) hipEventRecord(c->ev[5], as);
   // ---- tail on the slot's own stream ---------------------------------------------------------------
   if (tt != as) { HIPCHK(hipEventRecord(sl.ev_acc, as)); HIPCHK(hipStreamWaitEvent(tt, sl.ev_acc, 0)); }
+  // the fold of cut buckets (almost always a no-op) belongs to the tail: on the accumulation stream it would sit between two
+  // chip-filling launches and cost a launch gap per MSM
+  hipLaunchKernelGGL(k_msm_heavy<F>, dim3(HEAVY_SMALL_BLOCKS + 512), dim3(256), 0, tt, sl.heavy.as<uint4>(), ctrl, records);
+  LAUNCHCHK();
   // 6. per-window weighted sums:  wsum = sum_g T_g + M * wsum0(R)
   {
     std::vector<int> Ms;

@@ -185,8 +185,8 @@ int blsgpu_last_msm_phase_ms(blsgpu_ctx* ctx, int phase, float* ms);
 int blsgpu_set_profiling(blsgpu_ctx* ctx, int enabled);
 /* Live duration of the bucket-accumulation kernel (the dominant kernel of an MSM) measured with HIP events on the stream
  * it is launched on, also while calls are pipelined: returns the average over the launches since the previous call and
- * their number, then resets the statistics and switches the measurement on (enable != 0) or off.  Costs two event records
- * per MSM while on. */
+ * their number, then resets the statistics and switches the measurement off (enable = 0) or on: enable = N > 0 times every
+ * N-th launch (two event records per timed launch cost ~0.05-0.1 ms of queue time in a pipelined run, so benchmarks sample). */
 int blsgpu_msm_accumulate_stats(blsgpu_ctx* ctx, int enable, double* avg_ms, unsigned* launches);
 
 /* ---- scalar field Fr (the producer side of the MSM's scalars) ----------------------- */
