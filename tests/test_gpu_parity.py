@@ -1210,3 +1210,38 @@ def test_msm_g2_psi_decomposition_boundaries(ctx, monkeypatch):
     ks2 = [r.scalar() for _ in range(n)]; ss2 = [r.scalar() for _ in range(n)]
     _msm_case(plain, 2, ks2, ss2)
     _msm_case(ctx, 2, ks2, ss2)
+
+
+def test_msm_decomposition_size_limits(ctx):
+    """the endomorphism decompositions multiply the number of sort entries (G1: 2n, G2: 4n) and the packed sort index has 24
+    bits: the largest calls that still take them -- 2^23 G1 points, 2^22 G2 points, where the index reaches 2^24 - 1 -- and the
+    first sizes past the limit (plain windows) must all agree with the discrete-log identity; uniform scalars in [0, r)"""
+    import bls12_381_amd as b
+    from bls12_381_amd import synthetic as sy
+    # G1: 2^23 (2n = 2^24, GLV) and 2^23 + 5 (plain 16 windows), one resident base set
+    n = (1 << 23) + 5
+    kb = sy.scalars(n, sy.SEED + 31); sb = sy.scalars(n, sy.SEED + 32)
+    bases = ctx.bases_from_scalars(1, kb)
+    tot = sy.dot_mod_r(kb[:1 << 23], sb[:1 << 23])
+    assert _g1_point_bytes(ctx, ctx.msm(bases, sb[:1 << 23])) == _expected_g1(tot)
+    tot = (tot + sy.dot_mod_r(kb[1 << 23:], sb[1 << 23:])) % o.R_ORDER
+    assert _g1_point_bytes(ctx, ctx.msm(bases, sb)) == _expected_g1(tot)
+    bases.free()
+    # G2: 2^22 points (4n = 2^24, psi decomposition; the images take 4 GB); a base set of 2^22 + 1 points keeps no images
+    m = 1 << 22
+    kb = sy.scalars(m + 1, sy.SEED + 41); sb = sy.scalars(m + 1, sy.SEED + 42)
+
+    def g2_bytes(out):
+        xy, inf = ctx.batch_normalize(2, out[None, :])
+        return b.G2Affine(xy[0], bool(inf[0])).to_uncompressed()
+
+    def want(t):
+        return o.g2_to_uncompressed(o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, t)))
+    bases = ctx.bases_from_scalars(2, kb[:m])
+    tot = sy.dot_mod_r(kb[:m], sb[:m])
+    assert g2_bytes(ctx.msm(bases, sb[:m])) == want(tot)
+    bases.free()
+    bases = ctx.bases_from_scalars(2, kb)
+    tot = (tot + sy.dot_mod_r(kb[m:], sb[m:])) % o.R_ORDER
+    assert g2_bytes(ctx.msm(bases, sb)) == want(tot)
+    bases.free()
