@@ -1245,3 +1245,27 @@ def test_msm_decomposition_size_limits(ctx):
     tot = (tot + sy.dot_mod_r(kb[m:], sb[m:])) % o.R_ORDER
     assert g2_bytes(ctx.msm(bases, sb)) == want(tot)
     bases.free()
+
+
+@pytest.mark.parametrize("hook,value", [("BLSGPU_G1_PAIR", "1"), ("BLSGPU_ITEM_CAP", "16"), ("BLSGPU_WSUM_ONE_LANE", "1"), ("BLSGPU_NO_GLV", "1")])
+def test_msm_alternative_paths_behind_ab_hooks(monkeypatch, hook, value):
+    """the library keeps a few alternative kernels / settings behind environment switches read at context creation (the A/B
+    experiments of DESIGN.md 9: lane-pair G1 accumulation, short work items -- every bucket cut, partial sums folded --, the
+    one-lane bottom reduction level, plain windows without the endomorphism decompositions): each must produce the same group
+    elements as the default path on the edge cases and on a medium random case, for both groups"""
+    import bls12_381_amd as b
+    monkeypatch.setenv(hook, value)
+    c = b.Context(0)
+    monkeypatch.delenv(hook)
+    r = o.SplitMix64(1234)
+    rr = o.R_ORDER
+    ks = [1, 2, 3, 0, 5, 5, 5, rr - 5, 7, rr - 7, 0, 11] + [r.scalar() for _ in range(20)]
+    ss = [0, 1, rr - 1, 12345, 9, 9, rr - 9, 9, (1 << 254), (1 << 254), 0, (1 << 16) - 1] + \
+         [(1 << (16 * i)) - 1 for i in range(1, 11)] + [(1 << 15) + (1 << (16 * i + 15)) for i in range(10)]
+    for group in (1, 2):
+        for w in (0, 7, 16):
+            _msm_case(c, group, ks, ss, window=w)
+        _msm_case(c, group, [3] * 300, [1] * 300)
+        _msm_case(c, group, [4, rr - 4, 4, 4], [77, 77, 77, 5])
+        n = 1 << (14 if group == 1 else 12)
+        _msm_case(c, group, [r.scalar() for _ in range(n)], [r.scalar() for _ in range(n)])
