@@ -200,8 +200,9 @@ def run_msm(args, e):
         step()
     drain()
     fence(e)
-    ctx.msm_accumulate_stats(4)                # HIP events around every 4th launch of the dominant kernel inside the timed region (the
-                                               # two event records cost ~0.05-0.1 ms of queue time per timed MSM in a pipelined run)
+    ctx.msm_accumulate_stats(3)                # HIP events around every 3rd launch of the dominant kernel inside the timed region (the
+                                               # two event records cost ~0.05-0.1 ms of queue time per timed MSM in a pipelined run;
+                                               # 3 is coprime to the four pipeline slots, so every slot is sampled)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -245,7 +246,7 @@ def run_msm(args, e):
             "bound": "int-valu", "kernel": "k_msm_accumulate<G1>",
             "achieved": mac32_per_launch / dur / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s",
             "frac": mac32_per_launch / dur / peak, "frac_isolated": mac32_per_launch / (float(np.mean(acc_ms)) * 1e-3) / peak, "traffic": traffic,
-            "launch_ms": dur * 1e3, "launches_timed": int(live_acc_n), "launch_sampling": "HIP events around every 4th launch of the timed region", "launch_ms_isolated": float(np.mean(acc_ms)), "mac32_per_launch": mac32_per_launch,
+            "launch_ms": dur * 1e3, "launches_timed": int(live_acc_n), "launch_sampling": "HIP events around every 3rd launch of the timed region", "launch_ms_isolated": float(np.mean(acc_ms)), "mac32_per_launch": mac32_per_launch,
             "whole_msm_frac_pipelined": (float(n) * MAC32_G1_MSM_2_20) / (dt / steps) / peak,
             "whole_msm_frac_single_call": (float(n) * MAC32_G1_MSM_2_20) / (float(np.mean(tot_ms)) * 1e-3) / peak,
             "note": "integer-VALU bound (no MFMA, HBM traffic ~13% of peak, see traffic): canonical 300 MAC32 per Fp mul, 11 Fp mul per mixed add, "

@@ -804,13 +804,14 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(max_items, 256)), dim3(256), 0, as, base_rec, glv ? bases->endo + first * Store<F>::AFF_WORDS : (const u32*)nullptr,
                        glv ? (u32)n : 0xffffffffu, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
   if (time_this) { hipEventRecord(sl.ev_k1, as); sl.k_pending = true; }
+  // the fold of cut buckets (almost always a no-op) stays on the accumulation stream: as the first kernel of the tail it made
+  // the next accumulation start ~90 us earlier, inside the previous call's bottom reduction level, and the pipelined rate FELL
+  // by 2.6 % (A/B on one box, twice: 3.57 vs 3.66*10^8 scalar-muls/s)
+  hipLaunchKernelGGL(k_msm_heavy<F>, dim3(HEAVY_SMALL_BLOCKS + 512), dim3(256), 0, as, sl.heavy.as<uint4>(), ctrl, records);
+  LAUNCHCHK();
   if (prof) hipEventRecord(c->ev[5], as);
   // ---- tail on the slot's own stream ---------------------------------------------------------------
   if (tt != as) { HIPCHK(hipEventRecord(sl.ev_acc, as)); HIPCHK(hipStreamWaitEvent(tt, sl.ev_acc, 0)); }
-  // the fold of cut buckets (almost always a no-op) belongs to the tail: on the accumulation stream it would sit between two
-  // chip-filling launches and cost a launch gap per MSM
-  hipLaunchKernelGGL(k_msm_heavy<F>, dim3(HEAVY_SMALL_BLOCKS + 512), dim3(256), 0, tt, sl.heavy.as<uint4>(), ctrl, records);
-  LAUNCHCHK();
   // 6. per-window weighted sums:  wsum = sum_g T_g + M * wsum0(R)
   {
     std::vector<int> Ms;
