@@ -47,7 +47,10 @@ struct DevBuf {
   template <class T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
-constexpr int NSLOT = 4;       // MSM calls whose tails may be in flight at once
+#ifndef BLS_NSLOT
+#define BLS_NSLOT 4
+#endif
+constexpr int NSLOT = BLS_NSLOT;       // MSM calls whose tails may be in flight at once (A/B: 3 / 4 / 6 slots)
 struct blsgpu_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
@@ -346,16 +349,21 @@ static int ctx_init(blsgpu_ctx* c) {
   for (auto& e : c->ev_fr) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   int prio_lo = 0, prio_hi = 0;
   HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-  HIPCHK(hipStreamCreateWithFlags(&c->acc_stream, hipStreamNonBlocking));
+  // A/B hooks for the stream priorities: BLSGPU_PRIO = three characters for accumulation / tail / front, each h, n or l
+  // (default "nhl": accumulation normal, tail high, front low)
+  int pr[3] = {(prio_lo + prio_hi) / 2, prio_hi, prio_lo};
+  if (const char* v = getenv("BLSGPU_PRIO"))
+    for (int i = 0; i < 3 && v[i]; i++) pr[i] = v[i] == 'h' ? prio_hi : v[i] == 'l' ? prio_lo : (prio_lo + prio_hi) / 2;
+  HIPCHK(hipStreamCreateWithPriority(&c->acc_stream, hipStreamNonBlocking, pr[0]));
   HIPCHK(hipMalloc((void**)&c->d_status, 16));
   HIPCHK(hipMemset(c->d_status, 0, 16));
   for (auto& sl : c->slot) {
     // the tail is a handful of wavefronts racing a chip-filling kernel: give its queue the highest priority
-    HIPCHK(hipStreamCreateWithPriority(&sl.tail, hipStreamNonBlocking, prio_hi));
-    HIPCHK(hipStreamCreateWithPriority(&sl.tail2, hipStreamNonBlocking, prio_hi));
+    HIPCHK(hipStreamCreateWithPriority(&sl.tail, hipStreamNonBlocking, pr[1]));
+    HIPCHK(hipStreamCreateWithPriority(&sl.tail2, hipStreamNonBlocking, pr[1]));
     for (auto& e : sl.ev_lvl) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&sl.ev_tree, hipEventDisableTiming));
-    HIPCHK(hipStreamCreateWithPriority(&sl.front, hipStreamNonBlocking, prio_lo));     // sort / items fill the gaps the accumulation leaves
+    HIPCHK(hipStreamCreateWithPriority(&sl.front, hipStreamNonBlocking, pr[2]));     // sort / items fill the gaps the accumulation leaves
     HIPCHK(hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&sl.ev_front, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&sl.ev_acc, hipEventDisableTiming));
