@@ -18,7 +18,7 @@ RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 def one(pattern):
     f = glob.glob(os.path.join(G, pattern), recursive=True)
-    return f[0] if f else None
+    return max(f, key=os.path.getmtime) if f else None        # gpurun merges every run into gpurun_out/: take the newest
 
 
 def stats_table(path, title, out):
@@ -33,7 +33,12 @@ def stats_table(path, title, out):
 def counters(d, kernel):
     """averages per launch of every counter collected for `kernel` under gpurun_out/<d>/pmc_*"""
     res = {}
-    for f in sorted(glob.glob(os.path.join(G, d, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
+    files = {}
+    for f in glob.glob(os.path.join(G, d, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        k = f[len(os.path.join(G, d)) + 1:].split(os.sep)[0]               # one file per pmc_<i> directory: the newest
+        if k not in files or os.path.getmtime(f) > os.path.getmtime(files[k]):
+            files[k] = f
+    for f in sorted(files.values()):
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if kernel in r["Kernel_Name"]:
