@@ -489,11 +489,12 @@ extern "C" int blsgpu_last_msm_phase_ms(blsgpu_ctx* c, int phase, float* ms) {
 static int bases_make_endo(blsgpu_ctx* c, blsgpu_bases* b) {
   if (!b->n) return BLSGPU_OK;
   if (b->group == 1) {
-    if (hipMalloc((void**)&b->endo, b->n * Store<FpPolicy>::AFF_WORDS * 4) != hipSuccess) { g_err = "hipMalloc(bases endo) failed"; return BLSGPU_ERR_HIP; }
+    // the images are an accelerator, not a requirement: without memory for them the MSM runs on plain 256-bit windows
+    if (hipMalloc((void**)&b->endo, b->n * Store<FpPolicy>::AFF_WORDS * 4) != hipSuccess) { (void)hipGetLastError(); b->endo = nullptr; return BLSGPU_OK; }
     hipLaunchKernelGGL(k_bases_endo, dim3(nblk(b->n, 256)), dim3(256), 0, c->stream, b->rec, b->endo, b->n);
   } else {
     if (b->n > ((size_t)1 << 22)) return BLSGPU_OK;          // 4 n must fit the sort's 24-bit indices: larger sets use plain windows
-    if (hipMalloc((void**)&b->endo, 4 * b->n * Store<Fp2Policy>::AFF_WORDS * 4) != hipSuccess) { g_err = "hipMalloc(bases endo) failed"; return BLSGPU_ERR_HIP; }
+    if (hipMalloc((void**)&b->endo, 4 * b->n * Store<Fp2Policy>::AFF_WORDS * 4) != hipSuccess) { (void)hipGetLastError(); b->endo = nullptr; return BLSGPU_OK; }
     hipLaunchKernelGGL(k_bases_endo_g2, dim3(nblk(b->n, 256)), dim3(256), 0, c->stream, b->rec, b->endo, b->n);
   }
   LAUNCHCHK();
