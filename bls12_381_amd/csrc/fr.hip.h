@@ -329,22 +329,41 @@ __global__ void __launch_bounds__(256) k_fr_tile(const u32* __restrict__ x, u32*
     for (int k = 0; k < 9; k++) lds[k * T + e] = v.l[k];
   }
   __syncthreads();
-  bool relaxed = true;                           // R-stage next (all elements A1 V2)
-  for (int lh = tl - 1; lh >= 0; lh--) {
-    const int h = 1 << lh;
+  // Two stages per round trip through LDS: lane t owns the four elements p, p + q, p + 2q, p + 3q (q = half-span of the second
+  // stage) and runs an R stage (sums kept unreduced) and an F stage (sums reduced) on them in registers, exactly like
+  // k_fr_stage2 -- half the LDS traffic and half the barriers of one stage per pass.  An odd tile depth leaves one R stage.
+  int lh = tl - 1;
+  for (; lh >= 1; lh -= 2) {
+    const int q = 1 << (lh - 1);
+    for (int t = threadIdx.x; t < T / 4; t += blockDim.x) {
+      const int i = t & (q - 1), p = ((t >> (lh - 1)) << (lh + 1)) + i;
+      FrL a0, a1, a2, a3;
+#pragma unroll
+      for (int k = 0; k < 9; k++) { a0.l[k] = lds[k * T + p]; a1.l[k] = lds[k * T + p + q]; a2.l[k] = lds[k * T + p + 2 * q]; a3.l[k] = lds[k * T + p + 3 * q]; }
+      FrL w0 = frl_load(tw + (fr_tw_off(lh) + i) * 8), w1 = frl_load(tw + (fr_tw_off(lh) + i + q) * 8);
+      FrL w2 = frl_load(tw + (fr_tw_off(lh - 1) + i) * 8);
+      // stage with half-span 2q (R): pairs (a0, a2), (a1, a3)
+      FrL b0 = frl_add(a0, a2), b2 = frl_mul(frl_sub<1>(a0, a2), w0);
+      FrL b1 = frl_add(a1, a3), b3 = frl_mul(frl_sub<1>(a1, a3), w1);
+      // stage with half-span q (F): pairs (b0, b1), (b2, b3)
+      FrL c0 = frl_reduce(frl_add(b0, b1)), c1 = frl_mul(frl_sub<2>(b0, b1), w2);
+      FrL c2 = frl_reduce(frl_add(b2, b3)), c3 = frl_mul(frl_sub<2>(b2, b3), w2);
+#pragma unroll
+      for (int k = 0; k < 9; k++) { lds[k * T + p] = c0.l[k]; lds[k * T + p + q] = c1.l[k]; lds[k * T + p + 2 * q] = c2.l[k]; lds[k * T + p + 3 * q] = c3.l[k]; }
+    }
+    __syncthreads();
+  }
+  if (lh == 0) {                                   // odd depth: one more stage (R), half-span 1
     for (int t = threadIdx.x; t < T / 2; t += blockDim.x) {
-      const int i = t & (h - 1), p = ((t >> lh) << (lh + 1)) + i;
+      const int p = t << 1;
       FrL a, b;
 #pragma unroll
-      for (int k = 0; k < 9; k++) { a.l[k] = lds[k * T + p]; b.l[k] = lds[k * T + p + h]; }
-      FrL w = frl_load(tw + (fr_tw_off(lh) + i) * 8);
-      FrL s = frl_add(a, b), d;
-      if (relaxed) d = frl_mul(frl_sub<1>(a, b), w);
-      else { d = frl_mul(frl_sub<2>(a, b), w); s = frl_reduce(s); }
+      for (int k = 0; k < 9; k++) { a.l[k] = lds[k * T + p]; b.l[k] = lds[k * T + p + 1]; }
+      FrL w = frl_load(tw + (fr_tw_off(0)) * 8);
+      FrL s2 = frl_add(a, b), d = frl_mul(frl_sub<1>(a, b), w);
 #pragma unroll
-      for (int k = 0; k < 9; k++) { lds[k * T + p] = s.l[k]; lds[k * T + p + h] = d.l[k]; }
+      for (int k = 0; k < 9; k++) { lds[k * T + p] = s2.l[k]; lds[k * T + p + 1] = d.l[k]; }
     }
-    relaxed = !relaxed;
     __syncthreads();
   }
   FrL sc;
