@@ -17,7 +17,13 @@ template <int A, int V> struct FeP { Fe<A, V> v; static constexpr int kA = A, kV
   template <int A2, int V2> DEV operator FeP<A2, V2>() const { FeP<A2, V2> r; r.v = v; return r; } };
 
 DEV bool lane_is_c1() { return (threadIdx.x & 1) != 0; }
+#ifdef BLS_DPP_OLD_ZERO
 DEV u32 dpp_swap1(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false); }
+#else
+// every lane is written (row / bank masks 0xF, a quad permutation has no invalid source lane), so the "old" operand is dead: passing
+// the source itself instead of 0 spares the v_mov_b32 that materialised the zero in front of every exchange
+DEV u32 dpp_swap1(u32 x) { return (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true); }
+#endif
 // RULE: never subtract an exchanged value -- exchange the negation and add.  The compiler's DPP-combine pass folds
 // `b - dpp(a)` into `v_subrev_u32_dpp d, a, b`, and on this toolchain / gfx950 the *rev* forms do not compute what LLVM assumes:
 // measured with inline assembly, `v_subrev_u32_dpp d, x, y quad_perm:[1,0,3,2]` returns dpp(y) - x (v_lshlrev_b32_dpp is off
