@@ -223,7 +223,9 @@ def run_msm(args, e):
     # ---- roofline of the dominant kernel, measured live with HIP events on the library's stream ----------
     roof = phases = latency = None
     if rank == 0:
-        peak = ctx.mad_throughput(2000)                          # v_mad_u64_u32 lane-ops/s = MAC32/s
+        # v_mad_u64_u32 lane-ops/s = MAC32/s; the best of three probes (a probe right after a long chip-filling run can read
+        # 10 % low, which would flatter every fraction below)
+        peak = max(ctx.mad_throughput(2000) for _ in range(3))
         ctx.set_profiling(True)
         acc_ms, tot_ms = [], []
         for _ in range(5):
