@@ -204,9 +204,14 @@ def run_msm(args, e):
                                                # two event records cost ~0.05-0.1 ms of queue time per timed MSM in a pipelined run;
                                                # 3 is coprime to the four pipeline slots, so every slot is sampled)
     t0 = time.perf_counter()
+    trace = os.environ.get("BENCH_TRACE")
     for _ in range(steps):
         step()
+        if trace:
+            sys.stderr.write("rank %d step done at %.3f s\n" % (rank, time.perf_counter() - t0))
     drain()
+    if trace:
+        sys.stderr.write("rank %d drained at %.3f s\n" % (rank, time.perf_counter() - t0))
     fence(e)
     dt = time.perf_counter() - t0
     live_acc_ms, live_acc_n = ctx.msm_accumulate_stats(False)
