@@ -810,7 +810,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     hipLaunchKernelGGL(k_msm_accumulate_g1pair, dim3(nblk(2 * max_items, 256)), dim3(256), 0, as, base_rec, glv ? bases->endo + first * Store<F>::AFF_WORDS : (const u32*)nullptr,
                        glv ? (u32)n : 0xffffffffu, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
   else
-    hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(max_items, 256)), dim3(256), 0, as, base_rec, glv ? bases->endo + first * Store<F>::AFF_WORDS : (const u32*)nullptr,
+    hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(max_items, BLS_ACC_BLOCK)), dim3(BLS_ACC_BLOCK), 0, as, base_rec, glv ? bases->endo + first * Store<F>::AFF_WORDS : (const u32*)nullptr,
                        glv ? (u32)n : 0xffffffffu, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
   if (time_this) { hipEventRecord(sl.ev_k1, as); sl.k_pending = true; }
   // the fold of cut buckets (almost always a no-op) stays on the accumulation stream: as the first kernel of the tail it made

@@ -711,11 +711,21 @@ __global__ void __launch_bounds__(256) k_item_fill(const u32* __restrict__ offs,
 // ---- 5. bucket accumulation ---------------------------------------------------------------------------
 // Point index e (31 bits): records [0, nsplit) live in `bases`, records [nsplit, ...) in `bases2` (the images under the GLV
 // endomorphism; nsplit = 0xffffffff when there is no second array).
+#ifndef BLS_ACC_BLOCK
+#define BLS_ACC_BLOCK 256
+#endif
+// wave priority of the accumulation kernels: above the sort / item kernels of the neighbouring calls (priority 0), below the tails
+// (3).  A/B on one box, default bench: 0 -> 3.67-3.69, 1 -> 3.73, 2 -> 3.71, 3 -> 3.55 *10^8 scalar-muls/s; 64- or 128-lane blocks make
+// the launch itself faster (2.59-2.67 vs 2.73 ms) and the pipeline slower (3.53-3.60), 512-lane blocks lose 20 %
+#ifndef BLS_ACC_PRIO
+#define BLS_ACC_PRIO 1
+#endif
 template <class F>
-__global__ void __launch_bounds__(256) k_msm_accumulate(const u32* __restrict__ bases, const u32* __restrict__ bases2, u32 nsplit,
+__global__ void __launch_bounds__(BLS_ACC_BLOCK) k_msm_accumulate(const u32* __restrict__ bases, const u32* __restrict__ bases2, u32 nsplit,
                                                         const u32* __restrict__ sorted,
                                                         const ItemDesc* __restrict__ items, const u32* __restrict__ ctrl,
                                                         u32* __restrict__ records) {
+  if (BLS_ACC_PRIO) __builtin_amdgcn_s_setprio(BLS_ACC_PRIO);
   u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ctrl[2]) return;
   ItemDesc d = items[t];
@@ -867,6 +877,7 @@ __global__ void __launch_bounds__(256, 2) k_msm_accumulate_g2pair(const u32* __r
                                                                u32* __restrict__ records) {
   typedef Fp2PairPolicy F;
   constexpr int AW = Store<Fp2Policy>::AFF_WORDS, PW = Store<Fp2Policy>::PROJ_WORDS;
+  if (BLS_ACC_PRIO) __builtin_amdgcn_s_setprio(BLS_ACC_PRIO);
   u32 t = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;
   if (t >= ctrl[2]) return;                     // both lanes of a pair leave together
   const u32 par = threadIdx.x & 1;
