@@ -801,7 +801,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   u32* records = sl.buckets.as<u32>();
   const u32* base_rec = (merged ? bases->table : bases->rec) + first * Store<F>::AFF_WORDS;
   if constexpr (GroupTag<F>::id == 2)
-    hipLaunchKernelGGL(k_msm_accumulate_g2pair, dim3(nblk(2 * max_items, 256)), dim3(256), 0, as, gls ? bases->endo + 4 * first * Store<F>::AFF_WORDS : base_rec,
+    hipLaunchKernelGGL(k_msm_accumulate_g2pair, dim3(nblk(2 * max_items, BLS_G2ACC_BLOCK)), dim3(BLS_G2ACC_BLOCK), 0, as, gls ? bases->endo + 4 * first * Store<F>::AFF_WORDS : base_rec,
                        sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
   else if (c->g1_kernel == 0)
     hipLaunchKernelGGL(k_msm_accumulate_g1, dim3(nblk(max_items, 256)), dim3(256), 0, as, base_rec, glv ? bases->endo + first * Store<F>::AFF_WORDS : (const u32*)nullptr,
