@@ -868,7 +868,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
       else if constexpr (GroupTag<F>::id == 2)
         hipLaunchKernelGGL(k_wsum_level_g2pair, dim3(nblk((size_t)nseg * G * 2, 256)), dim3(256), 0, tt, E, Rout, Tout, nseg, nn, M, off);
       else if (!c->wsum_one_lane)
-        hipLaunchKernelGGL(k_wsum_level_pair, dim3(nblk((size_t)nseg * G * 2, 256)), dim3(256), 0, tt, E, Rout, Tout, nseg, nn, M, off);
+        hipLaunchKernelGGL(k_wsum_level_pair, dim3(nblk((size_t)nseg * G * 2, BLS_WSUM_BLOCK)), dim3(BLS_WSUM_BLOCK), 0, tt, E, Rout, Tout, nseg, nn, M, off);
       else
         hipLaunchKernelGGL(k_wsum_level<F>, dim3(nblk((size_t)nseg * G, 256)), dim3(256), 0, tt, E, Rout, Tout, nseg, nn, M, off);
       LAUNCHCHK();

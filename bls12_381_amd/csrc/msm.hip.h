@@ -1140,7 +1140,10 @@ __global__ void __launch_bounds__(256) k_wsum_level(const u32* __restrict__ E, u
 #ifndef BLS_WSUM_PRIO
 #define BLS_WSUM_PRIO 1
 #endif
-__global__ void __launch_bounds__(256) k_wsum_level_pair(const u32* __restrict__ E, u32* __restrict__ Rout, u32* __restrict__ Tout,
+#ifndef BLS_WSUM_BLOCK
+#define BLS_WSUM_BLOCK 256
+#endif
+__global__ void __launch_bounds__(BLS_WSUM_BLOCK) k_wsum_level_pair(const u32* __restrict__ E, u32* __restrict__ Rout, u32* __restrict__ Tout,
                                                          int nseg, int n, int M, int off) {
   typedef FpPolicy F;
   constexpr int PW = Store<F>::PROJ_WORDS;
