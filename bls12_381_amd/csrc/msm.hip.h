@@ -5,17 +5,20 @@
 // i.e. 255-step double-and-add per point (src/g1.rs:754-774, src/g2.rs:825-845) folded with `Sum`
 // (src/g1.rs:161-171).  The same group element is produced here with the bucket method:
 //
-//   1. digits      scalars (32 B LE canonical integers, the output format of Scalar::to_bytes,
-//                  src/scalar.rs:284-296) -> W signed c-bit digits each; histogram of bucket loads
-//   2. scan        exclusive prefix sum of the histogram -> bucket offsets
-//   3. scatter     counting sort of (sign, point index) by (window, |digit|)
-//   4. items       buckets cut into work items of <= 128 entries, sorted by length (descending) so that
-//                  the 64 lanes of a wavefront walk items of equal length and no lane walks a long bucket
-//   5. accumulate  one lane per item: gathers its points (128 B / 256 B records) and adds them with the
-//                  exception-free mixed addition of curve.hip.h -- this is >90% of the arithmetic; partial
-//                  sums of buckets that were cut are folded by a block-level tree
-//   6. reduce      sum_k k * B_k per window by chunked running sums (log-depth recursion)
-//   7. combine     Horner over the windows (c doublings + 1 addition each)
+//   0. split       G1: GLV, k = k1 + k2 z^2 with 127-bit halves over the bases and their images under the endomorphism
+//                  (k_glv_decompose); G2: four 63-bit digits of base |x| over the images under psi^j (k_gls_decompose);
+//                  also the canonical-scalar check.  Plain 256-bit scalars when the images are not resident / too many.
+//   1.-3. sort     signed c-bit digits (DigitIter); two-level counting sort of (sign, point index) by (window, |digit|):
+//                  coarse 8 bits through per-tile LDS histograms, fine 7 bits per region in LDS (k_sort_hist / scan /
+//                  scatter / fine); beyond 2^24 entries per window set the global-atomic fallback (k_msm_digits, k_msm_scatter)
+//   4. items       buckets cut into work items of <= cap entries (cap ~ 4x the mean load), sorted by length (descending) so
+//                  that the 64 lanes of a wavefront walk items of equal length and no lane walks a long bucket
+//   5. accumulate  one lane per item (G2: one lane PAIR): gathers its points (128 B / 256 B records) and adds them with the
+//                  XYZZ mixed addition of curve.hip.h, exceptional cases exact -- this is >90% of the arithmetic; partial
+//                  sums of buckets that were cut are folded by k_msm_heavy
+//   6. reduce      sum_k k * B_k per window by chunked running sums, fan 8; the two running sums of a chain on two lanes
+//                  (bottom level) / two 8-lane teams (above); the T records of all levels tree-summed by multi-job launches
+//   7. combine     Horner over the levels (3 doublings + 1 addition each) and over the windows (c doublings + 1 addition)
 //
 // Data layout in HBM: bases are converted once at upload to the internal field form and stored as
 // 128-byte (G1) / 256-byte (G2) records, so a gather is 8 / 16 aligned 16-byte loads per lane; scalars
