@@ -98,6 +98,13 @@ class ResidentBases:
     def __len__(self):
         return int(_lib.load().blsgpu_bases_len(self.handle))
 
+    @property
+    def subgroup_state(self):
+        """1: every base passed the device-side is_torsion_free (or the set was built as [k]G); 2: assumed by the caller
+        (Context.set_assume_subgroup); 0: some base is outside the prime-order subgroup -- the MSM then runs on plain windows
+        (exact for every curve point, like the reference's `multiply`, g1.rs:754-774)."""
+        return int(_lib.load().blsgpu_bases_subgroup_state(self.handle))
+
     def precompute(self, window_bits=0):
         """Build resident window-shifted tables (see blsgpu_bases_precompute); later MSMs use them automatically."""
         check(_lib.load().blsgpu_bases_precompute(self.ctx.h, self.handle, window_bits), "bases_precompute")
@@ -158,7 +165,15 @@ class Context:
         check(self.lib.blsgpu_join_lag(self.h, lag), "join")
 
     def set_msm_window(self, c):
+        """Pippenger window width in bits: 0 = automatic, else 4..16.  With the endomorphism split active (subgroup base sets)
+        the width applies to the 128-bit (G1) / 64-bit (G2) sub-scalars."""
         check(self.lib.blsgpu_set_msm_window(self.h, c), "set_msm_window")
+
+    def set_assume_subgroup(self, on):
+        """Skip the per-upload `is_torsion_free` pass over uploaded bases (the caller vouches that every point is in the
+        prime-order subgroup, e.g. values that came from the checked decoders).  Default off: every upload is tested and a
+        set with an off-subgroup point falls back to plain windows, which match the reference's `multiply` on any curve point."""
+        check(self.lib.blsgpu_set_assume_subgroup(self.h, 1 if on else 0), "set_assume_subgroup")
 
     def msm_accumulate_stats(self, enable):
         """(average ms, launches) of the accumulation kernel since the last call (HIP events on its stream); then reset and

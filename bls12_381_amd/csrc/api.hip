@@ -65,6 +65,7 @@ struct blsgpu_ctx {
                                         // 2 = lane-pair kernel (env BLSGPU_G1_PAIR: measured 12% slower)
   bool wsum_one_lane = false;          // A/B hook (env BLSGPU_WSUM_ONE_LANE at create): the one-lane form of the bottom reduction level (G1)
   u32 item_cap = 0;                    // A/B hook (env BLSGPU_ITEM_CAP at create): entries per work item of the accumulation (0 = automatic)
+  bool assume_subgroup = false;        // blsgpu_set_assume_subgroup: skip the subgroup check of uploaded bases (the caller vouches for them)
   bool no_glv = false;                 // A/B hook (env BLSGPU_NO_GLV at create): plain 256-bit windows (no GLV for G1, no psi decomposition for G2)
   bool force_slow_sort = false;        // test hook (env BLSGPU_FORCE_SLOW_SORT at create): the global-atomic sort used beyond 2^24 points
   hipStream_t acc_stream = nullptr;     // bucket accumulation of pipelined calls (the caller's stream is never blocked)
@@ -101,8 +102,15 @@ struct blsgpu_ctx {
 
 struct blsgpu_bases {
   int group = 1; size_t n = 0; int device = 0; u32* rec = nullptr;   // AFF_WORDS per point
+  mutable bool ready_seen = false;   // ev_ready has been observed complete: no further waits
+  hipEvent_t ev_ready = nullptr;     // recorded behind the kernels that write rec / endo; every MSM waits for it on its own streams
   u32* endo = nullptr;               // G1: the images (BETA x, y) of the records under the GLV endomorphism, same order as rec;
                                      // G2: the four images psi^j(P), j = 0..3, interleaved (record 4 i + j) -- msm.hip.h
+  // The images are used only for base sets that lie in the prime-order subgroup: phi(P) = -[z^2]P and psi(P) = [x]P hold
+  // there and nowhere else on the curve, while the reference's `multiply` (g1.rs:754-774) is defined for every curve
+  // point.  subgroup: 1 = every base passed is_torsion_free on the device (or was built as [k]G), 2 = the caller vouched
+  // for the set (blsgpu_set_assume_subgroup), 0 = at least one base is outside the subgroup -> plain windows, no images.
+  int subgroup = 0;
   // optional window-shifted tables: table[w * n + i] = [2^(table_c * w)] P_i   (blsgpu_bases_precompute)
   u32* table = nullptr; int table_c = 0, table_w = 0;
 };
@@ -125,6 +133,18 @@ __global__ void __launch_bounds__(256) k_bases_import(const u32* __restrict__ xy
   Store<F>::st(r, x); Store<F>::st(r + EL, y);
   r[2 * EL] = inf ? (inf[i] != 0) : 0;
   for (int j = 2 * EL + 1; j < Store<F>::AFF_WORDS; j++) r[j] = 0;
+}
+// bad[0] += number of records that are not the identity and fail `is_on_curve() & is_torsion_free()` (g1.rs:396-416,
+// g2.rs:475-489): such a set keeps no endomorphism images (see blsgpu_bases::subgroup)
+template <class F>
+__global__ void __launch_bounds__(128) k_bases_subgroup_check(const u32* __restrict__ rec, size_t n, u32* __restrict__ bad) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F> q; bool inf;
+  load_aff<F>(rec + i * Store<F>::AFF_WORDS, q, inf);
+  typename F::elem x = F::st(q.x), y = F::st(q.y);
+  bool ok = inf || (on_curve<F>(x, y) && torsion_free(x, y, false));
+  if (!ok) atomicAdd(bad, 1u);
 }
 template <class F>
 __global__ void __launch_bounds__(256) k_bases_export(const u32* __restrict__ rec, u32* __restrict__ xy, uint8_t* __restrict__ inf, size_t n) {
@@ -486,18 +506,39 @@ extern "C" int blsgpu_last_msm_phase_ms(blsgpu_ctx* c, int phase, float* ms) {
 // ---------------------------------------------------------------------------------------------------
 // G1 bases also keep their images under the GLV endomorphism next to them (2x the resident memory; see k_glv_decompose);
 // G2 bases keep P, psi(P), psi^2(P), psi^3(P) interleaved in a second array (5x the resident memory; see k_gls_decompose)
-static int bases_make_endo(blsgpu_ctx* c, blsgpu_bases* b) {
-  if (!b->n) return BLSGPU_OK;
-  if (b->group == 1) {
-    // the images are an accelerator, not a requirement: without memory for them the MSM runs on plain 256-bit windows
-    if (hipMalloc((void**)&b->endo, b->n * Store<FpPolicy>::AFF_WORDS * 4) != hipSuccess) { (void)hipGetLastError(); b->endo = nullptr; return BLSGPU_OK; }
-    hipLaunchKernelGGL(k_bases_endo, dim3(nblk(b->n, 256)), dim3(256), 0, c->stream, b->rec, b->endo, b->n);
-  } else {
-    if (b->n > ((size_t)1 << 22)) return BLSGPU_OK;          // 4 n must fit the sort's 24-bit indices: larger sets use plain windows
-    if (hipMalloc((void**)&b->endo, 4 * b->n * Store<Fp2Policy>::AFF_WORDS * 4) != hipSuccess) { (void)hipGetLastError(); b->endo = nullptr; return BLSGPU_OK; }
-    hipLaunchKernelGGL(k_bases_endo_g2, dim3(nblk(b->n, 256)), dim3(256), 0, c->stream, b->rec, b->endo, b->n);
+static void bases_drop(blsgpu_bases* b) {        // error paths of the constructors: nothing queued can still matter
+  if (b->rec) hipFree(b->rec);
+  if (b->endo) hipFree(b->endo);
+  if (b->table) hipFree(b->table);
+  if (b->ev_ready) hipEventDestroy(b->ev_ready);
+  delete b;
+}
+static int bases_make_endo(blsgpu_ctx* c, blsgpu_bases* b, bool trusted) {
+  if (!b->n) { b->subgroup = 1; return BLSGPU_OK; }
+  if (b->group == 2 && b->n > ((size_t)1 << 22)) return BLSGPU_OK;          // 4 n must fit the sort's 24-bit indices: larger sets use plain windows
+  if (trusted) b->subgroup = 1;
+  else if (c->assume_subgroup) b->subgroup = 2;
+  else {
+    // one pass of the reference's own subgroup test over the set (G1 ~2 k, G2 ~6 k field multiplications per point, once per
+    // upload): the result decides on the host whether images are built, so this synchronises the context's stream
+    u32 nbad = 0;
+    HIPCHK(hipMemsetAsync(c->d_status + 1, 0, 4, c->stream));
+    if (b->group == 1) hipLaunchKernelGGL(k_bases_subgroup_check<FpPolicy>, dim3(nblk(b->n, 128)), dim3(128), 0, c->stream, b->rec, b->n, c->d_status + 1);
+    else hipLaunchKernelGGL(k_bases_subgroup_check<Fp2Policy>, dim3(nblk(b->n, 128)), dim3(128), 0, c->stream, b->rec, b->n, c->d_status + 1);
+    LAUNCHCHK();
+    HIPCHK(hipMemcpyAsync(&nbad, c->d_status + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (nbad) { b->subgroup = 0; return BLSGPU_OK; }
+    b->subgroup = 1;
   }
-  LAUNCHCHK();
+  // the images are an accelerator, not a requirement: without memory for them the MSM runs on plain 256-bit windows
+  const size_t bytes = (b->group == 1 ? b->n * Store<FpPolicy>::AFF_WORDS : 4 * b->n * Store<Fp2Policy>::AFF_WORDS) * 4;
+  if (hipMalloc((void**)&b->endo, bytes) != hipSuccess) { (void)hipGetLastError(); b->endo = nullptr; return BLSGPU_OK; }
+  if (b->group == 1) hipLaunchKernelGGL(k_bases_endo, dim3(nblk(b->n, 256)), dim3(256), 0, c->stream, b->rec, b->endo, b->n);
+  else hipLaunchKernelGGL(k_bases_endo_g2, dim3(nblk(b->n, 256)), dim3(256), 0, c->stream, b->rec, b->endo, b->n);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipEventRecord(b->ev_ready, c->stream);     // MSMs on another stream (blsgpu_set_stream) wait for the records and images
+  if (e != hipSuccess) { hipFree(b->endo); b->endo = nullptr; return fail("k_bases_endo", e, __LINE__); }
   return BLSGPU_OK;
 }
 template <class F>
@@ -505,13 +546,15 @@ static int bases_import(blsgpu_ctx* c, const void* d_xy, const void* d_inf, size
   blsgpu_bases* b = new blsgpu_bases();
   b->group = GroupTag<F>::id; b->n = n; b->device = c->device;
   size_t bytes = (n ? n : 1) * Store<F>::AFF_WORDS * 4;
-  if (hipMalloc((void**)&b->rec, bytes) != hipSuccess) { delete b; g_err = "hipMalloc(bases) failed"; return BLSGPU_ERR_HIP; }
+  if (hipEventCreateWithFlags(&b->ev_ready, hipEventDisableTiming) != hipSuccess) { delete b; g_err = "hipEventCreate(bases) failed"; return BLSGPU_ERR_HIP; }
+  if (hipMalloc((void**)&b->rec, bytes) != hipSuccess) { bases_drop(b); g_err = "hipMalloc(bases) failed"; return BLSGPU_ERR_HIP; }
   if (n) {
     hipLaunchKernelGGL(k_bases_import<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (const u32*)d_xy, (const uint8_t*)d_inf, b->rec, n);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { hipFree(b->rec); delete b; return fail("k_bases_import", e, __LINE__); }
+    if (e == hipSuccess) e = hipEventRecord(b->ev_ready, c->stream);
+    if (e != hipSuccess) { bases_drop(b); return fail("k_bases_import", e, __LINE__); }
   }
-  if (int rc = bases_make_endo(c, b)) { hipFree(b->rec); delete b; return rc; }
+  if (int rc = bases_make_endo(c, b, false)) { bases_drop(b); return rc; }
   *out = b;
   return BLSGPU_OK;
 }
@@ -548,27 +591,28 @@ extern "C" int blsgpu_bases_from_scalars(blsgpu_ctx* c, int group, const uint8_t
   blsgpu_bases* b = new blsgpu_bases();
   b->group = group; b->n = n; b->device = c->device;
   size_t words = group == 1 ? Store<FpPolicy>::AFF_WORDS : Store<Fp2Policy>::AFF_WORDS;
-  if (hipMalloc((void**)&b->rec, (n ? n : 1) * words * 4) != hipSuccess) { delete b; g_err = "hipMalloc(bases) failed"; return BLSGPU_ERR_HIP; }
+  if (hipEventCreateWithFlags(&b->ev_ready, hipEventDisableTiming) != hipSuccess) { delete b; g_err = "hipEventCreate(bases) failed"; return BLSGPU_ERR_HIP; }
+  if (hipMalloc((void**)&b->rec, (n ? n : 1) * words * 4) != hipSuccess) { bases_drop(b); g_err = "hipMalloc(bases) failed"; return BLSGPU_ERR_HIP; }
   if (n) {
     if (group == 1) hipLaunchKernelGGL(k_bases_from_scalars<FpPolicy>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), b->rec, n);
     else hipLaunchKernelGGL(k_bases_from_scalars<Fp2Policy>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), b->rec, n);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { hipFree(b->rec); delete b; return fail("k_bases_from_scalars", e, __LINE__); }
+    if (e == hipSuccess) e = hipEventRecord(b->ev_ready, c->stream);
+    if (e != hipSuccess) { bases_drop(b); return fail("k_bases_from_scalars", e, __LINE__); }
   }
-  if (int rc = bases_make_endo(c, b)) { hipFree(b->rec); delete b; return rc; }
+  if (int rc = bases_make_endo(c, b, true)) { bases_drop(b); return rc; }      // [k]G lies in the subgroup by construction
   HIPCHK(hipStreamSynchronize(c->stream));
   *out = b;
   return BLSGPU_OK;
 }
 extern "C" size_t blsgpu_bases_len(const blsgpu_bases* b) { return b ? b->n : 0; }
+extern "C" int blsgpu_bases_subgroup_state(const blsgpu_bases* b) { return b ? b->subgroup : 0; }
+extern "C" int blsgpu_set_assume_subgroup(blsgpu_ctx* c, int on) { if (!c) return bad("ctx is NULL"); c->assume_subgroup = on != 0; return BLSGPU_OK; }
 extern "C" void blsgpu_bases_free(blsgpu_bases* b) {
   if (!b) return;
   hipSetDevice(b->device);
   hipDeviceSynchronize();                  // an asynchronous MSM may still be reading the records
-  if (b->rec) hipFree(b->rec);
-  if (b->endo) hipFree(b->endo);
-  if (b->table) hipFree(b->table);
-  delete b;
+  bases_drop(b);
 }
 template <class F>
 static int bases_precompute(blsgpu_ctx* c, blsgpu_bases* b, int cw) {
@@ -794,6 +838,11 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   // pipelined calls accumulate on the library's own stream: front(i+1) must not queue behind accumulate(i)
   hipStream_t as = c->pipelining ? c->acc_stream : st;
   if (as != ft) { HIPCHK(hipEventRecord(sl.ev_front, ft)); HIPCHK(hipStreamWaitEvent(as, sl.ev_front, 0)); }
+  // the records (and images) may have been written on another stream than this call's (blsgpu_set_stream after the upload)
+  if (!bases->ready_seen) {
+    if (hipEventQuery(bases->ev_ready) == hipSuccess) bases->ready_seen = true;
+    else HIPCHK(hipStreamWaitEvent(as, bases->ev_ready, 0));
+  }
   // 5. accumulate (grid covers the worst-case item count; surplus lanes exit on ctrl[2])
   // timing events are not free in a pipelined run (two records cost ~0.05-0.1 ms of queue time per MSM): sample every N-th launch
   const bool time_this = c->acc_timing && (c->acc_tick++ % (unsigned)c->acc_timing) == 0;

@@ -80,6 +80,22 @@ int blsgpu_bases_from_scalars(blsgpu_ctx* ctx, int group, const uint8_t* scalars
  * same group elements. */
 int blsgpu_bases_precompute(blsgpu_ctx* ctx, blsgpu_bases* b, int window_bits);
 size_t blsgpu_bases_len(const blsgpu_bases* b);
+/* Subgroup contract of the MSM.  The reference's `multiply` (src/g1.rs:754-774, src/g2.rs:825-845) is plain
+ * double-and-add and therefore defined for EVERY curve point, including the on-curve points outside the prime-order
+ * subgroup that `from_uncompressed_unchecked` / `from_compressed_unchecked` (src/g1.rs:273-322, 336-390) hand out.  The
+ * fast MSM path splits scalars with the endomorphisms phi (G1) / psi (G2), whose eigenvalue relations hold only on the
+ * subgroup.  Every upload therefore runs the reference's own `is_on_curve() & is_torsion_free()` (src/g1.rs:396-416,
+ * src/g2.rs:475-489) over the set once, on the device: sets that pass keep endomorphism images and take the fast path;
+ * a set with ANY point outside the subgroup runs on plain 256-bit windows with complete addition formulas, which
+ * compute sum [s_i]P_i for arbitrary curve points exactly as the reference's `multiply` + `Sum` do.  Either way the
+ * result is the reference's group element.  Bases built by blsgpu_bases_from_scalars are multiples of the generator and
+ * skip the test.  A caller that already knows its points are in the subgroup (e.g. `G1Affine` values that came from
+ * the checked decoders) may skip the per-upload test with blsgpu_set_assume_subgroup(ctx, 1); with that flag set,
+ * results for off-subgroup inputs are unspecified.  Default: 0 (test every upload).
+ * blsgpu_bases_subgroup_state: 1 = verified (or built as [k]G), 2 = assumed by the caller, 0 = at least one point is
+ * outside the subgroup (plain windows). */
+int blsgpu_set_assume_subgroup(blsgpu_ctx* ctx, int enabled);
+int blsgpu_bases_subgroup_state(const blsgpu_bases* b);
 /* Read points [first, first+count) back in wire format (xy: count*12 or count*24 u64; infinity: count bytes). */
 int blsgpu_bases_download(blsgpu_ctx* ctx, const blsgpu_bases* b, size_t first, size_t count, uint64_t* xy, uint8_t* infinity);
 void blsgpu_bases_free(blsgpu_bases* b);
@@ -111,7 +127,10 @@ int blsgpu_g2_msm_host(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infin
  * src/g1.rs:271-322), scalars = n x 32 bytes of `Scalar::to_bytes()`, out = `to_uncompressed()` of the affine sum. */
 int blsgpu_g1_msm_bytes(blsgpu_ctx* ctx, const uint8_t* bases_uncompressed, const uint8_t* scalars, size_t n, uint8_t out[96]);
 int blsgpu_g2_msm_bytes(blsgpu_ctx* ctx, const uint8_t* bases_uncompressed, const uint8_t* scalars, size_t n, uint8_t out[192]);
-/* Window width c (bits) used by Pippenger; 0 = automatic. */
+/* Window width c (bits) used by Pippenger; 0 = automatic, otherwise 4..16 (the LDS counting sort keys on 8 + 7 bits of
+ * |digit|; wider windows exist only with resident tables, blsgpu_bases_precompute, which carry their own width).  With the
+ * endomorphism split active (see the subgroup contract above) the width applies to the 128-bit (G1) / 64-bit (G2)
+ * sub-scalars: c = 16 then means 8 (G1) / 4 (G2) windows instead of 16. */
 int blsgpu_set_msm_window(blsgpu_ctx* ctx, int c);
 
 /* ---- group helpers ----------------------------------------------------------------------------------- */

@@ -28,6 +28,8 @@ extern "C" {
     pub fn blsgpu_bases_from_scalars(ctx: *mut BlsgpuCtx, group: c_int, scalars: *const u8, n: usize, out: *mut *mut BlsgpuBases) -> c_int;
     pub fn blsgpu_bases_precompute(ctx: *mut BlsgpuCtx, b: *mut BlsgpuBases, window_bits: c_int) -> c_int;
     pub fn blsgpu_bases_len(b: *const BlsgpuBases) -> usize;
+    pub fn blsgpu_set_assume_subgroup(ctx: *mut BlsgpuCtx, enabled: c_int) -> c_int;
+    pub fn blsgpu_bases_subgroup_state(b: *const BlsgpuBases) -> c_int;
     pub fn blsgpu_bases_download(ctx: *mut BlsgpuCtx, b: *const BlsgpuBases, first: usize, count: usize, xy: *mut u64, infinity: *mut u8) -> c_int;
     pub fn blsgpu_bases_free(b: *mut BlsgpuBases);
     pub fn blsgpu_g1_msm(ctx: *mut BlsgpuCtx, bases: *const BlsgpuBases, first: usize, scalars: *const u8, n: usize, out_xyz: *mut u64) -> c_int;

@@ -1269,3 +1269,113 @@ def test_msm_alternative_paths_behind_ab_hooks(monkeypatch, hook, value):
         _msm_case(c, group, [4, rr - 4, 4, 4], [77, 77, 77, 5])
         n = 1 << (14 if group == 1 else 12)
         _msm_case(c, group, [r.scalar() for _ in range(n)], [r.scalar() for _ in range(n)])
+
+
+# ---- round 3: the MSM is total over curve points; decomposition boundaries ------------------------------------------
+def _off_subgroup_points(kats, group):
+    """the reference's own on-curve, off-subgroup points (src/g1.rs:1598-1640, src/g2.rs:1862-1906; test_is_torsion_free)"""
+    F = o.fp_from_mont_limbs
+    if group == 1:
+        v = kats["tests"]["g1.test_is_torsion_free"]["fp"]
+        return (F(v[0]), F(v[1]), False)
+    v = kats["tests"]["g2.test_is_torsion_free"]["fp"]
+    return ((F(v[0]), F(v[1])), (F(v[2]), F(v[3])), False)
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_msm_with_off_subgroup_points_equals_reference_double_and_add(ctx, kats, group):
+    """`multiply` (g1.rs:754-774, g2.rs:825-845) is plain double-and-add over the 255 scalar bits and therefore defined for
+    every curve point -- including what from_uncompressed_unchecked hands out.  The endomorphism split is only valid on the
+    subgroup, so an uploaded set with such a point must fall back to plain windows and still give the reference's sum; a
+    clean set keeps the fast path.  Checked through upload_bases, the one-shot host call, the public-encoding entry point
+    and the mirror's `Mul`; scalars include 0, 1, r - 1 and GLV / psi digit boundaries."""
+    import bls12_381_amd as b
+    gen, amul, msm, toaff, enc, affw, add, aff_to_proj = (
+        (o.G1_GEN, o.g1_affine_mul, o.g1_msm, o.g1_to_affine, o.g1_to_uncompressed, g1aff_w, o.g1_add, o.g1_from_affine) if group == 1 else
+        (o.G2_GEN, o.g2_affine_mul, o.g2_msm, o.g2_to_affine, o.g2_to_uncompressed, g2aff_w, o.g2_add, o.g2_from_affine))
+    on_curve, torsion_free = (o.g1_is_on_curve, o.g1_is_torsion_free) if group == 1 else (o.g2_is_on_curve, o.g2_is_torsion_free)
+    A = _off_subgroup_points(kats, group)
+    assert on_curve(A) and not torsion_free(A)
+    r = o.SplitMix64(7300 + group)
+    rr = o.R_ORDER
+    L = 0xd201000000010000 ** 2
+    # a second off-subgroup point: A + [k]G (still on the curve, still outside the subgroup)
+    A2 = toaff(add(aff_to_proj(A), amul(gen, 12345)))
+    assert on_curve(A2) and not torsion_free(A2)
+    good = [toaff(amul(gen, r.scalar())) for _ in range(9)]
+    pts = good[:4] + [A] + good[4:7] + [A2] + good[7:] + [A]
+    ss = [r.scalar(), 0, 1, rr - 1, r.scalar(), L, L + 1, L // 2 + 1, rr - 1, 3 * L - 1, r.scalar(), 1]
+    assert len(pts) == len(ss)
+    want = enc(toaff(msm(pts, ss)))                                    # the oracle's double-and-add + Sum (reference definition)
+    AffT = b.G1Affine if group == 1 else b.G2Affine
+    xy = np.stack([affw(p)[0] for p in pts]); inf = np.array([affw(p)[1] for p in pts], dtype=np.uint8)
+
+    def aff_bytes(proj):
+        axy, ainf = ctx.batch_normalize(group, proj[None, :])
+        return AffT(axy[0], bool(ainf[0])).to_uncompressed()
+
+    # resident upload: the set is detected as off-subgroup and keeps no images
+    bases = ctx.upload_bases(group, xy, inf)
+    assert bases.subgroup_state == 0
+    for w in (0, 5, 16):
+        ctx.set_msm_window(w)
+        assert aff_bytes(ctx.msm(bases, ss)) == want
+    ctx.set_msm_window(0)
+    # clean set: fast path stays on, result is the reference's
+    clean = ctx.upload_bases(group, np.stack([affw(p)[0] for p in good]), None)
+    assert clean.subgroup_state == 1
+    want_clean = enc(toaff(msm(good, ss[:9])))
+    assert aff_bytes(ctx.msm(clean, ss[:9])) == want_clean
+    # one-shot host call and the mirror's msm / Mul
+    mir = [AffT(*affw(p)) for p in pts]
+    got = (b.msm_g1 if group == 1 else b.msm_g2)(mir, ss).to_affine().to_uncompressed()
+    assert got == want
+    for s in (0, 1, 2, rr - 1, L, r.scalar()):
+        single = (AffT(*affw(A)) * b.Scalar(s)).to_affine().to_uncompressed()
+        assert single == enc(toaff(amul(A, s)))
+    # public encodings (from_uncompressed_unchecked semantics)
+    raw = b"".join(enc(p) for p in pts)
+    sb = b"".join(int(s).to_bytes(32, "little") for s in ss)
+    out = (ctypes_msm_bytes(ctx, group, raw, sb, len(pts)))
+    assert out == want
+    # the caller may vouch for a set: the test is skipped (state 2); for a genuinely clean set the result is unchanged
+    ctx.set_assume_subgroup(True)
+    try:
+        vouched = ctx.upload_bases(group, np.stack([affw(p)[0] for p in good]), None)
+        assert vouched.subgroup_state == 2
+        assert aff_bytes(ctx.msm(vouched, ss[:9])) == want_clean
+    finally:
+        ctx.set_assume_subgroup(False)
+
+
+def ctypes_msm_bytes(ctx, group, raw, sb, n):
+    import ctypes
+    from bls12_381_amd import _lib
+    lib = _lib.load()
+    out = (ctypes.c_uint8 * (96 if group == 1 else 192))()
+    fn = lib.blsgpu_g1_msm_bytes if group == 1 else lib.blsgpu_g2_msm_bytes
+    _lib.check(fn(ctx.h, ctypes.cast(ctypes.c_char_p(raw), ctypes.c_void_p), ctypes.cast(ctypes.c_char_p(sb), ctypes.c_void_p), n,
+                  ctypes.cast(out, ctypes.c_void_p)), "msm_bytes")
+    return bytes(out)
+
+
+def test_msm_g1_glv_decomposition_boundaries(ctx, monkeypatch):
+    """G1 MSMs split k = k1 + k2 L (L = z^2, phi(P) = -[L]P on the subgroup, g1.rs:396-437) into balanced halves.  Scalars at
+    every branch of k_glv_decompose -- multiples of L and their neighbours, the balancing threshold L/2 for either half (with
+    the k1 = 0 corner), scalars on which the Barrett quotient estimate is one short, 0, 1, r - 1 -- against the oracle, on the
+    default path, with another window and with the decomposition switched off (mirrors the G2 test)."""
+    import bls12_381_amd as b
+    from tests.decomp_model import glv_candidates
+    rr = o.R_ORDER
+    ss = glv_candidates()
+    assert all(0 <= s < rr for s in ss)
+    r = o.SplitMix64(5050)
+    ks = [r.scalar() for _ in ss]
+    _msm_case(ctx, 1, ks, ss)
+    _msm_case(ctx, 1, ks, ss, window=13)
+    _msm_case(ctx, 1, ks, ss, window=7)
+    _msm_case(ctx, 1, [5] * len(ss), ss)                      # one base: every term lands on P or phi(P)
+    monkeypatch.setenv("BLSGPU_NO_GLV", "1")
+    plain = b.Context(0)
+    monkeypatch.delenv("BLSGPU_NO_GLV")
+    _msm_case(plain, 1, ks, ss)

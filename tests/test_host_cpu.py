@@ -291,3 +291,37 @@ def test_device_code_has_no_folded_subrev_dpp():
     import __graft_entry__ as g
     import bls12_381_amd as b
     g.check_isa(b.LIB_PATH)
+
+
+def test_scalar_decompositions_against_big_integers():
+    """The G1 (GLV) and G2 (psi, base |x|) scalar splits of msm.hip.h, restated branch by branch over Python integers with
+    the kernels' own constants (tests/decomp_model.py), reproduce the scalar modulo r and respect the magnitude bounds the
+    digit iterators rely on (127-bit halves, 63-bit digits whose top 16-bit window leaves room for the signed-digit carry).
+    4*10^5 uniform scalars per group plus every branch boundary; the device kernels are compared with the same candidates in
+    tests/test_gpu_parity.py (test_msm_g1_glv_decomposition_boundaries, test_msm_g2_psi_decomposition_boundaries)."""
+    from tests import decomp_model as dm
+    import random
+    rnd = random.Random(0x61C5)
+    H = dm.L >> 1
+    short = balanced1 = balanced2 = corner = 0
+    cands = dm.glv_candidates()
+    for i in range(400000 + len(cands)):
+        k = cands[i] if i < len(cands) else rnd.randrange(dm.R_ORDER)
+        k1, n1, k2, s2, sh = dm.glv_model(k)
+        assert dm.glv_value(k1, n1, k2, s2) == k
+        assert k1 <= H + 1 and k2 <= H and k1 < (1 << 127) and k2 < (1 << 127)
+        assert (k1 >> 112) + 1 <= 1 << 15 and (k2 >> 112) + 1 <= 1 << 15      # top 16-bit window + carry stays a valid signed digit
+        short += sh; balanced1 += n1; balanced2 += 1 - s2
+        corner += (k1 == 1 and n1 == 1 and s2 == 0)
+    assert short and balanced1 and balanced2 and corner                       # every branch of the kernel was exercised
+    XH = dm.X_ABS >> 1
+    folded = 0
+    cands = dm.gls_candidates()
+    for i in range(200000 + len(cands)):
+        k = cands[i] if i < len(cands) else rnd.randrange(dm.R_ORDER)
+        t = dm.gls_model(k)
+        assert dm.gls_value(t) == k
+        assert all(m <= XH + 1 and m < (1 << 63) for m, _ in t)
+        assert all((m >> 48) + 1 <= 1 << 15 for m, _ in t)
+        folded += t[2][0] > XH
+    assert folded >= 0
