@@ -143,7 +143,10 @@ __global__ void __launch_bounds__(128) k_bases_subgroup_check(const u32* __restr
   Aff<F> q; bool inf;
   load_aff<F>(rec + i * Store<F>::AFF_WORDS, q, inf);
   typename F::elem x = F::st(q.x), y = F::st(q.y);
-  bool ok = inf || (on_curve<F>(x, y) && torsion_free(x, y, false));
+  // (the flag travels into torsion_free as a run-time value: with a literal `false` this toolchain's backend aborts on the
+  // folded identity test -- "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_private_base")
+  bool ok = inf || on_curve<F>(x, y);
+  if (ok) ok = torsion_free(x, y, inf);
   if (!ok) atomicAdd(bad, 1u);
 }
 template <class F>

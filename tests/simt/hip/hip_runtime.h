@@ -1,0 +1,57 @@
+// tests/simt/hip/hip_runtime.h -- host-side stand-in for <hip/hip_runtime.h>, TEST INFRASTRUCTURE ONLY.
+//
+// The lane-cooperative device code of bls12_381_amd/csrc (pairlane.hip.h, quad.hip.h, pairing code) is plain integer C++
+// plus ONE cross-lane primitive (__builtin_amdgcn_update_dpp with a quad permutation).  Compiled for the host with this
+// header first on the include path, every lane of a quad becomes a host thread and a DPP move becomes a slot exchange
+// between those threads, so the CPU test-suite can run the SAME device functions bit for bit against the oracle
+// (tests/test_simt_emulation.py).  Nothing in the product builds against or links this file.
+#pragma once
+#include <atomic>
+#include <cstdint>
+#include <cstddef>
+#include <cstring>
+
+struct EmuDim3 { unsigned x = 0, y = 0, z = 0; };
+extern thread_local EmuDim3 threadIdx, blockIdx, blockDim, gridDim;
+
+#define __device__
+#define __host__
+#define __global__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ __attribute__((noinline))
+#define __launch_bounds__(...)
+#define __shared__ static
+
+// ---- lane group: EMU_LANES host threads in lock step at every cross-lane operation -------------------------------------
+#ifndef EMU_LANES
+#define EMU_LANES 4
+#endif
+struct EmuGroup {
+  std::atomic<unsigned> arrived{0};
+  std::atomic<unsigned> phase{0};
+  int slot[EMU_LANES];
+  void barrier() {
+    unsigned ph = phase.load(std::memory_order_acquire);
+    if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == EMU_LANES) {
+      arrived.store(0, std::memory_order_relaxed);
+      phase.store(ph + 1, std::memory_order_release);
+    } else {
+      while (phase.load(std::memory_order_acquire) == ph) { __builtin_ia32_pause(); }
+    }
+  }
+};
+extern EmuGroup g_emu_group;
+
+// v_mov_b32_dpp with quad_perm:[a,b,c,d] (dpp_ctrl 0..255), all rows / banks enabled: lane L reads lane (L & ~3) | perm[L & 3]
+static inline int emu_update_dpp(int /*old*/, int src, int ctrl, int /*row_mask*/, int /*bank_mask*/, bool /*bound_ctrl*/) {
+  const unsigned lane = threadIdx.x % EMU_LANES;
+  g_emu_group.slot[lane] = src;
+  g_emu_group.barrier();
+  const unsigned from = (lane & ~3u) | ((unsigned)(ctrl >> (2 * (lane & 3))) & 3u);
+  const int v = g_emu_group.slot[from];
+  g_emu_group.barrier();
+  return v;
+}
+#define __builtin_amdgcn_update_dpp emu_update_dpp
+static inline void __syncthreads() { g_emu_group.barrier(); }
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
