@@ -12,6 +12,7 @@
 #include "../../include/bls12_381_hip.h"
 #include "msm.hip.h"
 #include "pairing.hip.h"
+#include "quad.hip.h"
 #include "fr.hip.h"
 #include "h2c.hip.h"
 #include "codec.hip.h"
@@ -65,6 +66,7 @@ struct blsgpu_ctx {
                                         // 2 = lane-pair kernel (env BLSGPU_G1_PAIR: measured 12% slower)
   bool wsum_one_lane = false;          // A/B hook (env BLSGPU_WSUM_ONE_LANE at create): the one-lane form of the bottom reduction level (G1)
   u32 item_cap = 0;                    // A/B hook (env BLSGPU_ITEM_CAP at create): entries per work item of the accumulation (0 = automatic)
+  int pairing_layout = 2;              // lanes per pairing of the batched kernels: 2 = lane pair (pairing.hip.h), 4 = quad (quad.hip.h); env BLSGPU_PAIRING_LAYOUT at create
   bool assume_subgroup = false;        // blsgpu_set_assume_subgroup: skip the subgroup check of uploaded bases (the caller vouches for them)
   bool no_glv = false;                 // A/B hook (env BLSGPU_NO_GLV at create): plain 256-bit windows (no GLV for G1, no psi decomposition for G2)
   bool force_slow_sort = false;        // test hook (env BLSGPU_FORCE_SLOW_SORT at create): the global-atomic sort used beyond 2^24 points
@@ -406,6 +408,7 @@ extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
   c->device = device;
   c->force_slow_sort = getenv("BLSGPU_FORCE_SLOW_SORT") != nullptr;
   c->no_glv = getenv("BLSGPU_NO_GLV") != nullptr;
+  if (const char* v = getenv("BLSGPU_PAIRING_LAYOUT")) c->pairing_layout = (v[0] == 'q' || v[0] == '4') ? 4 : 2;
   c->wsum_one_lane = getenv("BLSGPU_WSUM_ONE_LANE") != nullptr;
   if (const char* v = getenv("BLSGPU_ITEM_CAP")) { long k = atol(v); if (k >= 8 && k <= ITEM_CAP_MAX) c->item_cap = (u32)k; }
   c->g1_kernel = getenv("BLSGPU_G1_PAIR") ? 2 : getenv("BLSGPU_G1_SPLIT") ? 0 : 1;
@@ -1135,6 +1138,7 @@ static int elem_op(blsgpu_ctx* c, int words, int kind, int op, const uint64_t* a
   const u32* bp = b ? c->io_b.as<u32>() : nullptr;
   if (kind == 1) hipLaunchKernelGGL(k_fp_op, dim3(nblk(n, 256)), dim3(256), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
   else if (kind == 2) hipLaunchKernelGGL(k_fp2_op, dim3(nblk(n, 256)), dim3(256), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
+  else if (c->pairing_layout == 4 && op != 3) hipLaunchKernelGGL(k_fp12_op_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
   else hipLaunchKernelGGL(k_fp12_op, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
   LAUNCHCHK();
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -1150,7 +1154,8 @@ extern "C" int blsgpu_fp2_op(blsgpu_ctx* c, int op, const uint64_t* a, const uin
   return elem_op(c, 24, 2, op, a, b, n, out);
 }
 extern "C" int blsgpu_fp12_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
-  if (!(op == 0 || op == 3 || op == 4 || op == 7 || op == 8 || op == 9)) return bad("fp12_op: unknown op");
+  if (!(op == 0 || op == 3 || op == 4 || op == 7 || op == 8 || op == 9 || op == 10)) return bad("fp12_op: unknown op");
+  if (op == 10 && c && c->pairing_layout != 4) return bad("fp12_op: op 10 (cyclotomic exponentiation) exists in the quad layout only");
   return elem_op(c, 144, 12, op, a, b, n, out);
 }
 template <class F>
@@ -1392,6 +1397,12 @@ extern "C" int blsgpu_fr_ntt(blsgpu_ctx* c, uint64_t* data, int log_n, int inver
 // ---------------------------------------------------------------------------------------------------
 static int pairing_launch(blsgpu_ctx* c, int mode, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) {
   // mode 0: full pairing, 1: Miller loop only
+  if (c->pairing_layout == 4) {
+    hipLaunchKernelGGL(k_pairing_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, mode, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2,
+                       (const uint8_t*)g2inf, (u32*)out, n);
+    LAUNCHCHK();
+    return BLSGPU_OK;
+  }
   hipLaunchKernelGGL(k_pairing, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, mode, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2,
                      (const uint8_t*)g2inf, (u32*)out, n);
   LAUNCHCHK();
@@ -1437,7 +1448,8 @@ extern "C" int blsgpu_final_exponentiation_device(blsgpu_ctx* c, const void* in,
   if (!c || (n && (!in || !out))) return bad("final_exponentiation: NULL argument");
   if (!n) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
-  hipLaunchKernelGGL(k_final_exp, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)in, (u32*)out, n);
+  if (c->pairing_layout == 4) hipLaunchKernelGGL(k_final_exp_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, (const u32*)in, (u32*)out, n);
+  else hipLaunchKernelGGL(k_final_exp, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)in, (u32*)out, n);
   LAUNCHCHK();
   return BLSGPU_OK;
 }
@@ -1507,7 +1519,8 @@ extern "C" int blsgpu_final_exponentiation_batch(blsgpu_ctx* c, const uint64_t* 
   HIPCHK(hipSetDevice(c->device));
   if (c->io_a.reserve(n * 576) || c->io_out.reserve(n * 576)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
   HIPCHK(hipMemcpyAsync(c->io_a.p, in, n * 576, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_final_exp, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, c->io_a.as<u32>(), c->io_out.as<u32>(), n);
+  if (c->pairing_layout == 4) hipLaunchKernelGGL(k_final_exp_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, c->io_a.as<u32>(), c->io_out.as<u32>(), n);
+  else hipLaunchKernelGGL(k_final_exp, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, c->io_a.as<u32>(), c->io_out.as<u32>(), n);
   LAUNCHCHK();
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, n * 576, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));

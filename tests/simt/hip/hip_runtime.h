@@ -55,3 +55,4 @@ static inline int emu_update_dpp(int /*old*/, int src, int ctrl, int /*row_mask*
 #define __builtin_amdgcn_update_dpp emu_update_dpp
 static inline void __syncthreads() { g_emu_group.barrier(); }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)

@@ -1379,3 +1379,46 @@ def test_msm_g1_glv_decomposition_boundaries(ctx, monkeypatch):
     plain = b.Context(0)
     monkeypatch.delenv("BLSGPU_NO_GLV")
     _msm_case(plain, 1, ks, ss)
+
+
+# ---- round 3: the quad-lane pairing kernels (quad.hip.h) ----------------------------------------------------------------
+@pytest.fixture(scope="module")
+def layout_contexts():
+    """one context per pairing layout (lane pair / quad); the layout is fixed when a context is created"""
+    import bls12_381_amd as b
+    ctxs = {}
+    for name in ("pair", "quad"):
+        os.environ["BLSGPU_PAIRING_LAYOUT"] = name
+        try:
+            ctxs[name] = b.Context(0)
+        finally:
+            os.environ.pop("BLSGPU_PAIRING_LAYOUT")
+    return ctxs
+
+
+def test_quad_layout_miller_and_pairing_match_pair_layout_and_oracle(layout_contexts):
+    """the quad kernels against (i) the oracle on a few pairs incl. identities on either side, raw Miller values and full
+    pairings, (ii) the lane-pair kernels limb for limb on 4099 pairs (odd size: a partially filled last block)"""
+    r = o.SplitMix64(3303)
+    n = 6
+    P = [o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, r.scalar())) for _ in range(n)]
+    Q = [o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, r.scalar())) for _ in range(n)]
+    P[2] = o.G1_IDENTITY_AFF; Q[4] = o.G2_IDENTITY_AFF
+    g1 = np.stack([g1aff_w(p)[0] for p in P]); g1f = np.array([g1aff_w(p)[1] for p in P], dtype=np.uint8)
+    g2 = np.stack([g2aff_w(q)[0] for q in Q]); g2f = np.array([g2aff_w(q)[1] for q in Q], dtype=np.uint8)
+    q = layout_contexts["quad"]
+    ml = q.miller_loop_batch(g1, g1f, g2, g2f)
+    gt = q.pairing_batch(g1, g1f, g2, g2f)
+    for i in range(n):
+        ident = P[i][2] or Q[i][2]
+        want_ml = o.FP12_ONE if ident else o.miller_loop(P[i], Q[i])
+        assert np.array_equal(ml[i], fp12w(want_ml)), i
+        assert np.array_equal(gt[i], fp12w(o.pairing(P[i], Q[i]))), i
+    assert np.array_equal(q.final_exponentiation_batch(ml), gt)
+    # bulk: both layouts, same inputs
+    nb = 4099
+    ka = [r.scalar() for _ in range(nb)]; kq = [r.scalar() for _ in range(nb)]
+    p = layout_contexts["pair"]
+    bxy, _ = p.bases_from_scalars(1, ka).download(); qxy, _ = p.bases_from_scalars(2, kq).download()
+    assert np.array_equal(q.miller_loop_batch(bxy, None, qxy, None), p.miller_loop_batch(bxy, None, qxy, None))
+    assert np.array_equal(q.pairing_batch(bxy, None, qxy, None), p.pairing_batch(bxy, None, qxy, None))

@@ -1,0 +1,74 @@
+"""The lane-cooperative pairing kernels, compiled for the HOST and run one thread per lane (tests/simt), against the oracle.
+
+The GPU box is where these kernels are timed and tested at size (tests/test_gpu_parity.py); this file lets the CPU suite run
+the very same device functions -- pair-lane and quad-lane towers, Miller loop, final exponentiation -- bit for bit against
+the oracle, so that a change in the tower code is checked before it ever reaches a GPU.  The emulation library is test
+infrastructure: it is built into build/ (git-ignored) from tests/simt/emu_pairing.cpp and is never loaded by the product."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import bls12_381_ref as o
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+LIB = os.path.join(ROOT, "build", "libemu_test.so")
+
+
+def fpw(x):
+    return np.array(o.fp_to_mont_limbs(x), dtype=np.uint64)
+
+
+def fp12w(f):
+    return np.concatenate([fpw(c) for c in o.fp12_flatten(f)])
+
+
+def vp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    if not os.path.exists(CLANG):
+        pytest.skip("no host clang++ in this image")
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    src = os.path.join(ROOT, "tests", "simt", "emu_pairing.cpp")
+    csrc = os.path.join(ROOT, "bls12_381_amd", "csrc")
+    deps = [src, os.path.join(ROOT, "tests", "simt", "hip", "hip_runtime.h")] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call([CLANG, "-O1", "-std=c++17", "-pthread", "-fPIC", "-shared", "-Wno-unused-value", "-Wno-psabi", "-DEMU_WITH_QUAD",
+                               "-I" + os.path.join(ROOT, "tests", "simt"), "-I" + csrc, src, "-o", LIB])
+    return ctypes.CDLL(LIB)
+
+
+def _pairs(seed, n):
+    r = o.SplitMix64(seed)
+    P = [o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, r.scalar())) for _ in range(n)]
+    Q = [o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, r.scalar())) for _ in range(n)]
+    g1 = np.concatenate([np.concatenate([fpw(p[0]), fpw(p[1])]) for p in P])
+    g2 = np.concatenate([np.concatenate([fpw(q[0][0]), fpw(q[0][1]), fpw(q[1][0]), fpw(q[1][1])]) for q in Q])
+    return P, Q, g1, g2
+
+
+def test_emulated_pair_lane_pairing_matches_oracle(emu):
+    """validates the emulation itself on the round-1/2 kernels: k_pairing on one quad = two lane pairs"""
+    P, Q, g1, g2 = _pairs(11, 2)
+    out = np.zeros(2 * 72, dtype=np.uint64)
+    emu.emu_pair_pairing(1, vp(g1), vp(g2), vp(out), ctypes.c_size_t(2))
+    for i in range(2):
+        assert np.array_equal(out[72 * i:72 * i + 72], fp12w(o.miller_loop(P[i], Q[i])))
+    emu.emu_pair_pairing(0, vp(g1), vp(g2), vp(out), ctypes.c_size_t(2))
+    for i in range(2):
+        assert np.array_equal(out[72 * i:72 * i + 72], fp12w(o.pairing(P[i], Q[i])))
+
+
+def test_emulated_quad_miller_loop_matches_oracle(emu):
+    """quad.hip.h: raw Miller value of one pairing spread over four lanes == the reference's (pairings.rs:668-770)"""
+    for seed in (12, 13):
+        P, Q, g1, g2 = _pairs(seed, 1)
+        out = np.zeros(72, dtype=np.uint64)
+        emu.emu_quad_miller(vp(g1), vp(g2), vp(out), ctypes.c_size_t(1))
+        assert np.array_equal(out, fp12w(o.miller_loop(P[0], Q[0])))
