@@ -60,6 +60,10 @@ SIGNATURES = {
     "blsgpu_g1_msm_many_device": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_sz, c_vp]),
     "blsgpu_g2_msm_many_device": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_sz, c_vp]),
     "blsgpu_set_msm_window": (c_int, [c_vp, c_int]),
+    "blsgpu_g1_mul_batch": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_g2_mul_batch": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_g1_mul_batch_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_g2_mul_batch_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g1_sum": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g2_sum": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g1_sum_device": (c_int, [c_vp, c_vp, c_sz, c_vp]),

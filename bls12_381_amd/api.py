@@ -269,6 +269,24 @@ class Context:
         check(fn(self.h, _ptr(xy), _ptr(inf), _ptr(s), xy.shape[0], _ptr(out)), "msm_host")
         return out
 
+    def mul_batch(self, group, xy, infinity, scalars):
+        """out[i] = scalars[i] * points[i]: n affine points (n, 12|24) + n scalars -> (n, 18|36) projective wire limbs
+        (`&G1Affine * &Scalar` element-wise, g1.rs:573-579 / g2.rs:626-632; exact for every curve point)."""
+        w = 12 if group == 1 else 24
+        xy = _u64(xy, (-1, w))
+        s = scalars_to_bytes(scalars)
+        if s.shape[0] != xy.shape[0]:
+            raise ValueError("points and scalars differ in length")
+        inf = _flags(infinity, xy.shape[0])
+        out = np.zeros((xy.shape[0], 18 if group == 1 else 36), dtype=np.uint64)
+        fn = self.lib.blsgpu_g1_mul_batch if group == 1 else self.lib.blsgpu_g2_mul_batch
+        check(fn(self.h, _ptr(xy), _ptr(inf), _ptr(s), xy.shape[0], _ptr(out)), "mul_batch")
+        return out
+
+    def mul_batch_device(self, group, d_xy, d_inf, d_scalars, n, d_out):
+        fn = self.lib.blsgpu_g1_mul_batch_device if group == 1 else self.lib.blsgpu_g2_mul_batch_device
+        check(fn(self.h, ctypes.c_void_p(d_xy), ctypes.c_void_p(d_inf) if d_inf else None, ctypes.c_void_p(d_scalars), n, ctypes.c_void_p(d_out)), "mul_batch_device")
+
     # -- group helpers -----------------------------------------------------------------------------------
     def point_sum(self, group, xyz):
         w = 18 if group == 1 else 36
@@ -574,10 +592,20 @@ class G1Affine(_Group):
         return self._PROJ(np.concatenate([self.xy, z]))
 
     def __mul__(self, s):
-        """`&G1Affine * &Scalar` (g1.rs:573-579): a 1-term MSM on the GPU."""
+        """`&G1Affine * &Scalar` (g1.rs:573-579): the batched variable-base kernel with one element."""
         ctx = default_context()
-        out = ctx.msm_host(self.G, self.xy[None, :], np.array([self.infinity], dtype=np.uint8), [s])
-        return self._PROJ(out)
+        out = ctx.mul_batch(self.G, self.xy[None, :], np.array([self.infinity], dtype=np.uint8), [s])
+        return self._PROJ(out[0])
+
+    @classmethod
+    def mul_batch(cls, points, scalars):
+        """points.iter().zip(scalars).map(|(p, s)| p * s) as ONE device call: [G1Projective] (`Mul` over slices)."""
+        points = list(points)
+        if not points:
+            return []
+        xy = np.stack([p.xy for p in points]); inf = np.array([p.infinity for p in points], dtype=np.uint8)
+        out = default_context().mul_batch(cls.G, xy, inf, scalars)
+        return [cls._PROJ(o) for o in out]
 
     # -- encodings (src/notes/serialization.rs; g1.rs:221-260, g2.rs:254-299) --
     def to_uncompressed(self):

@@ -13,6 +13,7 @@
 #include "msm.hip.h"
 #include "pairing.hip.h"
 #include "quad.hip.h"
+#include "mulbatch.hip.h"
 #include "fr.hip.h"
 #include "h2c.hip.h"
 #include "codec.hip.h"
@@ -66,7 +67,8 @@ struct blsgpu_ctx {
                                         // 2 = lane-pair kernel (env BLSGPU_G1_PAIR: measured 12% slower)
   bool wsum_one_lane = false;          // A/B hook (env BLSGPU_WSUM_ONE_LANE at create): the one-lane form of the bottom reduction level (G1)
   u32 item_cap = 0;                    // A/B hook (env BLSGPU_ITEM_CAP at create): entries per work item of the accumulation (0 = automatic)
-  int pairing_layout = 2;              // lanes per pairing of the batched kernels: 2 = lane pair (pairing.hip.h), 4 = quad (quad.hip.h); env BLSGPU_PAIRING_LAYOUT at create
+  int pairing_layout = 4;              // lanes per pairing of pairing / Miller loop / final exponentiation batches: 4 = quad (quad.hip.h, default: no hot-loop scratch,
+                                       // half the latency of small batches, +2..11 % pairings/s up to 2^16), 2 = lane pair (pairing.hip.h); env BLSGPU_PAIRING_LAYOUT=pair|quad at create
   bool assume_subgroup = false;        // blsgpu_set_assume_subgroup: skip the subgroup check of uploaded bases (the caller vouches for them)
   bool no_glv = false;                 // A/B hook (env BLSGPU_NO_GLV at create): plain 256-bit windows (no GLV for G1, no psi decomposition for G2)
   bool force_slow_sort = false;        // test hook (env BLSGPU_FORCE_SLOW_SORT at create): the global-atomic sort used beyond 2^24 points
@@ -1055,6 +1057,40 @@ static int msm_oneshot(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, co
 }
 extern "C" int blsgpu_g1_msm_host(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) { return msm_oneshot<FpPolicy>(c, xy, inf, s, n, out); }
 extern "C" int blsgpu_g2_msm_host(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) { return msm_oneshot<Fp2Policy>(c, xy, inf, s, n, out); }
+
+// ---------------------------------------------------------------------------------------------------
+// batched variable-base scalar multiplication (mulbatch.hip.h): out[i] = [s_i] P_i, N in -> N out
+// ---------------------------------------------------------------------------------------------------
+template <class F>
+static int mul_batch_device(blsgpu_ctx* c, const void* d_xy, const void* d_inf, const void* d_scalars, size_t n, void* d_out) {
+  if (!c || (n && (!d_xy || !d_scalars || !d_out))) return bad("mul_batch: NULL argument");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_mul_batch<F>, dim3(nblk(n * MbIO<F>::LANES, 256)), dim3(256), 0, c->stream, (const u32*)d_xy, (const uint8_t*)d_inf, (const u32*)d_scalars,
+                     (u32*)d_out, n, c->d_status);
+  LAUNCHCHK();
+  return BLSGPU_OK;
+}
+template <class F>
+static int mul_batch_host(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* scalars, size_t n, uint64_t* out) {
+  if (!c || (n && (!xy || !scalars || !out))) return bad("mul_batch: NULL argument");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  constexpr size_t WB = MbIO<F>::WW * 4;
+  if (c->io_a.reserve(n * 2 * WB) || c->io_b.reserve(n * 32) || c->flags_a.reserve(n) || c->io_out.reserve(n * 3 * WB)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  HIPCHK(hipMemcpyAsync(c->io_a.p, xy, n * 2 * WB, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->io_b.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+  if (inf) HIPCHK(hipMemcpyAsync(c->flags_a.p, inf, n, hipMemcpyHostToDevice, c->stream));
+  int rc = mul_batch_device<F>(c, c->io_a.p, inf ? c->flags_a.p : nullptr, c->io_b.p, n, c->io_out.p);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(out, c->io_out.p, n * 3 * WB, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return take_status(c);
+}
+extern "C" int blsgpu_g1_mul_batch(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) { return mul_batch_host<FpPolicy>(c, xy, inf, s, n, out); }
+extern "C" int blsgpu_g2_mul_batch(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) { return mul_batch_host<Fp2PairPolicy>(c, xy, inf, s, n, out); }
+extern "C" int blsgpu_g1_mul_batch_device(blsgpu_ctx* c, const void* xy, const void* inf, const void* s, size_t n, void* out) { return mul_batch_device<FpPolicy>(c, xy, inf, s, n, out); }
+extern "C" int blsgpu_g2_mul_batch_device(blsgpu_ctx* c, const void* xy, const void* inf, const void* s, size_t n, void* out) { return mul_batch_device<Fp2PairPolicy>(c, xy, inf, s, n, out); }
 
 // ---------------------------------------------------------------------------------------------------
 // group helpers

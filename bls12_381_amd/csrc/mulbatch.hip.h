@@ -1,0 +1,92 @@
+// mulbatch.hip.h -- batched variable-base scalar multiplication: N (point, scalar) pairs in, N points out.
+//
+// Reference: the crate's unit operation `&G1Affine * &Scalar` / `&G1Projective * &Scalar` (src/g1.rs:556-594 -> `multiply`
+// :754-774: 255 x (double, add, select) over `Scalar::to_bytes()`), the same for G2 (src/g2.rs:609-647, 825-845); the
+// criterion points "G1 scalar multiplication" etc. of benches/groups.rs:44,89,113,158.  The reference's result is a group
+// element; its projective representative depends on the addition chain, so results are compared after affine conversion
+// (SURVEY.md "five facts" 2) -- as for the MSM.
+//
+// One scalar multiplication per lane (G1) or per lane pair (G2, pairlane.hip.h), signed 4-bit fixed windows:
+//   table [1..8] P built with 4 doublings + 3 additions, kept in per-lane scratch (8 x 42 words; the run-time index makes
+//   it a gather from scratch, ~1 % of the time), then 64 windows of 4 doublings + ONE complete addition each (a zero digit
+//   adds the identity, which the complete formulas of curve.hip.h take like any other point: no divergence).
+// 256 doublings x 8 + 67 additions x 12 = 2 852 field multiplications against the reference's 255 x (8 + 12) = 5 100.
+// The complete RCB formulas make the result exact for EVERY curve point (identity, points outside the subgroup that the
+// unchecked decoders hand out, scalars 0 and r - 1): no endomorphism is used here, so there is no subgroup precondition.
+#pragma once
+#include "msm.hip.h"
+
+namespace bls {
+
+template <class F> struct MbIO;
+template <> struct MbIO<FpPolicy> {
+  static constexpr int LANES = 1, WW = 12;
+  static DEV FpPolicy::elem load(const u32* w) { return FpPolicy::st(fe_from_ref(w)); }
+  template <class T> static DEV void save(const T& a, u32* w) { fe_to_ref(a, w); }
+};
+template <> struct MbIO<Fp2PairPolicy> {
+  static constexpr int LANES = 2, WW = 24;
+  static DEV Fp2PairPolicy::elem load(const u32* w) { Fp2PairPolicy::elem r; r.v = (Fe<1, VS2>)fe_from_ref(w + (lane_is_c1() ? 12 : 0)); return r; }
+  template <class T> static DEV void save(const T& a, u32* w) { fe_to_ref(a.v, w + (lane_is_c1() ? 12 : 0)); }
+};
+
+// out[i] = [scalars[i]] (xy[i], inf[i])   as a projective point in wire limbs (X | Y | Z)
+template <class F>
+__global__ void __launch_bounds__(256, 2)
+k_mul_batch(const u32* __restrict__ xy, const uint8_t* __restrict__ inf, const u32* __restrict__ scalars, u32* __restrict__ out, size_t n,
+            u32* __restrict__ status) {
+  constexpr int LANES = MbIO<F>::LANES, WW = MbIO<F>::WW;
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES;
+  if (i >= n) return;
+  u32 s[8];
+  {
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
+    uint4 a = sp[0], b = sp[1];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+  }
+  if (!scalar_is_canonical(s)) atomicOr(status, 1u);          // no `Scalar` has such bytes (scalar.rs:256-280): reported, result unspecified
+  // signed digits d_w in [-8, 8], k = sum d_w 16^w; k < 2^255 leaves the top window at most 7 + carry: no 65th window
+  u32 mag[8], sgn[2] = {0, 0};
+  {
+    u32 carry = 0;
+#pragma unroll
+    for (int w = 0; w < 64; w++) {
+      u32 d = ((s[w >> 3] >> ((w & 7) * 4)) & 15u) + carry;
+      const u32 over = d > 8u ? 1u : 0u;
+      d = over ? 16u - d : d;
+      carry = over;
+      if ((w & 7) == 0) mag[w >> 3] = 0;
+      mag[w >> 3] |= d << ((w & 7) * 4);
+      sgn[w >> 5] |= over << (w & 31);
+    }
+  }
+  Proj<F> tab[8];
+  {
+    Proj<F> p;
+    p.x = MbIO<F>::load(xy + i * 2 * WW); p.y = MbIO<F>::load(xy + i * 2 * WW + WW);
+    p.z = (inf && inf[i]) ? F::zero() : F::one();
+    tab[0] = p;
+    tab[1] = pt_double<F>(p);
+    tab[2] = pt_add<F>(tab[1], p);
+    tab[3] = pt_double<F>(tab[1]);
+    tab[4] = pt_add<F>(tab[3], p);
+    tab[5] = pt_double<F>(tab[2]);
+    tab[6] = pt_add<F>(tab[5], p);
+    tab[7] = pt_double<F>(tab[3]);
+  }
+  Proj<F> acc = pt_identity<F>();
+#pragma nounroll
+  for (int w = 63; w >= 0; w--) {
+    if (w != 63) { acc = pt_double<F>(acc); acc = pt_double<F>(acc); acc = pt_double<F>(acc); acc = pt_double<F>(acc); }
+    const u32 d = (mag[w >> 3] >> ((w & 7) * 4)) & 15u;
+    const bool neg_d = (sgn[w >> 5] >> (w & 31)) & 1u;
+    Proj<F> t = tab[d ? d - 1 : 0];
+    if (!d) t = pt_identity<F>();
+    t.y = select(neg_d, F::st(neg(t.y)), t.y);
+    acc = pt_add<F>(acc, t);
+  }
+  u32* o = out + i * 3 * WW;
+  MbIO<F>::save(acc.x, o); MbIO<F>::save(acc.y, o + WW); MbIO<F>::save(acc.z, o + 2 * WW);
+}
+
+}  // namespace bls

@@ -70,11 +70,28 @@ template <int VT, int A, int V> DEV FeP<1, VT> fit(const FeP<A, V>& a) {
 #ifndef QFENCE
 #define QFENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
+// c_L = X B0 + Y B1 with X this lane's coefficient of a, B0 / B1 the pair's (b0, b1) broadcast to both lanes, and Y the partner's
+// coefficient of a, which the c1 lane SENDS negated: c0 = a0 b0 + (-a1) b1, c1 = a1 b0 + a0 b1 -- three DPP moves, one
+// subtraction and one select per limb (mul_inl of pairlane.hip.h needs two selects)
+DEV u32 dpp_bcast0(u32 x) { return (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xA0 /* quad_perm:[0,0,2,2] */, 0xF, 0xF, true); }
+DEV u32 dpp_bcast1(u32 x) { return (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xF5 /* quad_perm:[1,1,3,3] */, 0xF, 0xF, true); }
+template <int A1, int V1, int A2, int V2>
+DEV FeP<1, pair_mul_v(V1, V2)> qmul_core(const FeP<A1, V1>& a, const FeP<A2, V2>& b) {
+  static_assert(A1 * A2 + (A1 + 1) * A2 + 1 <= MAX_A_PROD + 1, "quad fe2 mul: limb bound too large, norm() an operand");
+  const bool c1 = lane_is_c1();
+  const Fe<A1 + 1, V1 + 1> send = select(c1, neg(a.v), (Fe<A1 + 1, V1 + 1>)a.v);
+  Fe<A1 + 1, V1 + 1> y; Fe<A2, V2> b0, b1;
+#pragma unroll
+  for (int i = 0; i < NL; i++) { y.l[i] = dpp_swap1(send.l[i]); b0.l[i] = dpp_bcast0(b.v.l[i]); b1.l[i] = dpp_bcast1(b.v.l[i]); }
+  FeP<1, pair_mul_v(V1, V2)> r;
+  r.v = from_v16<pair_mul_v(V1, V2)>(fe_sop2_body(to_v16(a.v), to_v16(b0), to_v16(y), to_v16(b1)));
+  return r;
+}
 template <int A1, int V1, int A2, int V2> DEV auto qmul_(const FeP<A1, V1>& a, const FeP<A2, V2>& b) {
-  if constexpr ((2 * A1 + 1) * A2 + 1 <= MAX_A_PROD + 1) return mul_inl(a, b);
-  else if constexpr (3 * A2 + 1 <= MAX_A_PROD + 1) return mul_inl(norm(a), b);
-  else if constexpr ((2 * A1 + 1) + 1 <= MAX_A_PROD + 1) return mul_inl(a, norm(b));
-  else return mul_inl(norm(a), norm(b));
+  if constexpr ((2 * A1 + 1) * A2 + 1 <= MAX_A_PROD + 1) return qmul_core(a, b);
+  else if constexpr (3 * A2 + 1 <= MAX_A_PROD + 1) return qmul_core(norm(a), b);
+  else if constexpr ((2 * A1 + 1) + 1 <= MAX_A_PROD + 1) return qmul_core(a, norm(b));
+  else return qmul_core(norm(a), norm(b));
 }
 template <int A1, int V1, int A2, int V2> DEV auto qmul(const FeP<A1, V1>& a, const FeP<A2, V2>& b) {
   QFENCE(); auto r = qmul_(a, b); QFENCE(); return r;
@@ -115,14 +132,11 @@ template <int VA, int VB> DEV auto q6_mul(const Q6<VA>& a, const Q6<VB>& b) {
   auto v1 = qmul(a.c1, b.c1);
   auto v2 = qmul(a.c2, b.c2);
   auto t12 = qmul(add(a.c1, a.c2), add(b.c1, b.c2));
-  auto x12 = norm(sub(sub(t12, v1), v2));                 // a1 b2 + a2 b1
-  auto c0 = add(v0, mul_by_nonresidue(x12));
+  auto c0 = add(v0, mul_by_nonresidue(sub(sub(t12, v1), v2)));      // v0 + xi (a1 b2 + a2 b1); limbs stay below 15 * 2^28 unnormalised
   auto t01 = qmul(add(a.c0, a.c1), add(b.c0, b.c1));
-  auto x01 = norm(sub(sub(t01, v0), v1));                 // a0 b1 + a1 b0
-  auto c1 = add(x01, mul_by_nonresidue(v2));
+  auto c1 = add(sub(sub(t01, v0), v1), mul_by_nonresidue(v2));      // a0 b1 + a1 b0 + xi a2 b2
   auto t02 = qmul(add(a.c0, a.c2), add(b.c0, b.c2));
-  auto x02 = norm(sub(sub(t02, v0), v2));                 // a0 b2 + a2 b0
-  auto c2 = add(x02, v1);
+  auto c2 = add(sub(sub(t02, v0), v2), v1);                         // a0 b2 + a2 b0 + a1 b1
   struct R { decltype(c0) c0; decltype(c1) c1; decltype(c2) c2; };
   R r{c0, c1, c2};
   return r;
@@ -148,12 +162,9 @@ template <int VI> DEV Q12<VQ> q12_sqr(const Q12<VI>& f) {
   auto m0 = norm(M.c0);
   auto m1 = norm(M.c1);
   auto m2 = norm(M.c2);
-  auto z0 = neg(norm(add(m0, mul_by_nonresidue(m2))));
-  auto z1 = neg(norm(add(m1, m0)));
-  auto z2 = neg(norm(add(m2, m1)));
-  auto r0 = xpair(norm(z0));
-  auto r1 = xpair(norm(z1));
-  auto r2 = xpair(norm(z2));
+  auto r0 = xpair(norm(neg(add(m0, mul_by_nonresidue(m2)))));
+  auto r1 = xpair(norm(neg(add(m1, m0))));
+  auto r2 = xpair(norm(neg(add(m2, m1))));
   // A: c1' = 2 ab        B: c0' = M + Z
   auto n0 = selB(B, add(m0, r0), dbl(m0));
   auto n1 = selB(B, add(m1, r1), dbl(m1));
@@ -187,30 +198,33 @@ DEV Q12<VQM> q12_mul_by_014(const Q12<VI>& f, const FeP<1, V0>& c0, const FeP<1,
   auto T1 = qmul(selB(B, own.c2, own.c0), selB(B, c4, c0));
   auto T2 = qmul(selB(B, own.c0, own.c1), selB(B, c4, c1));
   auto T3 = qmul(selB(B, own.c1, own.c2), selB(B, c4, c1));
-  auto xT3 = norm(mul_by_nonresidue(T3));
-  auto W1 = norm(mul_by_nonresidue(T1));                             // B sends (xi T3, xi T1, T2)
-  auto l0 = norm(selB(B, neg(T1), add(T1, xT3)));                    // A: aa0 = xi T3 + T1          B: -T1            (xi applied at the end)
-  auto l1 = norm(selB(B, neg(T2), neg(norm(add(T1, T2)))));          // A: -T1 - T2                  B: -T2
-  auto l2 = norm(selB(B, neg(T3), T2));                              // A: T2                        B: -T3
+  // linear work stays unnormalised while the limbs stay below 15 * 2^28 (the static bounds check it); values are
+  // renormalised where they are sent or stored
+  auto xT3 = mul_by_nonresidue(T3);                                  // B sends (xi T3, xi T1, T2)
+  auto W1 = mul_by_nonresidue(T1);
+  auto l0 = selB(B, neg(T1), add(T1, xT3));                          // A: aa0 = xi T3 + T1          B: -T1            (xi applied at the end)
+  auto l1 = selB(B, neg(T2), neg(add(T1, T2)));                      // A: -T1 - T2                  B: -T2
+  auto l2 = selB(B, neg(T3), T2);                                    // A: T2                        B: -T3
   auto o = add(c1, c4);
   auto S1 = add(own.c1, oth.c1);
   auto T4 = qmul(selB(B, S1, add(own.c0, own.c1)), selB(B, o, add(c0, c1)));
-  auto l1b = norm(add(l1, selB(B, neg(T4), T4)));                    // A: aa1 = T4 - T1 - T2        B: -T4 - T2
-  auto l2b = norm(selB(B, add(l2, T4), l2));                         //                              B: T4 - T3
+  auto l1b = add(l1, selB(B, neg(T4), T4));                          // A: aa1 = T4 - T1 - T2        B: -T4 - T2
+  auto l2b = selB(B, add(l2, T4), l2);                               //                              B: T4 - T3
   auto S2 = add(own.c2, oth.c2);
   auto T5 = qmul(selB(B, S2, own.c2), selB(B, o, c0));
   auto l0b = norm(selB(B, add(l0, T5), l0));                         //                              B: T5 - T1
-  auto l2c = norm(selB(B, l2b, add(l2b, T5)));                       // A: aa2 = T5 + T2
+  auto l2c = selB(B, l2b, add(l2b, T5));                             // A: aa2 = T5 + T2
   auto S0 = add(own.c0, oth.c0);
   auto T6 = qmul(selB(B, S2, S0), c0);
   auto l2d = norm(selB(B, add(l2c, T6), l2c));                       //                              B: bn2 = T6 + T4 - T3
+  auto l1n = norm(l1b);
   // A sends U = (T6 - aa0, -T6 - aa1, -aa2)
-  auto U0 = norm(sub(T6, l0b));
-  auto U1 = norm(neg(norm(add(T6, l1b))));
-  auto U2 = norm(neg(l2d));
+  auto U0 = sub(T6, l0b);
+  auto U1 = neg(add(T6, l1n));
+  auto U2 = neg(l2d);
   auto T7 = qmul(norm(add(S0, S1)), norm(add(c0, o)));
-  auto l1c = norm(selB(B, add(l1b, T7), l1b));                       //                              B: bn1 = T7 - T4 - T2
-  auto l0c = norm(selB(B, mul_by_nonresidue(l0b), l0b));             //                              B: bn0 = xi (T5 - T1)
+  auto l1c = selB(B, add(l1n, T7), l1n);                             //                              B: bn1 = T7 - T4 - T2
+  auto l0c = selB(B, mul_by_nonresidue(l0b), l0b);                   //                              B: bn0 = xi (T5 - T1)
   auto g0 = xpair(selB(B, xT3, U0));
   auto g1 = xpair(selB(B, W1, U1));
   auto g2 = xpair(selB(B, T2, U2));
@@ -231,17 +245,17 @@ DEV void q_doubling_step(QJac& r, QLin& l) {
   const bool B = lane_is_B();
   // level 1: x^2 | y^2 ;  z^2 | (z + y)^2
   auto S1 = qsqr(selB(B, r.y, r.x));
-  auto S2 = qsqr(selB(B, norm(add(r.z, r.y)), r.z));
+  auto S2 = qsqr(selB(B, add(r.z, r.y), r.z));
   auto S1x = xpair(S1); auto S2x = xpair(S2);
   auto tmp0 = selB(B, S1x, S1);
   auto tmp1 = selB(B, S1, S1x);
   auto zsq = selB(B, S2x, S2);
   auto zy2 = selB(B, S2, S2x);
-  auto tmp4 = norm(add(dbl(tmp0), tmp0));
+  auto tmp4 = add(dbl(tmp0), tmp0);
   QR rz = fit<VSP>(sub(sub(zy2, tmp1), zsq));
   // level 2: tmp4^2 | tmp1^2 ;  (x + tmp4)^2 | (tmp1 + x)^2 ;  tmp4 zsq | rz zsq
   auto S3 = qsqr(selB(B, tmp1, tmp4));
-  auto S4 = qsqr(selB(B, norm(add(tmp1, r.x)), norm(add(r.x, tmp4))));
+  auto S4 = qsqr(selB(B, add(tmp1, r.x), add(r.x, tmp4)));
   auto M1 = qmul(selB(B, rz, tmp4), zsq);
   auto S3x = xpair(S3); auto S4x = xpair(S4); auto M1x = xpair(M1);
   auto tmp5 = selB(B, S3x, S3);
@@ -250,14 +264,14 @@ DEV void q_doubling_step(QJac& r, QLin& l) {
   auto t3s = selB(B, S4, S4x);
   auto t3 = selB(B, M1x, M1);
   auto t0 = selB(B, M1, M1x);
-  auto tmp3d = norm(dbl(norm(sub(sub(t3s, tmp0), tmp2))));
-  auto rx = norm(sub(sub(tmp5, tmp3d), tmp3d));
+  auto tmp3d = norm(dbl(sub(sub(t3s, tmp0), tmp2)));
+  auto rx = sub(sub(tmp5, tmp3d), tmp3d);
   // level 3 (both pairs: the running point stays replicated)
-  auto ry = qmul(norm(sub(tmp3d, rx)), tmp4);
-  auto ryo = sub(ry, norm(mul_small<8>(tmp2)));
-  auto t6 = sub(norm(sub(sub(t6s, tmp0), tmp5)), norm(mul_small<4>(tmp1)));
+  auto ry = qmul(sub(tmp3d, rx), tmp4);
+  auto ryo = sub(ry, mul_small<8>(tmp2));
+  auto t6 = sub(sub(sub(t6s, tmp0), tmp5), mul_small<4>(tmp1));
   r.x = fit<VSP>(rx); r.y = fit<VSP>(ryo); r.z = rz;
-  l.a = fit<VSP>(dbl(t0)); l.b = fit<VSP>(neg(norm(dbl(t3)))); l.c = fit<VSP>(t6);
+  l.a = fit<VSP>(dbl(t0)); l.b = fit<VSP>(neg(dbl(t3))); l.c = fit<VSP>(t6);
 }
 // pairings.rs:696-707: the line evaluated at P -- c4 = l.a * py on pair A, c1 = l.b * px on pair B, one Fp product per lane
 // (pp = py on pair A, px on pair B) -- and multiplied into f
@@ -458,14 +472,14 @@ DEV void q_cyc_sqr_compressed(QZ& a, QZ& b) {
   auto t0 = qsqr(a);
   auto t1 = qsqr(b);
   auto t3s = qsqr(add(a, b));
-  auto u0 = norm(add(mul_by_nonresidue(t1), t0));         // this pair's fp4_square: (u0, u1)
-  auto u1 = norm(sub(sub(t3s, t0), t1));
+  auto u0 = add(mul_by_nonresidue(t1), t0);               // this pair's fp4_square: (u0, u1), limbs unnormalised
+  auto u1 = sub(sub(t3s, t0), t1);
   // what the other pair needs: A wants (xi t3, t2) = (xi u1, u0) of B; B wants (t0, t1) = (u0, u1) of A
   auto r0 = xpair(norm(selB(B, mul_by_nonresidue(u1), u0)));
-  auto r1 = xpair(selB(B, u0, u1));
+  auto r1 = xpair(norm(selB(B, u0, u1)));
   // A: nz2 = 2 (r0 + z2) + r0, nz3 = 2 (r1 - z3) + r1        B: nz4 = 2 (r0 - z4) + r0, nz5 = 2 (r1 + z5) + r1
-  QZ na = fit<VQ>(add(dbl(norm(selB(B, sub(r0, a), add(r0, a)))), r0));
-  QZ nb = fit<VQ>(add(dbl(norm(selB(B, add(r1, b), sub(r1, b)))), r1));
+  QZ na = fit<VQ>(add(dbl(selB(B, sub(r0, a), add(r0, a))), r0));
+  QZ nb = fit<VQ>(add(dbl(selB(B, add(r1, b), sub(r1, b))), r1));
   a = na; b = nb;
 }
 // f^|x| conjugated (pairings.rs:114-132), |x| = 2^63 + 2^62 + 2^60 + 2^57 + 2^48 + 2^16: 57 compressed squarings with the

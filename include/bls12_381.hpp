@@ -134,7 +134,21 @@ template <int G> Projective<G> msm(const std::vector<Affine<G>>& bases, const st
   check((G == 1 ? blsgpu_g1_msm_host : blsgpu_g2_msm_host)(Context::instance().handle(), xy.data(), inf.data(), s.data(), n, r.xyz.data()), "msm");
   return r;
 }
-template <int G> Projective<G> Affine<G>::operator*(const Scalar& s) const { return msm<G>({*this}, {s}); }
+// points.iter().zip(scalars).map(|(p, s)| p * s) collected: `Mul<&Scalar>` over slices (src/g1.rs:573-579, src/g2.rs:626-632)
+template <int G> std::vector<Projective<G>> mul_batch(const std::vector<Affine<G>>& points, const std::vector<Scalar>& scalars) {
+  if (points.size() != scalars.size()) throw std::invalid_argument("mul_batch: points and scalars differ in length");
+  size_t n = points.size();
+  std::vector<uint64_t> xy(n * Affine<G>::W), out(n * Projective<G>::W); std::vector<uint8_t> inf(n), s(n * 32);
+  for (size_t i = 0; i < n; i++) {
+    std::memcpy(xy.data() + i * Affine<G>::W, points[i].xy.data(), Affine<G>::W * 8);
+    inf[i] = points[i].infinity; std::memcpy(s.data() + 32 * i, scalars[i].bytes.data(), 32);
+  }
+  check((G == 1 ? blsgpu_g1_mul_batch : blsgpu_g2_mul_batch)(Context::instance().handle(), xy.data(), inf.data(), s.data(), n, out.data()), "mul_batch");
+  std::vector<Projective<G>> r(n);
+  for (size_t i = 0; i < n; i++) std::memcpy(r[i].xyz.data(), out.data() + i * Projective<G>::W, Projective<G>::W * 8);
+  return r;
+}
+template <int G> Projective<G> Affine<G>::operator*(const Scalar& s) const { return mul_batch<G>({*this}, {s})[0]; }
 
 using G1Affine = Affine<1>;
 using G2Affine = Affine<2>;

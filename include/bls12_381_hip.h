@@ -133,6 +133,19 @@ int blsgpu_g2_msm_bytes(blsgpu_ctx* ctx, const uint8_t* bases_uncompressed, cons
  * sub-scalars: c = 16 then means 8 (G1) / 4 (G2) windows instead of 16. */
 int blsgpu_set_msm_window(blsgpu_ctx* ctx, int c);
 
+/* ---- batched variable-base scalar multiplication ------------------------------------------------------------ */
+/* out[i] = scalars[i] * points[i] for n independent (point, scalar) pairs: n affine points in, n projective points out
+ * (18 / 36 u64 each).  Replaces n evaluations of `&G1Affine * &Scalar` / `&G2Affine * &Scalar` (src/g1.rs:556-594 ->
+ * `multiply` :754-774; src/g2.rs:609-647, 825-845; the "scalar multiplication" points of benches/groups.rs:44,89,113,158).
+ * Signed 4-bit windows over complete addition formulas: exact for every curve point (identity, scalars 0 and r - 1, points
+ * outside the prime-order subgroup) -- no subgroup precondition.  The projective representative differs from the one the
+ * reference's double-and-add produces; the group element (affine coordinates) is the same.  `infinity` may be NULL. */
+int blsgpu_g1_mul_batch(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, const uint8_t* scalars, size_t n, uint64_t* out_xyz);
+int blsgpu_g2_mul_batch(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, const uint8_t* scalars, size_t n, uint64_t* out_xyz);
+/* Same with device pointers, asynchronous on the context's stream. */
+int blsgpu_g1_mul_batch_device(blsgpu_ctx* ctx, const void* d_xy, const void* d_infinity, const void* d_scalars, size_t n, void* d_out_xyz);
+int blsgpu_g2_mul_batch_device(blsgpu_ctx* ctx, const void* d_xy, const void* d_infinity, const void* d_scalars, size_t n, void* d_out_xyz);
+
 /* ---- group helpers ----------------------------------------------------------------------------------- */
 /* out = sum of n projective points (`Sum for G1Projective`, src/g1.rs:161-171) -- the fold used after the
  * cross-GPU all-gather of per-rank partial results. */

@@ -230,6 +230,22 @@ int ora_g1_msm(const u64* xy, const uint8_t* inf, const uint8_t* scalars, long n
   memcpy(out_xyz, &acc, 144);
   return used;
 }
+/* n independent `&G1Affine * &Scalar` (g1.rs:573-579, 754-774), each converted to affine (g1.rs:49-63): the checker of the
+ * batched variable-base kernel.  out_xy: n x 12 limbs, out_inf: n bytes. */
+int ora_g1_mul_batch_affine(const u64* xy, const uint8_t* inf, const uint8_t* scalars, long n, int threads, u64* out_xy, uint8_t* out_inf) {
+  int used = 1;
+#ifdef _OPENMP
+  if (threads <= 0) threads = omp_get_max_threads();
+  used = threads;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads)
+#endif
+  for (long i = 0; i < n; i++) {
+    g1p p; memcpy(&p.x, xy + 12 * i, 48); memcpy(&p.y, xy + 12 * i + 6, 48); p.z = (inf && inf[i]) ? FP_ZERO : FP_ONE;
+    g1p m = g1_multiply(&p, scalars + 32 * i);
+    out_inf[i] = (uint8_t)ora_g1_to_affine((const u64*)&m, out_xy + 12 * i);
+  }
+  return used;
+}
 int ora_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
@@ -602,4 +618,20 @@ int ora_g2_to_affine(const u64* xyz, u64* xy) {
   if (fp2_is_zero(&p->z)) { memset(xy, 0, 192); memcpy(xy + 12, FP_ONE.l, 48); return 1; }
   fp2 zi = fp2_inv(&p->z), x = fp2_mul(&p->x, &zi), y = fp2_mul(&p->y, &zi);
   memcpy(xy, &x, 96); memcpy(xy + 12, &y, 96); return 0;
+}
+/* n independent `&G2Affine * &Scalar` (g2.rs:626-632, 825-845), each converted to affine */
+int ora_g2_mul_batch_affine(const u64* xy, const uint8_t* inf, const uint8_t* scalars, long n, int threads, u64* out_xy, uint8_t* out_inf) {
+  int used = 1;
+#ifdef _OPENMP
+  if (threads <= 0) threads = omp_get_max_threads();
+  used = threads;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads)
+#endif
+  for (long i = 0; i < n; i++) {
+    g2p p; memcpy(&p.x, xy + 24 * i, 96); memcpy(&p.y, xy + 24 * i + 12, 96);
+    p.z = (inf && inf[i]) ? FP2_ZERO_C : fp2_one();
+    g2p m = g2_multiply(&p, scalars + 32 * i);
+    out_inf[i] = (uint8_t)ora_g2_to_affine((const u64*)&m, out_xy + 24 * i);
+  }
+  return used;
 }

@@ -97,6 +97,29 @@ pub fn msm_g2(bases: &[G2Affine], scalars: &[Scalar]) -> G2Projective {
     });
     gpu.unwrap_or_else(|| bases.iter().zip(scalars).map(|(p, s)| p * s).sum())
 }
+/// `points.iter().zip(scalars).map(|(p, s)| p * s)` collected -- N variable-base scalar multiplications in one device call
+/// (`Mul<&Scalar> for &G1Affine`, src/g1.rs:573-579 -> `multiply` :754-774); exact for every curve point
+pub fn mul_batch_g1(points: &[G1Affine], scalars: &[Scalar]) -> Vec<G1Projective> {
+    assert_eq!(points.len(), scalars.len());
+    let gpu = with_ctx(|ctx| {
+        let ((xy, inf), s) = (g1_wire(points), scalar_bytes(scalars));
+        let mut out = alloc::vec![0u64; points.len() * 18];
+        ok(unsafe { ffi::blsgpu_g1_mul_batch(ctx, xy.as_ptr(), inf.as_ptr(), s.as_ptr(), points.len(), out.as_mut_ptr()) })?;
+        Some(out.chunks_exact(18).map(|c| G1Projective { x: fp(&c[0..6]), y: fp(&c[6..12]), z: fp(&c[12..18]) }).collect::<Vec<_>>())
+    });
+    gpu.unwrap_or_else(|| points.iter().zip(scalars).map(|(p, s)| p * s).collect())
+}
+/// the same over G2 (src/g2.rs:626-632, 825-845)
+pub fn mul_batch_g2(points: &[G2Affine], scalars: &[Scalar]) -> Vec<G2Projective> {
+    assert_eq!(points.len(), scalars.len());
+    let gpu = with_ctx(|ctx| {
+        let ((xy, inf), s) = (g2_wire(points), scalar_bytes(scalars));
+        let mut out = alloc::vec![0u64; points.len() * 36];
+        ok(unsafe { ffi::blsgpu_g2_mul_batch(ctx, xy.as_ptr(), inf.as_ptr(), s.as_ptr(), points.len(), out.as_mut_ptr()) })?;
+        Some(out.chunks_exact(36).map(|c| G2Projective { x: fp2(&c[0..12]), y: fp2(&c[12..24]), z: fp2(&c[24..36]) }).collect::<Vec<_>>())
+    });
+    gpu.unwrap_or_else(|| points.iter().zip(scalars).map(|(p, s)| p * s).collect())
+}
 /// `Sum` over a slice of projective points (src/g1.rs:161-171) on the device (used to fold per-GPU partial sums)
 pub fn sum_g1(points: &[G1Projective]) -> G1Projective {
     let gpu = with_ctx(|ctx| {
@@ -130,6 +153,7 @@ pub fn batch_normalize_g1(p: &[G1Projective], q: &mut [G1Affine]) {
 /// Batched `pairing` (src/pairings.rs:607-653): out[i] = e(p[i], q[i]); identities give `Gt::identity()` as in :636-651.
 pub fn pairing_batch(p: &[G1Affine], q: &[G2Affine]) -> Vec<Gt> {
     assert_eq!(p.len(), q.len());
+    if p.len() < GPU_MIN_PAIRINGS { return p.iter().zip(q).map(|(a, b)| crate::pairings::pairing_cpu(a, b)).collect(); }
     let gpu = with_ctx(|ctx| {
         let ((g1, f1), (g2, f2)) = (g1_wire(p), g2_wire(q));
         let mut out = alloc::vec![0u64; p.len() * 72];
@@ -138,11 +162,18 @@ pub fn pairing_batch(p: &[G1Affine], q: &[G2Affine]) -> Vec<Gt> {
     });
     gpu.unwrap_or_else(|| p.iter().zip(q).map(|(a, b)| crate::pairings::pairing_cpu(a, b)).collect())
 }
-/// `pairing` for one pair (what `Engine::pairing` forwards to; one pair keeps a GPU idle -- batch where possible)
-pub fn pairing(p: &G1Affine, q: &G2Affine) -> Gt { pairing_batch(core::slice::from_ref(p), core::slice::from_ref(q)).pop().unwrap() }
+/// Below these batch sizes the crate's own CPU code is faster than a device round trip: one pairing is ~1.3 ms on a host
+/// core (`per_op_ns.full_pairing_ns`) against ~6 ms for a lone quad of lanes on the GPU (a single wavefront
+/// issues one multiply-add per ~9 cycles whatever the batch size; tools/lat_small.py) -- the device pays from ~8 pairs on.
+pub const GPU_MIN_PAIRINGS: usize = 8;
+pub const GPU_MIN_MILLER_TERMS: usize = 8;
+/// `pairing` for one pair (what `Engine::pairing` forwards to): the CPU path of the crate, unchanged (src/pairings.rs:607-653,
+/// renamed `pairing_cpu`) -- a single pair never goes to the device.  Callers with many pairs use `pairing_batch`.
+pub fn pairing(p: &G1Affine, q: &G2Affine) -> Gt { crate::pairings::pairing_cpu(p, q) }
 
 /// `multi_miller_loop` (src/pairings.rs:554-603); terms with an identity are skipped (:566-569); no terms give `default()`.
 pub fn multi_miller_loop(terms: &[(&G1Affine, &G2PreparedHip)]) -> MillerLoopResult {
+    if terms.len() < GPU_MIN_MILLER_TERMS { return crate::pairings::multi_miller_loop_cpu(terms); }
     let gpu = with_ctx(|ctx| {
         let p: Vec<G1Affine> = terms.iter().map(|t| *t.0).collect();
         let q: Vec<G2Affine> = terms.iter().map(|t| t.1.q).collect();
@@ -153,16 +184,19 @@ pub fn multi_miller_loop(terms: &[(&G1Affine, &G2PreparedHip)]) -> MillerLoopRes
     });
     gpu.unwrap_or_else(|| crate::pairings::multi_miller_loop_cpu(terms))
 }
-/// `MillerLoopResult::final_exponentiation` (src/pairings.rs:48-176)
-pub fn final_exponentiation(f: &MillerLoopResult) -> Gt {
+/// `MillerLoopResult::final_exponentiation` (src/pairings.rs:48-176) of ONE value: the crate's CPU code (~0.7 ms on a host
+/// core against ~3.5 ms for one value on the device); `final_exponentiation_batch` is the device entry point
+pub fn final_exponentiation(f: &MillerLoopResult) -> Gt { f.final_exponentiation_cpu() }
+pub fn final_exponentiation_batch(fs: &[MillerLoopResult]) -> Vec<Gt> {
+    if fs.len() < GPU_MIN_PAIRINGS { return fs.iter().map(|f| f.final_exponentiation_cpu()).collect(); }
     let gpu = with_ctx(|ctx| {
-        let mut inp = Vec::with_capacity(72);
-        put_fp12(&mut inp, &f.0);
-        let mut out = [0u64; 72];
-        ok(unsafe { ffi::blsgpu_final_exponentiation_batch(ctx, inp.as_ptr(), 1, out.as_mut_ptr()) })?;
-        Some(Gt(fp12(&out)))
+        let mut inp = Vec::with_capacity(72 * fs.len());
+        for f in fs { put_fp12(&mut inp, &f.0); }
+        let mut out = alloc::vec![0u64; 72 * fs.len()];
+        ok(unsafe { ffi::blsgpu_final_exponentiation_batch(ctx, inp.as_ptr(), fs.len(), out.as_mut_ptr()) })?;
+        Some(out.chunks_exact(72).map(|c| Gt(fp12(c))).collect::<Vec<_>>())
     });
-    gpu.unwrap_or_else(|| f.final_exponentiation_cpu())
+    gpu.unwrap_or_else(|| fs.iter().map(|f| f.final_exponentiation_cpu()).collect())
 }
 /// `MillerLoopResult + MillerLoopResult` over a slice (src/pairings.rs:179-186): fold of per-GPU partial products
 pub fn miller_product(parts: &[MillerLoopResult]) -> MillerLoopResult {
@@ -201,8 +235,11 @@ impl pairing::MultiMillerLoop for crate::Bls12 {
 /// slice-level helpers next to the element-wise operators (`Mul<&Scalar>` src/g1.rs:556-594 and `Sum` :161-171 are unchanged)
 impl G1Projective {
     pub fn msm(bases: &[G1Affine], scalars: &[Scalar]) -> G1Projective { msm_g1(bases, scalars) }
+    /// `Mul<&Scalar>` over slices: out[i] = points[i] * scalars[i]
+    pub fn mul_slices(points: &[G1Affine], scalars: &[Scalar]) -> Vec<G1Projective> { mul_batch_g1(points, scalars) }
     pub fn sum_slice(points: &[G1Projective]) -> G1Projective { sum_g1(points) }
 }
 impl G2Projective {
     pub fn msm(bases: &[G2Affine], scalars: &[Scalar]) -> G2Projective { msm_g2(bases, scalars) }
+    pub fn mul_slices(points: &[G2Affine], scalars: &[Scalar]) -> Vec<G2Projective> { mul_batch_g2(points, scalars) }
 }

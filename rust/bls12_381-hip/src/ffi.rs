@@ -45,6 +45,10 @@ extern "C" {
     pub fn blsgpu_g1_msm_bytes(ctx: *mut BlsgpuCtx, bases_uncompressed: *const u8, scalars: *const u8, n: usize, out: *mut u8) -> c_int;
     pub fn blsgpu_g2_msm_bytes(ctx: *mut BlsgpuCtx, bases_uncompressed: *const u8, scalars: *const u8, n: usize, out: *mut u8) -> c_int;
     pub fn blsgpu_set_msm_window(ctx: *mut BlsgpuCtx, c: c_int) -> c_int;
+    pub fn blsgpu_g1_mul_batch(ctx: *mut BlsgpuCtx, xy: *const u64, infinity: *const u8, scalars: *const u8, n: usize, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_g2_mul_batch(ctx: *mut BlsgpuCtx, xy: *const u64, infinity: *const u8, scalars: *const u8, n: usize, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_g1_mul_batch_device(ctx: *mut BlsgpuCtx, d_xy: *const c_void, d_infinity: *const c_void, d_scalars: *const c_void, n: usize, d_out_xyz: *mut c_void) -> c_int;
+    pub fn blsgpu_g2_mul_batch_device(ctx: *mut BlsgpuCtx, d_xy: *const c_void, d_infinity: *const c_void, d_scalars: *const c_void, n: usize, d_out_xyz: *mut c_void) -> c_int;
     pub fn blsgpu_g1_sum(ctx: *mut BlsgpuCtx, xyz: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
     pub fn blsgpu_g2_sum(ctx: *mut BlsgpuCtx, xyz: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
     pub fn blsgpu_g1_sum_device(ctx: *mut BlsgpuCtx, d_xyz: *const c_void, n: usize, d_out_xyz: *mut c_void) -> c_int;

@@ -111,6 +111,36 @@ fn g2_wire(gpu: &Gpu, points: &[G2Affine]) -> Result<(Vec<u64>, Vec<u8>), Error>
     debug_assert!(ok.iter().all(|&o| o == 1));
     Ok((xy, inf))
 }
+/// Drop-in for `points.iter().zip(scalars).map(|(p, s)| p * s).collect::<Vec<G1Projective>>()` -- `Mul<&Scalar>` over
+/// slices (src/g1.rs:573-579, 754-774): decode on the device, N variable-base multiplications in one launch, one batched
+/// affine conversion, encode; exact for every curve point (no subgroup precondition).
+pub fn mul_batch_g1(gpu: &Gpu, points: &[G1Affine], scalars: &[Scalar]) -> Result<Vec<G1Projective>, Error> {
+    assert_eq!(points.len(), scalars.len());
+    let n = points.len();
+    let ((xy, inf), s) = (g1_wire(gpu, points)?, scalar_bytes(scalars));
+    let (mut xyz, mut axy, mut ainf, mut enc) = (vec![0u64; n * 18], vec![0u64; n * 12], vec![0u8; n], vec![0u8; n * 96]);
+    check(unsafe { ffi::blsgpu_g1_mul_batch(gpu.ctx, xy.as_ptr(), inf.as_ptr(), s.as_ptr(), n, xyz.as_mut_ptr()) })?;
+    check(unsafe { ffi::blsgpu_g1_batch_normalize(gpu.ctx, xyz.as_ptr(), n, axy.as_mut_ptr(), ainf.as_mut_ptr()) })?;
+    check(unsafe { ffi::blsgpu_g1_to_bytes_batch(gpu.ctx, axy.as_ptr(), ainf.as_ptr(), n, 0, enc.as_mut_ptr()) })?;
+    Ok(enc.chunks_exact(96).map(|c| {
+        let mut b = [0u8; 96]; b.copy_from_slice(c);
+        G1Projective::from(Option::<G1Affine>::from(G1Affine::from_uncompressed_unchecked(&b)).expect("libblsgpu returned an invalid G1 encoding"))
+    }).collect())
+}
+/// the same over G2 (src/g2.rs:626-632, 825-845)
+pub fn mul_batch_g2(gpu: &Gpu, points: &[G2Affine], scalars: &[Scalar]) -> Result<Vec<G2Projective>, Error> {
+    assert_eq!(points.len(), scalars.len());
+    let n = points.len();
+    let ((xy, inf), s) = (g2_wire(gpu, points)?, scalar_bytes(scalars));
+    let (mut xyz, mut axy, mut ainf, mut enc) = (vec![0u64; n * 36], vec![0u64; n * 24], vec![0u8; n], vec![0u8; n * 192]);
+    check(unsafe { ffi::blsgpu_g2_mul_batch(gpu.ctx, xy.as_ptr(), inf.as_ptr(), s.as_ptr(), n, xyz.as_mut_ptr()) })?;
+    check(unsafe { ffi::blsgpu_g2_batch_normalize(gpu.ctx, xyz.as_ptr(), n, axy.as_mut_ptr(), ainf.as_mut_ptr()) })?;
+    check(unsafe { ffi::blsgpu_g2_to_bytes_batch(gpu.ctx, axy.as_ptr(), ainf.as_ptr(), n, 0, enc.as_mut_ptr()) })?;
+    Ok(enc.chunks_exact(192).map(|c| {
+        let mut b = [0u8; 192]; b.copy_from_slice(c);
+        G2Projective::from(Option::<G2Affine>::from(G2Affine::from_uncompressed_unchecked(&b)).expect("libblsgpu returned an invalid G2 encoding"))
+    }).collect())
+}
 fn split72(flat: Vec<u64>) -> Vec<GtLimbs> {
     flat.chunks_exact(72).map(|c| { let mut a = [0u64; 72]; a.copy_from_slice(c); GtLimbs(a) }).collect()
 }

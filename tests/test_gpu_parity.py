@@ -1422,3 +1422,69 @@ def test_quad_layout_miller_and_pairing_match_pair_layout_and_oracle(layout_cont
     bxy, _ = p.bases_from_scalars(1, ka).download(); qxy, _ = p.bases_from_scalars(2, kq).download()
     assert np.array_equal(q.miller_loop_batch(bxy, None, qxy, None), p.miller_loop_batch(bxy, None, qxy, None))
     assert np.array_equal(q.pairing_batch(bxy, None, qxy, None), p.pairing_batch(bxy, None, qxy, None))
+
+
+# ---- round 3: batched variable-base scalar multiplication (N in -> N out) --------------------------------------------------
+def _golden_points(golden_dir, group):
+    size = 96 if group == 1 else 192
+    name = "g1_uncompressed_valid_test_vectors.dat" if group == 1 else "g2_uncompressed_valid_test_vectors.dat"
+    raw = open(os.path.join(golden_dir, name), "rb").read()
+    return [raw[i * size:(i + 1) * size] for i in range(len(raw) // size)]
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_mul_batch_golden_multiples_of_the_generator(ctx, golden_dir, group):
+    """the reference's golden files hold k * G for k = 0..999 (src/tests/mod.rs:3-76): mul_batch with P = G and s = k for every
+    record, compared on uncompressed bytes"""
+    import bls12_381_amd as b
+    recs = _golden_points(golden_dir, group)
+    n = len(recs)
+    AffT = b.G1Affine if group == 1 else b.G2Affine
+    g = AffT.generator()
+    xy = np.repeat(g.xy[None, :], n, axis=0)
+    out = ctx.mul_batch(group, xy, None, list(range(n)))
+    axy, ainf = ctx.batch_normalize(group, out)
+    for k in range(n):
+        assert AffT(axy[k], bool(ainf[k])).to_uncompressed() == recs[k], k
+
+
+@pytest.mark.parametrize("group,logn", [(1, 15), (2, 12)])
+def test_mul_batch_random_pairs_vs_tier1_multiply(ctx, group, logn):
+    """2^15 (G1) / 2^12 (G2) random (point, scalar) pairs, every output against the tier-1 C restatement of `multiply`
+    (g1.rs:754-774 / g2.rs:825-845) after affine conversion; identities, s in {0, 1, r - 1} and an off-subgroup point mixed in"""
+    from oracle import c_oracle
+    from bls12_381_amd import synthetic as sy
+    n = 1 << logn
+    kb = sy.scalars(n, sy.SEED + 71 + group); sb = np.array(sy.scalars(n, sy.SEED + 73 + group), dtype=np.uint8).reshape(n, 32).copy()
+    xy, inf = ctx.bases_from_scalars(group, kb).download()
+    xy = xy.copy(); inf = inf.copy()
+    rr = o.R_ORDER
+    for j, s in enumerate((0, 1, rr - 1, 2, 1 << 254)):
+        sb[j] = np.frombuffer(int(s).to_bytes(32, "little"), dtype=np.uint8)
+    inf[7] = 1; xy[7] = g1aff_w(o.G1_IDENTITY_AFF)[0] if group == 1 else g2aff_w(o.G2_IDENTITY_AFF)[0]
+    out = ctx.mul_batch(group, xy, inf, sb)
+    axy, ainf = ctx.batch_normalize(group, out)
+    want_xy, want_inf = c_oracle.mul_batch_affine(group, xy, inf, sb)
+    assert np.array_equal(ainf, want_inf)
+    assert np.array_equal(axy[ainf == 0], want_xy[want_inf == 0])
+    assert ainf[0] == 1 and ainf[7] == 1 and ainf.sum() == 2          # s = 0 and the identity base: exactly these give the identity
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_mul_batch_off_subgroup_points_and_mirror(ctx, kats, group):
+    """no subgroup precondition: the reference's off-subgroup curve points times boundary scalars equal the oracle's
+    double-and-add; the Python mirror's `Mul` and slice form go through the same kernel"""
+    import bls12_381_amd as b
+    A = _off_subgroup_points(kats, group)
+    amul, toaff, enc, affw = ((o.g1_affine_mul, o.g1_to_affine, o.g1_to_uncompressed, g1aff_w) if group == 1 else
+                              (o.g2_affine_mul, o.g2_to_affine, o.g2_to_uncompressed, g2aff_w))
+    AffT = b.G1Affine if group == 1 else b.G2Affine
+    r = o.SplitMix64(9100 + group)
+    L = 0xd201000000010000 ** 2
+    ss = [0, 1, 2, o.R_ORDER - 1, L, L + 1, (1 << 255) % o.R_ORDER, r.scalar(), r.scalar()]
+    pts = [AffT(*affw(A))] * len(ss)
+    got = AffT.mul_batch(pts, ss)
+    for s, gp in zip(ss, got):
+        assert gp.to_affine().to_uncompressed() == enc(toaff(amul(A, s))), s
+    assert (AffT(*affw(A)) * b.Scalar(ss[-1])).to_affine().to_uncompressed() == enc(toaff(amul(A, ss[-1])))
+    assert AffT.mul_batch([], []) == []

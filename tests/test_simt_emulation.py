@@ -65,10 +65,54 @@ def test_emulated_pair_lane_pairing_matches_oracle(emu):
         assert np.array_equal(out[72 * i:72 * i + 72], fp12w(o.pairing(P[i], Q[i])))
 
 
-def test_emulated_quad_miller_loop_matches_oracle(emu):
-    """quad.hip.h: raw Miller value of one pairing spread over four lanes == the reference's (pairings.rs:668-770)"""
+def test_emulated_quad_miller_loop_and_pairing_match_oracle(emu):
+    """quad.hip.h: raw Miller value and full pairing of one pair spread over four lanes == the reference's
+    (pairings.rs:668-770, :48-176, :607-653)"""
     for seed in (12, 13):
         P, Q, g1, g2 = _pairs(seed, 1)
         out = np.zeros(72, dtype=np.uint64)
-        emu.emu_quad_miller(vp(g1), vp(g2), vp(out), ctypes.c_size_t(1))
-        assert np.array_equal(out, fp12w(o.miller_loop(P[0], Q[0])))
+        ml = o.miller_loop(P[0], Q[0])
+        emu.emu_quad_pairing(1, vp(g1), vp(g2), vp(out), ctypes.c_size_t(1))
+        assert np.array_equal(out, fp12w(ml))
+        emu.emu_quad_pairing(0, vp(g1), vp(g2), vp(out), ctypes.c_size_t(1))
+        assert np.array_equal(out, fp12w(o.final_exponentiation(ml)))
+
+
+def test_emulated_quad_tower_ops_match_oracle(emu):
+    """the quad forms of Fp12 multiplication, inversion, Frobenius, conjugation, cyclotomic squaring, the compressed-squaring
+    exponentiation by |x| (with its degenerate input 1) and the final exponentiation, on random field elements"""
+    r = o.SplitMix64(77)
+
+    def rfp12():
+        vals = []
+        for _ in range(12):
+            v = 0
+            for i in range(6):
+                v |= r.next() << (64 * i)
+            vals.append(v % o.P)
+        return o.fp12_unflatten(vals)
+
+    def run(op, a, b=None):
+        out = np.zeros(72, dtype=np.uint64)
+        aw = fp12w(a)
+        bw = fp12w(b) if b is not None else None
+        emu.emu_quad_fp12_op(op, vp(aw), vp(bw) if bw is not None else None, vp(out), ctypes.c_size_t(1))
+        return out
+
+    x, y = rfp12(), rfp12()
+    assert np.array_equal(run(0, x, y), fp12w(o.fp12_mul(x, y)))
+    assert np.array_equal(run(4, x), fp12w(o.fp12_inv(x)))
+    assert np.array_equal(run(7, x), fp12w(o.fp12_frobenius(x)))
+    assert np.array_equal(run(8, x), fp12w(o.fp12_conj(x)))
+    t0 = x
+    for _ in range(6):
+        t0 = o.fp12_frobenius(t0)
+    t2 = o.fp12_mul(t0, o.fp12_inv(x))
+    t2 = o.fp12_mul(o.fp12_frobenius(o.fp12_frobenius(t2)), t2)          # in the cyclotomic subgroup
+    assert np.array_equal(run(9, t2), fp12w(o.cyclotomic_square(t2)))
+    assert np.array_equal(run(10, t2), fp12w(o.cyclotomic_exp(t2)))
+    assert np.array_equal(run(10, o.FP12_ONE), fp12w(o.cyclotomic_exp(o.FP12_ONE)))
+    out = np.zeros(72, dtype=np.uint64)
+    xw = fp12w(x)
+    emu.emu_quad_final_exp(vp(xw), vp(out), ctypes.c_size_t(1))
+    assert np.array_equal(out, fp12w(o.final_exponentiation(x)))
