@@ -47,6 +47,22 @@ MAC32_G1_MSM_2_20 = 188 * 300              # whole 2^20-point MSM, per scalar-mu
 MAC32_G2_MSM_2_20 = 666 * 300              # per scalar-mul
 MAC32_PAIRING = 16000 * 300
 MAC32_MML_TERM = 6900 * 300
+MAC32_G1_MUL = 5100 * 300                  # one `&G1Affine * &Scalar`: 255 x (double 8 + add 12) field multiplications
+MAC32_G2_MUL = 17085 * 300                 # the same over Fp2 (row a16)
+
+
+def static_traffic(tag):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc summary of the SAME workload (profiles/<round>_<tag>_pmc.json,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE).  Counters cannot be read inside a timed
+    run, so this is a STATIC figure from a separate profiled run -- labelled as such in the bench line."""
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (rnd, tag))
+        if os.path.exists(path):
+            try:
+                return json.load(open(path))["hbm_bytes_per_launch_corrected"], "profiles/%s_%s_pmc.json (static: separate rocprofv3 --pmc passes of this workload, not measured in this run)" % (rnd, tag)
+            except Exception:
+                pass
+    return None, None
 
 
 def parse():
@@ -243,16 +259,11 @@ def run_msm(args, e):
         # duration of the dominant kernel: average over its launches INSIDE the timed (pipelined) region, HIP events on the
         # stream it runs on; the isolated (one MSM at a time) duration is reported next to it
         dur = (live_acc_ms if live_acc_n else float(np.mean(acc_ms))) * 1e-3
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r02_msm_pmc.json")
-        if log_n == 20 and os.path.exists(pmc_path):
-            # HBM-side bytes per launch of this kernel on this workload, from separate rocprofv3 --pmc passes
-            # (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); see profiles/r02_msm_pmc.md
-            traffic = json.load(open(pmc_path))["hbm_bytes_per_launch_corrected"]
+        traffic, traffic_source = static_traffic("msm") if log_n == 20 else (None, None)
         roof = {
             "bound": "int-valu", "kernel": "k_msm_accumulate<G1>",
             "achieved": mac32_per_launch / dur / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s",
-            "frac": mac32_per_launch / dur / peak, "frac_isolated": mac32_per_launch / (float(np.mean(acc_ms)) * 1e-3) / peak, "traffic": traffic,
+            "frac": mac32_per_launch / dur / peak, "frac_isolated": mac32_per_launch / (float(np.mean(acc_ms)) * 1e-3) / peak, "traffic": traffic, "traffic_source": traffic_source,
             "launch_ms": dur * 1e3, "launches_timed": int(live_acc_n), "launch_sampling": "HIP events around every 3rd launch of the timed region", "launch_ms_isolated": float(np.mean(acc_ms)), "mac32_per_launch": mac32_per_launch,
             "whole_msm_frac_pipelined": (float(n) * MAC32_G1_MSM_2_20) / (dt / steps) / peak,
             "whole_msm_frac_single_call": (float(n) * MAC32_G1_MSM_2_20) / (float(np.mean(tot_ms)) * 1e-3) / peak,
@@ -375,9 +386,26 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
     pms = median_ms(lambda: ctx.pairing_batch_device(d_g1.data_ptr(), d_g2.data_ptr(), np_, d_gt.data_ptr()), sync, warm=1, reps=5)
     pdt = pms * 1e-3
     extras["pairings_per_s"] = np_ / pdt
-    extras["pairing_batch"] = {"n": np_, "ms": pms, "note": "2^16 independent pairing(P_i, Q_i), inputs and outputs in HBM",
-                               "roofline": {"bound": "int-valu", "kernel": "k_pairing", "mac32_per_unit": MAC32_PAIRING, "achieved": np_ * MAC32_PAIRING / pdt / 1e12,
-                                            "peak": peak / 1e12, "unit": "TMAC32/s", "frac": np_ * MAC32_PAIRING / pdt / peak}}
+    ptraf, ptraf_src = static_traffic("pairing")
+    extras["pairing_batch"] = {"n": np_, "ms": pms, "note": "2^16 independent pairing(P_i, Q_i), inputs and outputs in HBM; quad layout (one pairing per four lanes, quad.hip.h)",
+                               "roofline": {"bound": "int-valu", "kernel": "k_pairing_quad", "mac32_per_unit": MAC32_PAIRING, "achieved": np_ * MAC32_PAIRING / pdt / 1e12,
+                                            "peak": peak / 1e12, "unit": "TMAC32/s", "frac": np_ * MAC32_PAIRING / pdt / peak,
+                                            "traffic": ptraf, "traffic_source": ptraf_src, "algorithmic_bytes": np_ * 864}}
+    # small batches: latency of ONE call with n = 1, 8, 64, 1024 pairs (pairing) and of one final exponentiation -- the sizes the
+    # reference's own criterion points measure one at a time (benches/groups.rs:15-29); per_op_ns of the CPU port is next to them
+    small = {}
+    for k in (1, 8, 64, 1024):
+        small["pairing_n%d_ms" % k] = median_ms(lambda: ctx.pairing_batch_device(d_g1.data_ptr(), d_g2.data_ptr(), k, d_gt.data_ptr()), sync, warm=1, reps=5)
+    d_ml = torch.zeros((1024, 72), dtype=torch.int64, device=dev)
+    ctx.miller_loop_batch_device(d_g1.data_ptr(), d_g2.data_ptr(), 1024, d_ml.data_ptr())
+    for k in (1, 1024):
+        small["final_exponentiation_n%d_ms" % k] = median_ms(
+            lambda: bls._lib.check(ctx.lib.blsgpu_final_exponentiation_device(ctx.h, d_ml.data_ptr(), k, d_gt.data_ptr()), "final_exponentiation"), sync, warm=1, reps=5)
+    small["miller_loop_n1_ms"] = median_ms(lambda: ctx.miller_loop_batch_device(d_g1.data_ptr(), d_g2.data_ptr(), 1, d_ml.data_ptr()), sync, warm=1, reps=5)
+    small["note"] = ("one call, nothing else in flight, inputs and outputs in HBM; a lone quad of lanes issues one multiply-add per ~9 cycles whatever the batch "
+                     "size, so the latency is flat up to ~10^3 pairs -- below ~8 pairs the crate's CPU path is faster (rust/bls12_381-hip/in-tree/hip.rs keeps it)")
+    extras["pairing_small_batches"] = small
+    ctx.pairing_batch_device(d_g1.data_ptr(), d_g2.data_ptr(), np_, d_gt.data_ptr()); sync()        # the CPU comparison below reads d_gt
     if not args.no_cpu_baseline:
         from oracle import c_oracle
         per_op = {}
@@ -409,7 +437,8 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
     extras["multi_miller_loop_terms_per_s"] = nm / mdt
     extras["multi_miller_loop"] = {"n": nm, "ms": mms, "note": "one product of 2^18 Miller values (no final exponentiation)",
                                    "roofline": {"bound": "int-valu", "kernel": "k_multi_miller_shared", "mac32_per_unit": MAC32_MML_TERM, "achieved": nm * MAC32_MML_TERM / mdt / 1e12,
-                                                "peak": peak / 1e12, "unit": "TMAC32/s", "frac": nm * MAC32_MML_TERM / mdt / peak}}
+                                                "peak": peak / 1e12, "unit": "TMAC32/s", "frac": nm * MAC32_MML_TERM / mdt / peak,
+                                                "traffic": static_traffic("mml")[0], "traffic_source": static_traffic("mml")[1], "algorithmic_bytes": nm * 288}}
     del d_g1m, d_g2m
     # Fr transform of the MSM's scalar vector
     if n & (n - 1) == 0:
@@ -471,6 +500,35 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
     extras["g2_msm"] = {"n": n2, "ms": 1e3 * g2dt, "single_call_ms": g2single,
                         "roofline": {"bound": "int-valu", "kernel": "whole G2 MSM (k_msm_accumulate_g2pair dominant)", "mac32_per_unit": MAC32_G2_MSM_2_20,
                                      "achieved": n2 * MAC32_G2_MSM_2_20 / g2dt / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s", "frac": n2 * MAC32_G2_MSM_2_20 / g2dt / peak}}
+    # batched variable-base scalar multiplication, N in -> N out (the reference's unit operation `&G1Affine * &Scalar`)
+    xy1, _ = bases.download(0, n)
+    d_xy1 = torch.from_numpy(xy1.view(np.int64)).to(dev)
+    d_mo = torch.zeros((n, 18), dtype=torch.int64, device=dev)
+    mbms = median_ms(lambda: ctx.mul_batch_device(1, d_xy1.data_ptr(), 0, d_scalars.data_ptr(), n, d_mo.data_ptr()), sync, warm=1, reps=3)
+    mb = {"n": n, "ms": mbms, "scalar_muls_per_s": n / (mbms * 1e-3),
+          "note": "n independent P_i * s_i -> n projective points (blsgpu_g1_mul_batch_device), signed 4-bit windows over the complete formulas: 2 852 field "
+                  "multiplications executed per unit against the 5 100 of the reference's double-and-add that the canonical figure counts",
+          "roofline": {"bound": "int-valu", "kernel": "k_mul_batch<G1>", "mac32_per_unit": MAC32_G1_MUL, "achieved": n * MAC32_G1_MUL / (mbms * 1e-3) / 1e12,
+                       "peak": peak / 1e12, "unit": "TMAC32/s", "frac": n * MAC32_G1_MUL / (mbms * 1e-3) / peak,
+                       "executed_mac_per_unit": 2852 * 406, "executed_frac_of_peak": n * 2852 * 406 / (mbms * 1e-3) / peak}}
+    if not args.no_cpu_baseline:
+        from oracle import c_oracle
+        mm = 1 << 12
+        want_xy, want_inf = c_oracle.mul_batch_affine(1, xy1[:mm], None, sb[:mm], host_threads())
+        got_xy, got_inf = ctx.batch_normalize(1, d_mo[:mm].cpu().numpy().view(np.uint64))
+        mb["gpu_result_matches"] = bool(np.array_equal(got_xy, want_xy) and np.array_equal(got_inf, want_inf))
+        if not mb["gpu_result_matches"]:
+            raise SystemExit("bench: GPU mul_batch differs from the CPU oracle on the sample")
+    extras["g1_mul_batch"] = mb
+    n2m = min(1 << 18, n2)
+    xy2m, _ = b2.download(0, n2m)
+    d_xy2 = torch.from_numpy(xy2m.view(np.int64)).to(dev)
+    d_mo2 = torch.zeros((n2m, 36), dtype=torch.int64, device=dev)
+    mb2ms = median_ms(lambda: ctx.mul_batch_device(2, d_xy2.data_ptr(), 0, d_s2.data_ptr(), n2m, d_mo2.data_ptr()), sync, warm=1, reps=3)
+    extras["g2_mul_batch"] = {"n": n2m, "ms": mb2ms, "scalar_muls_per_s": n2m / (mb2ms * 1e-3),
+                              "roofline": {"bound": "int-valu", "kernel": "k_mul_batch<G2, lane pair>", "mac32_per_unit": MAC32_G2_MUL, "achieved": n2m * MAC32_G2_MUL / (mb2ms * 1e-3) / 1e12,
+                                           "peak": peak / 1e12, "unit": "TMAC32/s", "frac": n2m * MAC32_G2_MUL / (mb2ms * 1e-3) / peak}}
+    del d_xy1, d_mo, d_xy2, d_mo2
     # fixed-base mode: resident window-shifted tables (13 windows of 20 bits, one bucket set, no window combine)
     t1 = time.perf_counter()
     bases.precompute(0)
@@ -508,8 +566,14 @@ class MixedJobs:
         dev = torch.device("cuda", device_index)
         seed = synthetic.SEED if seed_base is None else seed_base
         self.ctx = [bls.Context(device_index) for _ in range(3)]
+        # All three contexts take torch's current stream as THEIR stream: the MSM phases still run on each context's internal
+        # streams (pipelining on), the Miller kernel on the shared stream beside them, and `join` orders the shared stream behind
+        # the MSM tails -- so the collectives, the folds and the final exponentiation that follow are stream-ordered and a step
+        # needs no host synchronisation at all (the buffers of step i+1 wait for the readers of step i through the same stream).
+        st = torch.cuda.current_stream().cuda_stream
         for c in self.ctx:
             c.set_pipelining(True)
+            c.set_stream(st)
         n1 = shard_range(1 << sizes[0], rank, world); n2 = shard_range(1 << sizes[1], rank, world); nm = shard_range(1 << sizes[2], rank, world)
         self.n = (n1[1] - n1[0], n2[1] - n2[0], nm[1] - nm[0])
         self.kb1 = synthetic.scalars(self.n[0], seed + 100 + rank); self.sb1 = synthetic.scalars(self.n[0], seed + 200 + rank)
@@ -568,7 +632,7 @@ def run_mixed(args, e):
 
     def step(which=(0, 1, 2)):
         jobs.launch(which)
-        jobs.sync()                        # the three rank-local results (one element each) are ready
+        jobs.join()                        # stream-level: the shared stream now follows the two MSM tails (no host round trip)
         srcm = jobs.om
         if multi:
             # the three tiny exchanges (144 B, 288 B, 576 B per rank) + folds on every rank
@@ -584,7 +648,8 @@ def run_mixed(args, e):
                 srcm = fm
         if 2 in which:
             fold_ctx.final_exponentiation_device(srcm.data_ptr(), 1, gt.data_ptr())     # ONE final exponentiation per product
-        fold_ctx.synchronize()
+        if e.xdev != dev:
+            fold_ctx.synchronize()         # CPU collectives (gloo test path) read host copies: keep the steps apart
 
     def timed(which, k):
         fence(e)

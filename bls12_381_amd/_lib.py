@@ -86,6 +86,7 @@ SIGNATURES = {
     "blsgpu_fp12_product_device": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_fp_op": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_fp2_op": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_fp6_op": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_fp12_op": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_point_op": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_fp_mul_throughput": (c_int, [c_vp, c_int, ctypes.POINTER(ctypes.c_double)]),

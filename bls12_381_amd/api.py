@@ -358,6 +358,9 @@ class Context:
     def fp2_op(self, op, a, b=None):
         return self._elem_op(self.lib.blsgpu_fp2_op, 12, op, a, b)
 
+    def fp6_op(self, op, a, b=None):
+        return self._elem_op(self.lib.blsgpu_fp6_op, 36, op, a, b)
+
     def fp12_op(self, op, a, b=None):
         return self._elem_op(self.lib.blsgpu_fp12_op, 72, op, a, b)
 

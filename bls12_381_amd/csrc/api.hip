@@ -62,10 +62,6 @@ struct blsgpu_ctx {
   int acc_timing = 0;                   // blsgpu_msm_accumulate_stats: HIP-event duration of every acc_timing-th accumulation launch (0 = off)
   unsigned acc_tick = 0;
   double acc_ms_sum = 0.0; unsigned acc_count = 0;
-  int g1_kernel = 1;                    // G1 bucket accumulation: 1 = k_msm_accumulate<FpPolicy> (one lane per chain, 241 VGPRs, two wavefronts per SIMD;
-                                        // default), 0 = k_msm_accumulate_g1 (three wavefronts per SIMD, LDS-DMA prefetch; env BLSGPU_G1_SPLIT: measured 7% slower),
-                                        // 2 = lane-pair kernel (env BLSGPU_G1_PAIR: measured 12% slower)
-  bool wsum_one_lane = false;          // A/B hook (env BLSGPU_WSUM_ONE_LANE at create): the one-lane form of the bottom reduction level (G1)
   u32 item_cap = 0;                    // A/B hook (env BLSGPU_ITEM_CAP at create): entries per work item of the accumulation (0 = automatic)
   int pairing_layout = 4;              // lanes per pairing of pairing / Miller loop / final exponentiation batches: 4 = quad (quad.hip.h, default: no hot-loop scratch,
                                        // half the latency of small batches, +2..11 % pairings/s up to 2^16), 2 = lane pair (pairing.hip.h); env BLSGPU_PAIRING_LAYOUT=pair|quad at create
@@ -411,9 +407,7 @@ extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
   c->force_slow_sort = getenv("BLSGPU_FORCE_SLOW_SORT") != nullptr;
   c->no_glv = getenv("BLSGPU_NO_GLV") != nullptr;
   if (const char* v = getenv("BLSGPU_PAIRING_LAYOUT")) c->pairing_layout = (v[0] == 'q' || v[0] == '4') ? 4 : 2;
-  c->wsum_one_lane = getenv("BLSGPU_WSUM_ONE_LANE") != nullptr;
   if (const char* v = getenv("BLSGPU_ITEM_CAP")) { long k = atol(v); if (k >= 8 && k <= ITEM_CAP_MAX) c->item_cap = (u32)k; }
-  c->g1_kernel = getenv("BLSGPU_G1_PAIR") ? 2 : getenv("BLSGPU_G1_SPLIT") ? 0 : 1;
   int rc = ctx_init(c);
   if (rc != BLSGPU_OK) { blsgpu_destroy(c); return rc; }       // destroy tolerates the half-built context (null handles are skipped)
   *out = c;
@@ -860,12 +854,6 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   if constexpr (GroupTag<F>::id == 2)
     hipLaunchKernelGGL(k_msm_accumulate_g2pair, dim3(nblk(2 * max_items, BLS_G2ACC_BLOCK)), dim3(BLS_G2ACC_BLOCK), 0, as, gls ? bases->endo + 4 * first * Store<F>::AFF_WORDS : base_rec,
                        sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
-  else if (c->g1_kernel == 0)
-    hipLaunchKernelGGL(k_msm_accumulate_g1, dim3(nblk(max_items, 256)), dim3(256), 0, as, base_rec, glv ? bases->endo + first * Store<F>::AFF_WORDS : (const u32*)nullptr,
-                       glv ? (u32)n : 0xffffffffu, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
-  else if (c->g1_kernel == 2)
-    hipLaunchKernelGGL(k_msm_accumulate_g1pair, dim3(nblk(2 * max_items, 256)), dim3(256), 0, as, base_rec, glv ? bases->endo + first * Store<F>::AFF_WORDS : (const u32*)nullptr,
-                       glv ? (u32)n : 0xffffffffu, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
   else
     hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(max_items, BLS_ACC_BLOCK)), dim3(BLS_ACC_BLOCK), 0, as, base_rec, glv ? bases->endo + first * Store<F>::AFF_WORDS : (const u32*)nullptr,
                        glv ? (u32)n : 0xffffffffu, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
@@ -924,10 +912,8 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
         hipLaunchKernelGGL(k_wsum_level_team<F>, dim3(nblk((size_t)nseg * G * TEAM, 256)), dim3(256), TEAM_LDS(256), tt, E, Rout, Tout, nseg, nn, M, off);
       else if constexpr (GroupTag<F>::id == 2)
         hipLaunchKernelGGL(k_wsum_level_g2pair, dim3(nblk((size_t)nseg * G * 2, 256)), dim3(256), 0, tt, E, Rout, Tout, nseg, nn, M, off);
-      else if (!c->wsum_one_lane)
-        hipLaunchKernelGGL(k_wsum_level_pair, dim3(nblk((size_t)nseg * G * 2, BLS_WSUM_BLOCK)), dim3(BLS_WSUM_BLOCK), 0, tt, E, Rout, Tout, nseg, nn, M, off);
       else
-        hipLaunchKernelGGL(k_wsum_level<F>, dim3(nblk((size_t)nseg * G, 256)), dim3(256), 0, tt, E, Rout, Tout, nseg, nn, M, off);
+        hipLaunchKernelGGL(k_wsum_level_pair, dim3(nblk((size_t)nseg * G * 2, BLS_WSUM_BLOCK)), dim3(BLS_WSUM_BLOCK), 0, tt, E, Rout, Tout, nseg, nn, M, off);
       LAUNCHCHK();
       // sum the G T-records of each window down to one -- on the second tail stream: the next level needs only Rout.  Level l
       // needs log8(G_l) passes; after every level ONE launch carries the next pass of every tree that still has one (the T
@@ -1174,6 +1160,7 @@ static int elem_op(blsgpu_ctx* c, int words, int kind, int op, const uint64_t* a
   const u32* bp = b ? c->io_b.as<u32>() : nullptr;
   if (kind == 1) hipLaunchKernelGGL(k_fp_op, dim3(nblk(n, 256)), dim3(256), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
   else if (kind == 2) hipLaunchKernelGGL(k_fp2_op, dim3(nblk(n, 256)), dim3(256), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
+  else if (kind == 6) hipLaunchKernelGGL(k_fp6_op, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
   else if (c->pairing_layout == 4 && op != 3) hipLaunchKernelGGL(k_fp12_op_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
   else hipLaunchKernelGGL(k_fp12_op, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
   LAUNCHCHK();
@@ -1188,6 +1175,11 @@ extern "C" int blsgpu_fp_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint
 extern "C" int blsgpu_fp2_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
   if (op < 0 || op > 6) return bad("fp2_op: unknown op");
   return elem_op(c, 24, 2, op, a, b, n, out);
+}
+extern "C" int blsgpu_fp6_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+  if (!(op == 0 || op == 3 || op == 4 || op == 5 || op == 7 || op == 11 || op == 12)) return bad("fp6_op: unknown op");
+  if ((op == 0 || op == 11 || op == 12) && n && !b) return bad("fp6_op: the second operand is missing");
+  return elem_op(c, 72, 6, op, a, b, n, out);
 }
 extern "C" int blsgpu_fp12_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
   if (!(op == 0 || op == 3 || op == 4 || op == 7 || op == 8 || op == 9 || op == 10)) return bad("fp12_op: unknown op");

@@ -638,6 +638,25 @@ PAIR_KERNEL k_gt_mul_scalar(const u32* __restrict__ gt, const u32* __restrict__ 
 __global__ void k_fp12_one(u32* out) {
   if (threadIdx.x < PL && blockIdx.x == 0) { Fp12T<PE> f = fp12_one<PE>(); fp12_save(f, out); }
 }
+// parity hook for the Fp6 layer (fp6.rs): op 0 mul (:200-274), 3 square (:277-291), 4 invert (:294-312), 5 mul_by_nonresidue
+// (:139-150), 7 frobenius_map (:154-188), 11 mul_by_1 (b.c1; :113-119), 12 mul_by_01 (b.c0, b.c1; :121-136).  36 u64 per element.
+PAIR_KERNEL k_fp6_op(int op, const u32* __restrict__ a, const u32* __restrict__ b, u32* __restrict__ out, size_t n) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / PL;
+  if (i >= n) return;
+  Fp6T<PE> x, y, r;
+  x.c0 = E2<PE>::load(a + i * 72); x.c1 = E2<PE>::load(a + i * 72 + 24); x.c2 = E2<PE>::load(a + i * 72 + 48);
+  if (b) { y.c0 = E2<PE>::load(b + i * 72); y.c1 = E2<PE>::load(b + i * 72 + 24); y.c2 = E2<PE>::load(b + i * 72 + 48); } else y = x;
+  switch (op) {
+    case 0: fp6_mul(r, x, y); break;
+    case 3: fp6_sqr(r, x); break;
+    case 4: fp6_inv(r, x); break;
+    case 5: r = fp6_mul_by_nonresidue(x); break;
+    case 7: fp6_frobenius(r, x); break;
+    case 11: fp6_mul_by_1(r, x, y.c1); break;
+    default: fp6_mul_by_01(r, x, y.c0, y.c1); break;
+  }
+  E2<PE>::save(r.c0, out + i * 72); E2<PE>::save(r.c1, out + i * 72 + 24); E2<PE>::save(r.c2, out + i * 72 + 48);
+}
 PAIR_KERNEL k_fp12_op(int op, const u32* __restrict__ a, const u32* __restrict__ b, u32* __restrict__ out, size_t n) {
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / PL;
   if (i >= n) return;

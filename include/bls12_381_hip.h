@@ -202,7 +202,12 @@ int blsgpu_fp12_product_device(blsgpu_ctx* ctx, const void* d_in_f, size_t n, vo
 int blsgpu_fp_op(blsgpu_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
 /* Same over Fp2 (12 u64 per element); op: 0 mul, 1 add, 2 sub, 3 square, 4 invert, 5 neg, 6 mul_by_nonresidue. */
 int blsgpu_fp2_op(blsgpu_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
-/* Same over Fp12 (72 u64 per element); op: 0 mul, 3 square, 4 invert, 7 frobenius_map, 8 conjugate, 9 cyclotomic_square. */
+/* Same over Fp6 (36 u64 per element: c0 | c1 | c2, src/fp6.rs:12-16); op: 0 mul (fp6.rs:200-274), 3 square (:277-291), 4 invert
+ * (:294-312), 5 mul_by_nonresidue (:139-150), 7 frobenius_map (:154-188), 11 mul_by_1 with c1 = b.c1 (:113-119), 12 mul_by_01 with
+ * (c0, c1) = (b.c0, b.c1) (:121-136). */
+int blsgpu_fp6_op(blsgpu_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
+/* Same over Fp12 (72 u64 per element); op: 0 mul, 3 square, 4 invert, 7 frobenius_map, 8 conjugate, 9 cyclotomic_square,
+ * 10 the final exponentiation's power by |x| followed by conjugation (`cycolotomic_exp`, src/pairings.rs:114-132; quad layout only). */
 int blsgpu_fp12_op(blsgpu_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
 /* Point ops over n pairs in wire format; op: 0 add (proj+proj), 1 double (a), 2 add_mixed (proj + affine b). group 1|2. */
 int blsgpu_point_op(blsgpu_ctx* ctx, int group, int op, const uint64_t* a, const uint64_t* b, const uint8_t* b_inf, size_t n, uint64_t* out);

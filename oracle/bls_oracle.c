@@ -86,8 +86,43 @@ static inline fp fp_mul(const fp* a, const fp* b) {
   }
   return montgomery_reduce(t);
 }
-/* fp.rs:613-660 (computed as a product here; same field element, same limbs) */
-static inline fp fp_sqr(const fp* a) { return fp_mul(a, a); }
+/* fp.rs:613-660: the 15 cross products once, doubled by a one-bit shift, plus the six diagonal terms */
+static inline fp fp_sqr(const fp* a) {
+  u64 t[12] = {0};
+  for (int i = 0; i < 5; i++) {
+    u64 carry = 0;
+    for (int j = i + 1; j < 6; j++) t[i + j] = mac(t[i + j], a->l[i], a->l[j], &carry);
+    t[i + 6] = carry;
+  }
+  t[11] = t[10] >> 63;
+  for (int k = 10; k >= 2; k--) t[k] = (t[k] << 1) | (t[k - 1] >> 63);
+  t[1] <<= 1;
+  u64 carry = 0;
+  for (int i = 0; i < 6; i++) {
+    t[2 * i] = mac(t[2 * i], a->l[i], a->l[i], &carry);
+    t[2 * i + 1] = adc(t[2 * i + 1], 0, &carry);
+  }
+  return montgomery_reduce(t);
+}
+/* fp.rs:430-484 (Longa, ePrint 2022/367 Alg. 2): sum_i a_i b_i with the operand scanning of all T pairs interleaved and ONE
+ * Montgomery reduction step per limb -- what Fp2::mul (T = 2) and Fp6::mul_interleaved (T = 6) are built on */
+static inline fp fp_sum_of_products(int T, const fp* const* a, const fp* const* b) {
+  u64 u[6] = {0, 0, 0, 0, 0, 0};
+  for (int j = 0; j < 6; j++) {
+    u64 t[7] = {u[0], u[1], u[2], u[3], u[4], u[5], 0};
+    for (int i = 0; i < T; i++) {
+      u64 carry = 0;
+      for (int k = 0; k < 6; k++) t[k] = mac(t[k], a[i]->l[j], b[i]->l[k], &carry);
+      u64 c2 = 0; t[6] = adc(t[6], carry, &c2);
+    }
+    u64 k = t[0] * INV, carry = 0;
+    (void)mac(t[0], k, MODULUS[0], &carry);
+    for (int m = 1; m < 6; m++) u[m - 1] = mac(t[m], k, MODULUS[m], &carry);
+    u64 c2 = 0; u[5] = adc(t[6], carry, &c2);
+  }
+  fp r; for (int i = 0; i < 6; i++) r.l[i] = u[i];
+  return subtract_p(&r);
+}
 
 /* fp.rs:309-321,346-358 */
 static fp fp_pow(const fp* a, const u64 e[6]) {
@@ -273,8 +308,10 @@ static inline fp2 fp2_neg(const fp2* a) { fp2 r = {fp_neg(&a->c0), fp_neg(&a->c1
 static inline fp2 fp2_conj(const fp2* a) { fp2 r = {a->c0, fp_neg(&a->c1)}; return r; }                                         /* :148-153 */
 static inline fp2 fp2_dbl(const fp2* a) { return fp2_add(a, a); }
 static inline fp2 fp2_mul(const fp2* a, const fp2* b) {                                                                          /* :205-222 */
-  fp t0 = fp_mul(&a->c0, &b->c0), t1 = fp_mul(&a->c1, &b->c1), t2 = fp_mul(&a->c0, &b->c1), t3 = fp_mul(&a->c1, &b->c0);
-  fp2 r = {fp_sub(&t0, &t1), fp_add(&t2, &t3)};
+  fp na1 = fp_neg(&a->c1);
+  const fp* x0[2] = {&a->c0, &na1};   const fp* y0[2] = {&b->c0, &b->c1};      /* c0 = a0 b0 - a1 b1 */
+  const fp* x1[2] = {&a->c0, &a->c1}; const fp* y1[2] = {&b->c1, &b->c0};      /* c1 = a0 b1 + a1 b0 */
+  fp2 r = {fp_sum_of_products(2, x0, y0), fp_sum_of_products(2, x1, y1)};
   return r;
 }
 static inline fp2 fp2_sqr(const fp2* a) {                                                                                       /* :182-203 */
@@ -295,13 +332,22 @@ static inline fp6 fp6_add(const fp6* a, const fp6* b) { fp6 r = {fp2_add(&a->c0,
 static inline fp6 fp6_sub(const fp6* a, const fp6* b) { fp6 r = {fp2_sub(&a->c0, &b->c0), fp2_sub(&a->c1, &b->c1), fp2_sub(&a->c2, &b->c2)}; return r; }
 static inline fp6 fp6_neg(const fp6* a) { fp6 r = {fp2_neg(&a->c0), fp2_neg(&a->c1), fp2_neg(&a->c2)}; return r; }
 static inline fp6 fp6_mul_by_nonresidue(const fp6* a) { fp6 r = {fp2_mul_by_nonresidue(&a->c2), a->c0, a->c1}; return r; }      /* fp6.rs:139-150 */
-static fp6 fp6_mul(const fp6* a, const fp6* b) {                                                                               /* :200-274 */
-  fp2 a0b0 = fp2_mul(&a->c0, &b->c0), a1b2 = fp2_mul(&a->c1, &b->c2), a2b1 = fp2_mul(&a->c2, &b->c1);
-  fp2 a0b1 = fp2_mul(&a->c0, &b->c1), a1b0 = fp2_mul(&a->c1, &b->c0), a2b2 = fp2_mul(&a->c2, &b->c2);
-  fp2 a0b2 = fp2_mul(&a->c0, &b->c2), a1b1 = fp2_mul(&a->c1, &b->c1), a2b0 = fp2_mul(&a->c2, &b->c0);
-  fp2 s = fp2_add(&a1b2, &a2b1), ns = fp2_mul_by_nonresidue(&s), n22 = fp2_mul_by_nonresidue(&a2b2);
-  fp2 t1 = fp2_add(&a0b1, &a1b0), t2 = fp2_add(&a0b2, &a1b1);
-  fp6 r = {fp2_add(&a0b0, &ns), fp2_add(&t1, &n22), fp2_add(&t2, &a2b0)};
+static fp6 fp6_mul(const fp6* a, const fp6* b) {                                                                               /* :200-274 mul_interleaved */
+  /* six sums of six products, one interleaved reduction each (fp6.rs:241-273) */
+  fp b10p = fp_add(&b->c1.c0, &b->c1.c1), b10m = fp_sub(&b->c1.c0, &b->c1.c1);
+  fp b20p = fp_add(&b->c2.c0, &b->c2.c1), b20m = fp_sub(&b->c2.c0, &b->c2.c1);
+  fp n01 = fp_neg(&a->c0.c1), n11 = fp_neg(&a->c1.c1), n21 = fp_neg(&a->c2.c1);
+  const fp* xe[6] = {&a->c0.c0, &n01, &a->c1.c0, &n11, &a->c2.c0, &n21};                 /* real parts: a_i0, -a_i1 */
+  const fp* xo[6] = {&a->c0.c0, &a->c0.c1, &a->c1.c0, &a->c1.c1, &a->c2.c0, &a->c2.c1};  /* imaginary parts */
+  const fp* y00[6] = {&b->c0.c0, &b->c0.c1, &b20m, &b20p, &b10m, &b10p};
+  const fp* y01[6] = {&b->c0.c1, &b->c0.c0, &b20p, &b20m, &b10p, &b10m};
+  const fp* y10[6] = {&b->c1.c0, &b->c1.c1, &b->c0.c0, &b->c0.c1, &b20m, &b20p};
+  const fp* y11[6] = {&b->c1.c1, &b->c1.c0, &b->c0.c1, &b->c0.c0, &b20p, &b20m};
+  const fp* y20[6] = {&b->c2.c0, &b->c2.c1, &b->c1.c0, &b->c1.c1, &b->c0.c0, &b->c0.c1};
+  const fp* y21[6] = {&b->c2.c1, &b->c2.c0, &b->c1.c1, &b->c1.c0, &b->c0.c1, &b->c0.c0};
+  fp6 r = {{fp_sum_of_products(6, xe, y00), fp_sum_of_products(6, xo, y01)},
+           {fp_sum_of_products(6, xe, y10), fp_sum_of_products(6, xo, y11)},
+           {fp_sum_of_products(6, xe, y20), fp_sum_of_products(6, xo, y21)}};
   return r;
 }
 static fp6 fp6_sqr(const fp6* a) {                                                                                             /* :277-291 */

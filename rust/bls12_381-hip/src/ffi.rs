@@ -72,6 +72,7 @@ extern "C" {
     pub fn blsgpu_fp12_product_device(ctx: *mut BlsgpuCtx, d_in_f: *const c_void, n: usize, d_out_f: *mut c_void) -> c_int;
     pub fn blsgpu_fp_op(ctx: *mut BlsgpuCtx, op: c_int, a: *const u64, b: *const u64, n: usize, out: *mut u64) -> c_int;
     pub fn blsgpu_fp2_op(ctx: *mut BlsgpuCtx, op: c_int, a: *const u64, b: *const u64, n: usize, out: *mut u64) -> c_int;
+    pub fn blsgpu_fp6_op(ctx: *mut BlsgpuCtx, op: c_int, a: *const u64, b: *const u64, n: usize, out: *mut u64) -> c_int;
     pub fn blsgpu_fp12_op(ctx: *mut BlsgpuCtx, op: c_int, a: *const u64, b: *const u64, n: usize, out: *mut u64) -> c_int;
     pub fn blsgpu_point_op(ctx: *mut BlsgpuCtx, group: c_int, op: c_int, a: *const u64, b: *const u64, b_inf: *const u8, n: usize, out: *mut u64) -> c_int;
     pub fn blsgpu_fp_mul_throughput(ctx: *mut BlsgpuCtx, iters: c_int, muls_per_second: *mut f64) -> c_int;

@@ -1156,30 +1156,6 @@ def test_bench_distributed_branch_over_rccl_with_one_rank(workload):
         assert line["ranks_agree"] is True
 
 
-def test_msm_split_accumulation_kernel(monkeypatch):
-    """the experimental G1 accumulation kernel (k_msm_accumulate_g1: generic-case fast loop at three wavefronts per SIMD with the
-    next record staged by the gfx950 LDS-DMA path, exceptional cases finished by the reference's complete mixed addition;
-    BLSGPU_G1_SPLIT) must give the same group elements as the default kernel: duplicates, +-pairs, identities, one bucket
-    holding everything, every window width, and a medium random case"""
-    import bls12_381_amd as b
-    monkeypatch.setenv("BLSGPU_G1_SPLIT", "1")
-    c = b.Context(0)
-    monkeypatch.delenv("BLSGPU_G1_SPLIT")
-    r = o.SplitMix64(777)
-    rr = o.R_ORDER
-    ks = [1, 2, 3, 0, 5, 5, 5, rr - 5, 7, rr - 7, 0, 11] + [r.scalar() for _ in range(20)]
-    ss = [0, 1, rr - 1, 12345, 9, 9, rr - 9, 9, (1 << 254), (1 << 254), 0, (1 << 16) - 1] + \
-         [(1 << (16 * i)) - 1 for i in range(1, 11)] + [(1 << 15) + (1 << (16 * i + 15)) for i in range(10)]
-    for w in (0, 4, 7, 13, 16):
-        _msm_case(c, 1, ks, ss, window=w)
-    _msm_case(c, 1, [3] * 300, [1] * 300)
-    _msm_case(c, 1, [3] * 3000, [7] * 3000)
-    _msm_case(c, 1, [4, rr - 4], [77, 77])
-    _msm_case(c, 1, [4, 4, rr - 4, 4, 0, 4], [77, 77, 77, 77, 5, 77])
-    n = 1 << 14
-    _msm_case(c, 1, [r.scalar() for _ in range(n)], [r.scalar() for _ in range(n)])
-
-
 def test_msm_g2_psi_decomposition_boundaries(ctx, monkeypatch):
     """G2 MSMs split every scalar into four signed base-|x| digits (psi acts as [x] on the subgroup, g2.rs:475-482 / :847-890).
     Scalars at the digit boundaries -- multiples of X, X^2, X^3 and their neighbours, the balancing threshold X/2, the carry
@@ -1247,12 +1223,13 @@ def test_msm_decomposition_size_limits(ctx):
     bases.free()
 
 
-@pytest.mark.parametrize("hook,value", [("BLSGPU_G1_PAIR", "1"), ("BLSGPU_ITEM_CAP", "16"), ("BLSGPU_WSUM_ONE_LANE", "1"), ("BLSGPU_NO_GLV", "1")])
+@pytest.mark.parametrize("hook,value", [("BLSGPU_ITEM_CAP", "16"), ("BLSGPU_NO_GLV", "1")])
 def test_msm_alternative_paths_behind_ab_hooks(monkeypatch, hook, value):
-    """the library keeps a few alternative kernels / settings behind environment switches read at context creation (the A/B
-    experiments of DESIGN.md 9: lane-pair G1 accumulation, short work items -- every bucket cut, partial sums folded --, the
-    one-lane bottom reduction level, plain windows without the endomorphism decompositions): each must produce the same group
-    elements as the default path on the edge cases and on a medium random case, for both groups"""
+    """two settings stay switchable at context creation because product paths depend on them: short work items (every bucket cut,
+    partial sums folded -- the path heavy buckets take) and plain windows without the endomorphism decompositions (the path of
+    off-subgroup base sets and of sets beyond the sort's index width): each must produce the same group elements as the default
+    path on the edge cases and on a medium random case, for both groups.  (The slower experimental kernels of round 2 now live
+    in tools/experiments/, outside the product.)"""
     import bls12_381_amd as b
     monkeypatch.setenv(hook, value)
     c = b.Context(0)
@@ -1488,3 +1465,33 @@ def test_mul_batch_off_subgroup_points_and_mirror(ctx, kats, group):
         assert gp.to_affine().to_uncompressed() == enc(toaff(amul(A, s))), s
     assert (AffT(*affw(A)) * b.Scalar(ss[-1])).to_affine().to_uncompressed() == enc(toaff(amul(A, ss[-1])))
     assert AffT.mul_batch([], []) == []
+
+
+def test_fp6_ops(ctx):
+    """the Fp6 layer directly: mul (fp6.rs:200-274), square (:277-291), invert (:294-312),
+    mul_by_nonresidue (:139-150), frobenius_map (:154-188), the sparse mul_by_1 / mul_by_01 (:113-136); random operands plus
+    0, 1 and elements with zero coefficients"""
+    r = o.SplitMix64(606)
+
+    def rnd2():
+        return (rng_fp(r), rng_fp(r))
+
+    def rnd6():
+        return (rnd2(), rnd2(), rnd2())
+
+    def w6(a):
+        return np.concatenate([fp2w(c) for c in a])
+
+    z2 = (0, 0)
+    a = [rnd6() for _ in range(30)] + [o.FP6_ONE, (rnd2(), z2, z2), (z2, rnd2(), z2), (z2, z2, rnd2())]
+    b = [rnd6() for _ in range(len(a))]
+    A, B = np.stack([w6(x) for x in a]), np.stack([w6(x) for x in b])
+    assert np.array_equal(ctx.fp6_op(0, A, B), np.stack([w6(o.fp6_mul(x, y)) for x, y in zip(a, b)]))
+    assert np.array_equal(ctx.fp6_op(3, A), np.stack([w6(o.fp6_sqr(x)) for x in a]))
+    assert np.array_equal(ctx.fp6_op(4, A), np.stack([w6(o.fp6_inv(x)) for x in a]))
+    assert np.array_equal(ctx.fp6_op(5, A), np.stack([w6(o.fp6_mul_by_nonresidue(x)) for x in a]))
+    assert np.array_equal(ctx.fp6_op(7, A), np.stack([w6(o.fp6_frobenius(x)) for x in a]))
+    assert np.array_equal(ctx.fp6_op(11, A, B), np.stack([w6(o.fp6_mul_by_1(x, y[1])) for x, y in zip(a, b)]))
+    assert np.array_equal(ctx.fp6_op(12, A, B), np.stack([w6(o.fp6_mul_by_01(x, y[0], y[1])) for x, y in zip(a, b)]))
+    # the sparse forms agree with the dense product (fp6.rs:376-561 checks the same identities)
+    assert np.array_equal(ctx.fp6_op(12, A, B), ctx.fp6_op(0, A, np.stack([w6((y[0], y[1], z2)) for y in b])))

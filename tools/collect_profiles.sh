@@ -11,6 +11,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$R"
 rm -rf gpurun_out/prof_msm/stats
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_msm/stats -- python bench.py --no-cpu-baseline --no-extras > gpurun_out/prof_msm/bench_under_rocprof.json 2> /dev/null
 tools/pmc.sh prof_pair python tools/run_pairing.py pairing 16 3
+BLSGPU_PAIRING_LAYOUT=pair tools/pmc.sh prof_pair_lp python tools/run_pairing.py pairing 16 3
 tools/pmc.sh prof_mml python tools/run_pairing.py mml 18 3
-find gpurun_out/prof_msm gpurun_out/prof_pair gpurun_out/prof_mml -name "*agent_info.csv" -delete
+find gpurun_out/prof_msm gpurun_out/prof_pair gpurun_out/prof_pair_lp gpurun_out/prof_mml -name "*agent_info.csv" -delete
 du -sh gpurun_out/prof_*

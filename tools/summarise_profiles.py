@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """gpurun_out/prof_{msm,pair,mml} (tools/collect_profiles.sh) -> profiles/<round>_*.md / .json
 
-    python tools/summarise_profiles.py r02
+    python tools/summarise_profiles.py r03
 """
 import collections
 import csv
@@ -11,9 +11,12 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from kernel_meta import kernel_meta, find as meta_find      # registers / scratch / LDS from the code object, not from rocprof's VGPR_Count column
+META = kernel_meta()
 G = os.path.join(ROOT, "gpurun_out")
 OUT = os.path.join(ROOT, "profiles")
-RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def one(pattern):
@@ -80,7 +83,8 @@ def msm():
          "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb, "hbm_bytes_per_launch_corrected": hbm,
          "correction": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 16-byte-per-lane reads at half); Infinity-Cache hits are included",
          "algorithmic_bytes_per_launch": alg, "counters": {k: v for k, v in c.items() if not k.startswith("_")},
-         "mad_wave_insts_expected": mads / 64, "vgpr": row.get("VGPR_Count"), "scratch": row.get("Scratch_Size")}
+         "mad_wave_insts_expected": mads / 64, "vgpr": meta_find(META, "k_msm_accumulate FpPolicy").get("vgpr_count"),
+         "scratch": meta_find(META, "k_msm_accumulate FpPolicy").get("private_segment_fixed_size")}
     json.dump(j, open(os.path.join(OUT, f"{RND}_msm_pmc.json"), "w"), indent=1)
     ghz = c.get("GRBM_GUI_ACTIVE", 0) / 8 / (dur * 1e-9) / 1e9 if dur else 0
     wc = c.get("SQ_WAVE_CYCLES", 1)
@@ -90,7 +94,7 @@ def msm():
 Separate rocprofv3 passes (one `--pmc` group each, `--kernel-trace` only; tools/pmc.sh, tools/collect_profiles.sh) over `python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras`; counter averages over the {c.get('_launches', 0)} launches of a pass.
 
 * launch duration (kernel trace of the DEFAULT bench command): {dur/1e3:.0f} us over all {len(d)} launches = {sum(pipe)/max(1,len(pipe))/1e3:.0f} us for the timed pipelined launches (what `bench.py` reports as `roofline.launch_ms`) and {sum(iso)/max(1,len(iso))/1e3:.0f} us for the 5 isolated probes at the end (`launch_ms_isolated`); {note}
-* registers / scratch per lane: {row.get('VGPR_Count')} VGPR, {row.get('Scratch_Size')} B scratch
+* registers / scratch per lane (code-object metadata): {j['vgpr']} VGPR, {j['scratch']} B scratch
 * FETCH_SIZE = {fetch_kb:.0f} KB raw -> x2 (gfx950 half-count of 16-byte-per-lane reads) = {2*fetch_kb*1024/1e9:.2f} GB;  WRITE_SIZE = {write_kb:.0f} KB = {write_kb*1024/1e9:.2f} GB
 * HBM-side traffic per launch = {hbm/1e9:.2f} GB (algorithmic: 8 windows x 2^21 gathers x (128 B record + 4 B index) + 2^18 x 176 B bucket records = {alg/1e9:.2f} GB); at {dur/1e3:.0f} us that is {hbm/dur/1e3:.2f} TB/s = {100*hbm/dur/1e3/8:.0f}% of the 8 TB/s HBM peak: not memory-bound.  With GLV the gathers range over 256 MB (bases + their endomorphism images), the size of the Infinity Cache.
 * SQ_INSTS_VALU = {c.get('SQ_INSTS_VALU',0):.3e} wave-instructions, of which {mads/64:.3e} are the v_mad_u64_u32 of the 7 mul + 2 sqr + one two-product sum per mixed addition ({100*mads/64/max(c.get('SQ_INSTS_VALU',1),1):.0f}%).
@@ -100,26 +104,36 @@ Separate rocprofv3 passes (one `--pmc` group each, `--kernel-trace` only; tools/
 """)
 
 
-def pairing(d, K, units, unit_name, mac32, tag, what):
+def pairing(d, K, units, unit_name, mac32, tag, what, layout, alg_bytes_per_unit):
     dd, row = durations(d, K)
     if not dd:
         return
     dur = sum(dd) / len(dd)
     c = counters(d, K)
+    m = meta_find(META, K)
     stats_table(one(d + "/stats/**/*kernel_stats.csv"), f"{RND}: rocprofv3 --kernel-trace --stats -- python tools/run_pairing.py {what}", os.path.join(OUT, f"{RND}_{tag}_kernel_stats.md"))
-    lanes = units * 2 if tag == "pairing" else None
     wc = c.get("SQ_WAVE_CYCLES", 1)
+    fetch_kb, write_kb = c.get("FETCH_SIZE", 0), c.get("WRITE_SIZE", 0)
+    hbm = (2 * fetch_kb + write_kb) * 1024
+    alg = units * alg_bytes_per_unit
+    j = {"kernel": K, "layout": layout, "units": units, "unit": unit_name, "launch_avg_ns": dur, "launches": len(dd), "mac32_per_unit": mac32,
+         "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb, "hbm_bytes_per_launch_corrected": hbm, "algorithmic_bytes_per_launch": alg,
+         "traffic_over_algorithmic": hbm / alg if alg else None,
+         "correction": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 16-byte-per-lane reads at half); WRITE_SIZE as reported; Infinity-Cache hits are included",
+         "vgpr": m.get("vgpr_count"), "scratch_frame_bytes": m.get("private_segment_fixed_size"), "lds_bytes_per_block": m.get("group_segment_fixed_size"),
+         "counters": {k: v for k, v in c.items() if not k.startswith("_")}}
+    json.dump(j, open(os.path.join(OUT, f"{RND}_{tag}_pmc.json"), "w"), indent=1)
     with open(os.path.join(OUT, f"{RND}_{tag}_pmc.md"), "w") as fh:
-        fh.write(f"""# {RND}: PMC counters of {K} ({units} {unit_name} per launch, lane-pair layout, 2 wavefronts/SIMD)
+        fh.write(f"""# {RND}: PMC counters of {K} ({units} {unit_name} per launch, {layout})
 
 `tools/run_pairing.py {what}` under rocprofv3 (`--kernel-trace` + one `--pmc` group per pass; tools/pmc.sh); averages over {len(dd)} launches.
 
 * launch duration: {dur/1e6:.2f} ms -> {units/(dur*1e-9):.3e} {unit_name}/s; canonical work {mac32/1e6:.2f} M MAC32 per unit (SURVEY.md 8d) -> {units*mac32/(dur*1e-9)/1e12:.2f} TMAC32/s
-* registers / scratch per lane: {row.get('VGPR_Count')} VGPR, {row.get('Scratch_Size')} B of scratch frame (the deepest call path; the Miller loop touches ~1.7 KB of it)
-* FETCH_SIZE = {c.get('FETCH_SIZE',0)/1e6:.2f} GB raw (x2 if counted as 16-byte reads: {2*c.get('FETCH_SIZE',0)*1024/1e9:.1f} GB), WRITE_SIZE = {c.get('WRITE_SIZE',0)*1024/1e9:.1f} GB per launch: per-lane scratch (spills around the out-of-line Fp2 products, by-reference Fp12 operands of the final exponentiation); r01 measured 13.1 / 31.2 GB
-* SQ_INSTS_VALU = {c.get('SQ_INSTS_VALU',0):.3e} wave-instructions; SQ_INSTS_VMEM_RD / WR = {c.get('SQ_INSTS_VMEM_RD',0):.3e} / {c.get('SQ_INSTS_VMEM_WR',0):.3e}
+* registers / scratch / LDS (code-object metadata): {m.get('vgpr_count')} VGPR, {m.get('private_segment_fixed_size')} B scratch frame per lane (the deepest call path of the final exponentiation; the hot loops touch none of it), {m.get('group_segment_fixed_size')} B LDS per block
+* HBM-side traffic per launch: FETCH_SIZE = {fetch_kb/1e6:.3f} GB raw -> x2 = {2*fetch_kb*1024/1e9:.2f} GB, WRITE_SIZE = {write_kb*1024/1e9:.2f} GB, together {hbm/1e9:.2f} GB against {alg/1e6:.0f} MB of inputs and outputs ({alg_bytes_per_unit} B per unit) = {hbm/alg if alg else 0:.1f}x
+* SQ_INSTS_VALU = {c.get('SQ_INSTS_VALU',0):.3e} wave-instructions; SQ_INSTS_VMEM_RD / WR = {c.get('SQ_INSTS_VMEM_RD',0):.3e} / {c.get('SQ_INSTS_VMEM_WR',0):.3e}; SQ_INSTS_LDS = {c.get('SQ_INSTS_LDS',0):.3e}
 * wave-cycle split: SQ_ACTIVE_INST_ANY {100*c.get('SQ_ACTIVE_INST_ANY',0)/wc:.0f}%, SQ_WAIT_INST_ANY (issue stalls) {100*c.get('SQ_WAIT_INST_ANY',0)/wc:.0f}%, SQ_WAIT_ANY (s_waitcnt) {100*c.get('SQ_WAIT_ANY',0)/wc:.0f}% of SQ_WAVE_CYCLES = {wc:.3e}
-* instruction cache: {c.get('SQC_ICACHE_MISSES',0):.3e} misses of {c.get('SQC_ICACHE_REQ',0):.3e} requests (the 64 KB hot loop of the inlined Miller loop does not thrash it)
+* instruction cache: {c.get('SQC_ICACHE_MISSES',0):.3e} misses of {c.get('SQC_ICACHE_REQ',0):.3e} requests
 * GRBM_GUI_ACTIVE = {c.get('GRBM_GUI_ACTIVE',0):.3e} (8 XCDs) -> {c.get('GRBM_GUI_ACTIVE',0)/8/(dur*1e-9)/1e9:.2f} GHz under profiling
 """)
 
@@ -128,7 +142,9 @@ os.makedirs(OUT, exist_ok=True)
 if one("prof_msm/stats/**/*kernel_stats.csv"):
     msm()
 if one("prof_pair/stats/**/*kernel_trace.csv"):
-    pairing("prof_pair", "k_pairing", 65536, "pairings", 4.8e6, "pairing", "pairing 16 3")
+    pairing("prof_pair", "k_pairing_quad", 65536, "pairings", 4.8e6, "pairing", "pairing 16 3", "quad layout: one pairing per four lanes, 2 wavefronts/SIMD", 864)
+if one("prof_pair_lp/stats/**/*kernel_trace.csv"):
+    pairing("prof_pair_lp", "k_pairing(", 65536, "pairings", 4.8e6, "pairing_lanepair", "pairing 16 3 (BLSGPU_PAIRING_LAYOUT=pair)", "lane-pair layout of rounds 1-2, 2 wavefronts/SIMD", 864)
 if one("prof_mml/stats/**/*kernel_trace.csv"):
-    pairing("prof_mml", "k_multi_miller_shared", 262144, "terms", 2.07e6, "mml", "mml 18 3")
+    pairing("prof_mml", "k_multi_miller_shared", 262144, "terms", 2.07e6, "mml", "mml 18 3", "lane-pair layout, four terms per shared accumulator", 288)
 print("profiles written for", RND)
