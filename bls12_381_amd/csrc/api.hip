@@ -109,7 +109,8 @@ struct blsgpu_bases {
   // The images are used only for base sets that lie in the prime-order subgroup: phi(P) = -[z^2]P and psi(P) = [x]P hold
   // there and nowhere else on the curve, while the reference's `multiply` (g1.rs:754-774) is defined for every curve
   // point.  subgroup: 1 = every base passed is_torsion_free on the device (or was built as [k]G), 2 = the caller vouched
-  // for the set (blsgpu_set_assume_subgroup), 0 = at least one base is outside the subgroup -> plain windows, no images.
+  // for the set (blsgpu_set_assume_subgroup), 0 = at least one base is outside the subgroup -> plain windows, no images,
+  // 3 = not tested because the set is too large for the split anyway (plain windows).
   int subgroup = 0;
   // optional window-shifted tables: table[w * n + i] = [2^(table_c * w)] P_i   (blsgpu_bases_precompute)
   u32* table = nullptr; int table_c = 0, table_w = 0;
@@ -517,7 +518,9 @@ static void bases_drop(blsgpu_bases* b) {        // error paths of the construct
 }
 static int bases_make_endo(blsgpu_ctx* c, blsgpu_bases* b, bool trusted) {
   if (!b->n) { b->subgroup = 1; return BLSGPU_OK; }
-  if (b->group == 2 && b->n > ((size_t)1 << 22)) return BLSGPU_OK;          // 4 n must fit the sort's 24-bit indices: larger sets use plain windows
+  // G2 sets with 4 n beyond the sort's 24-bit indices never take the split: no images, plain windows (exact for any curve
+  // point), so there is nothing to test either
+  if (b->group == 2 && b->n > ((size_t)1 << 22)) { b->subgroup = trusted ? 1 : (c->assume_subgroup ? 2 : 3); return BLSGPU_OK; }
   if (trusted) b->subgroup = 1;
   else if (c->assume_subgroup) b->subgroup = 2;
   else {
@@ -685,6 +688,10 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   if (bases->device != c->device) return bad("msm: bases live on another device than the context");
   if (n > ((size_t)1 << 27)) return bad("msm: n too large for one call (shard the input)");
   HIPCHK(hipSetDevice(c->device));
+  // Calls beyond the sort's index width with the endomorphism split (G1: 2 n > 2^24, G2: 4 n > 2^24) run on plain windows.
+  // Cutting them into passes that each keep the split was measured (round 3, 2^24 G1 points on one MI355X: two GLV passes
+  // 52.6 ms against 45.9 ms for one plain pass): the split halves the WINDOWS, not the bucket additions, and at this size
+  // the additions are everything -- two tails and gathers over twice the memory only add to them.
   hipStream_t st = c->stream;
   constexpr int PW = Store<F>::PROJ_WORDS;
   if (c->result.reserve(PW * 4)) { g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP; }
@@ -879,7 +886,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     std::vector<Tree> trees;                            // T trees with passes left
     // one pass of every unfinished tree: a single multi-job launch when all of them fit the team form
     auto tree_step = [&]() -> int {
-      TreeJobs J; J.njobs = 0; J.nseg = nseg; J.first_team[0] = 0;
+      TreeJobs J; J.njobs = 0; J.nseg = nseg; J.first_team[0] = 0; J.maxM = 0;
       for (auto& tr : trees) {
         if (tr.n <= 1) continue;
         int TM = tr.n >= 8 ? 8 : tr.n, TG = (tr.n + TM - 1) / TM;
@@ -887,6 +894,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
         if ((size_t)nseg * TG * TEAM <= TEAM_LANES_MAX && J.njobs < TREE_JOBS_MAX) {
           int j = J.njobs++;
           J.in[j] = tr.in; J.out[j] = o; J.n[j] = tr.n; J.M[j] = TM; J.G[j] = TG; J.first_team[j + 1] = J.first_team[j] + nseg * TG;
+          if (TM > J.maxM) J.maxM = TM;
         } else {
           hipLaunchKernelGGL(k_tree_sum<F>, dim3(nblk((size_t)nseg * TG, 256)), dim3(256), 0, t2, tr.in, o, nseg, tr.n, TM);
         }

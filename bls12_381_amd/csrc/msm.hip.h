@@ -1072,6 +1072,7 @@ struct TreeJobs {
   int n[TREE_JOBS_MAX], M[TREE_JOBS_MAX], G[TREE_JOBS_MAX];
   int first_team[TREE_JOBS_MAX + 1];          // teams of job j: [first_team[j], first_team[j + 1])
   int njobs, nseg;
+  int maxM;                                   // largest fan-in of the launch: every team runs this many (barrier-carrying) steps
 };
 template <class F>
 __global__ void __launch_bounds__(256) k_tree_sum_team_multi(TreeJobs J) {
@@ -1091,10 +1092,12 @@ __global__ void __launch_bounds__(256) k_tree_sum_team_multi(TreeJobs J) {
   const int seg = local / G, g = local - seg * G;
   const u32* E = J.in[j];
   Proj<F> acc = pt_identity<F>();
-  for (int k = 0; k < M; k++) {
+  // pt_add_team carries block-wide barriers and teams of different jobs share a block: the trip count is the launch-wide
+  // maximum, jobs with a smaller fan-in add identities for the surplus steps (the complete formulas take them like any point)
+  for (int k = 0; k < J.maxM; k++) {
     int i = g * M + k;
     Proj<F> e = pt_identity<F>();
-    if (i < n) load_proj<F>(E + ((size_t)seg * n + i) * Store<F>::PROJ_WORDS, e);
+    if (k < M && i < n) load_proj<F>(E + ((size_t)seg * n + i) * Store<F>::PROJ_WORDS, e);
     acc = pt_add_team<F>(acc, e, mbox, tl);
   }
   if (live && tl == 0) store_proj<F>(J.out[j] + (size_t)local * Store<F>::PROJ_WORDS, acc);

@@ -93,7 +93,8 @@ size_t blsgpu_bases_len(const blsgpu_bases* b);
  * the checked decoders) may skip the per-upload test with blsgpu_set_assume_subgroup(ctx, 1); with that flag set,
  * results for off-subgroup inputs are unspecified.  Default: 0 (test every upload).
  * blsgpu_bases_subgroup_state: 1 = verified (or built as [k]G), 2 = assumed by the caller, 0 = at least one point is
- * outside the subgroup (plain windows). */
+ * outside the subgroup (plain windows), 3 = not tested: the set is beyond the size the split supports (G2: more than 2^22
+ * points) and runs on plain windows in any case. */
 int blsgpu_set_assume_subgroup(blsgpu_ctx* ctx, int enabled);
 int blsgpu_bases_subgroup_state(const blsgpu_bases* b);
 /* Read points [first, first+count) back in wire format (xy: count*12 or count*24 u64; infinity: count bytes). */

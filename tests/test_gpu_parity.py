@@ -1191,7 +1191,8 @@ def test_msm_g2_psi_decomposition_boundaries(ctx, monkeypatch):
 def test_msm_decomposition_size_limits(ctx):
     """the endomorphism decompositions multiply the number of sort entries (G1: 2n, G2: 4n) and the packed sort index has 24
     bits: the largest calls that still take them -- 2^23 G1 points, 2^22 G2 points, where the index reaches 2^24 - 1 -- and the
-    first sizes past the limit (plain windows) must all agree with the discrete-log identity; uniform scalars in [0, r)"""
+    first sizes past the limit (plain windows: cutting larger calls into passes that keep the split was measured slower,
+    DESIGN.md 9) must all agree with the discrete-log identity; uniform scalars in [0, r)"""
     import bls12_381_amd as b
     from bls12_381_amd import synthetic as sy
     # G1: 2^23 (2n = 2^24, GLV) and 2^23 + 5 (plain 16 windows), one resident base set

@@ -104,13 +104,13 @@ Separate rocprofv3 passes (one `--pmc` group each, `--kernel-trace` only; tools/
 """)
 
 
-def pairing(d, K, units, unit_name, mac32, tag, what, layout, alg_bytes_per_unit):
+def pairing(d, K, units, unit_name, mac32, tag, what, layout, alg_bytes_per_unit, meta_key=None):
     dd, row = durations(d, K)
     if not dd:
         return
     dur = sum(dd) / len(dd)
     c = counters(d, K)
-    m = meta_find(META, K)
+    m = meta_find(META, meta_key or K)
     stats_table(one(d + "/stats/**/*kernel_stats.csv"), f"{RND}: rocprofv3 --kernel-trace --stats -- python tools/run_pairing.py {what}", os.path.join(OUT, f"{RND}_{tag}_kernel_stats.md"))
     wc = c.get("SQ_WAVE_CYCLES", 1)
     fetch_kb, write_kb = c.get("FETCH_SIZE", 0), c.get("WRITE_SIZE", 0)
@@ -134,7 +134,7 @@ def pairing(d, K, units, unit_name, mac32, tag, what, layout, alg_bytes_per_unit
 * SQ_INSTS_VALU = {c.get('SQ_INSTS_VALU',0):.3e} wave-instructions; SQ_INSTS_VMEM_RD / WR = {c.get('SQ_INSTS_VMEM_RD',0):.3e} / {c.get('SQ_INSTS_VMEM_WR',0):.3e}; SQ_INSTS_LDS = {c.get('SQ_INSTS_LDS',0):.3e}
 * wave-cycle split: SQ_ACTIVE_INST_ANY {100*c.get('SQ_ACTIVE_INST_ANY',0)/wc:.0f}%, SQ_WAIT_INST_ANY (issue stalls) {100*c.get('SQ_WAIT_INST_ANY',0)/wc:.0f}%, SQ_WAIT_ANY (s_waitcnt) {100*c.get('SQ_WAIT_ANY',0)/wc:.0f}% of SQ_WAVE_CYCLES = {wc:.3e}
 * instruction cache: {c.get('SQC_ICACHE_MISSES',0):.3e} misses of {c.get('SQC_ICACHE_REQ',0):.3e} requests
-* GRBM_GUI_ACTIVE = {c.get('GRBM_GUI_ACTIVE',0):.3e} (8 XCDs) -> {c.get('GRBM_GUI_ACTIVE',0)/8/(dur*1e-9)/1e9:.2f} GHz under profiling
+* GRBM_GUI_ACTIVE = {c.get('GRBM_GUI_ACTIVE',0):.3e} (GRBM_GUI_ACTIVE / launch duration; the counter is summed over the chip's engines, so only its ratio between variants is meaningful)
 """)
 
 
@@ -144,7 +144,7 @@ if one("prof_msm/stats/**/*kernel_stats.csv"):
 if one("prof_pair/stats/**/*kernel_trace.csv"):
     pairing("prof_pair", "k_pairing_quad", 65536, "pairings", 4.8e6, "pairing", "pairing 16 3", "quad layout: one pairing per four lanes, 2 wavefronts/SIMD", 864)
 if one("prof_pair_lp/stats/**/*kernel_trace.csv"):
-    pairing("prof_pair_lp", "k_pairing(", 65536, "pairings", 4.8e6, "pairing_lanepair", "pairing 16 3 (BLSGPU_PAIRING_LAYOUT=pair)", "lane-pair layout of rounds 1-2, 2 wavefronts/SIMD", 864)
+    pairing("prof_pair_lp", "k_pairing(", 65536, "pairings", 4.8e6, "pairing_lanepair", "pairing 16 3 (BLSGPU_PAIRING_LAYOUT=pair)", "lane-pair layout of rounds 1-2, 2 wavefronts/SIMD", 864, meta_key="9k_pairingEi")
 if one("prof_mml/stats/**/*kernel_trace.csv"):
     pairing("prof_mml", "k_multi_miller_shared", 262144, "terms", 2.07e6, "mml", "mml 18 3", "lane-pair layout, four terms per shared accumulator", 288)
 print("profiles written for", RND)
