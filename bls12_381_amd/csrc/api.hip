@@ -14,6 +14,8 @@
 #include "pairing.hip.h"
 #include "quad.hip.h"
 #include "mulbatch.hip.h"
+#include "wide.hip.h"
+#include <dlfcn.h>
 #include "fr.hip.h"
 #include "h2c.hip.h"
 #include "codec.hip.h"
@@ -63,8 +65,12 @@ struct blsgpu_ctx {
   unsigned acc_tick = 0;
   double acc_ms_sum = 0.0; unsigned acc_count = 0;
   u32 item_cap = 0;                    // A/B hook (env BLSGPU_ITEM_CAP at create): entries per work item of the accumulation (0 = automatic)
-  int pairing_layout = 4;              // lanes per pairing of pairing / Miller loop / final exponentiation batches: 4 = quad (quad.hip.h, default: no hot-loop scratch,
-                                       // half the latency of small batches, +2..11 % pairings/s up to 2^16), 2 = lane pair (pairing.hip.h); env BLSGPU_PAIRING_LAYOUT=pair|quad at create
+  int pairing_layout = 0;              // lanes per pairing of pairing / Miller loop / final exponentiation batches: 0 = automatic (default: a workgroup per pairing --
+                                       // wide.hip.h -- up to WIDE_AUTO_MAX items, the quad layout above), 4 = quad (quad.hip.h: no hot-loop scratch), 2 = lane pair
+                                       // (pairing.hip.h, rounds 1-2), 256 = wide; env BLSGPU_PAIRING_LAYOUT=pair|quad|wide at create fixes one for A/B runs
+  u32* d_wide = nullptr;               // the wide programs (bls12_381_amd/wide_prog.bin, generated at build time by tools/gen_wide_prog.py) in device memory
+  size_t wide_off[2] = {0, 0};         // word offsets of the Miller-loop / final-exponentiation program
+  int wide_state = 0;                  // 0 = not tried, 1 = loaded, -1 = unavailable (the quad kernels take every size then)
   bool assume_subgroup = false;        // blsgpu_set_assume_subgroup: skip the subgroup check of uploaded bases (the caller vouches for them)
   bool no_glv = false;                 // A/B hook (env BLSGPU_NO_GLV at create): plain 256-bit windows (no GLV for G1, no psi decomposition for G2)
   bool force_slow_sort = false;        // test hook (env BLSGPU_FORCE_SLOW_SORT at create): the global-atomic sort used beyond 2^24 points
@@ -407,7 +413,7 @@ extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
   c->device = device;
   c->force_slow_sort = getenv("BLSGPU_FORCE_SLOW_SORT") != nullptr;
   c->no_glv = getenv("BLSGPU_NO_GLV") != nullptr;
-  if (const char* v = getenv("BLSGPU_PAIRING_LAYOUT")) c->pairing_layout = (v[0] == 'q' || v[0] == '4') ? 4 : 2;
+  if (const char* v = getenv("BLSGPU_PAIRING_LAYOUT")) c->pairing_layout = (v[0] == 'q' || v[0] == '4') ? 4 : (v[0] == 'w') ? 256 : (v[0] == 'a') ? 0 : 2;
   if (const char* v = getenv("BLSGPU_ITEM_CAP")) { long k = atol(v); if (k >= 8 && k <= ITEM_CAP_MAX) c->item_cap = (u32)k; }
   int rc = ctx_init(c);
   if (rc != BLSGPU_OK) { blsgpu_destroy(c); return rc; }       // destroy tolerates the half-built context (null handles are skipped)
@@ -419,6 +425,7 @@ extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   if (c->d_status) hipFree(c->d_status);
+  if (c->d_wide) hipFree(c->d_wide);
   DevBuf* bufs[] = {&c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_out, &c->flags_a, &c->flags_b, &c->fr_tw[0], &c->fr_tw[1], &c->fr_tmp, &c->fr_ninv};
   for (auto b : bufs) b->release();
   for (auto& sl : c->slot) {
@@ -1169,7 +1176,7 @@ static int elem_op(blsgpu_ctx* c, int words, int kind, int op, const uint64_t* a
   if (kind == 1) hipLaunchKernelGGL(k_fp_op, dim3(nblk(n, 256)), dim3(256), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
   else if (kind == 2) hipLaunchKernelGGL(k_fp2_op, dim3(nblk(n, 256)), dim3(256), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
   else if (kind == 6) hipLaunchKernelGGL(k_fp6_op, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
-  else if (c->pairing_layout == 4 && op != 3) hipLaunchKernelGGL(k_fp12_op_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
+  else if (c->pairing_layout != 2 && op != 3) hipLaunchKernelGGL(k_fp12_op_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
   else hipLaunchKernelGGL(k_fp12_op, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
   LAUNCHCHK();
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -1191,7 +1198,7 @@ extern "C" int blsgpu_fp6_op(blsgpu_ctx* c, int op, const uint64_t* a, const uin
 }
 extern "C" int blsgpu_fp12_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
   if (!(op == 0 || op == 3 || op == 4 || op == 7 || op == 8 || op == 9 || op == 10)) return bad("fp12_op: unknown op");
-  if (op == 10 && c && c->pairing_layout != 4) return bad("fp12_op: op 10 (cyclotomic exponentiation) exists in the quad layout only");
+  if (op == 10 && c && c->pairing_layout == 2) return bad("fp12_op: op 10 (cyclotomic exponentiation) exists in the quad layout only");
   return elem_op(c, 144, 12, op, a, b, n, out);
 }
 template <class F>
@@ -1431,9 +1438,52 @@ extern "C" int blsgpu_fr_ntt(blsgpu_ctx* c, uint64_t* data, int log_n, int inver
 }
 
 // ---------------------------------------------------------------------------------------------------
+// ---- the wide (one workgroup per pairing) path -------------------------------------------------------------------
+constexpr size_t WIDE_AUTO_MAX = 1024;       // two workgroups per CU: up to 512 items run at the latency of one, 1024 in two rounds (still below the quad kernels' ~6 ms)
+static int wide_load(blsgpu_ctx* c) {
+  if (c->wide_state) return c->wide_state;
+  c->wide_state = -1;
+  std::string path;
+  if (const char* e = getenv("BLSGPU_WIDE_PROG")) path = e;
+  else {
+    Dl_info info;
+    if (!dladdr((const void*)&blsgpu_create, &info) || !info.dli_fname) return -1;
+    path = info.dli_fname;
+    const size_t slash = path.find_last_of('/');
+    path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/wide_prog.bin";
+  }
+  FILE* fh = fopen(path.c_str(), "rb");
+  if (!fh) return -1;
+  std::vector<u32> w;
+  u32 buf[4096]; size_t got;
+  while ((got = fread(buf, 4, 4096, fh)) > 0) w.insert(w.end(), buf, buf + got);
+  fclose(fh);
+  if (w.size() < 32 || w[0] != WIDE_BLOB_MAGIC || w[1] != 2) return -1;
+  for (int k = 0; k < 2; k++) {
+    const size_t off = w[2 + 2 * k], len = w[3 + 2 * k];
+    if (off + len > w.size() || len < 16 || w[off] != WIDE_PROG_MAGIC || w[off + 2] > (u32)WIDE_MAX_SLOTS) return -1;
+    c->wide_off[k] = off;
+  }
+  if (hipMalloc((void**)&c->d_wide, w.size() * 4) != hipSuccess) { (void)hipGetLastError(); c->d_wide = nullptr; return -1; }
+  if (hipMemcpy(c->d_wide, w.data(), w.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); hipFree(c->d_wide); c->d_wide = nullptr; return -1; }
+  c->wide_state = 1;
+  return 1;
+}
+// which kernels take a batch of n pairings / Miller loops / final exponentiations: 256 = wide, 4 = quad, 2 = lane pair
+static int pairing_layout_for(blsgpu_ctx* c, size_t n) {
+  if (c->pairing_layout == 2 || c->pairing_layout == 4) return c->pairing_layout;
+  if (c->pairing_layout == 256) return wide_load(c) == 1 ? 256 : 4;
+  return (n <= WIDE_AUTO_MAX && wide_load(c) == 1) ? 256 : 4;
+}
+static void wide_launch(blsgpu_ctx* c, int mode, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) {
+  hipLaunchKernelGGL(k_pairing_wide, dim3((unsigned)n), dim3(WIDE_LANES), 0, c->stream, mode, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2, (const uint8_t*)g2inf,
+                     (u32*)out, n, c->d_wide + c->wide_off[0], c->d_wide + c->wide_off[1]);
+}
 static int pairing_launch(blsgpu_ctx* c, int mode, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) {
   // mode 0: full pairing, 1: Miller loop only
-  if (c->pairing_layout == 4) {
+  const int layout = pairing_layout_for(c, n);
+  if (layout == 256) { wide_launch(c, mode, g1, g1inf, g2, g2inf, n, out); LAUNCHCHK(); return BLSGPU_OK; }
+  if (layout == 4) {
     hipLaunchKernelGGL(k_pairing_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, mode, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2,
                        (const uint8_t*)g2inf, (u32*)out, n);
     LAUNCHCHK();
@@ -1484,7 +1534,9 @@ extern "C" int blsgpu_final_exponentiation_device(blsgpu_ctx* c, const void* in,
   if (!c || (n && (!in || !out))) return bad("final_exponentiation: NULL argument");
   if (!n) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
-  if (c->pairing_layout == 4) hipLaunchKernelGGL(k_final_exp_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, (const u32*)in, (u32*)out, n);
+  const int layout = pairing_layout_for(c, n);
+  if (layout == 256) wide_launch(c, 2, in, nullptr, nullptr, nullptr, n, out);
+  else if (layout == 4) hipLaunchKernelGGL(k_final_exp_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, (const u32*)in, (u32*)out, n);
   else hipLaunchKernelGGL(k_final_exp, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)in, (u32*)out, n);
   LAUNCHCHK();
   return BLSGPU_OK;
@@ -1555,7 +1607,9 @@ extern "C" int blsgpu_final_exponentiation_batch(blsgpu_ctx* c, const uint64_t* 
   HIPCHK(hipSetDevice(c->device));
   if (c->io_a.reserve(n * 576) || c->io_out.reserve(n * 576)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
   HIPCHK(hipMemcpyAsync(c->io_a.p, in, n * 576, hipMemcpyHostToDevice, c->stream));
-  if (c->pairing_layout == 4) hipLaunchKernelGGL(k_final_exp_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, c->io_a.as<u32>(), c->io_out.as<u32>(), n);
+  const int layout = pairing_layout_for(c, n);
+  if (layout == 256) wide_launch(c, 2, c->io_a.p, nullptr, nullptr, nullptr, n, c->io_out.p);
+  else if (layout == 4) hipLaunchKernelGGL(k_final_exp_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, c->io_a.as<u32>(), c->io_out.as<u32>(), n);
   else hipLaunchKernelGGL(k_final_exp, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, c->io_a.as<u32>(), c->io_out.as<u32>(), n);
   LAUNCHCHK();
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, n * 576, hipMemcpyDeviceToHost, c->stream));

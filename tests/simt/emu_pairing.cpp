@@ -13,6 +13,9 @@ EmuGroup g_emu_group;
 #ifdef EMU_WITH_QUAD
 #include "quad.hip.h"
 #endif
+#ifdef EMU_WITH_WIDE
+#include "wide.hip.h"
+#endif
 
 using namespace bls;
 
@@ -24,6 +27,13 @@ template <class Fn> static void run_quad(Fn fn) {
 }
 
 extern "C" {
+#ifdef EMU_WITH_WIDE
+// one workgroup (EMU_LANES = 256 host threads) = one item; mode 0 pairing, 1 Miller value, 2 final exponentiation of g1 (72 u64)
+void emu_wide(int mode, const u32* g1, const u32* g2, u32* out, const u32* prog_miller, const u32* prog_fe) {
+  run_quad([=] { k_pairing_wide(mode, g1, nullptr, g2, nullptr, out, 1, prog_miller, prog_fe); });
+}
+#endif
+#if EMU_LANES == 4
 // pair layout (two pairings per quad): mode 0 pairing, 1 raw Miller value
 void emu_pair_pairing(int mode, const u32* g1, const u32* g2, u32* out, size_t n) {
   run_quad([=] { k_pairing(mode, g1, nullptr, g2, nullptr, out, n); });
@@ -44,5 +54,6 @@ void emu_quad_final_exp(const u32* in, u32* out, size_t n) {
 void emu_quad_fp12_op(int op, const u32* a, const u32* b, u32* out, size_t n) {
   run_quad([=] { k_fp12_op_quad(op, a, b, out, n); });
 }
+#endif
 #endif
 }

@@ -26,10 +26,17 @@ extern thread_local EmuDim3 threadIdx, blockIdx, blockDim, gridDim;
 #ifndef EMU_LANES
 #define EMU_LANES 4
 #endif
+#include <pthread.h>
 struct EmuGroup {
   std::atomic<unsigned> arrived{0};
   std::atomic<unsigned> phase{0};
   int slot[EMU_LANES];
+#if EMU_LANES > 8
+  // more lanes than host cores: a blocking barrier (spinning threads would starve the ones they wait for)
+  pthread_barrier_t pb;
+  EmuGroup() { pthread_barrier_init(&pb, nullptr, EMU_LANES); }
+  void barrier() { pthread_barrier_wait(&pb); }
+#else
   void barrier() {
     unsigned ph = phase.load(std::memory_order_acquire);
     if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == EMU_LANES) {
@@ -39,6 +46,7 @@ struct EmuGroup {
       while (phase.load(std::memory_order_acquire) == ph) { __builtin_ia32_pause(); }
     }
   }
+#endif
 };
 extern EmuGroup g_emu_group;
 
@@ -52,6 +60,8 @@ static inline int emu_update_dpp(int /*old*/, int src, int ctrl, int /*row_mask*
   g_emu_group.barrier();
   return v;
 }
+struct uint4 { unsigned x, y, z, w; };
+struct uint2 { unsigned x, y; };
 #define __builtin_amdgcn_update_dpp emu_update_dpp
 static inline void __syncthreads() { g_emu_group.barrier(); }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

@@ -1496,3 +1496,37 @@ def test_fp6_ops(ctx):
     assert np.array_equal(ctx.fp6_op(12, A, B), np.stack([w6(o.fp6_mul_by_01(x, y[0], y[1])) for x, y in zip(a, b)]))
     # the sparse forms agree with the dense product (fp6.rs:376-561 checks the same identities)
     assert np.array_equal(ctx.fp6_op(12, A, B), ctx.fp6_op(0, A, np.stack([w6((y[0], y[1], z2)) for y in b])))
+
+
+# ---- round 3: small batches -- one pairing per workgroup (wide.hip.h) ------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 3, 33, 1000])
+def test_small_batches_take_the_wide_path_and_match_every_other_layout(ctx, layout_contexts, n):
+    """pairing / Miller loop / final exponentiation batches of n <= 1024 run one item per workgroup by default; results must be
+    limb-identical to the quad and lane-pair kernels (n = 1000: a batch larger than the chip holds at once) and, for the first
+    items, to the oracle; identities on either side give Fp12::one()"""
+    import bls12_381_amd as b
+    from bls12_381_amd import synthetic as sy
+    os.environ["BLSGPU_PAIRING_LAYOUT"] = "wide"
+    try:
+        w = b.Context(0)
+    finally:
+        os.environ.pop("BLSGPU_PAIRING_LAYOUT")
+    ka = sy.scalars(n, sy.SEED + 900 + n); kq = sy.scalars(n, sy.SEED + 901 + n)
+    g1, f1 = ctx.bases_from_scalars(1, ka).download(); g2, f2 = ctx.bases_from_scalars(2, kq).download()
+    g1 = g1.copy(); g2 = g2.copy(); f1 = f1.copy(); f2 = f2.copy()
+    if n >= 3:
+        f1[1] = 1; f2[2] = 1
+    q = layout_contexts["quad"]
+    ml_w, gt_w = w.miller_loop_batch(g1, f1, g2, f2), w.pairing_batch(g1, f1, g2, f2)
+    assert np.array_equal(ml_w, q.miller_loop_batch(g1, f1, g2, f2))
+    assert np.array_equal(gt_w, q.pairing_batch(g1, f1, g2, f2))
+    assert np.array_equal(w.final_exponentiation_batch(ml_w), gt_w)
+    # the default context picks the same path by itself and agrees
+    assert np.array_equal(ctx.pairing_batch(g1, f1, g2, f2), gt_w)
+    assert np.array_equal(ctx.final_exponentiation_batch(ml_w), gt_w)
+    if n <= 3:
+        for i in range(n):
+            Pi = o.G1_IDENTITY_AFF if f1[i] else (wfp(g1[i][0:6]), wfp(g1[i][6:12]), False)
+            Qi = o.G2_IDENTITY_AFF if f2[i] else (wfp2(g2[i][0:12]), wfp2(g2[i][12:24]), False)
+            assert np.array_equal(gt_w[i], fp12w(o.pairing(Pi, Qi)))
+            assert np.array_equal(ml_w[i], fp12w(o.miller_loop(Pi, Qi)))

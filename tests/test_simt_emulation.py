@@ -116,3 +116,30 @@ def test_emulated_quad_tower_ops_match_oracle(emu):
     xw = fp12w(x)
     emu.emu_quad_final_exp(vp(xw), vp(out), ctypes.c_size_t(1))
     assert np.array_equal(out, fp12w(o.final_exponentiation(x)))
+
+
+def test_emulated_wide_kernel_matches_oracle():
+    """wide.hip.h (one pairing per 256-lane workgroup) interpreting the generated programs, 256 host threads as lanes: the raw
+    Miller value, the pairing and the final exponentiation alone, bit for bit against the oracle"""
+    if not os.path.exists(CLANG):
+        pytest.skip("no host clang++ in this image")
+    lib_path = os.path.join(ROOT, "build", "libemu_wide_test.so")
+    prog_path = os.path.join(ROOT, "build", "wide_prog_emu.bin")
+    src = os.path.join(ROOT, "tests", "simt", "emu_pairing.cpp")
+    csrc = os.path.join(ROOT, "bls12_381_amd", "csrc")
+    subprocess.check_call([CLANG, "-O1", "-std=c++17", "-pthread", "-fPIC", "-shared", "-Wno-unused-value", "-Wno-psabi", "-DEMU_WITH_WIDE", "-DEMU_LANES=256",
+                           "-I" + os.path.join(ROOT, "tests", "simt"), "-I" + csrc, src, "-o", lib_path])
+    subprocess.check_call([os.sys.executable, os.path.join(ROOT, "tools", "gen_wide_prog.py"), "--out", prog_path])
+    lib = ctypes.CDLL(lib_path)
+    blob = np.frombuffer(open(prog_path, "rb").read(), dtype=np.uint32).copy()
+    pm = ctypes.c_void_p(blob.ctypes.data + 4 * int(blob[2])); pf = ctypes.c_void_p(blob.ctypes.data + 4 * int(blob[4]))
+    P, Q, g1, g2 = _pairs(31, 1)
+    out = np.zeros(72, dtype=np.uint64)
+    ml = o.miller_loop(P[0], Q[0])
+    lib.emu_wide(1, vp(g1), vp(g2), vp(out), pm, pf)
+    assert np.array_equal(out, fp12w(ml))
+    lib.emu_wide(0, vp(g1), vp(g2), vp(out), pm, pf)
+    assert np.array_equal(out, fp12w(o.final_exponentiation(ml)))
+    mlw = fp12w(ml)
+    lib.emu_wide(2, vp(mlw), None, vp(out), pm, pf)
+    assert np.array_equal(out, fp12w(o.final_exponentiation(ml)))

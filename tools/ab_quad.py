@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the lane-pair and the quad pairing kernels inside ONE build (contexts created with BLSGPU_PAIRING_LAYOUT=pair|quad):
+"""A/B of the lane-pair, quad and wide pairing kernels inside ONE build (contexts created with BLSGPU_PAIRING_LAYOUT=pair|quad|wide):
 Miller loops, pairings and final exponentiations at several batch sizes, outputs hashed for bit-equality.
 
     python tools/ab_quad.py [log_n ...]          (default 16 14)"""
@@ -21,7 +21,7 @@ def main():
     logs = [int(a) for a in sys.argv[1:]] or [16, 14]
     nmax = 1 << max(logs)
     ctxs = {}
-    for name in ("pair", "quad"):
+    for name in ("pair", "quad", "wide"):
         os.environ["BLSGPU_PAIRING_LAYOUT"] = name
         ctxs[name] = bls.Context(0)
         ctxs[name].set_stream(torch.cuda.current_stream().cuda_stream)
@@ -48,6 +48,8 @@ def main():
         n = 1 << lg
         row = {"log_n": lg}
         for name, ctx in ctxs.items():
+            if name == "wide" and n > 4096:
+                continue
             dt = timed(lambda: ctx.miller_loop_batch_device(d_g1.data_ptr(), d_g2.data_ptr(), n, d_f.data_ptr()))
             row[name + "_miller_ms"] = round(dt, 3)
             row[name + "_miller_sha"] = hashlib.sha256(d_f[:n].cpu().numpy().tobytes()).hexdigest()[:12]
