@@ -1439,7 +1439,7 @@ extern "C" int blsgpu_fr_ntt(blsgpu_ctx* c, uint64_t* data, int log_n, int inver
 
 // ---------------------------------------------------------------------------------------------------
 // ---- the wide (one workgroup per pairing) path -------------------------------------------------------------------
-constexpr size_t WIDE_AUTO_MAX = 1024;       // two workgroups per CU: up to 512 items run at the latency of one, 1024 in two rounds (still below the quad kernels' ~6 ms)
+constexpr size_t WIDE_AUTO_MAX = 768;        // one 1024-lane workgroup per CU at a time: 256 items run at the latency of one (1.5 ms), 768 in three passes (4.4 ms), against the quad kernels' flat ~6 ms
 static int wide_load(blsgpu_ctx* c) {
   if (c->wide_state) return c->wide_state;
   c->wide_state = -1;
@@ -1461,7 +1461,10 @@ static int wide_load(blsgpu_ctx* c) {
   if (w.size() < 32 || w[0] != WIDE_BLOB_MAGIC || w[1] != 2) return -1;
   for (int k = 0; k < 2; k++) {
     const size_t off = w[2 + 2 * k], len = w[3 + 2 * k];
-    if (off + len > w.size() || len < 16 || w[off] != WIDE_PROG_MAGIC || w[off + 2] > (u32)WIDE_MAX_SLOTS) return -1;
+    // a program is only usable by the kernel it was generated for: same lanes per workgroup and limbs per product lane, slots and accumulators within the LDS arrays
+    if (off + len > w.size() || len < 16 || (off & 3) || w[off] != WIDE_PROG_MAGIC || w[off + 2] > (u32)WIDE_MAX_SLOTS || w[off + 10] != (u32)WIDE_LANES ||
+        w[off + 11] != (u32)WIDE_K || w[off + 12] >= (u32)WIDE_MAX_SLOTS || w[off + 13] > (u32)WIDE_MAX_ACC || (w[off + 7] & 3) || (w[off + 8] & 3) || (w[off + 9] & 1))
+      return -1;
     c->wide_off[k] = off;
   }
   if (hipMalloc((void**)&c->d_wide, w.size() * 4) != hipSuccess) { (void)hipGetLastError(); c->d_wide = nullptr; return -1; }

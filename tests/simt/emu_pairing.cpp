@@ -8,6 +8,9 @@
 
 thread_local EmuDim3 threadIdx, blockIdx, blockDim, gridDim;
 EmuGroup g_emu_group;
+#if EMU_LANES > 8
+EmuQuadBarriers g_emu_quads;
+#endif
 
 #include "pairing.hip.h"
 #ifdef EMU_WITH_QUAD
@@ -28,7 +31,7 @@ template <class Fn> static void run_quad(Fn fn) {
 
 extern "C" {
 #ifdef EMU_WITH_WIDE
-// one workgroup (EMU_LANES = 256 host threads) = one item; mode 0 pairing, 1 Miller value, 2 final exponentiation of g1 (72 u64)
+// one workgroup (EMU_LANES = WIDE_LANES host threads) = one item; mode 0 pairing, 1 Miller value, 2 final exponentiation of g1 (72 u64)
 void emu_wide(int mode, const u32* g1, const u32* g2, u32* out, const u32* prog_miller, const u32* prog_fe) {
   run_quad([=] { k_pairing_wide(mode, g1, nullptr, g2, nullptr, out, 1, prog_miller, prog_fe); });
 }

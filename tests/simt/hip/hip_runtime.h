@@ -51,17 +51,35 @@ struct EmuGroup {
 extern EmuGroup g_emu_group;
 
 // v_mov_b32_dpp with quad_perm:[a,b,c,d] (dpp_ctrl 0..255), all rows / banks enabled: lane L reads lane (L & ~3) | perm[L & 3]
+#if EMU_LANES > 8
+// a workgroup of many lanes: only the four lanes of a quad meet at a DPP move (other lanes may be in other branches), so every
+// quad has a barrier of its own
+struct EmuQuadBarriers {
+  pthread_barrier_t pb[EMU_LANES / 4];
+  EmuQuadBarriers() { for (auto& b : pb) pthread_barrier_init(&b, nullptr, 4); }
+};
+extern EmuQuadBarriers g_emu_quads;
+static inline void emu_dpp_sync(unsigned lane) { pthread_barrier_wait(&g_emu_quads.pb[lane >> 2]); }
+#else
+static inline void emu_dpp_sync(unsigned) { g_emu_group.barrier(); }
+#endif
 static inline int emu_update_dpp(int /*old*/, int src, int ctrl, int /*row_mask*/, int /*bank_mask*/, bool /*bound_ctrl*/) {
   const unsigned lane = threadIdx.x % EMU_LANES;
   g_emu_group.slot[lane] = src;
-  g_emu_group.barrier();
+  emu_dpp_sync(lane);
   const unsigned from = (lane & ~3u) | ((unsigned)(ctrl >> (2 * (lane & 3))) & 3u);
   const int v = g_emu_group.slot[from];
-  g_emu_group.barrier();
+  emu_dpp_sync(lane);
   return v;
 }
+// LDS atomics of the wide kernel (ds_add_u64 / ds_wrxchg_rtn_b64)
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned long long atomicExch(unsigned long long* p, unsigned long long v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
+template <class T> static inline T min(T a, T b) { return a < b ? a : b; }
 struct uint4 { unsigned x, y, z, w; };
 struct uint2 { unsigned x, y; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 #define __builtin_amdgcn_update_dpp emu_update_dpp
 static inline void __syncthreads() { g_emu_group.barrier(); }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

@@ -119,7 +119,7 @@ def test_emulated_quad_tower_ops_match_oracle(emu):
 
 
 def test_emulated_wide_kernel_matches_oracle():
-    """wide.hip.h (one pairing per 256-lane workgroup) interpreting the generated programs, 256 host threads as lanes: the raw
+    """wide.hip.h (one pairing per 1024-lane workgroup) interpreting the generated programs, 1024 host threads as lanes: the raw
     Miller value, the pairing and the final exponentiation alone, bit for bit against the oracle"""
     if not os.path.exists(CLANG):
         pytest.skip("no host clang++ in this image")
@@ -127,7 +127,7 @@ def test_emulated_wide_kernel_matches_oracle():
     prog_path = os.path.join(ROOT, "build", "wide_prog_emu.bin")
     src = os.path.join(ROOT, "tests", "simt", "emu_pairing.cpp")
     csrc = os.path.join(ROOT, "bls12_381_amd", "csrc")
-    subprocess.check_call([CLANG, "-O1", "-std=c++17", "-pthread", "-fPIC", "-shared", "-Wno-unused-value", "-Wno-psabi", "-DEMU_WITH_WIDE", "-DEMU_LANES=256",
+    subprocess.check_call([CLANG, "-O1", "-std=c++17", "-pthread", "-fPIC", "-shared", "-Wno-unused-value", "-Wno-psabi", "-DEMU_WITH_WIDE", "-DEMU_LANES=1024",
                            "-I" + os.path.join(ROOT, "tests", "simt"), "-I" + csrc, src, "-o", lib_path])
     subprocess.check_call([os.sys.executable, os.path.join(ROOT, "tools", "gen_wide_prog.py"), "--out", prog_path])
     lib = ctypes.CDLL(lib_path)

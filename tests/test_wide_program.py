@@ -17,10 +17,10 @@ P = o.P
 NL, LW = 14, 28
 MASK = (1 << LW) - 1
 RP = 1 << (NL * LW)
-COEF = [0, 1, -1, 2, -2, 3, -3, 4, -4, 6, -6, 8, -8, 12, -12, 9]
 VB = 4
 INV28 = (-pow(P, -1, 1 << LW)) % (1 << LW)
 P_L = [(P >> (LW * i)) & MASK for i in range(NL)]
+ACC_COLS = 32
 
 
 def make_bias(c, s):
@@ -57,96 +57,110 @@ def reduce_v(l):
     return limbs(v)
 
 
-def load_items(S, word, count):
-    """lazily formed operand: sum of coefficient * slot, negative coefficients against the bias; limbs must fit 32 bits"""
-    x = [0] * NL
-    for i in range(count):
-        f = (word[i // 2] >> (14 * (i % 2))) & 0x3FFF
-        slot, k = f & 0x3FF, COEF[f >> 10]
-        if k == 0:
-            continue
-        s = S[slot]
-        assert s is not None, "read of an unwritten slot"
-        for j in range(NL):
-            x[j] += k * s[j] if k > 0 else (-k) * (BIAS[j] - s[j])
-    assert all(0 <= v < (1 << 32) for v in x), "operand limb overflow"
+def s5(v):
+    v &= 31
+    return v - 32 if v & 16 else v
+
+
+def form(S, word, bias_slot):
+    """wide_form: c0 * slot0 + c1 * slot1 + wb * bias slot, limb by limb; every limb must be a non-negative 32-bit number
+    (the kernel computes it mod 2^32)"""
+    if word == 0:
+        return [0] * NL
+    k0, k1, kb = s5(word >> 8), s5(word >> 21), (word >> 26) & 15
+    s0, s1, sb = S[word & 0xFF], S[(word >> 13) & 0xFF], S[bias_slot]
+    assert (k0 == 0 or s0 is not None) and (k1 == 0 or s1 is not None), "read of an unwritten slot"
+    x = [(k0 * s0[j] if k0 else 0) + (k1 * s1[j] if k1 else 0) + kb * sb[j] for j in range(NL)]
+    assert all(0 <= v < (1 << 32) for v in x), "operand limb out of range"
     return x
 
 
-def pair_count(word):
-    return 2 if (word >> 24) & 0xF else 1
+def mont_reduce(acc):
+    """Montgomery reduction by 2^392 on the column sums (one 64-bit accumulator per column, as wide_mont_reduce does)"""
+    c, m, res = 0, [], [0] * NL
+    for k in range(NL):
+        t = acc[k] + c + sum(m[i] * P_L[k - i] for i in range(k))
+        m.append(((t & 0xFFFFFFFF) * INV28) & MASK)
+        t += m[k] * P_L[0]
+        assert t < (1 << 64) and t & MASK == 0, "column overflow"
+        c = t >> LW
+    for k in range(NL, 2 * NL - 1):
+        t = acc[k] + c + sum(m[i] * P_L[k - i] for i in range(k - NL + 1, NL))
+        assert t < (1 << 64), "column overflow"
+        res[k - NL] = t & MASK
+        c = t >> LW
+    res[NL - 1] = c
+    assert value(res) * RP % P == sum(a << (LW * i) for i, a in enumerate(acc)) % P
+    return res
 
 
 def run_program(prog, inputs):
     hdr = struct.unpack_from("<16I", prog, 0)
-    assert hdr[0] == 0x57494445
-    nrounds, nslots, nconst, n_in, n_out, c_off, r_off, d_off = hdr[1:9]
+    assert hdr[0] == 0x57494432
+    nrounds, nslots, nconst, n_in, n_out, c_off, r_off, p_off, d_off, lanes, chunk, bias_slot, max_acc = hdr[1:14]
+    assert nslots <= 256 and max_acc <= 128 and chunk in (4, 8)
     W = struct.unpack_from("<%dI" % (len(prog) // 4), prog, 0)
-    S = [None] * max(nslots, n_in, n_out)
+    S = [None] * 256
     for i in range(nconst):
         S[W[c_off + 15 * i]] = list(W[c_off + 15 * i + 1:c_off + 15 * i + 15])
+    assert S[bias_slot] == BIAS
     for slot, v in inputs.items():
         S[slot] = limbs(v * RP % P)
+    accs = [[0] * ACC_COLS for _ in range(max_acc)]
     for r in range(nrounds):
-        first, lanes = W[r_off + 2 * r], W[r_off + 2 * r + 1]
-        D = [W[d_off + 8 * (first + l):d_off + 8 * (first + l) + 8] for l in range(lanes)]
-        part, pend = {}, []
-        # phase 1: every read of S
-        for l, d in enumerate(D):
-            op, nt, red, nparts, out = d[0] & 3, (d[0] >> 2) & 15, (d[0] >> 6) & 1, (d[0] >> 7) & 0x1FF, (d[0] >> 16) & 0x3FF
+        pfirst, pcnt, rfirst, rcnt = W[r_off + 4 * r:r_off + 4 * r + 4]
+        assert pcnt <= lanes and rcnt <= lanes
+        pend = []
+        # phase 1: every read of S; products are added to the column accumulators
+        for l in range(pcnt):
+            d = W[p_off + 4 * (pfirst + l):p_off + 4 * (pfirst + l) + 4]
+            op = d[0] & 3
             if op == 1:
-                acc = [0] * (2 * NL - 1)
-                for t in range(nt):
-                    x = load_items(S, [d[1 + 2 * t]], pair_count(d[1 + 2 * t]))
-                    y = load_items(S, [d[2 + 2 * t]], pair_count(d[2 + 2 * t]))
-                    for i in range(NL):
-                        for j in range(NL):
-                            acc[i + j] += x[i] * y[j]
-                part[l] = acc
-                if red:
-                    post = None
-                    if d[7] >> 31:
-                        ps, cs, cv = d[7] & 0x3FF, COEF[(d[7] >> 10) & 15], COEF[(d[7] >> 14) & 15]
-                        post = (cv, list(S[ps]), cs)
-                    pend.append((l, "sop", nparts, out, post))
+                lo, ln, a = (d[0] >> 2) & 15, (d[0] >> 6) & 15, (d[0] >> 10) & 0x3FF
+                x, y = form(S, d[1], bias_slot), form(S, d[2], bias_slot)
+                assert lo % 4 == 0 and ln == min(chunk, NL - lo)
+                assert chunk != 4 or lo // 4 == l % 4, "the four lanes of a product must be one quad, in chunk order (DPP exchange of y)"
+                for i in range(lo, min(lo + chunk, NL)):
+                    for j in range(NL):
+                        accs[a][i + j] += x[i] * y[j]
             elif op == 2:
-                pend.append((l, "lin", load_items(S, [d[1], d[2]], nt), out, None))
+                x = [u + v for u, v in zip(form(S, d[1], bias_slot), form(S, d[2], bias_slot))]
+                assert all(v < (1 << 32) for v in x)
+                pend.append(("lin", x, d[3] & 0xFF))
             elif op == 3:
-                pend.append((l, "inv", load_items(S, [d[1]], 1), out, None))
+                pend.append(("inv", form(S, d[1], bias_slot), d[3] & 0xFF))
+        posts = {}
+        for l in range(rcnt):
+            w0, w1 = W[d_off + 2 * (rfirst + l)], W[d_off + 2 * (rfirst + l) + 1]
+            assert w0 & 1
+            if (w0 >> 19) & 1:
+                posts[l] = list(S[(w0 >> 20) & 0xFF])
         # phase 2: every write of S
-        for l, kind, arg, out, post in pend:
-            if kind == "sop":
-                acc = list(part[l])
-                for k in range(1, arg):
-                    acc = [a + b for a, b in zip(acc, part[l + k])]
-                # Montgomery reduction by 2^392 on the column sums (one 64-bit accumulator per column, as fe_sop2_body does)
-                c, m, res = 0, [], [0] * NL
-                for k in range(NL):
-                    t = acc[k] + c + sum(m[i] * P_L[k - i] for i in range(k))
-                    m.append(((t & 0xFFFFFFFF) * INV28) & MASK)
-                    t += m[k] * P_L[0]
-                    assert t < (1 << 64) and t & MASK == 0, "column overflow"
-                    c = t >> LW
-                for k in range(NL, 2 * NL - 1):
-                    t = acc[k] + c + sum(m[i] * P_L[k - i] for i in range(k - NL + 1, NL))
-                    assert t < (1 << 64), "column overflow"
-                    res[k - NL] = t & MASK
-                    c = t >> LW
-                res[NL - 1] = c
-                v = res
-                assert value(v) * RP % P == sum(a << (LW * i) for i, a in enumerate(acc)) % P
-                if post:
-                    cv, s, cs = post
-                    t = [cv * v[j] + (cs * s[j] if cs > 0 else (-cs) * (BIAS[j] - s[j])) for j in range(NL)]
-                    v = limbs(value(t))
-                assert value(v) < 1024 * P
-                S[out] = reduce_v(v)
-            elif kind == "lin":
-                assert value(arg) < 1024 * P
-                S[out] = reduce_v(limbs(value(arg)))
+        for kind, x, out in pend:
+            if kind == "lin":
+                assert value(x) < 1024 * P
+                S[out] = reduce_v(limbs(value(x)))
             else:
-                x = value(arg) % P
-                S[out] = limbs((pow(x, -1, P) if x else 0) * RP * RP % P)           # internal form of 1/x: (x R')^-1 R'^2
+                v = value(x) % P
+                S[out] = limbs((pow(v, -1, P) if v else 0) * RP * RP % P)           # internal form of 1/x: (x R')^-1 R'^2
+        for l in range(rcnt):
+            w0, w1 = W[d_off + 2 * (rfirst + l)], W[d_off + 2 * (rfirst + l) + 1]
+            a, out = (w0 >> 1) & 0x3FF, (w0 >> 11) & 0xFF
+            assert all(c < (1 << 64) for c in accs[a]) and not any(accs[a][27:])
+            v = mont_reduce(accs[a][:27])
+            accs[a] = [0] * ACC_COLS
+            if (w0 >> 19) & 1:
+                cv, cs, s = s5(w1), s5(w1 >> 5), posts[l]
+                t = [cv * v[j] + (cs * s[j] if cs >= 0 else (-cs) * (BIAS[j] - s[j])) for j in range(NL)]
+                assert all(0 <= c < (1 << 40) for c in t)
+                v = limbs(value(t))
+                assert value(v) < 1024 * P
+                v = reduce_v(v)
+            elif (w0 >> 28) & 1:
+                v = reduce_v(v)
+            assert value(v) < 2 * P, "stored value not below 2p"
+            S[out] = v
+    assert not any(any(a) for a in accs)
     return [value(S[i]) * pow(RP, -1, P) % P for i in range(n_out)]
 
 

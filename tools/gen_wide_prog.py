@@ -35,17 +35,20 @@ MAX_A_SUM = 17                         # sum over the terms of an SOP of A_x * A
 MAX_A = 15                             # limb bound of a lazily formed operand (28-bit limbs in 32-bit words)
 VB = 4                                 # negation adds VB * p (spread over the limbs); every stored value is weakly reduced below 2p
 COEF = [0, 1, -1, 2, -2, 3, -3, 4, -4, 6, -6, 8, -8, 12, -12, 9]
-MAXT = 3                               # terms per lane and round
-LANES = 256
+LANES = 1024                           # lanes of the workgroup (wide.hip.h WIDE_LANES)
+CHUNK = 4                              # limbs of x per product lane (wide.hip.h WIDE_K): every product is dealt to ceil(14 / CHUNK) lanes
+MAX_ACC = 128                          # sums of products per round (column accumulators in LDS)
+MAX_SLOTS = 256
+POST_CYCLOTOMIC = False
 OP_NOP, OP_SOP, OP_LIN, OP_INV = 0, 1, 2, 3
 
 
 class Node:
-    __slots__ = ("kind", "id", "val", "V", "level", "terms", "src", "slot", "fixed_slot", "post")
+    __slots__ = ("kind", "id", "val", "V", "level", "terms", "src", "slot", "fixed_slot", "post", "rv")
 
     def __init__(self, kind, val, V):
         self.kind, self.val, self.V = kind, val % P, V
-        self.level, self.terms, self.src, self.slot, self.fixed_slot, self.post = 0, None, None, None, None, None
+        self.level, self.terms, self.src, self.slot, self.fixed_slot, self.post, self.rv = 0, None, None, None, None, None, False
 
 
 class Lin:
@@ -220,8 +223,9 @@ class Graph:
         for g in groups:
             vsum = sum(x.V() * y.V() for x, y in g)
             assert 1 + (vsum + V_DIV - 1) // V_DIV <= 1024, "value bound of the unreduced result"
-            n = self._add(Node("sop", sum(x.val * y.val for x, y in g), 2))            # the reducer finishes with a weak reduction
+            n = self._add(Node("sop", sum(x.val * y.val for x, y in g), 2))
             n.terms = g
+            n.rv = vsum > V_DIV                        # T / R' < vsum p / 2520: at most p, so the Montgomery result is already below 2p
             n.level = max(max(x.level(), y.level()) for x, y in g) + 1
             out = out + Lin({n: 1})
         return out
@@ -235,8 +239,9 @@ class Graph:
             s = as_e(self.lin_node(self.reduce(s)))
         (sn, sk), = s.lin.c.items()
         cs *= sk                                           # a conjugated / negated stored value: the sign moves into the coefficient
+        fresh = bool(e.terms)                              # only a node made by THIS reduction may take the post-operation
         lin = self.reduce(e)
-        if len(lin.c) != 1 or list(lin.c.values())[0] != 1 or list(lin.c)[0].kind != "sop" or list(lin.c)[0].post is not None:
+        if not fresh or len(lin.c) != 1 or list(lin.c.values())[0] != 1 or list(lin.c)[0].kind != "sop" or list(lin.c)[0].post is not None:
             return self.store(E(lin.scale(cv) + Lin({sn: cs})))
         n = list(lin.c)[0]
         assert cv in COEF and cs in COEF and cv > 0
@@ -292,7 +297,9 @@ class F2:
 
     def __mul__(self, o):                                                       # fp2.rs:205-222 as two sums of two products
         a0, a1, b0, b1 = G.as_lin(self.re), G.as_lin(self.im), G.as_lin(o.re), G.as_lin(o.im)
-        return F2(E(None, [(a0, b0), (G.as_lin(E(a1.scale(-1))), b1)]), E(None, [(a0, b1), (a1, b0)]))
+        na1, nb1 = a1.scale(-1), b1.scale(-1)                                   # - a1 b1: the sign goes where it costs less headroom
+        neg = (na1, b1) if na1.A() * b1.A() <= a1.A() * nb1.A() else (a1, nb1)
+        return F2(E(None, [(a0, b0), neg]), E(None, [(a0, b1), (a1, b0)]))
 
     def sqr(self):                                                              # fp2.rs:182-203
         a0, a1 = G.as_lin(self.re), G.as_lin(self.im)
@@ -416,32 +423,66 @@ def f12_inv(f):
     return [r0[0], r1[0], r0[1], r1[1], r0[2], r1[2]]
 
 
-def cyclotomic_square(f):
-    """pairings.rs:66-112 (Granger-Scott), on the cyclotomic subgroup.  fp4_square(a, b) = (xi b^2 + a^2, 2 a b); every new
-    coefficient 3 t -+ 2 z is ONE sum of products with the linear step fused into its reduction: one round per squaring."""
+def cyclotomic_square(f, k=1):
+    """k * f^2, pairings.rs:66-112 (Granger-Scott), on the cyclotomic subgroup.  fp4_square(a, b) = (xi b^2 + a^2, 2 a b); every
+    new coefficient k (3 t -+ 2 z) is ONE sum of products with the linear step fused into its reduction: one round per squaring."""
     z0, z4, z3, z2, z1, z5 = f[0], f[2], f[4], f[1], f[3], f[5]
 
     def fp4(a, b):
         return b.sqr().xi() + a.sqr(), (a * b).times(2)
     t0, t1 = fp4(z0, z1)
-    nz0 = f2_fused(t0, 3, z0, -2)
-    nz1 = f2_fused(t1, 3, z1, 2)
+    nz0 = f2_fused(t0, 3 * k, z0, -2 * k)
+    nz1 = f2_fused(t1, 3 * k, z1, 2 * k)
     t0, t1 = fp4(z2, z3)
     t2, t3 = fp4(z4, z5)
-    nz4 = f2_fused(t0, 3, z4, -2)
-    nz5 = f2_fused(t1, 3, z5, 2)
-    nz2 = f2_fused(t3.xi(), 3, z2, 2)
-    nz3 = f2_fused(t2, 3, z3, -2)
+    nz4 = f2_fused(t0, 3 * k, z4, -2 * k)
+    nz5 = f2_fused(t1, 3 * k, z5, 2 * k)
+    nz2 = f2_fused(t3.xi(), 3 * k, z2, 2 * k)
+    nz3 = f2_fused(t2, 3 * k, z3, -2 * k)
     return [nz0, nz2, nz4, nz1, nz3, nz5]
+
+
+def cyclotomic_square3(f, f3):
+    """the same squaring inside a chain, where every value is kept TWICE: f and f3 = 3 f.  Then 3 t is a sum of products with
+    one operand taken from the tripled copy (and 9 t with both), the "- 2 z" is one more product with the constant one, and
+    every new coefficient -- of f^2 and of 3 f^2 -- is a PLAIN sum of products: no linear post-operation and no weak reduction
+    on the reducer's path (the sum of |coefficients| stays within the column bound, which scaling by three would not)."""
+    z = {0: f[0], 4: f[2], 3: f[4], 2: f[1], 1: f[3], 5: f[5]}
+    w = {0: f3[0], 4: f3[2], 3: f3[4], 2: f3[1], 1: f3[3], 5: f3[5]}
+
+    def fp4(a3, a, b3, b):                            # (3 or 9) * (xi b^2 + a^2, 2 a b), the factor carried by the first operands
+        return (b3 * b).xi() + a3 * a, (a3 * b).times(2)
+
+    def both(i, j):
+        return fp4(w[i], z[i], w[j], z[j]), fp4(w[i], w[i], w[j], w[j])
+    (t0, t1), (u0, u1) = both(0, 1)
+    (t2, t3), (u2, u3) = both(2, 3)
+    (t4, t5), (u4, u5) = both(4, 5)
+
+    def outs(a, b, c, d, e, g, zz):
+        nz0, nz1 = a - zz[0].times(2), b + zz[1].times(2)
+        nz4, nz5 = c - zz[4].times(2), d + zz[5].times(2)
+        nz2, nz3 = g.xi() + zz[2].times(2), e - zz[3].times(2)
+        return [x.stored() for x in (nz0, nz2, nz4, nz1, nz3, nz5)]
+    return outs(t0, t1, t2, t3, t4, t5, z), outs(u0, u1, u2, u3, u4, u5, w)
 
 
 def cyclotomic_exp(f):
     """pairings.rs:114-132: f^|x| by square-and-multiply, conjugated"""
-    tmp = f
+    if POST_CYCLOTOMIC:                               # experiment switch: the chain with the linear step as the reducer's post-operation
+        tmp = f
+        for b in reversed(range(63)):
+            tmp = cyclotomic_square(tmp)
+            if (BLS_X >> b) & 1:
+                tmp = f12_store(f12_mul(tmp, f))
+        return f12_conj(tmp)
+    tmp, tmp3 = f, None
     for b in reversed(range(63)):                     # bit 63 is the leading one
-        tmp = cyclotomic_square(tmp)
+        # a value that comes without its tripled copy (the chain's input, a product) is squared with the linear step as the
+        # reducer's post-operation, once for f^2 and once for 3 f^2; inside a run of squarings both copies are plain sums
+        tmp, tmp3 = cyclotomic_square3(tmp, tmp3) if tmp3 is not None else (cyclotomic_square(tmp), cyclotomic_square(tmp, 3))
         if (BLS_X >> b) & 1:
-            tmp = f12_store(f12_mul(tmp, f))
+            tmp, tmp3 = f12_store(f12_mul(tmp, f)), None
     return f12_conj(tmp)
 
 
@@ -491,14 +532,21 @@ def miller_loop(px, py, qx, qy):
         return f12_store(f12_mul_by_014(f, lc, c1, c4))
 
     def doubling():
+        """three levels per step (the critical chain is y -> y^2 -> new x, new y): level 1 x^2 (kept as 3 x^2), y^2, y z, z^2
+        and 8 x; level 2 the new x = (3x^2)^2 - 8x y^2, u = 3 x^3, y^4 and the line; level 3 the new y = 3 u (4 y^2 - u) - 8 y^4
+        (= (12 x y^2 - 9 x^4) 3 x^2 - 8 y^4).  z' = 2 y z stays a lazy multiple."""
         nonlocal x, y, z
-        xx, yy, zz, yz = x.sqr().stored(), y.sqr().stored(), z.sqr().stored(), (y * z).stored()
-        xyy, y4, xxzz, yzzz = (x * yy).stored(), yy.sqr().stored(), (xx * zz).stored(), (yz * zz).stored()
-        lc = f2_fused(x * xx, 6, yy, -4)              # 6 x^3 - 4 y^2
-        nx = f2_fused(xx.sqr(), 9, xyy, -8)           # 9 x^4 - 8 x y^2
-        ny = f2_fused((xyy.times(4) - nx) * xx, 3, y4, -8)          # (12 x y^2 - 9 x^4) 3 x^2 - 8 y^4
-        la, lb = yzzz.times(4), -xxzz.times(6)
-        x, y, z = nx, ny, yz.times(2).stored()
+        xx3 = f2_fused(x.sqr(), 3, x, 0)
+        yy, zz, yz = y.sqr().stored(), z.sqr().stored(), (y * z).stored()
+        x8 = x.times(8).stored()
+        nx = (xx3.sqr() - x8 * yy).stored()           # 9 x^4 - 8 x y^2
+        u = (x * xx3).stored()                        # 3 x^3
+        y4 = yy.sqr().stored()
+        xxzz3, yzzz = (xx3 * zz).stored(), (yz * zz).stored()
+        lc = f2_fused(u, 2, yy, -4)                   # 6 x^3 - 4 y^2
+        ny = f2_fused(u * (yy.times(4) - u), 3, y4, -8)
+        la, lb = yzzz.times(4), -xxzz3.times(2)
+        x, y, z = nx, ny, yz.times(2)
         return la, lb, lc
 
     def addition():
@@ -566,19 +614,24 @@ def schedule(g, nfixed):
     rounds = []
     for lv in sorted(byl):
         cur, lanes = [], 0
+        nchunk = (NL + CHUNK - 1) // CHUNK
+        nacc = 0
         for n in byl[lv]:
-            w = (len(n.terms) + MAXT - 1) // MAXT if n.kind == "sop" else 1
-            if lanes + w > LANES:
+            w = len(n.terms) * nchunk if n.kind == "sop" else 1
+            if lanes + w > LANES - 64 or (n.kind == "sop" and nacc == MAX_ACC):     # 64: room to start the LIN / INV lanes on a wavefront boundary
                 rounds.append(cur)
-                cur, lanes = [], 0
+                cur, lanes, nacc = [], 0, 0
             cur.append(n)
             lanes += w
+            nacc += n.kind == "sop"
         rounds.append(cur)
     rnd_of = {n: r for r, ns in enumerate(rounds) for n in ns}
     last = {}
     for n, r in rnd_of.items():
         for m in sources(n):
             last[m] = max(last.get(m, -1), r)
+        if n.kind == "sop" and n.post:                      # the post-operation reads its slot in the WRITE phase of the round:
+            last[n.post[1]] = max(last.get(n.post[1], -1), r + 1)        # nobody may write that slot before the next round
     consts = [c for c in g.consts.values() if c in need]
     for i, c in enumerate(consts):
         c.slot = nfixed + i
@@ -604,14 +657,33 @@ def schedule(g, nfixed):
     return rounds, consts, nslots
 
 
+def bias_limbs():
+    """fe.hip.h make_bias(VB, 1): VB * p spread over the limbs so that every limb is at least 2^28 - 1"""
+    pl = [(P >> (LW * i)) & ((1 << LW) - 1) for i in range(NL)]
+    r, carry = [0] * NL, 0
+    for i in range(NL):
+        t = pl[i] * VB + carry
+        r[i] = (t & ((1 << LW) - 1)) if i < NL - 1 else t
+        carry = (t >> LW) if i < NL - 1 else 0
+    r[0] += 1 << LW
+    for i in range(1, NL - 1):
+        r[i] += (1 << LW) - 1
+    r[NL - 1] -= 1
+    assert sum(v << (LW * i) for i, v in enumerate(r)) == VB * P
+    return r
+
+
 def enc_pairs(items):
-    """up to two (slot, coefficient) pairs in one word: slot 10 bits, coefficient code 4 bits, twice"""
+    """operand word: up to two (slot 8 bits, signed 5-bit coefficient) pairs at bits 0 and 13, the weight of the bias slot
+    (the sum of the negative coefficients' magnitudes) at bit 26"""
     assert 1 <= len(items) <= 2, len(items)
-    w = 0
+    w, wneg = 0, 0
     for i, (n, k) in enumerate(items):
-        assert n.slot is not None and n.slot < 1024 and k in COEF, (n.kind, n.slot, k)
-        w |= (n.slot | (COEF.index(k) << 10)) << (14 * i)
-    return w
+        assert n.slot is not None and n.slot < MAX_SLOTS and -16 <= k <= 15 and k, (n.kind, n.slot, k)
+        w |= (n.slot | ((k & 31) << 8)) << (13 * i)
+        wneg += -k if k < 0 else 0
+    assert wneg <= 15
+    return w | (wneg << 26)
 
 
 def enc_lin(lin):
@@ -620,74 +692,75 @@ def enc_lin(lin):
 
 def encode(g, rounds, consts, nslots, n_in, n_out):
     """binary layout (u32 words):
-       header[16]: magic, nrounds, nslots, nconst, n_in, n_out, const_off, rounds_off, desc_off, ...
-       consts:     nconst x (slot, 14 limbs of c * R' mod p)
-       rounds:     nrounds x (first descriptor index, lanes used)
-       descs:      8 words per lane: w0 = op | nterms << 2 | reducer << 6 | nparts << 7 | out_slot << 16 ; w1..w6 operands"""
-    descs, rtab = [], []
+       header[16]: magic, nrounds, nslots, nconst, n_in, n_out, const_off, rounds_off, pdesc_off, rdesc_off, lanes, chunk, bias_slot, max_acc
+       consts:     nconst x (slot, 14 limbs)  -- c * R' mod p, and the spread VB * p the negative coefficients lean on
+       rounds:     nrounds x (first product descriptor, product lanes, first reducer descriptor, reducer lanes)
+       pdesc:      4 words per lane: w0 = op | lo << 2 | len << 6 | accumulator << 10 ; w1, w2 = operand words ; w3 = out slot (LIN, INV)
+       rdesc:      2 words per reducer lane: w0 = 1 | accumulator << 1 | out << 11 | post << 19 | post_slot << 20 | weak_reduce << 28 ;
+                   w1 = cv (5 bits, signed) | cs << 5"""
+    nchunk = (NL + CHUNK - 1) // CHUNK
+    pdescs, rdescs, rtab = [], [], []
+    bias_slot = nslots
+    nslots += 1
+    assert nslots <= MAX_SLOTS
+    max_acc = 0
     for ns in rounds:
-        first = len(descs)
-        total_terms = sum(len(n.terms) for n in ns if n.kind == "sop")
-        nsop = sum(1 for n in ns if n.kind == "sop")
-        nother = len(ns) - nsop
-        # terms per lane: as few as fit
-        tpl = 1
-        while sum((len(n.terms) + tpl - 1) // tpl for n in ns if n.kind == "sop") + nother > LANES:
-            tpl += 1
-        assert tpl <= MAXT
-        lane_descs = []
-        for n in ns:
-            if n.kind != "sop":
-                continue
-            parts = [n.terms[i:i + tpl] for i in range(0, len(n.terms), tpl)]
-            for pi, part in enumerate(parts):
-                w = [0] * 8
-                w[0] = OP_SOP | (len(part) << 2) | ((1 if pi == 0 else 0) << 6) | ((len(parts) if pi == 0 else 0) << 7) | (n.slot << 16)
-                for t, (x, y) in enumerate(part):
-                    w[1 + 2 * t], w[2 + 2 * t] = enc_lin(x), enc_lin(y)
-                if pi == 0 and n.post:
-                    cv, sn, cs = n.post
-                    w[7] = (1 << 31) | sn.slot | (COEF.index(cs) << 10) | (COEF.index(cv) << 14)
-                lane_descs.append(w)
-        others = []
-        for n in ns:
-            if n.kind == "sop":
-                continue
-            w = [0] * 8
+        pfirst, rfirst = len(pdescs), len(rdescs)
+        sops = [n for n in ns if n.kind == "sop"]
+        others = [n for n in ns if n.kind != "sop"]
+        assert len(sops) <= MAX_ACC
+        max_acc = max(max_acc, len(sops))
+        lanes = []
+        # term-major: the lanes that add into the same columns of one accumulator sit len(sops) * nchunk lanes apart
+        for t in range(max([len(n.terms) for n in sops] + [0])):
+            for a, n in enumerate(sops):
+                if t >= len(n.terms):
+                    continue
+                x, y = n.terms[t]
+                for c in range(nchunk):
+                    lo = c * CHUNK
+                    ln = min(CHUNK, NL - lo)
+                    lanes.append([OP_SOP | (lo << 2) | (ln << 6) | (a << 10), enc_lin(x), enc_lin(y), 0])
+        for a, n in enumerate(sops):
+            w0 = 1 | (a << 1) | (n.slot << 11) | ((1 if n.rv else 0) << 28)
+            w1 = 0
+            if n.post:
+                cv, sn, cs = n.post
+                assert 0 < cv <= 15 and -16 <= cs <= 15
+                w0 |= (1 << 19) | (sn.slot << 20)
+                w1 = (cv & 31) | ((cs & 31) << 5)
+            rdescs.append([w0, w1])
+        if others and len(lanes) % 64 and len(lanes) + 64 - len(lanes) % 64 + len(others) <= LANES:
+            lanes += [[0, 0, 0, 0]] * (64 - len(lanes) % 64)          # LIN / INV lanes start a wavefront of their own (different code path)
+        for n in others:
             if n.kind == "lin":
                 items = n.src
                 assert 1 <= len(items) <= 4
-                w[0] = OP_LIN | (len(items) << 2) | (1 << 6) | (n.slot << 16)
-                for i in range(0, len(items), 2):
-                    w[1 + i // 2] = enc_pairs(items[i:i + 2])
+                lanes.append([OP_LIN, enc_pairs(items[0:2]), enc_pairs(items[2:4]) if len(items) > 2 else 0, n.slot])
             else:
-                w[0] = OP_INV | (1 << 2) | (1 << 6) | (n.slot << 16)
-                w[1] = enc_pairs(n.src)
-            others.append(w)
-        # SOP lanes from lane 0 upward, LIN / INV lanes in the LAST wavefront of the round's lanes (different code paths diverge per wavefront)
-        used = len(lane_descs) + len(others)
-        pad = 0
-        if others and len(lane_descs) % 64:
-            pad = min(64 - len(lane_descs) % 64, LANES - used)
-        lane_descs += [[0] * 8] * pad + others
-        assert len(lane_descs) <= LANES
-        rtab.append((first, len(lane_descs)))
-        descs += lane_descs
-    words = []
-    hdr = [0x57494445, len(rounds), nslots, len(consts), n_in, n_out, 0, 0, 0] + [0] * 7
+                lanes.append([OP_INV, enc_pairs(n.src), 0, n.slot])
+        assert len(lanes) <= LANES, len(lanes)
+        pdescs += lanes
+        rtab.append((pfirst, len(lanes), rfirst, len(sops)))
+    pdescs.append([0, 0, 0, 0])                                       # the prefetch of the round after the last reads index 0 of nothing: keep it inside the tables
+    rdescs.append([0, 0])
+    hdr = [0x57494432, len(rounds), nslots, len(consts) + 1, n_in, n_out, 0, 0, 0, 0, LANES, CHUNK, bias_slot, max_acc, 0, 0]
     const_words = []
     for c in consts:
         v = c.val * RP % P
         const_words += [c.slot] + [(v >> (LW * i)) & ((1 << LW) - 1) for i in range(NL)]
-    round_words = []
-    for first, cnt in rtab:
-        round_words += [first, cnt]
+    const_words += [bias_slot] + bias_limbs()
+    const_words += [0] * (-(16 + len(const_words)) % 4)              # the round table is read as 16-byte quads
+    round_words = [w for r in rtab for w in r]
+    pwords = [w for d in pdescs for w in d]
+    rwords = [w for d in rdescs for w in d]
     hdr[6] = 16
     hdr[7] = 16 + len(const_words)
     hdr[8] = hdr[7] + len(round_words)
-    for d in descs:
-        words += d
-    return struct.pack("<%dI" % (16 + len(const_words) + len(round_words) + len(words)), *(hdr + const_words + round_words + words))
+    hdr[9] = hdr[8] + len(pwords)
+    allw = hdr + const_words + round_words + pwords + rwords
+    allw += [0] * (-len(allw) % 4)
+    return struct.pack("<%dI" % len(allw), *allw)
 
 
 def build_programs(check=False):
@@ -735,6 +808,12 @@ def main():
     out = os.path.join(ROOT, "bls12_381_amd", "wide_prog.bin")
     if "--out" in sys.argv:
         out = sys.argv[sys.argv.index("--out") + 1]
+    global LANES, CHUNK, POST_CYCLOTOMIC
+    POST_CYCLOTOMIC = "--post-cyclotomic" in sys.argv
+    if "--lanes" in sys.argv:
+        LANES = int(sys.argv[sys.argv.index("--lanes") + 1])
+    if "--chunk" in sys.argv:
+        CHUNK = int(sys.argv[sys.argv.index("--chunk") + 1])
     progs = build_programs(check="--check" in sys.argv)
     blob = b""
     index = []
