@@ -1439,7 +1439,7 @@ extern "C" int blsgpu_fr_ntt(blsgpu_ctx* c, uint64_t* data, int log_n, int inver
 
 // ---------------------------------------------------------------------------------------------------
 // ---- the wide (one workgroup per pairing) path -------------------------------------------------------------------
-constexpr size_t WIDE_AUTO_MAX = 768;        // one 1024-lane workgroup per CU at a time: 256 items run at the latency of one (1.5 ms), 768 in three passes (4.4 ms), against the quad kernels' flat ~6 ms
+constexpr size_t WIDE_AUTO_MAX = 1024;       // one 1024-lane workgroup per CU at a time: 256 items run at the latency of one (1.25 ms), 1024 in four passes (4.9 ms), against the quad kernels' flat ~6.1 ms
 static int wide_load(blsgpu_ctx* c) {
   if (c->wide_state) return c->wide_state;
   c->wide_state = -1;

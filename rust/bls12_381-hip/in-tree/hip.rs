@@ -162,11 +162,13 @@ pub fn pairing_batch(p: &[G1Affine], q: &[G2Affine]) -> Vec<Gt> {
     });
     gpu.unwrap_or_else(|| p.iter().zip(q).map(|(a, b)| crate::pairings::pairing_cpu(a, b)).collect())
 }
-/// Below these batch sizes the crate's own CPU code is faster than a device round trip: one pairing is ~1.3 ms on a host
-/// core (`per_op_ns.full_pairing_ns`) against ~6 ms for a lone quad of lanes on the GPU (a single wavefront
-/// issues one multiply-add per ~9 cycles whatever the batch size; tools/lat_small.py) -- the device pays from ~8 pairs on.
-pub const GPU_MIN_PAIRINGS: usize = 8;
-pub const GPU_MIN_MILLER_TERMS: usize = 8;
+/// Below these batch sizes the crate's own CPU code is at least as fast as a device round trip.  One call with 1..256 items takes
+/// the library's wide path (one item per 1024-lane workgroup): ~1.25 ms for pairings, ~0.45 ms for Miller loops, ~0.8 ms for
+/// final exponentiations, whatever the count (bench.py `pairing_small_batches`); one pairing on a host core is ~1.1-1.3 ms, one
+/// Miller loop ~0.45 ms, one final exponentiation ~0.7 ms (`per_op_ns`).  So ONE item stays on the CPU (a tie, minus
+/// the copies) and the device pays from two items on.
+pub const GPU_MIN_PAIRINGS: usize = 2;
+pub const GPU_MIN_MILLER_TERMS: usize = 2;
 /// `pairing` for one pair (what `Engine::pairing` forwards to): the CPU path of the crate, unchanged (src/pairings.rs:607-653,
 /// renamed `pairing_cpu`) -- a single pair never goes to the device.  Callers with many pairs use `pairing_batch`.
 pub fn pairing(p: &G1Affine, q: &G2Affine) -> Gt { crate::pairings::pairing_cpu(p, q) }
@@ -185,7 +187,7 @@ pub fn multi_miller_loop(terms: &[(&G1Affine, &G2PreparedHip)]) -> MillerLoopRes
     gpu.unwrap_or_else(|| crate::pairings::multi_miller_loop_cpu(terms))
 }
 /// `MillerLoopResult::final_exponentiation` (src/pairings.rs:48-176) of ONE value: the crate's CPU code (~0.7 ms on a host
-/// core against ~3.5 ms for one value on the device); `final_exponentiation_batch` is the device entry point
+/// core against ~0.8 ms for one value on the device); `final_exponentiation_batch` is the device entry point
 pub fn final_exponentiation(f: &MillerLoopResult) -> Gt { f.final_exponentiation_cpu() }
 pub fn final_exponentiation_batch(fs: &[MillerLoopResult]) -> Vec<Gt> {
     if fs.len() < GPU_MIN_PAIRINGS { return fs.iter().map(|f| f.final_exponentiation_cpu()).collect(); }

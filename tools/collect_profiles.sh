@@ -3,6 +3,7 @@
 #   gpurun_out/prof_msm        kernel trace + stats of the default bench timed region, then PMC passes (tools/pmc.sh)
 #   gpurun_out/prof_pair       the same for 2^16 pairings (tools/run_pairing.py)
 #   gpurun_out/prof_mml        ... and for a 2^18-term multi_miller_loop
+#   gpurun_out/prof_wide       ... and for 2^8 pairings per call (the wide small-batch kernel)
 # tools/summarise_profiles.py <round> turns them into profiles/<round>_*.md / .json.
 R="${GRAFT_REPO_ROOT:-$PWD}"; cd "$R"
 tools/pmc.sh prof_msm python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras
@@ -13,5 +14,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_msm/stat
 tools/pmc.sh prof_pair python tools/run_pairing.py pairing 16 3
 BLSGPU_PAIRING_LAYOUT=pair tools/pmc.sh prof_pair_lp python tools/run_pairing.py pairing 16 3
 tools/pmc.sh prof_mml python tools/run_pairing.py mml 18 3
-find gpurun_out/prof_msm gpurun_out/prof_pair gpurun_out/prof_pair_lp gpurun_out/prof_mml -name "*agent_info.csv" -delete
+tools/pmc.sh prof_wide python tools/run_pairing.py pairing 8 20
+find gpurun_out/prof_msm gpurun_out/prof_pair gpurun_out/prof_pair_lp gpurun_out/prof_mml gpurun_out/prof_wide -name "*agent_info.csv" -delete
 du -sh gpurun_out/prof_*

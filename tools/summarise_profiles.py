@@ -130,7 +130,7 @@ def pairing(d, K, units, unit_name, mac32, tag, what, layout, alg_bytes_per_unit
 
 * launch duration: {dur/1e6:.2f} ms -> {units/(dur*1e-9):.3e} {unit_name}/s; canonical work {mac32/1e6:.2f} M MAC32 per unit (SURVEY.md 8d) -> {units*mac32/(dur*1e-9)/1e12:.2f} TMAC32/s
 * registers / scratch / LDS (code-object metadata): {m.get('vgpr_count')} VGPR, {m.get('private_segment_fixed_size')} B scratch frame per lane (the deepest call path of the final exponentiation; the hot loops touch none of it), {m.get('group_segment_fixed_size')} B LDS per block
-* HBM-side traffic per launch: FETCH_SIZE = {fetch_kb/1e6:.3f} GB raw -> x2 = {2*fetch_kb*1024/1e9:.2f} GB, WRITE_SIZE = {write_kb*1024/1e9:.2f} GB, together {hbm/1e9:.2f} GB against {alg/1e6:.0f} MB of inputs and outputs ({alg_bytes_per_unit} B per unit) = {hbm/alg if alg else 0:.1f}x
+* HBM-side traffic per launch: FETCH_SIZE = {fetch_kb/1e6:.3f} GB raw -> x2 = {2*fetch_kb*1024/1e9:.2f} GB, WRITE_SIZE = {write_kb*1024/1e9:.2f} GB, together {hbm/1e9:.2f} GB against {alg/1e6:.2f} MB of inputs and outputs ({alg_bytes_per_unit} B per unit) = {hbm/alg if alg else 0:.1f}x
 * SQ_INSTS_VALU = {c.get('SQ_INSTS_VALU',0):.3e} wave-instructions; SQ_INSTS_VMEM_RD / WR = {c.get('SQ_INSTS_VMEM_RD',0):.3e} / {c.get('SQ_INSTS_VMEM_WR',0):.3e}; SQ_INSTS_LDS = {c.get('SQ_INSTS_LDS',0):.3e}
 * wave-cycle split: SQ_ACTIVE_INST_ANY {100*c.get('SQ_ACTIVE_INST_ANY',0)/wc:.0f}%, SQ_WAIT_INST_ANY (issue stalls) {100*c.get('SQ_WAIT_INST_ANY',0)/wc:.0f}%, SQ_WAIT_ANY (s_waitcnt) {100*c.get('SQ_WAIT_ANY',0)/wc:.0f}% of SQ_WAVE_CYCLES = {wc:.3e}
 * instruction cache: {c.get('SQC_ICACHE_MISSES',0):.3e} misses of {c.get('SQC_ICACHE_REQ',0):.3e} requests
@@ -147,4 +147,7 @@ if one("prof_pair_lp/stats/**/*kernel_trace.csv"):
     pairing("prof_pair_lp", "k_pairing(", 65536, "pairings", 4.8e6, "pairing_lanepair", "pairing 16 3 (BLSGPU_PAIRING_LAYOUT=pair)", "lane-pair layout of rounds 1-2, 2 wavefronts/SIMD", 864, meta_key="9k_pairingEi")
 if one("prof_mml/stats/**/*kernel_trace.csv"):
     pairing("prof_mml", "k_multi_miller_shared", 262144, "terms", 2.07e6, "mml", "mml 18 3", "lane-pair layout, four terms per shared accumulator", 288)
+if one("prof_wide/stats/**/*kernel_trace.csv"):
+    pairing("prof_wide", "k_pairing_wide", 256, "pairings", 4.8e6, "pairing_wide", "pairing 8 20",
+            "wide layout: one pairing per 1024-lane workgroup, one workgroup per CU (the small-batch latency path)", 864)
 print("profiles written for", RND)
