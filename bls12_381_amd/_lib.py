@@ -36,6 +36,7 @@ SIGNATURES = {
     "blsgpu_bases_len": (c_sz, [c_vp]),
     "blsgpu_set_assume_subgroup": (c_int, [c_vp, c_int]),
     "blsgpu_bases_subgroup_state": (c_int, [c_vp]),
+    "blsgpu_pairing_layout": (c_int, [c_vp, c_sz]),
     "blsgpu_bases_download": (c_int, [c_vp, c_vp, c_sz, c_sz, c_vp, c_vp]),
     "blsgpu_bases_free": (None, [c_vp]),
     "blsgpu_g1_msm": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),

@@ -175,6 +175,14 @@ class Context:
         set with an off-subgroup point falls back to plain windows, which match the reference's `multiply` on any curve point."""
         check(self.lib.blsgpu_set_assume_subgroup(self.h, 1 if on else 0), "set_assume_subgroup")
 
+    def pairing_layout(self, n):
+        """which kernels a pairing / Miller-loop / final-exponentiation call with n items runs: 256 = wide (one item per
+        workgroup, small batches), 4 = quad, 2 = lane pair (include/bls12_381_hip.h `blsgpu_pairing_layout`)"""
+        r = int(self.lib.blsgpu_pairing_layout(self.h, n))
+        if r < 0:
+            check(r, "pairing_layout")
+        return r
+
     def msm_accumulate_stats(self, enable):
         """(average ms, launches) of the accumulation kernel since the last call (HIP events on its stream); then reset and
         switch the measurement off (False / 0) or on (True / 1: every launch; N: every N-th launch)"""

@@ -1475,8 +1475,14 @@ static int wide_load(blsgpu_ctx* c) {
 // which kernels take a batch of n pairings / Miller loops / final exponentiations: 256 = wide, 4 = quad, 2 = lane pair
 static int pairing_layout_for(blsgpu_ctx* c, size_t n) {
   if (c->pairing_layout == 2 || c->pairing_layout == 4) return c->pairing_layout;
-  if (c->pairing_layout == 256) return wide_load(c) == 1 ? 256 : 4;
+  if (c->pairing_layout == 256) return wide_load(c) == 1 ? 256 : -1;          // asked for by name: no silent substitute
   return (n <= WIDE_AUTO_MAX && wide_load(c) == 1) ? 256 : 4;
+}
+extern "C" int blsgpu_pairing_layout(blsgpu_ctx* c, size_t n) {
+  if (!c) return bad("pairing_layout: NULL context");
+  if (hipSetDevice(c->device) != hipSuccess) { (void)hipGetLastError(); return bad("pairing_layout: hipSetDevice failed"); }
+  const int l = pairing_layout_for(c, n);
+  return l < 0 ? bad("pairing_layout: BLSGPU_PAIRING_LAYOUT=wide but wide_prog.bin is missing or was generated for another kernel configuration") : l;
 }
 static void wide_launch(blsgpu_ctx* c, int mode, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) {
   hipLaunchKernelGGL(k_pairing_wide, dim3((unsigned)n), dim3(WIDE_LANES), 0, c->stream, mode, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2, (const uint8_t*)g2inf,
@@ -1485,6 +1491,7 @@ static void wide_launch(blsgpu_ctx* c, int mode, const void* g1, const void* g1i
 static int pairing_launch(blsgpu_ctx* c, int mode, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) {
   // mode 0: full pairing, 1: Miller loop only
   const int layout = pairing_layout_for(c, n);
+  if (layout < 0) return bad("pairing: BLSGPU_PAIRING_LAYOUT=wide but wide_prog.bin is missing or was generated for another kernel configuration");
   if (layout == 256) { wide_launch(c, mode, g1, g1inf, g2, g2inf, n, out); LAUNCHCHK(); return BLSGPU_OK; }
   if (layout == 4) {
     hipLaunchKernelGGL(k_pairing_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, mode, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2,
@@ -1538,6 +1545,7 @@ extern "C" int blsgpu_final_exponentiation_device(blsgpu_ctx* c, const void* in,
   if (!n) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
   const int layout = pairing_layout_for(c, n);
+  if (layout < 0) return bad("pairing: BLSGPU_PAIRING_LAYOUT=wide but wide_prog.bin is missing or was generated for another kernel configuration");
   if (layout == 256) wide_launch(c, 2, in, nullptr, nullptr, nullptr, n, out);
   else if (layout == 4) hipLaunchKernelGGL(k_final_exp_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, (const u32*)in, (u32*)out, n);
   else hipLaunchKernelGGL(k_final_exp, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)in, (u32*)out, n);
@@ -1611,6 +1619,7 @@ extern "C" int blsgpu_final_exponentiation_batch(blsgpu_ctx* c, const uint64_t* 
   if (c->io_a.reserve(n * 576) || c->io_out.reserve(n * 576)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
   HIPCHK(hipMemcpyAsync(c->io_a.p, in, n * 576, hipMemcpyHostToDevice, c->stream));
   const int layout = pairing_layout_for(c, n);
+  if (layout < 0) return bad("pairing: BLSGPU_PAIRING_LAYOUT=wide but wide_prog.bin is missing or was generated for another kernel configuration");
   if (layout == 256) wide_launch(c, 2, c->io_a.p, nullptr, nullptr, nullptr, n, c->io_out.p);
   else if (layout == 4) hipLaunchKernelGGL(k_final_exp_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, c->io_a.as<u32>(), c->io_out.as<u32>(), n);
   else hipLaunchKernelGGL(k_final_exp, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, c->io_a.as<u32>(), c->io_out.as<u32>(), n);

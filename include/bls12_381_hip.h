@@ -172,6 +172,17 @@ int blsgpu_g1_to_bytes_batch(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t*
 int blsgpu_g2_to_bytes_batch(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, size_t n, int compressed, uint8_t* out);
 
 /* ---- pairings ------------------------------------------------------------------------------------------ */
+/* Which kernels a call with n items (pairings, Miller loops or final exponentiations) runs on this context:
+ *   256 = wide  (one item per 1024-lane workgroup: the small-batch latency path, n <= 1024; needs the generated
+ *                program file `wide_prog.bin` next to the library -- build step of __graft_entry__.py -- or at
+ *                $BLSGPU_WIDE_PROG),
+ *     4 = quad  (one item per four lanes: the throughput path),
+ *     2 = lane pair (the layout of rounds 1-2, kept for A/B runs).
+ * BLSGPU_PAIRING_LAYOUT=wide|quad|pair|auto in the environment at blsgpu_create fixes the choice; with "wide" a missing
+ * or mismatching program file makes the pairing entry points FAIL (BLSGPU_ERR_ARG) instead of silently running another
+ * kernel; with "auto" (the default) the quad kernels take every size then and this function says so.
+ * All layouts return limb-identical results. */
+int blsgpu_pairing_layout(blsgpu_ctx* ctx, size_t n);
 /* out[i] = pairing(g1[i], g2[i]) for n independent pairs (`pairing`, src/pairings.rs:607-653; 72 u64 each).
  * An identity on either side yields Gt::identity() = Fp12::one(), as the reference does. */
 int blsgpu_pairing_batch(blsgpu_ctx* ctx, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy, const uint8_t* g2_inf, size_t n, uint64_t* out_gt);

@@ -59,6 +59,7 @@ extern "C" {
     pub fn blsgpu_g2_from_bytes_batch(ctx: *mut BlsgpuCtx, bytes: *const u8, n: usize, compressed: c_int, checked: c_int, xy: *mut u64, infinity: *mut u8, ok: *mut u8) -> c_int;
     pub fn blsgpu_g1_to_bytes_batch(ctx: *mut BlsgpuCtx, xy: *const u64, infinity: *const u8, n: usize, compressed: c_int, out: *mut u8) -> c_int;
     pub fn blsgpu_g2_to_bytes_batch(ctx: *mut BlsgpuCtx, xy: *const u64, infinity: *const u8, n: usize, compressed: c_int, out: *mut u8) -> c_int;
+    pub fn blsgpu_pairing_layout(ctx: *mut BlsgpuCtx, n: usize) -> c_int;
     pub fn blsgpu_pairing_batch(ctx: *mut BlsgpuCtx, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, n: usize, out_gt: *mut u64) -> c_int;
     pub fn blsgpu_miller_loop_batch(ctx: *mut BlsgpuCtx, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, n: usize, out_f: *mut u64) -> c_int;
     pub fn blsgpu_multi_miller_loop(ctx: *mut BlsgpuCtx, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, n: usize, out_f: *mut u64) -> c_int;

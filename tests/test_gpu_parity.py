@@ -1511,6 +1511,7 @@ def test_small_batches_take_the_wide_path_and_match_every_other_layout(ctx, layo
         w = b.Context(0)
     finally:
         os.environ.pop("BLSGPU_PAIRING_LAYOUT")
+    assert w.pairing_layout(n) == 256 and ctx.pairing_layout(n) == 256 and ctx.pairing_layout(1 << 16) == 4      # the program file is there and taken
     ka = sy.scalars(n, sy.SEED + 900 + n); kq = sy.scalars(n, sy.SEED + 901 + n)
     g1, f1 = ctx.bases_from_scalars(1, ka).download(); g2, f2 = ctx.bases_from_scalars(2, kq).download()
     g1 = g1.copy(); g2 = g2.copy(); f1 = f1.copy(); f2 = f2.copy()

@@ -64,8 +64,29 @@ template <int KIND> void run(const char* name, int per_iter, u64* d) {
   }
 }
 
+// the same kernel on the whole chip: does the per-wavefront figure survive 256 busy CUs (clocks, power)?
+template <int KIND> void run_chip(const char* name, int per_iter, u64* d) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int waves : {4, 8, 16}) {
+    for (int blocks_per_cu : {1, 2}) {
+      const int iters = 20000, blocks = 256 * blocks_per_cu;
+      k<KIND><<<blocks, 64 * waves>>>(d, 7, 100);
+      hipEventRecord(e0);
+      k<KIND><<<blocks, 64 * waves>>>(d, 9, iters);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      u64 h[2]; hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+      const double instr = (double)iters * per_iter;
+      printf("%-24s chip, %2d waves/block x %d blocks/CU: %6.2f ticks per instruction of one wave; wall %.3f ms -> %.2f T lane-ops/s, tick = %.3f ns\n", name, waves,
+             blocks_per_cu, (double)h[0] / instr, ms, instr * blocks * waves * 64 / (ms * 1e-3) / 1e12, ms * 1e6 / (double)h[0]);
+    }
+  }
+}
+
 int main() {
   u64* d; hipMalloc(&d, 64);
+  run_chip<0>("mad_u64_u32 independent", 8, d);
+  run_chip<2>("add/xor independent", 8, d);
   run<0>("mad_u64_u32 independent", 8, d);
   run<1>("mad_u64_u32 dependent", 8, d);
   run<2>("add/xor independent", 8, d);
