@@ -76,7 +76,9 @@ struct blsgpu_ctx {
   bool force_slow_sort = false;        // test hook (env BLSGPU_FORCE_SLOW_SORT at create): the global-atomic sort used beyond 2^24 points
   hipStream_t acc_stream = nullptr;     // bucket accumulation of pipelined calls (the caller's stream is never blocked)
   hipEvent_t ev[9] = {};
-  u32* d_status = nullptr;              // [0]: sticky "a scalar was not canonical (>= r)" flag, set by the digit kernels
+  u32* d_status = nullptr;              // [0]: sticky "a scalar was not canonical (>= r)" flag of the ASYNCHRONOUS (device-pointer) calls, reported by blsgpu_synchronize / blsgpu_join;
+                                        // [1]: scratch of the subgroup check; [2]: the flag of the synchronous call in progress (cleared before it, fetched with its result)
+  u32* status_word = nullptr;           // where the kernels of the calls being enqueued report: d_status (default) or d_status + 2 inside a synchronous entry point
   float phase_ms[8] = {0};
   // MSM: the chip-filling phases run on `stream`; the latency-bound tail (bucket reduction + window
   // combine, a few wavefronts) of call i runs on tail_stream[i & 1] and overlaps the next call's heavy
@@ -387,6 +389,7 @@ static int ctx_init(blsgpu_ctx* c) {
   HIPCHK(hipStreamCreateWithPriority(&c->acc_stream, hipStreamNonBlocking, pr[0]));
   HIPCHK(hipMalloc((void**)&c->d_status, 16));
   HIPCHK(hipMemset(c->d_status, 0, 16));
+  c->status_word = c->d_status;
   for (auto& sl : c->slot) {
     // the tail is a handful of wavefronts racing a chip-filling kernel: give its queue the highest priority
     HIPCHK(hipStreamCreateWithPriority(&sl.tail, hipStreamNonBlocking, pr[1]));
@@ -460,6 +463,17 @@ static int take_status(blsgpu_ctx* c) {
   }
   return BLSGPU_OK;
 }
+// A synchronous entry point owns its verdict: its kernels report into d_status[2] (cleared on the caller's stream before anything
+// of the call is enqueued), the word comes back with the call's result, and neither an earlier asynchronous call's flag is
+// blamed on this call nor is it cleared by it.
+struct SyncStatus {
+  blsgpu_ctx* c; u32 host = 0;
+  explicit SyncStatus(blsgpu_ctx* c_) : c(c_) { c->status_word = c->d_status + 2; }
+  ~SyncStatus() { c->status_word = c->d_status; }
+  int begin() { HIPCHK(hipMemsetAsync(c->d_status + 2, 0, 4, c->stream)); return BLSGPU_OK; }
+  int fetch() { HIPCHK(hipMemcpyAsync(&host, c->d_status + 2, 4, hipMemcpyDeviceToHost, c->stream)); return BLSGPU_OK; }      // then synchronise the stream
+  int verdict() const { return host ? bad("msm: a scalar is not canonical (>= r); Scalar::to_bytes never produces such bytes (scalar.rs:284-296)") : BLSGPU_OK; }
+};
 extern "C" int blsgpu_synchronize(blsgpu_ctx* c) {
   if (!c) return bad("ctx is NULL");
   HIPCHK(hipSetDevice(c->device));
@@ -795,15 +809,15 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     const unsigned tiles = nblk(ns, SORT_TILE);
     const u32* sort_in = (const u32*)d_scalars;
     if (glv) {
-      hipLaunchKernelGGL(k_glv_decompose, dim3(nblk(n, 256)), dim3(256), 0, ft, (const u32*)d_scalars, sl.glv.as<u32>(), (int)n, c->d_status);
+      hipLaunchKernelGGL(k_glv_decompose, dim3(nblk(n, 256)), dim3(256), 0, ft, (const u32*)d_scalars, sl.glv.as<u32>(), (int)n, c->status_word);
       sort_in = sl.glv.as<u32>();
-      hipLaunchKernelGGL(k_sort_hist<4>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, 0, c->d_status);
+      hipLaunchKernelGGL(k_sort_hist<4>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, 0, c->status_word);
     } else if (gls) {
-      hipLaunchKernelGGL(k_gls_decompose, dim3(nblk(n, 256)), dim3(256), 0, ft, (const u32*)d_scalars, sl.glv.as<u32>(), (int)n, c->d_status);
+      hipLaunchKernelGGL(k_gls_decompose, dim3(nblk(n, 256)), dim3(256), 0, ft, (const u32*)d_scalars, sl.glv.as<u32>(), (int)n, c->status_word);
       sort_in = sl.glv.as<u32>();
-      hipLaunchKernelGGL(k_sort_hist<2>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, 0, c->d_status);
+      hipLaunchKernelGGL(k_sort_hist<2>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, 0, c->status_word);
     } else {
-      hipLaunchKernelGGL(k_sort_hist<8>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, merged ? 1 : 0, c->d_status);
+      hipLaunchKernelGGL(k_sort_hist<8>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, merged ? 1 : 0, c->status_word);
     }
     LAUNCHCHK();
     mark(1);
@@ -825,7 +839,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     sl.hist_dirty = true;
     HIPCHK(hipMemsetAsync(sl.hist.p, 0, nb * 4, ft));
     HIPCHK(hipMemsetAsync(sl.ctrl.p, 0, (4 + 2 * ITEM_BINS) * 4, ft));
-    hipLaunchKernelGGL(k_msm_digits, dim3(nblk(n, 256)), dim3(256), 0, ft, (const u32*)d_scalars, sl.ent.as<u32>(), sl.cursor.as<u32>(), sl.hist.as<u32>(), (int)n, cw, nwin, c->d_status);
+    hipLaunchKernelGGL(k_msm_digits, dim3(nblk(n, 256)), dim3(256), 0, ft, (const u32*)d_scalars, sl.ent.as<u32>(), sl.cursor.as<u32>(), sl.hist.as<u32>(), (int)n, cw, nwin, c->status_word);
     LAUNCHCHK();
     mark(1);
     // 2. scan
@@ -1001,14 +1015,19 @@ static int msm_host(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, cons
   if (!c || !out || (n && !scalars)) return bad("msm: NULL argument");
   HIPCHK(hipSetDevice(c->device));
   if (c->io_b.reserve(n ? n * 32 : 16) || c->io_out.reserve(3 * Wire<F>::WORDS * 4)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  SyncStatus ss(c);
+  int rc = ss.begin();
+  if (rc) return rc;
   if (n) HIPCHK(hipMemcpyAsync(c->io_b.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
-  int rc = msm_device<F>(c, bases, first, c->io_b.p, n, c->io_out.p);
+  rc = msm_device<F>(c, bases, first, c->io_b.p, n, c->io_out.p);
   if (rc) return rc;
   rc = blsgpu_join(c);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, 3 * Wire<F>::WORDS * 4, hipMemcpyDeviceToHost, c->stream));
+  rc = ss.fetch();
+  if (rc) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
-  return take_status(c);
+  return ss.verdict();
 }
 extern "C" int blsgpu_g1_msm(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, uint64_t* out) { return msm_host<FpPolicy>(c, b, first, s, n, out); }
 extern "C" int blsgpu_g2_msm(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, uint64_t* out) { return msm_host<Fp2Policy>(c, b, first, s, n, out); }
@@ -1038,12 +1057,17 @@ static int msm_many_host(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first,
   HIPCHK(hipSetDevice(c->device));
   const size_t ob = 3 * Wire<F>::WORDS * 4;
   if (c->io_b.reserve(n * k ? n * k * 32 : 16) || c->io_out.reserve(k * ob)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  SyncStatus ss(c);
+  int rc = ss.begin();
+  if (rc) return rc;
   if (n) HIPCHK(hipMemcpyAsync(c->io_b.p, scalars, n * k * 32, hipMemcpyHostToDevice, c->stream));
-  int rc = msm_many_device<F>(c, bases, first, c->io_b.p, n, k, c->io_out.p);
+  rc = msm_many_device<F>(c, bases, first, c->io_b.p, n, k, c->io_out.p);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, k * ob, hipMemcpyDeviceToHost, c->stream));
+  rc = ss.fetch();
+  if (rc) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
-  return take_status(c);
+  return ss.verdict();
 }
 extern "C" int blsgpu_g1_msm_many(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, size_t k, uint64_t* out) { return msm_many_host<FpPolicy>(c, b, first, s, n, k, out); }
 extern "C" int blsgpu_g2_msm_many(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, size_t k, uint64_t* out) { return msm_many_host<Fp2Policy>(c, b, first, s, n, k, out); }
@@ -1068,7 +1092,7 @@ static int mul_batch_device(blsgpu_ctx* c, const void* d_xy, const void* d_inf, 
   if (!n) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
   hipLaunchKernelGGL(k_mul_batch<F>, dim3(nblk(n * MbIO<F>::LANES, 256)), dim3(256), 0, c->stream, (const u32*)d_xy, (const uint8_t*)d_inf, (const u32*)d_scalars,
-                     (u32*)d_out, n, c->d_status);
+                     (u32*)d_out, n, c->status_word);
   LAUNCHCHK();
   return BLSGPU_OK;
 }
@@ -1079,14 +1103,19 @@ static int mul_batch_host(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf,
   HIPCHK(hipSetDevice(c->device));
   constexpr size_t WB = MbIO<F>::WW * 4;
   if (c->io_a.reserve(n * 2 * WB) || c->io_b.reserve(n * 32) || c->flags_a.reserve(n) || c->io_out.reserve(n * 3 * WB)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  SyncStatus ss(c);
+  int rc = ss.begin();
+  if (rc) return rc;
   HIPCHK(hipMemcpyAsync(c->io_a.p, xy, n * 2 * WB, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->io_b.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
   if (inf) HIPCHK(hipMemcpyAsync(c->flags_a.p, inf, n, hipMemcpyHostToDevice, c->stream));
-  int rc = mul_batch_device<F>(c, c->io_a.p, inf ? c->flags_a.p : nullptr, c->io_b.p, n, c->io_out.p);
+  rc = mul_batch_device<F>(c, c->io_a.p, inf ? c->flags_a.p : nullptr, c->io_b.p, n, c->io_out.p);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, n * 3 * WB, hipMemcpyDeviceToHost, c->stream));
+  rc = ss.fetch();
+  if (rc) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
-  return take_status(c);
+  return ss.verdict();
 }
 extern "C" int blsgpu_g1_mul_batch(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) { return mul_batch_host<FpPolicy>(c, xy, inf, s, n, out); }
 extern "C" int blsgpu_g2_mul_batch(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) { return mul_batch_host<Fp2PairPolicy>(c, xy, inf, s, n, out); }

@@ -48,6 +48,11 @@ int blsgpu_device_count(void);
 /* Use an existing HIP stream (e.g. torch's current stream) for all work of this context; NULL restores
  * the context's own stream. */
 int blsgpu_set_stream(blsgpu_ctx* ctx, void* hip_stream);
+/* Wait for everything queued on the context.  Scalars must be canonical (< r; `Scalar::to_bytes` produces nothing else): a
+ * synchronous entry point (`*_msm`, `*_msm_many`, `*_msm_bytes`, `*_msm_host`, `*_mul_batch`) that meets one returns
+ * BLSGPU_ERR_ARG ITSELF -- its verdict travels with its result; the asynchronous `*_device` entry points cannot, so their
+ * verdict is kept in a sticky flag that THIS call reports (BLSGPU_ERR_ARG) and clears.  A valid synchronous call is never blamed
+ * for an earlier asynchronous one. */
 int blsgpu_synchronize(blsgpu_ctx* ctx);
 /* MSM pipelining.  An MSM is three phases with different bottlenecks: digit sort (LDS atomics), bucket
  * accumulation (integer VALU) and a latency-bound tail (bucket reduction + window combine: a few wavefronts

@@ -1019,6 +1019,21 @@ def test_noncanonical_scalars_are_reported_not_miscomputed(ctx):
     ctx.set_msm_window(0)
     # r - 1 is canonical and exact
     _msm_case(ctx, 1, ks[:3], [o.R_ORDER - 1, o.R_ORDER - 2, 1])
+    # attribution: an ASYNCHRONOUS call with a bad scalar is reported by blsgpu_synchronize; a valid synchronous call made in
+    # between returns OK (its verdict travels with its own result) and does not clear the asynchronous call's flag
+    import torch
+    dev = torch.device("cuda", 0)
+    d_bad = torch.from_numpy(s2.view(np.int64).copy()).to(dev); d_out = torch.zeros(18, dtype=torch.int64, device=dev)
+    assert ctx.lib.blsgpu_g1_msm_device(ctx.h, bases.handle, 0, ctypes.c_void_p(d_bad.data_ptr()), n, ctypes.c_void_p(d_out.data_ptr())) == 0
+    assert ctx.lib.blsgpu_g1_msm(ctx.h, bases.handle, 0, P(sb), n, P(out)) == 0
+    good = ctx.batch_normalize(1, out[None, :].copy())           # the projective representative depends on the summation order: compare the point
+    assert ctx.lib.blsgpu_synchronize(ctx.h) == -2 and b"canonical" in ctx.lib.blsgpu_last_error()
+    assert ctx.lib.blsgpu_synchronize(ctx.h) == 0
+    assert ctx.lib.blsgpu_g1_msm(ctx.h, bases.handle, 0, P(sb), n, P(out)) == 0
+    again = ctx.batch_normalize(1, out[None, :].copy())
+    assert np.array_equal(good[0], again[0]) and np.array_equal(good[1], again[1])
+    want = o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, sum(k * int.from_bytes(bytes(sb[i]), "little") for i, k in enumerate(ks)) % o.R_ORDER))
+    assert b.G1Affine(good[0][0], bool(good[1][0])).to_uncompressed() == o.g1_to_uncompressed(want)
 
 
 def test_two_contexts_on_two_host_threads(ctx):
