@@ -61,12 +61,12 @@ int main(int argc, char** argv) {
     }
 #ifdef WIDE_PROFILE
   for (int mode = 1; mode < 3; mode++) {
-    unsigned long long z[4] = {0, 0, 0, 0}, t[4];
+    unsigned long long z[5] = {0, 0, 0, 0, 0}, t[5];
     CK(hipMemcpyToSymbol(HIP_SYMBOL(bls::g_wide_ticks), z, sizeof z));
     bls::k_pairing_wide<<<1, bls::WIDE_LANES>>>(mode, mode == 2 ? d_f : d_g1, nullptr, d_g2, nullptr, d_out, 1, pm, pf);
     CK(hipDeviceSynchronize());
     CK(hipMemcpyFromSymbol(t, HIP_SYMBOL(bls::g_wide_ticks), sizeof t));
-    printf("mode %d ticks of wave 0: phase1 %llu  barrier1 %llu  phase2 %llu  barrier2 %llu\n", mode, t[0], t[1], t[2], t[3]);
+    printf("mode %d ticks of wave 0: phase1 %llu  barrier1 %llu  phase2 %llu  barrier2 %llu  longest phase2 %llu\n", mode, t[0], t[1], t[2], t[3], t[4]);
   }
 #endif
   return bad ? 1 : 0;

@@ -532,19 +532,25 @@ def miller_loop(px, py, qx, qy):
         return f12_store(f12_mul_by_014(f, lc, c1, c4))
 
     def doubling():
-        """three levels per step (the critical chain is y -> y^2 -> new x, new y): level 1 x^2 (kept as 3 x^2), y^2, y z, z^2
-        and 8 x; level 2 the new x = (3x^2)^2 - 8x y^2, u = 3 x^3, y^4 and the line; level 3 the new y = 3 u (4 y^2 - u) - 8 y^4
-        (= (12 x y^2 - 9 x^4) 3 x^2 - 8 y^4).  z' = 2 y z stays a lazy multiple."""
+        """three levels per step (the critical chain is y -> y^2 -> new x, new y), every value a PLAIN sum of products -- scaled
+        copies (3x^2, 3u, 4y^2, 4y^4) are separate sums or lazy multiples, so no reducer carries a linear post-operation:
+        level 1  3 x^2 (schoolbook, the factor on one operand), y^2, y z, z^2, 8 x;
+        level 2  x' = (3x^2)^2 - 8x y^2,  u = 3 x^3 and 3u,  4 y^4,  4 y^2,  the line's  4 y z^3  and  -6 x^2 z^2;
+        level 3  y' = 3u (4y^2 - u) - 8 y^4  written as  3u * 4y^2 - 3u * u - 2 * 4y^4,   6 x^3 - 4 y^2.
+        z' = 2 y z stays a lazy multiple.  Values are the reference's (pairings.rs:709-738)."""
         nonlocal x, y, z
-        xx3 = f2_fused(x.sqr(), 3, x, 0)
+        a0, a1 = G.as_lin(x.re), G.as_lin(x.im)
+        xx3 = F2(E(None, [(a0.scale(3), a0), (a1.scale(-3), a1)]), E(None, [(a0.scale(6), a1)])).stored()
         yy, zz, yz = y.sqr().stored(), z.sqr().stored(), (y * z).stored()
         x8 = x.times(8).stored()
         nx = (xx3.sqr() - x8 * yy).stored()           # 9 x^4 - 8 x y^2
-        u = (x * xx3).stored()                        # 3 x^3
-        y4 = yy.sqr().stored()
+        u, u3 = (x * xx3).stored(), (x.times(3) * xx3).stored()
+        b0, b1 = G.as_lin(yy.re), G.as_lin(yy.im)
+        y4x4 = F2(E(None, [(b0.scale(4), b0), (b1.scale(-4), b1)]), E(None, [(b0.scale(8), b1)])).stored()
+        yy4 = yy.times(4).stored()
         xxzz3, yzzz = (xx3 * zz).stored(), (yz * zz).stored()
-        lc = f2_fused(u, 2, yy, -4)                   # 6 x^3 - 4 y^2
-        ny = f2_fused(u * (yy.times(4) - u), 3, y4, -8)
+        lc = (u.times(2) - yy4).stored()              # 6 x^3 - 4 y^2
+        ny = (u3 * yy4 - u3 * u - y4x4.times(2)).stored()
         la, lb = yzzz.times(4), -xxzz3.times(2)
         x, y, z = nx, ny, yz.times(2)
         return la, lb, lc
