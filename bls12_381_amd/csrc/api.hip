@@ -1592,9 +1592,17 @@ static int fp12_product_device(blsgpu_ctx* c, const u32* d_in, size_t n, u32* d_
   }
   const u32* in = d_in; int flip = 0;
   while (n > 1) {
-    size_t m = (n + FP12_PROD_FAN - 1) / FP12_PROD_FAN;
+    // a level that does not fill the chip (fewer than 2^16 products in flight) is pure latency: one Fp12 multiplication of a lone
+    // lane pair is ~50 us, so such levels halve (fan 2: 50 us per level) instead of folding eight values in sequence (350 us);
+    // 2^16 values: 2.27 -> ~0.9 ms, 8 values: 0.38 -> 0.15 ms (tools/experiments/prod_time.py)
+    int fan = 2;
+    while (fan < FP12_PROD_FAN && (n + fan - 1) / fan > 65536) fan *= 2;
+    size_t m = (n + fan - 1) / fan;
     u32* o = (m == 1) ? d_out : (flip ? c->io_d.as<u32>() : c->io_c.as<u32>());
-    hipLaunchKernelGGL(k_fp12_prod, dim3(nblk(m * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, in, o, n, m);
+    if (m <= 32768 && c->pairing_layout != 2)            // latency-bound level: a quad per product
+      hipLaunchKernelGGL(k_fp12_prod_quad, dim3(nblk(m * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, in, o, n, m, fan);
+    else
+      hipLaunchKernelGGL(k_fp12_prod, dim3(nblk(m * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, in, o, n, m, fan);
     LAUNCHCHK();
     in = o; n = m; flip ^= 1;
   }

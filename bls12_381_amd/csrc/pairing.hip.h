@@ -74,7 +74,7 @@ template <int A, int V> DEV auto mul_by_u(const Fe2<A, V>& a) { Fe2<A + 1, V + 1
 #endif
 constexpr int PAIRING_BLOCK = BLS_PAIRING_BLOCK;       // two lanes per pairing
 constexpr int PAIRING_WAVES = BLS_PAIRING_WAVES;       // wavefronts per SIMD the register budget is set for
-constexpr int FP12_PROD_FAN = 8;
+constexpr int FP12_PROD_FAN = 8;                      // widest fan of the product tree (levels that fill the chip); narrow levels use 2
 
 #define S2(x) st2(x)
 // Inlining policy.  The hot loops (Miller loop, the run of compressed cyclotomic squarings) keep their state in NON-ESCAPING
@@ -608,11 +608,11 @@ PAIR_KERNEL k_final_exp(const u32* __restrict__ in, u32* __restrict__ out, size_
   final_exponentiation(g, f);
   fp12_save(g, out + i * 144);
 }
-// out[j] = product of in[j*FAN .. min(n, (j+1)*FAN))
-PAIR_KERNEL k_fp12_prod(const u32* __restrict__ in, u32* __restrict__ out, size_t n, size_t m) {
+// out[j] = product of in[j*fan .. min(n, (j+1)*fan))
+PAIR_KERNEL k_fp12_prod(const u32* __restrict__ in, u32* __restrict__ out, size_t n, size_t m, int fan) {
   size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / PL;
   if (j >= m) return;
-  size_t beg = j * FP12_PROD_FAN, end = beg + FP12_PROD_FAN < n ? beg + FP12_PROD_FAN : n;
+  size_t beg = j * (size_t)fan, end = beg + fan < n ? beg + fan : n;
   Fp12T<PE> acc; fp12_load(acc, in + beg * 144);
   for (size_t i = beg + 1; i < end; i++) {
     Fp12T<PE> x, t; fp12_load(x, in + i * 144);

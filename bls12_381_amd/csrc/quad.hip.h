@@ -627,6 +627,19 @@ QUAD_KERNEL k_final_exp_quad(const u32* __restrict__ in, u32* __restrict__ out, 
   q_final_exponentiation(g, f, park_lds + threadIdx.x);
   qc_save(g, out + i * 144);
 }
+// out[j] = product of in[j*fan .. min(n, (j+1)*fan)): the levels of the Fp12 product tree (`MillerLoopResult + MillerLoopResult`,
+// pairings.rs:179-186) that do not fill the chip -- one multiplication of a lone quad is ~half the latency of a lone lane pair's
+QUAD_KERNEL k_fp12_prod_quad(const u32* __restrict__ in, u32* __restrict__ out, size_t n, size_t m, int fan) {
+  size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / QL;
+  if (j >= m) return;
+  size_t beg = j * (size_t)fan, end = beg + fan < n ? beg + fan : n;
+  QC12 acc = qc_load(in + beg * 144);
+  for (size_t i = beg + 1; i < end; i++) {
+    QC12 x = qc_load(in + i * 144), t;
+    qc_mul(t, acc, x); acc = t;
+  }
+  qc_save(acc, out + j * 144);
+}
 // parity hook: op 0 mul, 4 invert, 7 frobenius_map, 8 conjugate, 9 cyclotomic_square, 10 cyclotomic exponentiation (f^|x| conjugated)
 QUAD_KERNEL k_fp12_op_quad(int op, const u32* __restrict__ a, const u32* __restrict__ b, u32* __restrict__ out, size_t n) {
   __shared__ u32 park_lds[QPARK_WORDS * QUAD_BLOCK];
