@@ -540,6 +540,39 @@ DEV SgMat sg_divsteps(int32_t& eta, u32 f, u32 g) {
   SgMat t; t.u = u; t.v = v; t.q = q; t.r = r;
   return t;
 }
+// The same 28 divsteps in VARIABLE time (the shape of libsecp256k1's modinv32 `divsteps_30_var`): runs of divisions by two are
+// taken in one step (count of trailing zeros), and when g is odd up to six of its low bits are cancelled at once by adding the
+// right multiple w of f (w = -g / f mod 2^k from a Newton inverse of f: f itself is its own inverse mod 8, one step gives six
+// bits), with k capped by eta + 1 -- the point where the constant-time sequence would swap f and g -- so that the transition
+// matrix, and with it every later value, is exactly that of sg_divsteps.  ~6 iterations of ~22 instructions per batch instead
+// of 28 x 17; lanes of a wavefront iterate until the slowest is done.
+DEV SgMat sg_divsteps_var(int32_t& eta_io, u32 f, u32 g) {
+  u32 u = 1, v = 0, q = 0, r = 1;
+  int32_t eta = eta_io;
+  int i = LW;
+  for (;;) {
+    const int zeros = __builtin_ctz(g | (0xFFFFFFFFu << i));
+    g >>= zeros; u <<= zeros; v <<= zeros; eta -= zeros; i -= zeros;
+    if (i == 0) break;
+    if (eta < 0) {
+      u32 t;
+      eta = -eta;
+      t = f; f = g; g = 0u - t;
+      t = u; u = q; q = 0u - t;
+      t = v; v = r; r = 0u - t;
+    }
+    int limit = eta + 1 > i ? i : eta + 1;
+    if (limit > 6) limit = 6;
+    const u32 m = (1u << limit) - 1u;
+    u32 fi = f;                                   // f^-1 mod 2^3 (f odd)
+    fi *= 2u - f * fi;                            // mod 2^6
+    const u32 w = (0u - g * fi) & m;
+    g += f * w; q += u * w; r += v * w;
+  }
+  eta_io = eta;
+  SgMat t; t.u = (int32_t)u; t.v = (int32_t)v; t.q = (int32_t)q; t.r = (int32_t)r;
+  return t;
+}
 // (f, g) <- t (f, g) / 2^28   (exact)
 DEV void sg_update_fg(int32_t* f, int32_t* g, const SgMat& t) {
   int64_t cf = (int64_t)t.u * f[0] + (int64_t)t.v * g[0];
@@ -605,9 +638,17 @@ DEVNI v16 fe_inv_raw(v16 xin) {
 #pragma nounroll
   for (int b = 0; b < 40; b++) {
     u32 fl = (u32)f[0] | ((u32)f[1] << LW), gl = (u32)g[0] | ((u32)g[1] << LW);
-    SgMat t = sg_divsteps(eta, fl, gl);
+    SgMat t = sg_divsteps_var(eta, fl, gl);
     sg_update_de(d, e, t);
     sg_update_fg(f, g, t);
+    // once g = 0 every further batch is the matrix (2^28, 0; 0, 1): f and d no longer change.  40 batches is the proven bound
+    // ((49 * 381 + 57) / 17 divsteps); a typical input is done after 28-30.  The exit is WAVE-UNIFORM (taken when every active lane
+    // is done: a per-lane exit makes the compiler keep a second copy of f, g, d, e for the lanes that left and spill), which is
+    // what matters where ONE lane inverts on a critical path (wide.hip.h).
+    u32 gz = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) gz |= (u32)g[i];
+    if (__all(gz == 0)) break;
   }
   // g = 0, f = +-1 (or +-p for input 0, where d = 0): inverse = sign(f) * d, brought into [0, p)
   sg_fix(d, 0, true);                         // (-2p, p) -> (-p, p)

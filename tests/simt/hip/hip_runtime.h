@@ -76,6 +76,8 @@ static inline int emu_update_dpp(int /*old*/, int src, int ctrl, int /*row_mask*
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned long long atomicExch(unsigned long long* p, unsigned long long v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
 template <class T> static inline T min(T a, T b) { return a < b ? a : b; }
+// wave vote: every emulated lane decides for itself (only used for an early loop exit whose extra iterations are identities)
+static inline int __all(int p) { return p; }
 struct uint4 { unsigned x, y, z, w; };
 struct uint2 { unsigned x, y; };
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
