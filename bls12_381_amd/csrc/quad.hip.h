@@ -587,7 +587,10 @@ DEV void q_final_exponentiation(QC12& out, const QC12& fin, u32* park) {
 }
 
 // ---- kernels: pairing i lives on lanes 4i .. 4i+3 of the grid ---------------------------------------------------------------
-#define QUAD_KERNEL __global__ void __launch_bounds__(QUAD_BLOCK, 2)
+#ifndef BLS_QUAD_WAVES
+#define BLS_QUAD_WAVES 2
+#endif
+#define QUAD_KERNEL __global__ void __launch_bounds__(QUAD_BLOCK, BLS_QUAD_WAVES)
 
 template <int V> DEV QC12 q12_to_cold(const Q12<V>& f) { QC12 r; r.h.c0 = fit<VSP>(f.h.c0); r.h.c1 = fit<VSP>(f.h.c1); r.h.c2 = fit<VSP>(f.h.c2); return r; }
 DEV void qc_save(const QC12& f, u32* w) {

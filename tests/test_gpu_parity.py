@@ -1546,3 +1546,24 @@ def test_small_batches_take_the_wide_path_and_match_every_other_layout(ctx, layo
             Qi = o.G2_IDENTITY_AFF if f2[i] else (wfp2(g2[i][0:12]), wfp2(g2[i][12:24]), False)
             assert np.array_equal(gt_w[i], fp12w(o.pairing(Pi, Qi)))
             assert np.array_equal(ml_w[i], fp12w(o.miller_loop(Pi, Qi)))
+
+
+def test_layout_switch_at_1024_items(ctx, layout_contexts):
+    """the library hands batches of up to 1024 items to the wide kernels and larger ones to the quad kernels: same limbs on
+    both sides of the switch (1024 through the wide path, 1025 through the quad path, both against the quad-only context)"""
+    from bls12_381_amd import synthetic as sy
+    assert ctx.pairing_layout(1024) == 256 and ctx.pairing_layout(1025) == 4
+    n = 1025
+    ka = sy.scalars(n, sy.SEED + 950); kq = sy.scalars(n, sy.SEED + 951)
+    g1, f1 = ctx.bases_from_scalars(1, ka).download(); g2, f2 = ctx.bases_from_scalars(2, kq).download()
+    q = layout_contexts["quad"]
+    want = q.pairing_batch(g1, f1, g2, f2)
+    assert np.array_equal(ctx.pairing_batch(g1, f1, g2, f2), want)
+    assert np.array_equal(ctx.pairing_batch(g1[:1024], f1[:1024], g2[:1024], f2[:1024]), want[:1024])
+    # multi_miller_loop over a handful of terms (wide Miller values, quad product tree) + final exponentiation = product of pairings
+    ml = ctx.multi_miller_loop(g1[:3], f1[:3], g2[:3], f2[:3])
+    gt = ctx.final_exponentiation_batch(ml[None, :])[0]
+    acc = o.FP12_ONE
+    for i in range(3):
+        acc = o.fp12_mul(acc, o.pairing((wfp(g1[i][0:6]), wfp(g1[i][6:12]), False), (wfp2(g2[i][0:12]), wfp2(g2[i][12:24]), False)))
+    assert np.array_equal(gt, fp12w(acc))
