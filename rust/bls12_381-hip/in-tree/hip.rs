@@ -163,7 +163,7 @@ pub fn pairing_batch(p: &[G1Affine], q: &[G2Affine]) -> Vec<Gt> {
     gpu.unwrap_or_else(|| p.iter().zip(q).map(|(a, b)| crate::pairings::pairing_cpu(a, b)).collect())
 }
 /// Below these batch sizes the crate's own CPU code is at least as fast as a device round trip.  One call with 1..256 items takes
-/// the library's wide path (one item per 1024-lane workgroup): ~1.2 ms for pairings, ~0.4 ms for Miller loops, ~0.8 ms for
+/// the library's wide path (one item per 1024-lane workgroup): ~1.15 ms for pairings, ~0.4 ms for Miller loops, ~0.8 ms for
 /// final exponentiations, whatever the count (bench.py `pairing_small_batches`); one pairing on a host core is ~1.1-1.3 ms, one
 /// Miller loop ~0.45 ms, one final exponentiation ~0.7 ms (`per_op_ns`).  So ONE item stays on the CPU (a tie, minus
 /// the copies) and the device pays from two items on.

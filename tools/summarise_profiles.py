@@ -104,7 +104,12 @@ Separate rocprofv3 passes (one `--pmc` group each, `--kernel-trace` only; tools/
 """)
 
 
-def pairing(d, K, units, unit_name, mac32, tag, what, layout, alg_bytes_per_unit, meta_key=None):
+WIDE_NOTES = """* what the traffic is: every workgroup streams the two generated programs (bls12_381_amd/wide_prog.bin, ~4 MB) once, 256 workgroups per launch = ~1 GB of descriptor reads, of which a few per cent reach HBM (the rest hits L2 / Infinity Cache); the pairing's own inputs and outputs are 864 B per item.
+* why three quarters of the wave cycles are `s_waitcnt`: twelve to fifteen of the sixteen wavefronts of a workgroup wait at the round's barrier while the one wavefront that holds the reducer lanes runs the Montgomery reduction (~55 % of a round, DESIGN.md 4.4) -- the path is built for the latency of ONE pairing, not for occupancy.
+"""
+
+
+def pairing(d, K, units, unit_name, mac32, tag, what, layout, alg_bytes_per_unit, meta_key=None, notes=""):
     dd, row = durations(d, K)
     if not dd:
         return
@@ -135,7 +140,7 @@ def pairing(d, K, units, unit_name, mac32, tag, what, layout, alg_bytes_per_unit
 * wave-cycle split: SQ_ACTIVE_INST_ANY {100*c.get('SQ_ACTIVE_INST_ANY',0)/wc:.0f}%, SQ_WAIT_INST_ANY (issue stalls) {100*c.get('SQ_WAIT_INST_ANY',0)/wc:.0f}%, SQ_WAIT_ANY (s_waitcnt) {100*c.get('SQ_WAIT_ANY',0)/wc:.0f}% of SQ_WAVE_CYCLES = {wc:.3e}
 * instruction cache: {c.get('SQC_ICACHE_MISSES',0):.3e} misses of {c.get('SQC_ICACHE_REQ',0):.3e} requests
 * GRBM_GUI_ACTIVE = {c.get('GRBM_GUI_ACTIVE',0):.3e} (GRBM_GUI_ACTIVE / launch duration; the counter is summed over the chip's engines, so only its ratio between variants is meaningful)
-""")
+{notes}""")
 
 
 os.makedirs(OUT, exist_ok=True)
@@ -149,5 +154,5 @@ if one("prof_mml/stats/**/*kernel_trace.csv"):
     pairing("prof_mml", "k_multi_miller_shared", 262144, "terms", 2.07e6, "mml", "mml 18 3", "lane-pair layout, four terms per shared accumulator", 288)
 if one("prof_wide/stats/**/*kernel_trace.csv"):
     pairing("prof_wide", "k_pairing_wide", 256, "pairings", 4.8e6, "pairing_wide", "pairing 8 20",
-            "wide layout: one pairing per 1024-lane workgroup, one workgroup per CU (the small-batch latency path)", 864)
+            "wide layout: one pairing per 1024-lane workgroup, one workgroup per CU (the small-batch latency path)", 864, notes=WIDE_NOTES)
 print("profiles written for", RND)
