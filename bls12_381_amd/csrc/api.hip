@@ -8,6 +8,9 @@
 #include <string>
 #include <cstdlib>
 #include <vector>
+#include <atomic>
+#include <thread>
+#include <functional>
 
 #include "../../include/bls12_381_hip.h"
 #include "msm.hip.h"
@@ -30,6 +33,25 @@ static int fail(const char* what, hipError_t e, int line) {
   return BLSGPU_ERR_HIP;
 }
 static int bad(const char* what) { g_err = what; return BLSGPU_ERR_ARG; }
+// A context is driven by ONE host thread at a time (include/bls12_381_hip.h).  Misuse is detected instead of corrupting the slot
+// bookkeeping: every public entry point that takes a context claims it for its thread for the duration of the call (re-entrant
+// for the same thread: entry points call one another) and fails with BLSGPU_ERR_ARG when another thread is inside.
+struct CtxClaim {
+  std::atomic<size_t>* owner; int* depth; bool clash = false;
+  CtxClaim(std::atomic<size_t>* o, int* d) : owner(o), depth(d) {
+    const size_t me = std::hash<std::thread::id>()(std::this_thread::get_id()) | 1;
+    size_t cur = owner->load(std::memory_order_acquire);
+    if (cur == me) { ++*depth; return; }
+    size_t none = 0;
+    if (owner->compare_exchange_strong(none, me, std::memory_order_acq_rel)) { *depth = 1; return; }
+    clash = true;
+  }
+  ~CtxClaim() { if (!clash && --*depth == 0) owner->store(0, std::memory_order_release); }
+};
+#define CTX_CLAIM(c) CtxClaim claim_((c) ? &(c)->owner_thread : &g_no_ctx_owner, (c) ? &(c)->owner_depth : &g_no_ctx_depth); \
+  if (claim_.clash) return bad("the context is in use by another host thread (one context per host thread: include/bls12_381_hip.h)")
+static thread_local std::atomic<size_t> g_no_ctx_owner{0};
+static thread_local int g_no_ctx_depth = 0;
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(#x, e_, __LINE__); } while (0)
 #define LAUNCHCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail("kernel launch", e_, __LINE__); } while (0)
 
@@ -78,6 +100,8 @@ struct blsgpu_ctx {
   hipEvent_t ev[9] = {};
   u32* d_status = nullptr;              // [0]: sticky "a scalar was not canonical (>= r)" flag of the ASYNCHRONOUS (device-pointer) calls, reported by blsgpu_synchronize / blsgpu_join;
                                         // [1]: scratch of the subgroup check; [2]: the flag of the synchronous call in progress (cleared before it, fetched with its result)
+  std::atomic<size_t> owner_thread{0};  // CtxClaim: the host thread inside an entry point (0 = none)
+  int owner_depth = 0;
   u32* status_word = nullptr;           // where the kernels of the calls being enqueued report: d_status (default) or d_status + 2 inside a synchronous entry point
   float phase_ms[8] = {0};
   // MSM: the chip-filling phases run on `stream`; the latency-bound tail (bucket reduction + window
@@ -447,7 +471,7 @@ extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
 }
-extern "C" int blsgpu_set_stream(blsgpu_ctx* c, void* s) {
+extern "C" int blsgpu_set_stream(blsgpu_ctx* c, void* s) { CTX_CLAIM(c);
   if (!c) return bad("ctx is NULL");
   c->stream = s ? (hipStream_t)s : c->own_stream;
   return BLSGPU_OK;
@@ -474,7 +498,7 @@ struct SyncStatus {
   int fetch() { HIPCHK(hipMemcpyAsync(&host, c->d_status + 2, 4, hipMemcpyDeviceToHost, c->stream)); return BLSGPU_OK; }      // then synchronise the stream
   int verdict() const { return host ? bad("msm: a scalar is not canonical (>= r); Scalar::to_bytes never produces such bytes (scalar.rs:284-296)") : BLSGPU_OK; }
 };
-extern "C" int blsgpu_synchronize(blsgpu_ctx* c) {
+extern "C" int blsgpu_synchronize(blsgpu_ctx* c) { CTX_CLAIM(c);
   if (!c) return bad("ctx is NULL");
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -493,7 +517,7 @@ static void acc_harvest(blsgpu_ctx* c, bool wait) {
     sl.k_pending = false;
   }
 }
-extern "C" int blsgpu_msm_accumulate_stats(blsgpu_ctx* c, int enable, double* avg_ms, unsigned* launches) {
+extern "C" int blsgpu_msm_accumulate_stats(blsgpu_ctx* c, int enable, double* avg_ms, unsigned* launches) { CTX_CLAIM(c);
   if (!c) return bad("ctx is NULL");
   HIPCHK(hipSetDevice(c->device));
   acc_harvest(c, true);
@@ -503,24 +527,24 @@ extern "C" int blsgpu_msm_accumulate_stats(blsgpu_ctx* c, int enable, double* av
   c->acc_timing = enable < 0 ? 0 : enable; c->acc_tick = 0;
   return BLSGPU_OK;
 }
-extern "C" int blsgpu_set_pipelining(blsgpu_ctx* c, int on) { if (!c) return bad("ctx is NULL"); c->pipelining = on != 0; return BLSGPU_OK; }
-extern "C" int blsgpu_join_lag(blsgpu_ctx* c, int lag) {
+extern "C" int blsgpu_set_pipelining(blsgpu_ctx* c, int on) { CTX_CLAIM(c); if (!c) return bad("ctx is NULL"); c->pipelining = on != 0; return BLSGPU_OK; }
+extern "C" int blsgpu_join_lag(blsgpu_ctx* c, int lag) { CTX_CLAIM(c);
   if (!c || lag < 0) return bad("join: bad argument");
   HIPCHK(hipSetDevice(c->device));
   for (auto& sl : c->slot)
     if (sl.tail_pending && sl.seq + (unsigned long long)lag <= c->msm_calls) HIPCHK(hipStreamWaitEvent(c->stream, sl.ev_tail, 0));
   return BLSGPU_OK;
 }
-extern "C" int blsgpu_join(blsgpu_ctx* c) { return blsgpu_join_lag(c, 0); }
-extern "C" int blsgpu_set_msm_window(blsgpu_ctx* c, int w) {
+extern "C" int blsgpu_join(blsgpu_ctx* c) { CTX_CLAIM(c); return blsgpu_join_lag(c, 0); }
+extern "C" int blsgpu_set_msm_window(blsgpu_ctx* c, int w) { CTX_CLAIM(c);
   if (!c) return bad("ctx is NULL");
   // 16 is the widest window of the LDS counting sort (8 coarse + 7 fine key bits); wider windows exist only with
   // resident tables (blsgpu_bases_precompute), which carry their own width
   if (w != 0 && (w < 4 || w > 16)) return bad("msm window must be 0 or in [4,16]");
   c->msm_c = w; return BLSGPU_OK;
 }
-extern "C" int blsgpu_set_profiling(blsgpu_ctx* c, int on) { if (!c) return bad("ctx is NULL"); c->profiling = on != 0; return BLSGPU_OK; }
-extern "C" int blsgpu_last_msm_phase_ms(blsgpu_ctx* c, int phase, float* ms) {
+extern "C" int blsgpu_set_profiling(blsgpu_ctx* c, int on) { CTX_CLAIM(c); if (!c) return bad("ctx is NULL"); c->profiling = on != 0; return BLSGPU_OK; }
+extern "C" int blsgpu_last_msm_phase_ms(blsgpu_ctx* c, int phase, float* ms) { CTX_CLAIM(c);
   if (!c || !ms || phase < 0 || phase > 7) return bad("bad phase query");
   *ms = c->phase_ms[phase]; return BLSGPU_OK;
 }
@@ -597,19 +621,19 @@ static int bases_upload(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, s
   HIPCHK(hipStreamSynchronize(c->stream));
   return BLSGPU_OK;
 }
-extern "C" int blsgpu_g1_bases_upload(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, blsgpu_bases** out) { return bases_upload<FpPolicy>(c, xy, inf, n, out); }
-extern "C" int blsgpu_g2_bases_upload(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, blsgpu_bases** out) { return bases_upload<Fp2Policy>(c, xy, inf, n, out); }
-extern "C" int blsgpu_g1_bases_from_device(blsgpu_ctx* c, const void* xy, const void* inf, size_t n, blsgpu_bases** out) {
+extern "C" int blsgpu_g1_bases_upload(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, blsgpu_bases** out) { CTX_CLAIM(c); return bases_upload<FpPolicy>(c, xy, inf, n, out); }
+extern "C" int blsgpu_g2_bases_upload(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, blsgpu_bases** out) { CTX_CLAIM(c); return bases_upload<Fp2Policy>(c, xy, inf, n, out); }
+extern "C" int blsgpu_g1_bases_from_device(blsgpu_ctx* c, const void* xy, const void* inf, size_t n, blsgpu_bases** out) { CTX_CLAIM(c);
   if (!c || !out || (n && !xy)) return bad("bases_from_device: NULL argument");
   HIPCHK(hipSetDevice(c->device));
   return bases_import<FpPolicy>(c, xy, inf, n, out);
 }
-extern "C" int blsgpu_g2_bases_from_device(blsgpu_ctx* c, const void* xy, const void* inf, size_t n, blsgpu_bases** out) {
+extern "C" int blsgpu_g2_bases_from_device(blsgpu_ctx* c, const void* xy, const void* inf, size_t n, blsgpu_bases** out) { CTX_CLAIM(c);
   if (!c || !out || (n && !xy)) return bad("bases_from_device: NULL argument");
   HIPCHK(hipSetDevice(c->device));
   return bases_import<Fp2Policy>(c, xy, inf, n, out);
 }
-extern "C" int blsgpu_bases_from_scalars(blsgpu_ctx* c, int group, const uint8_t* scalars, size_t n, blsgpu_bases** out) {
+extern "C" int blsgpu_bases_from_scalars(blsgpu_ctx* c, int group, const uint8_t* scalars, size_t n, blsgpu_bases** out) { CTX_CLAIM(c);
   if (!c || !out || (n && !scalars) || (group != 1 && group != 2)) return bad("bases_from_scalars: bad argument");
   HIPCHK(hipSetDevice(c->device));
   if (c->io_a.reserve(n ? n * 32 : 16)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
@@ -633,7 +657,7 @@ extern "C" int blsgpu_bases_from_scalars(blsgpu_ctx* c, int group, const uint8_t
 }
 extern "C" size_t blsgpu_bases_len(const blsgpu_bases* b) { return b ? b->n : 0; }
 extern "C" int blsgpu_bases_subgroup_state(const blsgpu_bases* b) { return b ? b->subgroup : 0; }
-extern "C" int blsgpu_set_assume_subgroup(blsgpu_ctx* c, int on) { if (!c) return bad("ctx is NULL"); c->assume_subgroup = on != 0; return BLSGPU_OK; }
+extern "C" int blsgpu_set_assume_subgroup(blsgpu_ctx* c, int on) { CTX_CLAIM(c); if (!c) return bad("ctx is NULL"); c->assume_subgroup = on != 0; return BLSGPU_OK; }
 extern "C" void blsgpu_bases_free(blsgpu_bases* b) {
   if (!b) return;
   hipSetDevice(b->device);
@@ -655,7 +679,7 @@ static int bases_precompute(blsgpu_ctx* c, blsgpu_bases* b, int cw) {
   b->table_c = cw; b->table_w = nwin;
   return BLSGPU_OK;
 }
-extern "C" int blsgpu_bases_precompute(blsgpu_ctx* c, blsgpu_bases* b, int window_bits) {
+extern "C" int blsgpu_bases_precompute(blsgpu_ctx* c, blsgpu_bases* b, int window_bits) { CTX_CLAIM(c);
   if (!c || !b) return bad("bases_precompute: NULL argument");
   if (window_bits == 0) window_bits = 20;
   if (window_bits < 9 || window_bits > 21) return bad("bases_precompute: window must be in [9, 21]");
@@ -676,7 +700,7 @@ static int bases_download(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, si
   HIPCHK(hipStreamSynchronize(c->stream));
   return BLSGPU_OK;
 }
-extern "C" int blsgpu_bases_download(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, size_t count, uint64_t* xy, uint8_t* inf) {
+extern "C" int blsgpu_bases_download(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, size_t count, uint64_t* xy, uint8_t* inf) { CTX_CLAIM(c);
   if (!c || !b || (count && !xy) || first > b->n || count > b->n - first) return bad("bases_download: bad argument");
   if (b->device != c->device) return bad("bases_download: bases live on another device than the context");
   HIPCHK(hipSetDevice(c->device));
@@ -1029,10 +1053,10 @@ static int msm_host(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, cons
   HIPCHK(hipStreamSynchronize(c->stream));
   return ss.verdict();
 }
-extern "C" int blsgpu_g1_msm(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, uint64_t* out) { return msm_host<FpPolicy>(c, b, first, s, n, out); }
-extern "C" int blsgpu_g2_msm(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, uint64_t* out) { return msm_host<Fp2Policy>(c, b, first, s, n, out); }
-extern "C" int blsgpu_g1_msm_device(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const void* s, size_t n, void* out) { return msm_device<FpPolicy>(c, b, first, s, n, out); }
-extern "C" int blsgpu_g2_msm_device(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const void* s, size_t n, void* out) { return msm_device<Fp2Policy>(c, b, first, s, n, out); }
+extern "C" int blsgpu_g1_msm(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, uint64_t* out) { CTX_CLAIM(c); return msm_host<FpPolicy>(c, b, first, s, n, out); }
+extern "C" int blsgpu_g2_msm(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, uint64_t* out) { CTX_CLAIM(c); return msm_host<Fp2Policy>(c, b, first, s, n, out); }
+extern "C" int blsgpu_g1_msm_device(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const void* s, size_t n, void* out) { CTX_CLAIM(c); return msm_device<FpPolicy>(c, b, first, s, n, out); }
+extern "C" int blsgpu_g2_msm_device(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const void* s, size_t n, void* out) { CTX_CLAIM(c); return msm_device<Fp2Policy>(c, b, first, s, n, out); }
 // k MSMs over the SAME resident bases (e.g. commitments to k polynomials under one SRS): scalars of call j at
 // d_scalars + j * n * 32, result j at d_out + j * 3 * WORDS * 4.  The calls go through the pipeline slots, so the sort,
 // accumulation and tail of consecutive MSMs overlap; results are ordered on the context's stream on return.
@@ -1048,8 +1072,8 @@ static int msm_many_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t firs
   int rj = blsgpu_join(c);
   return rc ? rc : rj;
 }
-extern "C" int blsgpu_g1_msm_many_device(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const void* s, size_t n, size_t k, void* out) { return msm_many_device<FpPolicy>(c, b, first, s, n, k, out); }
-extern "C" int blsgpu_g2_msm_many_device(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const void* s, size_t n, size_t k, void* out) { return msm_many_device<Fp2Policy>(c, b, first, s, n, k, out); }
+extern "C" int blsgpu_g1_msm_many_device(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const void* s, size_t n, size_t k, void* out) { CTX_CLAIM(c); return msm_many_device<FpPolicy>(c, b, first, s, n, k, out); }
+extern "C" int blsgpu_g2_msm_many_device(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const void* s, size_t n, size_t k, void* out) { CTX_CLAIM(c); return msm_many_device<Fp2Policy>(c, b, first, s, n, k, out); }
 template <class F>
 static int msm_many_host(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, const uint8_t* scalars, size_t n, size_t k, uint64_t* out) {
   if (!c || (k && (!out || (n && !scalars)))) return bad("msm_many: NULL argument");
@@ -1069,8 +1093,8 @@ static int msm_many_host(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first,
   HIPCHK(hipStreamSynchronize(c->stream));
   return ss.verdict();
 }
-extern "C" int blsgpu_g1_msm_many(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, size_t k, uint64_t* out) { return msm_many_host<FpPolicy>(c, b, first, s, n, k, out); }
-extern "C" int blsgpu_g2_msm_many(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, size_t k, uint64_t* out) { return msm_many_host<Fp2Policy>(c, b, first, s, n, k, out); }
+extern "C" int blsgpu_g1_msm_many(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, size_t k, uint64_t* out) { CTX_CLAIM(c); return msm_many_host<FpPolicy>(c, b, first, s, n, k, out); }
+extern "C" int blsgpu_g2_msm_many(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, size_t k, uint64_t* out) { CTX_CLAIM(c); return msm_many_host<Fp2Policy>(c, b, first, s, n, k, out); }
 template <class F>
 static int msm_oneshot(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) {
   blsgpu_bases* b = nullptr;
@@ -1080,8 +1104,8 @@ static int msm_oneshot(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, co
   blsgpu_bases_free(b);
   return rc;
 }
-extern "C" int blsgpu_g1_msm_host(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) { return msm_oneshot<FpPolicy>(c, xy, inf, s, n, out); }
-extern "C" int blsgpu_g2_msm_host(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) { return msm_oneshot<Fp2Policy>(c, xy, inf, s, n, out); }
+extern "C" int blsgpu_g1_msm_host(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) { CTX_CLAIM(c); return msm_oneshot<FpPolicy>(c, xy, inf, s, n, out); }
+extern "C" int blsgpu_g2_msm_host(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) { CTX_CLAIM(c); return msm_oneshot<Fp2Policy>(c, xy, inf, s, n, out); }
 
 // ---------------------------------------------------------------------------------------------------
 // batched variable-base scalar multiplication (mulbatch.hip.h): out[i] = [s_i] P_i, N in -> N out
@@ -1117,10 +1141,10 @@ static int mul_batch_host(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf,
   HIPCHK(hipStreamSynchronize(c->stream));
   return ss.verdict();
 }
-extern "C" int blsgpu_g1_mul_batch(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) { return mul_batch_host<FpPolicy>(c, xy, inf, s, n, out); }
-extern "C" int blsgpu_g2_mul_batch(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) { return mul_batch_host<Fp2PairPolicy>(c, xy, inf, s, n, out); }
-extern "C" int blsgpu_g1_mul_batch_device(blsgpu_ctx* c, const void* xy, const void* inf, const void* s, size_t n, void* out) { return mul_batch_device<FpPolicy>(c, xy, inf, s, n, out); }
-extern "C" int blsgpu_g2_mul_batch_device(blsgpu_ctx* c, const void* xy, const void* inf, const void* s, size_t n, void* out) { return mul_batch_device<Fp2PairPolicy>(c, xy, inf, s, n, out); }
+extern "C" int blsgpu_g1_mul_batch(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) { CTX_CLAIM(c); return mul_batch_host<FpPolicy>(c, xy, inf, s, n, out); }
+extern "C" int blsgpu_g2_mul_batch(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) { CTX_CLAIM(c); return mul_batch_host<Fp2PairPolicy>(c, xy, inf, s, n, out); }
+extern "C" int blsgpu_g1_mul_batch_device(blsgpu_ctx* c, const void* xy, const void* inf, const void* s, size_t n, void* out) { CTX_CLAIM(c); return mul_batch_device<FpPolicy>(c, xy, inf, s, n, out); }
+extern "C" int blsgpu_g2_mul_batch_device(blsgpu_ctx* c, const void* xy, const void* inf, const void* s, size_t n, void* out) { CTX_CLAIM(c); return mul_batch_device<Fp2PairPolicy>(c, xy, inf, s, n, out); }
 
 // ---------------------------------------------------------------------------------------------------
 // group helpers
@@ -1157,10 +1181,10 @@ static int proj_sum_device(blsgpu_ctx* c, const void* d_xyz, size_t n, void* d_o
   LAUNCHCHK();
   return BLSGPU_OK;
 }
-extern "C" int blsgpu_g1_sum_device(blsgpu_ctx* c, const void* xyz, size_t n, void* out) { return proj_sum_device<FpPolicy>(c, xyz, n, out); }
-extern "C" int blsgpu_g2_sum_device(blsgpu_ctx* c, const void* xyz, size_t n, void* out) { return proj_sum_device<Fp2Policy>(c, xyz, n, out); }
-extern "C" int blsgpu_g1_sum(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* out) { return proj_sum<FpPolicy>(c, xyz, n, out); }
-extern "C" int blsgpu_g2_sum(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* out) { return proj_sum<Fp2Policy>(c, xyz, n, out); }
+extern "C" int blsgpu_g1_sum_device(blsgpu_ctx* c, const void* xyz, size_t n, void* out) { CTX_CLAIM(c); return proj_sum_device<FpPolicy>(c, xyz, n, out); }
+extern "C" int blsgpu_g2_sum_device(blsgpu_ctx* c, const void* xyz, size_t n, void* out) { CTX_CLAIM(c); return proj_sum_device<Fp2Policy>(c, xyz, n, out); }
+extern "C" int blsgpu_g1_sum(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* out) { CTX_CLAIM(c); return proj_sum<FpPolicy>(c, xyz, n, out); }
+extern "C" int blsgpu_g2_sum(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* out) { CTX_CLAIM(c); return proj_sum<Fp2Policy>(c, xyz, n, out); }
 
 template <class F>
 static int batch_normalize(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* xy, uint8_t* inf) {
@@ -1187,8 +1211,8 @@ static int batch_normalize(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_
   HIPCHK(hipStreamSynchronize(c->stream));
   return BLSGPU_OK;
 }
-extern "C" int blsgpu_g1_batch_normalize(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* xy, uint8_t* inf) { return batch_normalize<FpPolicy>(c, xyz, n, xy, inf); }
-extern "C" int blsgpu_g2_batch_normalize(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* xy, uint8_t* inf) { return batch_normalize<Fp2Policy>(c, xyz, n, xy, inf); }
+extern "C" int blsgpu_g1_batch_normalize(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* xy, uint8_t* inf) { CTX_CLAIM(c); return batch_normalize<FpPolicy>(c, xyz, n, xy, inf); }
+extern "C" int blsgpu_g2_batch_normalize(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* xy, uint8_t* inf) { CTX_CLAIM(c); return batch_normalize<Fp2Policy>(c, xyz, n, xy, inf); }
 
 // ---------------------------------------------------------------------------------------------------
 // self-test hooks
@@ -1212,20 +1236,20 @@ static int elem_op(blsgpu_ctx* c, int words, int kind, int op, const uint64_t* a
   HIPCHK(hipStreamSynchronize(c->stream));
   return BLSGPU_OK;
 }
-extern "C" int blsgpu_fp_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+extern "C" int blsgpu_fp_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) { CTX_CLAIM(c);
   if (op < 0 || op > 6) return bad("fp_op: unknown op");
   return elem_op(c, 12, 1, op, a, b, n, out);
 }
-extern "C" int blsgpu_fp2_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+extern "C" int blsgpu_fp2_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) { CTX_CLAIM(c);
   if (op < 0 || op > 6) return bad("fp2_op: unknown op");
   return elem_op(c, 24, 2, op, a, b, n, out);
 }
-extern "C" int blsgpu_fp6_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+extern "C" int blsgpu_fp6_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) { CTX_CLAIM(c);
   if (!(op == 0 || op == 3 || op == 4 || op == 5 || op == 7 || op == 11 || op == 12)) return bad("fp6_op: unknown op");
   if ((op == 0 || op == 11 || op == 12) && n && !b) return bad("fp6_op: the second operand is missing");
   return elem_op(c, 72, 6, op, a, b, n, out);
 }
-extern "C" int blsgpu_fp12_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+extern "C" int blsgpu_fp12_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) { CTX_CLAIM(c);
   if (!(op == 0 || op == 3 || op == 4 || op == 7 || op == 8 || op == 9 || op == 10)) return bad("fp12_op: unknown op");
   if (op == 10 && c && c->pairing_layout == 2) return bad("fp12_op: op 10 (cyclotomic exponentiation) exists in the quad layout only");
   return elem_op(c, 144, 12, op, a, b, n, out);
@@ -1245,7 +1269,7 @@ static int point_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b,
   HIPCHK(hipStreamSynchronize(c->stream));
   return BLSGPU_OK;
 }
-extern "C" int blsgpu_point_op(blsgpu_ctx* c, int group, int op, const uint64_t* a, const uint64_t* b, const uint8_t* binf, size_t n, uint64_t* out) {
+extern "C" int blsgpu_point_op(blsgpu_ctx* c, int group, int op, const uint64_t* a, const uint64_t* b, const uint8_t* binf, size_t n, uint64_t* out) { CTX_CLAIM(c);
   if (!c || (n && (!a || !out || (op != 1 && !b))) || op < 0 || op > 2 || (group != 1 && group != 2)) return bad("point_op: bad argument");
   if (!n) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
@@ -1273,8 +1297,8 @@ static int chain_probe(blsgpu_ctx* c, int iters, double* rate, bool fp) {
   *rate = ops / (ms * 1e-3);
   return BLSGPU_OK;
 }
-extern "C" int blsgpu_fp_mul_throughput(blsgpu_ctx* c, int iters, double* r) { return chain_probe(c, iters, r, true); }
-extern "C" int blsgpu_mad_throughput(blsgpu_ctx* c, int iters, double* r) { return chain_probe(c, iters, r, false); }
+extern "C" int blsgpu_fp_mul_throughput(blsgpu_ctx* c, int iters, double* r) { CTX_CLAIM(c); return chain_probe(c, iters, r, true); }
+extern "C" int blsgpu_mad_throughput(blsgpu_ctx* c, int iters, double* r) { CTX_CLAIM(c); return chain_probe(c, iters, r, false); }
 
 // ---------------------------------------------------------------------------------------------------
 // pairings
@@ -1301,8 +1325,8 @@ static int msm_bytes(blsgpu_ctx* c, const uint8_t* bases, const uint8_t* scalars
   (void)BYTES;
   return G == 1 ? blsgpu_g1_to_bytes_batch(c, axy.data(), &ainf, 1, 0, out) : blsgpu_g2_to_bytes_batch(c, axy.data(), &ainf, 1, 0, out);
 }
-extern "C" int blsgpu_g1_msm_bytes(blsgpu_ctx* c, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]) { return msm_bytes<1>(c, bases, scalars, n, out); }
-extern "C" int blsgpu_g2_msm_bytes(blsgpu_ctx* c, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[192]) { return msm_bytes<2>(c, bases, scalars, n, out); }
+extern "C" int blsgpu_g1_msm_bytes(blsgpu_ctx* c, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]) { CTX_CLAIM(c); return msm_bytes<1>(c, bases, scalars, n, out); }
+extern "C" int blsgpu_g2_msm_bytes(blsgpu_ctx* c, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[192]) { CTX_CLAIM(c); return msm_bytes<2>(c, bases, scalars, n, out); }
 
 // ---------------------------------------------------------------------------------------------------
 // hash-to-curve (h2c.hip.h)
@@ -1348,16 +1372,16 @@ static int h2c_host(blsgpu_ctx* c, const uint8_t* msgs, const uint64_t* offsets,
   return BLSGPU_OK;
 }
 extern "C" int blsgpu_g1_hash_to_curve_batch(blsgpu_ctx* c, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst, size_t dst_len,
-                                             int encode_only, uint64_t* out_xyz) {
+                                             int encode_only, uint64_t* out_xyz) { CTX_CLAIM(c);
   return h2c_host<FpPolicy>(c, msgs, offsets, n, dst, dst_len, encode_only, out_xyz);
 }
 extern "C" int blsgpu_g2_hash_to_curve_batch(blsgpu_ctx* c, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst, size_t dst_len,
-                                             int encode_only, uint64_t* out_xyz) {
+                                             int encode_only, uint64_t* out_xyz) { CTX_CLAIM(c);
   return h2c_host<Fp2Policy>(c, msgs, offsets, n, dst, dst_len, encode_only, out_xyz);
 }
 // device-resident variant: messages, offsets (n + 1 u64) and the DST (<= 255 bytes) already in device memory
 extern "C" int blsgpu_hash_to_curve_device(blsgpu_ctx* c, int group, const void* d_msgs, const void* d_offsets, size_t n, const void* d_dst, size_t dst_len,
-                                           int encode_only, void* d_out_xyz) {
+                                           int encode_only, void* d_out_xyz) { CTX_CLAIM(c);
   if (!c || (n && (!d_offsets || !d_out_xyz)) || (dst_len && !d_dst)) return bad("hash_to_curve: NULL argument");
   if (dst_len > 255) return bad("hash_to_curve_device: reduce a DST longer than 255 bytes on the host first");
   if (group != 1 && group != 2) return bad("hash_to_curve: group must be 1 or 2");
@@ -1376,7 +1400,7 @@ extern "C" int blsgpu_hash_to_curve_device(blsgpu_ctx* c, int group, const void*
 // ---------------------------------------------------------------------------------------------------
 // scalar field Fr: element-wise vector operations and the radix-2 transform (fr.hip.h)
 // ---------------------------------------------------------------------------------------------------
-extern "C" int blsgpu_fr_op_device(blsgpu_ctx* c, int op, const void* a, const void* b, size_t n, void* out, void* nonzero_flags) {
+extern "C" int blsgpu_fr_op_device(blsgpu_ctx* c, int op, const void* a, const void* b, size_t n, void* out, void* nonzero_flags) { CTX_CLAIM(c);
   if (!c || (n && (!a || !out))) return bad("fr_op: NULL argument");
   if (op < 0 || op > 6) return bad("fr_op: unknown op");
   if (op <= 2 && n && !b) return bad("fr_op: binary op needs b");
@@ -1387,7 +1411,7 @@ extern "C" int blsgpu_fr_op_device(blsgpu_ctx* c, int op, const void* a, const v
   LAUNCHCHK();
   return BLSGPU_OK;
 }
-extern "C" int blsgpu_fr_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, uint8_t* nonzero_flags) {
+extern "C" int blsgpu_fr_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, uint8_t* nonzero_flags) { CTX_CLAIM(c);
   if (!c || (n && (!a || !out))) return bad("fr_op: NULL argument");
   if (op < 0 || op > 6) return bad("fr_op: unknown op");
   if (op <= 2 && n && !b) return bad("fr_op: binary op needs b");
@@ -1404,7 +1428,7 @@ extern "C" int blsgpu_fr_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint
   return BLSGPU_OK;
 }
 // in-place transform of 2^log_n scalars in device memory (natural order in and out)
-extern "C" int blsgpu_fr_ntt_device(blsgpu_ctx* c, void* d_data, int log_n, int inverse) {
+extern "C" int blsgpu_fr_ntt_device(blsgpu_ctx* c, void* d_data, int log_n, int inverse) { CTX_CLAIM(c);
   if (!c || !d_data) return bad("fr_ntt: NULL argument");
   if (log_n < 0 || log_n > 28) return bad("fr_ntt: log_n must be in [0, 28]");
   if (log_n == 0) return BLSGPU_OK;
@@ -1452,7 +1476,7 @@ extern "C" int blsgpu_fr_ntt_device(blsgpu_ctx* c, void* d_data, int log_n, int 
   if (dst != data) HIPCHK(hipMemcpyAsync(data, tmp, n * 32, hipMemcpyDeviceToDevice, st));
   return BLSGPU_OK;
 }
-extern "C" int blsgpu_fr_ntt(blsgpu_ctx* c, uint64_t* data, int log_n, int inverse) {
+extern "C" int blsgpu_fr_ntt(blsgpu_ctx* c, uint64_t* data, int log_n, int inverse) { CTX_CLAIM(c);
   if (!c || !data) return bad("fr_ntt: NULL argument");
   if (log_n < 0 || log_n > 28) return bad("fr_ntt: log_n must be in [0, 28]");
   HIPCHK(hipSetDevice(c->device));
@@ -1507,7 +1531,7 @@ static int pairing_layout_for(blsgpu_ctx* c, size_t n) {
   if (c->pairing_layout == 256) return wide_load(c) == 1 ? 256 : -1;          // asked for by name: no silent substitute
   return (n <= WIDE_AUTO_MAX && wide_load(c) == 1) ? 256 : 4;
 }
-extern "C" int blsgpu_pairing_layout(blsgpu_ctx* c, size_t n) {
+extern "C" int blsgpu_pairing_layout(blsgpu_ctx* c, size_t n) { CTX_CLAIM(c);
   if (!c) return bad("pairing_layout: NULL context");
   if (hipSetDevice(c->device) != hipSuccess) { (void)hipGetLastError(); return bad("pairing_layout: hipSetDevice failed"); }
   const int l = pairing_layout_for(c, n);
@@ -1550,26 +1574,26 @@ static int pairing_host(blsgpu_ctx* c, int mode, const uint64_t* g1, const uint8
   HIPCHK(hipStreamSynchronize(c->stream));
   return BLSGPU_OK;
 }
-extern "C" int blsgpu_pairing_batch(blsgpu_ctx* c, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, size_t n, uint64_t* out) {
+extern "C" int blsgpu_pairing_batch(blsgpu_ctx* c, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, size_t n, uint64_t* out) { CTX_CLAIM(c);
   return pairing_host(c, 0, g1, g1inf, g2, g2inf, n, out);
 }
-extern "C" int blsgpu_miller_loop_batch(blsgpu_ctx* c, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, size_t n, uint64_t* out) {
+extern "C" int blsgpu_miller_loop_batch(blsgpu_ctx* c, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, size_t n, uint64_t* out) { CTX_CLAIM(c);
   return pairing_host(c, 1, g1, g1inf, g2, g2inf, n, out);
 }
-extern "C" int blsgpu_pairing_batch_device(blsgpu_ctx* c, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) {
+extern "C" int blsgpu_pairing_batch_device(blsgpu_ctx* c, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) { CTX_CLAIM(c);
   if (!c || (n && (!g1 || !g2 || !out))) return bad("pairing: NULL argument");
   if (!n) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
   return pairing_launch(c, 0, g1, g1inf, g2, g2inf, n, out);
 }
 
-extern "C" int blsgpu_miller_loop_batch_device(blsgpu_ctx* c, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) {
+extern "C" int blsgpu_miller_loop_batch_device(blsgpu_ctx* c, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) { CTX_CLAIM(c);
   if (!c || (n && (!g1 || !g2 || !out))) return bad("miller_loop: NULL argument");
   if (!n) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
   return pairing_launch(c, 1, g1, g1inf, g2, g2inf, n, out);
 }
-extern "C" int blsgpu_final_exponentiation_device(blsgpu_ctx* c, const void* in, size_t n, void* out) {
+extern "C" int blsgpu_final_exponentiation_device(blsgpu_ctx* c, const void* in, size_t n, void* out) { CTX_CLAIM(c);
   if (!c || (n && (!in || !out))) return bad("final_exponentiation: NULL argument");
   if (!n) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
@@ -1609,12 +1633,12 @@ static int fp12_product_device(blsgpu_ctx* c, const u32* d_in, size_t n, u32* d_
   if (in != d_out) HIPCHK(hipMemcpyAsync(d_out, in, 576, hipMemcpyDeviceToDevice, c->stream));
   return BLSGPU_OK;
 }
-extern "C" int blsgpu_fp12_product_device(blsgpu_ctx* c, const void* in, size_t n, void* out) {
+extern "C" int blsgpu_fp12_product_device(blsgpu_ctx* c, const void* in, size_t n, void* out) { CTX_CLAIM(c);
   if (!c || !out || (n && !in)) return bad("fp12_product: NULL argument");
   HIPCHK(hipSetDevice(c->device));
   return fp12_product_device(c, (const u32*)in, n, (u32*)out);
 }
-extern "C" int blsgpu_multi_miller_loop_device(blsgpu_ctx* c, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) {
+extern "C" int blsgpu_multi_miller_loop_device(blsgpu_ctx* c, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) { CTX_CLAIM(c);
   if (!c || !out || (n && (!g1 || !g2))) return bad("multi_miller_loop: NULL argument");
   HIPCHK(hipSetDevice(c->device));
   if (c->io_out.reserve((n ? n : 1) * 576)) { g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP; }
@@ -1631,7 +1655,7 @@ extern "C" int blsgpu_multi_miller_loop_device(blsgpu_ctx* c, const void* g1, co
   LAUNCHCHK();
   return fp12_product_device(c, c->io_out.as<u32>(), groups, (u32*)out);
 }
-extern "C" int blsgpu_multi_miller_loop(blsgpu_ctx* c, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, size_t n, uint64_t* out) {
+extern "C" int blsgpu_multi_miller_loop(blsgpu_ctx* c, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, size_t n, uint64_t* out) { CTX_CLAIM(c);
   if (!c || !out || (n && (!g1 || !g2))) return bad("multi_miller_loop: NULL argument");
   HIPCHK(hipSetDevice(c->device));
   if (c->io_a.reserve(n ? n * 96 : 16) || c->io_b.reserve(n ? n * 192 : 16) || c->flags_a.reserve(n ? n : 16) || c->flags_b.reserve(n ? n : 16) || c->result.reserve(576)) {
@@ -1649,7 +1673,7 @@ extern "C" int blsgpu_multi_miller_loop(blsgpu_ctx* c, const uint64_t* g1, const
   HIPCHK(hipStreamSynchronize(c->stream));
   return BLSGPU_OK;
 }
-extern "C" int blsgpu_final_exponentiation_batch(blsgpu_ctx* c, const uint64_t* in, size_t n, uint64_t* out) {
+extern "C" int blsgpu_final_exponentiation_batch(blsgpu_ctx* c, const uint64_t* in, size_t n, uint64_t* out) { CTX_CLAIM(c);
   if (!c || (n && (!in || !out))) return bad("final_exponentiation: NULL argument");
   if (!n) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
@@ -1665,7 +1689,7 @@ extern "C" int blsgpu_final_exponentiation_batch(blsgpu_ctx* c, const uint64_t* 
   HIPCHK(hipStreamSynchronize(c->stream));
   return BLSGPU_OK;
 }
-extern "C" int blsgpu_gt_mul_scalar_batch(blsgpu_ctx* c, const uint64_t* gt, const uint8_t* scalars, size_t n, uint64_t* out) {
+extern "C" int blsgpu_gt_mul_scalar_batch(blsgpu_ctx* c, const uint64_t* gt, const uint8_t* scalars, size_t n, uint64_t* out) { CTX_CLAIM(c);
   if (!c || (n && (!gt || !scalars || !out))) return bad("gt_mul_scalar: NULL argument");
   if (!n) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
@@ -1678,7 +1702,7 @@ extern "C" int blsgpu_gt_mul_scalar_batch(blsgpu_ctx* c, const uint64_t* gt, con
   HIPCHK(hipStreamSynchronize(c->stream));
   return BLSGPU_OK;
 }
-extern "C" int blsgpu_fp12_product(blsgpu_ctx* c, const uint64_t* in, size_t n, uint64_t* out) {
+extern "C" int blsgpu_fp12_product(blsgpu_ctx* c, const uint64_t* in, size_t n, uint64_t* out) { CTX_CLAIM(c);
   if (!c || !out || (n && !in)) return bad("fp12_product: NULL argument");
   HIPCHK(hipSetDevice(c->device));
   if (c->io_a.reserve(n ? n * 576 : 16) || c->result.reserve(576)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
@@ -1728,15 +1752,15 @@ static int point_encode(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, s
   HIPCHK(hipStreamSynchronize(c->stream));
   return BLSGPU_OK;
 }
-extern "C" int blsgpu_g1_from_bytes_batch(blsgpu_ctx* c, const uint8_t* b, size_t n, int compressed, int checked, uint64_t* xy, uint8_t* inf, uint8_t* ok) {
+extern "C" int blsgpu_g1_from_bytes_batch(blsgpu_ctx* c, const uint8_t* b, size_t n, int compressed, int checked, uint64_t* xy, uint8_t* inf, uint8_t* ok) { CTX_CLAIM(c);
   return point_decode<FpPolicy>(c, b, n, compressed, checked, xy, inf, ok);
 }
-extern "C" int blsgpu_g2_from_bytes_batch(blsgpu_ctx* c, const uint8_t* b, size_t n, int compressed, int checked, uint64_t* xy, uint8_t* inf, uint8_t* ok) {
+extern "C" int blsgpu_g2_from_bytes_batch(blsgpu_ctx* c, const uint8_t* b, size_t n, int compressed, int checked, uint64_t* xy, uint8_t* inf, uint8_t* ok) { CTX_CLAIM(c);
   return point_decode<Fp2Policy>(c, b, n, compressed, checked, xy, inf, ok);
 }
-extern "C" int blsgpu_g1_to_bytes_batch(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, int compressed, uint8_t* out) {
+extern "C" int blsgpu_g1_to_bytes_batch(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, int compressed, uint8_t* out) { CTX_CLAIM(c);
   return point_encode<FpPolicy>(c, xy, inf, n, compressed, out);
 }
-extern "C" int blsgpu_g2_to_bytes_batch(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, int compressed, uint8_t* out) {
+extern "C" int blsgpu_g2_to_bytes_batch(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, int compressed, uint8_t* out) { CTX_CLAIM(c);
   return point_encode<Fp2Policy>(c, xy, inf, n, compressed, out);
 }

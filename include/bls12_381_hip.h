@@ -20,7 +20,9 @@
  *
  * Every function returns BLSGPU_OK (0) or a negative error code; nothing is retained from caller buffers
  * after return.  A context owns one device, one HIP stream and its scratch memory; it is not re-entrant
- * (use one context per host thread).
+ * (use one context per host thread).  The rule is enforced: an entry point called while another host thread is inside an
+ * entry point of the SAME context returns BLSGPU_ERR_ARG ("the context is in use by another host thread") and touches
+ * nothing; contexts are independent of one another (tests: two contexts on two threads; one context from two threads).
  */
 #ifndef BLS12_381_HIP_H
 #define BLS12_381_HIP_H

@@ -1567,3 +1567,35 @@ def test_layout_switch_at_1024_items(ctx, layout_contexts):
     for i in range(3):
         acc = o.fp12_mul(acc, o.pairing((wfp(g1[i][0:6]), wfp(g1[i][6:12]), False), (wfp2(g2[i][0:12]), wfp2(g2[i][12:24]), False)))
     assert np.array_equal(gt, fp12w(acc))
+
+
+def test_one_context_from_two_host_threads_is_refused_not_corrupted(ctx):
+    """include/bls12_381_hip.h: one context per host thread.  A second thread that enters the same context while a call is in
+    progress gets BLSGPU_ERR_ARG and the first call's result is what it would have been alone"""
+    import threading
+    import time
+    import bls12_381_amd as b
+    from bls12_381_amd import synthetic as sy
+    c = b.Context(0)
+    n = 1 << 15
+    ka = sy.scalars(n, sy.SEED + 970); kq = sy.scalars(n, sy.SEED + 971)
+    g1, f1 = c.bases_from_scalars(1, ka).download(); g2, f2 = c.bases_from_scalars(2, kq).download()
+    want = c.pairing_batch(g1[:64], f1[:64], g2[:64], f2[:64])
+    res = {}
+
+    def long_call():
+        res["gt"] = c.pairing_batch(g1, f1, g2, f2)              # ~15 ms of kernels plus the copies: the GIL is released inside
+
+    seen = []
+    t = threading.Thread(target=long_call)
+    t.start()
+    deadline = time.time() + 5.0
+    while t.is_alive() and time.time() < deadline:
+        r = int(c.lib.blsgpu_pairing_layout(c.h, 1))
+        if r < 0:
+            seen.append(c.lib.blsgpu_last_error())
+        time.sleep(0.0005)
+    t.join()
+    assert seen and all(b"another host thread" in m for m in seen), "the second thread was never refused"
+    assert np.array_equal(res["gt"][:64], want)
+    assert c.pairing_layout(1) == 256                           # and the context works as before afterwards
