@@ -396,7 +396,7 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
     # small batches: latency of ONE call with n = 1, 8, 64, 1024 pairs (pairing) and of one final exponentiation -- the sizes the
     # reference's own criterion points measure one at a time (benches/groups.rs:15-29); per_op_ns of the CPU port is next to them
     small = {}
-    for k in (1, 8, 64, 256, 1024, 4096):
+    for k in (1, 8, 64, 256, 512, 1024, 4096):
         small["pairing_n%d_ms" % k] = median_ms(lambda: ctx.pairing_batch_device(d_g1.data_ptr(), d_g2.data_ptr(), k, d_gt.data_ptr()), sync, warm=1, reps=5)
     d_ml = torch.zeros((1024, 72), dtype=torch.int64, device=dev)
     ctx.miller_loop_batch_device(d_g1.data_ptr(), d_g2.data_ptr(), 1024, d_ml.data_ptr())
@@ -407,9 +407,9 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
     small["multi_miller_loop_n3_plus_final_exponentiation_ms"] = median_ms(
         lambda: (ctx.multi_miller_loop_device(d_g1.data_ptr(), d_g2.data_ptr(), 3, d_ml.data_ptr()),
                  bls._lib.check(ctx.lib.blsgpu_final_exponentiation_device(ctx.h, d_ml.data_ptr(), 1, d_gt.data_ptr()), "final_exponentiation")), sync, warm=1, reps=5)
-    small["note"] = ("one call, nothing else in flight, inputs and outputs in HBM.  Up to 1024 items a call takes the wide path (wide.hip.h: one "
-                     "item per 1024-lane workgroup, one workgroup per CU at a time, so 1..256 items cost the same and 1024 cost four passes); larger "
-                     "batches take the quad kernels, flat at ~6 ms up to ~4096 items.  multi_miller_loop_n3 + final exponentiation is the shape of "
+    small["note"] = ("one call, nothing else in flight, inputs and outputs in HBM.  Up to 1536 items a call takes the wide path (wide.hip.h: one "
+                     "item per workgroup -- 1024 lanes, one workgroup per CU, for 1..256 items, which therefore cost the same; 512 lanes, two per "
+                     "CU, above: 512 items in one pass, 1024 in two); larger batches take the quad kernels, flat at ~6 ms up to ~4096 items.  multi_miller_loop_n3 + final exponentiation is the shape of "
                      "one signature-verification equation (benches/groups.rs:15-29 measure the same operations one at a time on the CPU)")
     extras["pairing_small_batches"] = small
     ctx.pairing_batch_device(d_g1.data_ptr(), d_g2.data_ptr(), np_, d_gt.data_ptr()); sync()        # the CPU comparison below reads d_gt

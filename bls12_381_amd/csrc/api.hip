@@ -91,7 +91,7 @@ struct blsgpu_ctx {
                                        // wide.hip.h -- up to WIDE_AUTO_MAX items, the quad layout above), 4 = quad (quad.hip.h: no hot-loop scratch), 2 = lane pair
                                        // (pairing.hip.h, rounds 1-2), 256 = wide; env BLSGPU_PAIRING_LAYOUT=pair|quad|wide at create fixes one for A/B runs
   u32* d_wide = nullptr;               // the wide programs (bls12_381_amd/wide_prog.bin, generated at build time by tools/gen_wide_prog.py) in device memory
-  size_t wide_off[2] = {0, 0};         // word offsets of the Miller-loop / final-exponentiation program
+  size_t wide_off[4] = {0, 0, 0, 0};   // word offsets of the Miller-loop / final-exponentiation programs: [0..1] 1024 lanes x 4 limbs, [2..3] 512 lanes x 8 limbs
   int wide_state = 0;                  // 0 = not tried, 1 = loaded, -1 = unavailable (the quad kernels take every size then)
   bool assume_subgroup = false;        // blsgpu_set_assume_subgroup: skip the subgroup check of uploaded bases (the caller vouches for them)
   bool no_glv = false;                 // A/B hook (env BLSGPU_NO_GLV at create): plain 256-bit windows (no GLV for G1, no psi decomposition for G2)
@@ -1492,7 +1492,11 @@ extern "C" int blsgpu_fr_ntt(blsgpu_ctx* c, uint64_t* data, int log_n, int inver
 
 // ---------------------------------------------------------------------------------------------------
 // ---- the wide (one workgroup per pairing) path -------------------------------------------------------------------
-constexpr size_t WIDE_AUTO_MAX = 1024;       // one 1024-lane workgroup per CU at a time: 256 items run at the latency of one (1.25 ms), 1024 in four passes (4.9 ms), against the quad kernels' flat ~6.1 ms
+// Two built-in configurations (wide.hip.h): up to WIDE_ONE_PER_CU items one 1024-lane workgroup per CU (256 items at the latency of
+// one, 1.1 ms); above that 512-lane workgroups, two per CU (512 items 1.6 ms, 1024 items 3.1 ms, 1536 items 4.7 ms), against the
+// quad kernels' flat ~6.1 ms
+constexpr size_t WIDE_ONE_PER_CU = 256;
+constexpr size_t WIDE_AUTO_MAX = 1536;
 static int wide_load(blsgpu_ctx* c) {
   if (c->wide_state) return c->wide_state;
   c->wide_state = -1;
@@ -1511,12 +1515,13 @@ static int wide_load(blsgpu_ctx* c) {
   u32 buf[4096]; size_t got;
   while ((got = fread(buf, 4, 4096, fh)) > 0) w.insert(w.end(), buf, buf + got);
   fclose(fh);
-  if (w.size() < 32 || w[0] != WIDE_BLOB_MAGIC || w[1] != 2) return -1;
-  for (int k = 0; k < 2; k++) {
+  if (w.size() < 32 || w[0] != WIDE_BLOB_MAGIC || w[1] != 4) return -1;
+  static const u32 cfg[4][2] = {{1024, 4}, {1024, 4}, {512, 8}, {512, 8}};
+  for (int k = 0; k < 4; k++) {
     const size_t off = w[2 + 2 * k], len = w[3 + 2 * k];
     // a program is only usable by the kernel it was generated for: same lanes per workgroup and limbs per product lane, slots and accumulators within the LDS arrays
-    if (off + len > w.size() || len < 16 || (off & 3) || w[off] != WIDE_PROG_MAGIC || w[off + 2] > (u32)WIDE_MAX_SLOTS || w[off + 10] != (u32)WIDE_LANES ||
-        w[off + 11] != (u32)WIDE_K || w[off + 12] >= (u32)WIDE_MAX_SLOTS || w[off + 13] > (u32)WIDE_MAX_ACC || (w[off + 7] & 3) || (w[off + 8] & 3) || (w[off + 9] & 1))
+    if (off + len > w.size() || len < 16 || (off & 3) || w[off] != WIDE_PROG_MAGIC || w[off + 2] > (u32)WIDE_MAX_SLOTS || w[off + 10] != cfg[k][0] ||
+        w[off + 11] != cfg[k][1] || w[off + 12] >= (u32)WIDE_MAX_SLOTS || w[off + 13] > (u32)WIDE_MAX_ACC || (w[off + 7] & 3) || (w[off + 8] & 3) || (w[off + 9] & 1))
       return -1;
     c->wide_off[k] = off;
   }
@@ -1538,8 +1543,12 @@ extern "C" int blsgpu_pairing_layout(blsgpu_ctx* c, size_t n) { CTX_CLAIM(c);
   return l < 0 ? bad("pairing_layout: BLSGPU_PAIRING_LAYOUT=wide but wide_prog.bin is missing or was generated for another kernel configuration") : l;
 }
 static void wide_launch(blsgpu_ctx* c, int mode, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) {
-  hipLaunchKernelGGL(k_pairing_wide, dim3((unsigned)n), dim3(WIDE_LANES), 0, c->stream, mode, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2, (const uint8_t*)g2inf,
-                     (u32*)out, n, c->d_wide + c->wide_off[0], c->d_wide + c->wide_off[1]);
+  if (n <= WIDE_ONE_PER_CU)
+    hipLaunchKernelGGL((k_pairing_wide_t<1024, 4>), dim3((unsigned)n), dim3(1024), 0, c->stream, mode, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2, (const uint8_t*)g2inf,
+                       (u32*)out, n, c->d_wide + c->wide_off[0], c->d_wide + c->wide_off[1]);
+  else
+    hipLaunchKernelGGL((k_pairing_wide_t<512, 8>), dim3((unsigned)n), dim3(512), 0, c->stream, mode, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2, (const uint8_t*)g2inf,
+                       (u32*)out, n, c->d_wide + c->wide_off[2], c->d_wide + c->wide_off[3]);
 }
 static int pairing_launch(blsgpu_ctx* c, int mode, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) {
   // mode 0: full pairing, 1: Miller loop only

@@ -180,7 +180,7 @@ int blsgpu_g2_to_bytes_batch(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t*
 
 /* ---- pairings ------------------------------------------------------------------------------------------ */
 /* Which kernels a call with n items (pairings, Miller loops or final exponentiations) runs on this context:
- *   256 = wide  (one item per 1024-lane workgroup: the small-batch latency path, n <= 1024; needs the generated
+ *   256 = wide  (one item per 1024- or 512-lane workgroup: the small-batch latency path, n <= 1536; needs the generated
  *                program file `wide_prog.bin` next to the library -- build step of __graft_entry__.py -- or at
  *                $BLSGPU_WIDE_PROG),
  *     4 = quad  (one item per four lanes: the throughput path),

@@ -17,6 +17,7 @@ EmuQuadBarriers g_emu_quads;
 #include "quad.hip.h"
 #endif
 #ifdef EMU_WITH_WIDE
+#define WIDE_STANDALONE
 #include "wide.hip.h"
 #endif
 

@@ -1548,18 +1548,22 @@ def test_small_batches_take_the_wide_path_and_match_every_other_layout(ctx, layo
             assert np.array_equal(ml_w[i], fp12w(o.miller_loop(Pi, Qi)))
 
 
-def test_layout_switch_at_1024_items(ctx, layout_contexts):
-    """the library hands batches of up to 1024 items to the wide kernels and larger ones to the quad kernels: same limbs on
-    both sides of the switch (1024 through the wide path, 1025 through the quad path, both against the quad-only context)"""
+def test_layout_switches_at_256_and_1536_items(ctx, layout_contexts):
+    """the library hands batches of up to 256 items to 1024-lane workgroups (one per CU), up to 1536 items to 512-lane workgroups
+    (two per CU) and larger ones to the quad kernels: same limbs on every side of the switches (against the quad-only context)"""
     from bls12_381_amd import synthetic as sy
-    assert ctx.pairing_layout(1024) == 256 and ctx.pairing_layout(1025) == 4
-    n = 1025
+    assert ctx.pairing_layout(256) == 256 and ctx.pairing_layout(1536) == 256 and ctx.pairing_layout(1537) == 4
+    n = 1537
     ka = sy.scalars(n, sy.SEED + 950); kq = sy.scalars(n, sy.SEED + 951)
     g1, f1 = ctx.bases_from_scalars(1, ka).download(); g2, f2 = ctx.bases_from_scalars(2, kq).download()
     q = layout_contexts["quad"]
     want = q.pairing_batch(g1, f1, g2, f2)
     assert np.array_equal(ctx.pairing_batch(g1, f1, g2, f2), want)
-    assert np.array_equal(ctx.pairing_batch(g1[:1024], f1[:1024], g2[:1024], f2[:1024]), want[:1024])
+    for m in (256, 257, 1536):
+        assert np.array_equal(ctx.pairing_batch(g1[:m], f1[:m], g2[:m], f2[:m]), want[:m]), m
+    wantm = q.miller_loop_batch(g1[:300], f1[:300], g2[:300], f2[:300])
+    assert np.array_equal(ctx.miller_loop_batch(g1[:300], f1[:300], g2[:300], f2[:300]), wantm)
+    assert np.array_equal(ctx.final_exponentiation_batch(wantm), want[:300])
     # multi_miller_loop over a handful of terms (wide Miller values, quad product tree) + final exponentiation = product of pairings
     ml = ctx.multi_miller_loop(g1[:3], f1[:3], g2[:3], f2[:3])
     gt = ctx.final_exponentiation_batch(ml[None, :])[0]

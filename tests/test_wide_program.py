@@ -171,19 +171,25 @@ def blob():
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_wide_prog.py"), "--check", "--out", path])
     data = open(path, "rb").read()
     head = struct.unpack_from("<16I", data, 0)
-    assert head[0] == 0x57504752 and head[1] == 2
-    return {"miller": data[4 * head[2]:4 * (head[2] + head[3])], "final_exp": data[4 * head[4]:4 * (head[4] + head[5])]}
+    assert head[0] == 0x57504752 and head[1] == 4          # (Miller loop, final exponentiation) x the two built-in configurations
+    progs = [data[4 * head[2 + 2 * k]:4 * (head[2 + 2 * k] + head[3 + 2 * k])] for k in range(4)]
+    return {(1024, 4): {"miller": progs[0], "final_exp": progs[1]}, (512, 8): {"miller": progs[2], "final_exp": progs[3]}}
 
 
-def test_encoded_wide_programs_match_oracle(blob):
-    r = o.SplitMix64(4711)
+@pytest.mark.parametrize("config", [(1024, 4), (512, 8)])
+def test_encoded_wide_programs_match_oracle(blob, config):
+    progs = blob[config]
+    for p in progs.values():
+        hdr = struct.unpack_from("<16I", p, 0)
+        assert (hdr[10], hdr[11]) == config
+    r = o.SplitMix64(4711 + config[0])
     Pa = o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, r.scalar()))
     Qa = o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, r.scalar()))
     ins = {12: Pa[0], 13: Pa[1], 14: Qa[0][0], 15: Qa[0][1], 16: Qa[1][0], 17: Qa[1][1]}
-    ml = run_program(blob["miller"], ins)
+    ml = run_program(progs["miller"], ins)
     assert ml == [v % P for v in o.fp12_flatten(o.miller_loop(Pa, Qa))]
-    gt = run_program(blob["final_exp"], {i: v for i, v in enumerate(ml)})
+    gt = run_program(progs["final_exp"], {i: v for i, v in enumerate(ml)})
     assert gt == [v % P for v in o.fp12_flatten(o.pairing(Pa, Qa))]
-    # the final exponentiation alone, on the generator pairing's Miller value and on 1
+    # the final exponentiation alone on 1
     one = o.fp12_flatten(o.FP12_ONE)
-    assert run_program(blob["final_exp"], {i: v for i, v in enumerate(one)}) == [v % P for v in one]
+    assert run_program(progs["final_exp"], {i: v for i, v in enumerate(one)}) == [v % P for v in one]

@@ -48,7 +48,7 @@ def main():
         n = 1 << lg
         row = {"log_n": lg}
         for name, ctx in ctxs.items():
-            if name == "wide" and n > 4096:
+            if name == "wide" and n > 2048:
                 continue
             dt = timed(lambda: ctx.miller_loop_batch_device(d_g1.data_ptr(), d_g2.data_ptr(), n, d_f.data_ptr()))
             row[name + "_miller_ms"] = round(dt, 3)

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#define WIDE_STANDALONE
 #include "wide.hip.h"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
@@ -35,7 +36,12 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(d_g2 + i * 48, &g2[(i % n) * 48], 192, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_f + i * 144, &ml[(i % n) * 144], 576, hipMemcpyHostToDevice));
   }
-  const uint32_t* pm = d_blob + blob[2]; const uint32_t* pf = d_blob + blob[4];
+  // the blob holds the programs of every built-in configuration: pick the pair generated for this build's (lanes, limbs)
+  int cfg = -1;
+  for (uint32_t k = 0; k + 1 < blob[1]; k += 2)
+    if (blob[blob[2 + 2 * k] + 10] == (uint32_t)bls::WIDE_LANES && blob[blob[2 + 2 * k] + 11] == (uint32_t)bls::WIDE_K) cfg = (int)k;
+  if (cfg < 0) { fprintf(stderr, "no program for %d lanes x %d limbs in the blob\n", bls::WIDE_LANES, bls::WIDE_K); return 1; }
+  const uint32_t* pm = d_blob + blob[2 + 2 * cfg]; const uint32_t* pf = d_blob + blob[4 + 2 * cfg];
   std::vector<uint32_t> out(N * 144);
   int bad = 0;
   for (int mode = 0; mode < 3; mode++) {

@@ -810,27 +810,34 @@ def build_programs(check=False):
     return progs
 
 
+CONFIGS = [(1024, 4), (512, 8)]           # (lanes, limbs of x per product lane) built into the library: lowest latency / two workgroups per CU
+
+
 def main():
+    """blob: 16-word header [magic, number of programs, (offset, length) x programs] then, for every configuration in CONFIGS
+    (or the single --lanes / --chunk one), the Miller-loop and the final-exponentiation program"""
+    global LANES, CHUNK, POST_CYCLOTOMIC
+    POST_CYCLOTOMIC = "--post-cyclotomic" in sys.argv
     out = os.path.join(ROOT, "bls12_381_amd", "wide_prog.bin")
     if "--out" in sys.argv:
         out = sys.argv[sys.argv.index("--out") + 1]
-    global LANES, CHUNK, POST_CYCLOTOMIC
-    POST_CYCLOTOMIC = "--post-cyclotomic" in sys.argv
-    if "--lanes" in sys.argv:
-        LANES = int(sys.argv[sys.argv.index("--lanes") + 1])
-    if "--chunk" in sys.argv:
-        CHUNK = int(sys.argv[sys.argv.index("--chunk") + 1])
-    progs = build_programs(check="--check" in sys.argv)
+    configs = CONFIGS
+    if "--lanes" in sys.argv or "--chunk" in sys.argv:
+        configs = [(int(sys.argv[sys.argv.index("--lanes") + 1]) if "--lanes" in sys.argv else LANES,
+                    int(sys.argv[sys.argv.index("--chunk") + 1]) if "--chunk" in sys.argv else CHUNK)]
     blob = b""
     index = []
     off = 16 * 4
-    for name in ("miller", "final_exp"):
-        data, nr, ns, nn = progs[name]
-        index += [off // 4, len(data) // 4]
-        off += len(data)
-        blob += data
-        print("%-10s %5d rounds, %4d slots, %6d nodes, %7d bytes" % (name, nr, ns, nn, len(data)), file=sys.stderr)
-    head = struct.pack("<16I", 0x57504752, 2, *index, *([0] * 10))
+    for LANES, CHUNK in configs:
+        progs = build_programs(check="--check" in sys.argv)
+        for name in ("miller", "final_exp"):
+            data, nr, ns, nn = progs[name]
+            index += [off // 4, len(data) // 4]
+            off += len(data)
+            blob += data
+            print("%4d x %d  %-10s %5d rounds, %4d slots, %6d nodes, %7d bytes" % (LANES, CHUNK, name, nr, ns, nn, len(data)), file=sys.stderr)
+    assert len(index) <= 14
+    head = struct.pack("<16I", 0x57504752, len(index) // 2, *index, *([0] * (14 - len(index))))
     with open(out, "wb") as fh:
         fh.write(head + blob)
     print("wrote", out, len(head) + len(blob), "bytes", file=sys.stderr)
