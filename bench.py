@@ -441,8 +441,13 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
     d_g1m, d_g2m = d_g1.repeat(4, 1), d_g2.repeat(4, 1)
     mms = median_ms(lambda: ctx.multi_miller_loop_device(d_g1m.data_ptr(), d_g2m.data_ptr(), nm, d_gt.data_ptr()), sync, warm=1, reps=5)
     mdt = mms * 1e-3
+    d_one = torch.zeros(72, dtype=torch.int64, device=dev)
+    mfe = median_ms(lambda: (ctx.multi_miller_loop_device(d_g1m.data_ptr(), d_g2m.data_ptr(), nm, d_gt.data_ptr()),
+                             bls._lib.check(ctx.lib.blsgpu_final_exponentiation_device(ctx.h, d_gt.data_ptr(), 1, d_one.data_ptr()), "final_exponentiation")), sync, warm=1, reps=3)
     extras["multi_miller_loop_terms_per_s"] = nm / mdt
-    extras["multi_miller_loop"] = {"n": nm, "ms": mms, "note": "one product of 2^18 Miller values (no final exponentiation)",
+    extras["multi_miller_loop"] = {"n": nm, "ms": mms, "with_final_exponentiation_ms": mfe,
+                                   "note": "one product of 2^18 Miller values; `ms` and the roofline are the product alone, `with_final_exponentiation_ms` adds the ONE "
+                                           "final exponentiation of BASELINE configs[4] (SURVEY.md 8d: one product + one final exp; wide path, ~0.8 ms)",
                                    "roofline": {"bound": "int-valu", "kernel": "k_multi_miller_shared", "mac32_per_unit": MAC32_MML_TERM, "achieved": nm * MAC32_MML_TERM / mdt / 1e12,
                                                 "peak": peak / 1e12, "unit": "TMAC32/s", "frac": nm * MAC32_MML_TERM / mdt / peak,
                                                 "traffic": static_traffic("mml")[0], "traffic_source": static_traffic("mml")[1], "algorithmic_bytes": nm * 288}}
