@@ -127,9 +127,14 @@ def test_emulated_wide_kernel_matches_oracle():
     prog_path = os.path.join(ROOT, "build", "wide_prog_emu.bin")
     src = os.path.join(ROOT, "tests", "simt", "emu_pairing.cpp")
     csrc = os.path.join(ROOT, "bls12_381_amd", "csrc")
-    subprocess.check_call([CLANG, "-O1", "-std=c++17", "-pthread", "-fPIC", "-shared", "-Wno-unused-value", "-Wno-psabi", "-DEMU_WITH_WIDE", "-DEMU_LANES=1024",
-                           "-I" + os.path.join(ROOT, "tests", "simt"), "-I" + csrc, src, "-o", lib_path])
-    subprocess.check_call([os.sys.executable, os.path.join(ROOT, "tools", "gen_wide_prog.py"), "--out", prog_path])
+    deps = [src, os.path.join(ROOT, "tests", "simt", "hip", "hip_runtime.h")] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
+    if not os.path.exists(lib_path) or os.path.getmtime(lib_path) < max(os.path.getmtime(d) for d in deps):          # rebuilt only when a source changed
+        subprocess.check_call([CLANG, "-O1", "-std=c++17", "-pthread", "-fPIC", "-shared", "-Wno-unused-value", "-Wno-psabi", "-DEMU_WITH_WIDE", "-DEMU_LANES=1024",
+                               "-I" + os.path.join(ROOT, "tests", "simt"), "-I" + csrc, src, "-o", lib_path])
+    gen = os.path.join(ROOT, "tools", "gen_wide_prog.py")
+    gdeps = [gen, os.path.join(ROOT, "oracle", "bls12_381_ref.py")]
+    if not os.path.exists(prog_path) or os.path.getmtime(prog_path) < max(os.path.getmtime(d) for d in gdeps):
+        subprocess.check_call([os.sys.executable, gen, "--lanes", "1024", "--chunk", "4", "--out", prog_path])
     lib = ctypes.CDLL(lib_path)
     blob = np.frombuffer(open(prog_path, "rb").read(), dtype=np.uint32).copy()
     pm = ctypes.c_void_p(blob.ctypes.data + 4 * int(blob[2])); pf = ctypes.c_void_p(blob.ctypes.data + 4 * int(blob[4]))
