@@ -2,8 +2,8 @@
 """Generator of the WIDE pairing programs (bls12_381_amd/csrc/wide.hip.h): one pairing on a whole workgroup.
 
 The batched kernels give a pairing 2 or 4 lanes; one pairing then takes 6-12 ms however small the batch, because a lone
-wavefront issues one multiply-add per ~9 cycles.  For small batches the arithmetic of ONE pairing is spread over the 256 lanes
-of a workgroup instead.  What runs there is not tower code but a straight-line PROGRAM of rounds over Fp values that live in
+wavefront issues one multiply-add per ~10 cycles.  For small batches the arithmetic of ONE pairing is spread over the 1024 (or
+512) lanes of a workgroup instead.  What runs there is not tower code but a straight-line PROGRAM of rounds over Fp values that live in
 LDS slots; in a round every lane computes (part of) one
 
     SOP   out = (sum_t x_t * y_t) / R'      one Montgomery reduction for the whole sum (the reference's sum_of_products idea,
@@ -11,14 +11,17 @@ LDS slots; in a round every lane computes (part of) one
     LIN   out = weak_reduce(sum_i c_i s_i)  a linear combination made a stored value
     INV   out = 1 / s                       the one inversion of the final exponentiation
 
-with the terms of an SOP dealt to several lanes whose unreduced column sums meet in LDS.  This script writes the reference's
+with every product of an SOP dealt to a quad (or pair) of lanes -- four (eight) limbs of x each -- that add their unreduced column
+sums to the SOP's accumulator in LDS, from where ONE lane reduces.  This script writes the reference's
 Miller loop (pairings.rs:668-770) and final exponentiation (:48-176) over a symbolic Fp type -- Fp12 in the basis 1, w, ..., w^5
 over Fp2 (w^2 = v, w^6 = u + 1), where a product coefficient is ONE sum of twelve Fp products -- levels the resulting DAG into
 rounds, deals lanes, allocates slots by liveness and emits the tables the kernel interprets.  Every node carries its exact
 value for a test input, so the formulas are checked against oracle/bls12_381_ref.py while the program is generated (--check),
 and tests/test_wide_program.py re-runs the ENCODED tables at limb level against the oracle.
 
-    python tools/gen_wide_prog.py [--check] [--out bls12_381_amd/wide_prog.bin]
+    python tools/gen_wide_prog.py [--check] [--out bls12_381_amd/wide_prog.bin] [--lanes N --chunk K]
+
+Without --lanes / --chunk the blob holds the programs of both configurations built into the library (CONFIGS).
 """
 import os
 import struct
