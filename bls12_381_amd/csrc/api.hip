@@ -88,7 +88,7 @@ struct blsgpu_ctx {
   double acc_ms_sum = 0.0; unsigned acc_count = 0;
   u32 item_cap = 0;                    // A/B hook (env BLSGPU_ITEM_CAP at create): entries per work item of the accumulation (0 = automatic)
   int pairing_layout = 0;              // lanes per pairing of pairing / Miller loop / final exponentiation batches: 0 = automatic (default: a workgroup per pairing --
-                                       // wide.hip.h -- up to WIDE_AUTO_MAX items, the quad layout above), 4 = quad (quad.hip.h: no hot-loop scratch), 2 = lane pair
+                                       // wide.hip.h -- up to WIDE_AUTO_MAX items, the quad layout above), 4 = quad (quad.hip.h: next to no hot-loop scratch), 2 = lane pair
                                        // (pairing.hip.h, rounds 1-2), 256 = wide; env BLSGPU_PAIRING_LAYOUT=pair|quad|wide at create fixes one for A/B runs
   u32* d_wide = nullptr;               // the wide programs (bls12_381_amd/wide_prog.bin, generated at build time by tools/gen_wide_prog.py) in device memory
   size_t wide_off[4] = {0, 0, 0, 0};   // word offsets of the Miller-loop / final-exponentiation programs: [0..1] 1024 lanes x 4 limbs, [2..3] 512 lanes x 8 limbs
