@@ -457,17 +457,17 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
         log_n = int(np.log2(n))
         d_fr = d_scalars.clone()
         nms = median_ms(lambda: ctx.fr_ntt_device(d_fr.data_ptr(), log_n, False), sync, warm=1, reps=10)
-        # two rooflines: the transform's own bytes (every element read once and written once: 64 B) against HBM, and its
-        # butterflies (n/2 log2 n multiplications of 8 x 32-bit limbs = 136 MAC32 each, SURVEY.md 8d's counting) against the
-        # integer VALU; what the kernels actually move (six passes over the data plus twiddles, ~0.6 GB at 2^20) is in `note`
+        # the transform is bound by the integer VALU like everything else here: n/2 log2 n butterflies of one multiplication
+        # (8 x 32-bit limbs: 136 MAC32 in SURVEY.md 8d's counting) -- its own bytes (every element read and written once, 64 B)
+        # are 5 % of the HBM peak at this rate, and a one-pass-per-ten-stages variant that moved a third of the bytes ran at the
+        # same speed
         ntt_bytes = n * 64
         ntt_mac = (n // 2) * log_n * 136
         extras["fr_ntt"] = {"log_n": log_n, "ms": nms, "elements_per_s": n / (nms * 1e-3),
-                            "note": "radix-2 NTT over the scalar field, in place, natural order; 5 radix-4 passes over the data + one LDS pass at 2^20: "
-                                    "the kernels move ~9x the algorithmic bytes (passes + twiddle tables), i.e. run at ~45 % of the HBM peak",
-                            "roofline": {"bound": "hbm", "kernel": "k_fr_stage2 x 5 + k_fr_tile", "achieved": ntt_bytes / (nms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                         "frac": ntt_bytes / (nms * 1e-3) / 8e12, "algorithmic_bytes": ntt_bytes, "traffic": None,
-                                         "valu_achieved_tmac32": ntt_mac / (nms * 1e-3) / 1e12, "valu_frac": ntt_mac / (nms * 1e-3) / peak}}
+                            "note": "radix-2 NTT over the scalar field, in place, natural order; 5 radix-4 passes over the data + one LDS pass at 2^20",
+                            "roofline": {"bound": "int-valu", "kernel": "k_fr_stage2 x 5 + k_fr_tile", "mac32_per_unit": (log_n * 136) // 2,
+                                         "achieved": ntt_mac / (nms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s", "frac": ntt_mac / (nms * 1e-3) / peak,
+                                         "algorithmic_bytes": ntt_bytes, "hbm_frac_of_8TBs": ntt_bytes / (nms * 1e-3) / 8e12, "traffic": None}}
         del d_fr
     # hash-to-curve in front of the pairings: 2^16 32-byte messages -> G2
     rs = np.random.RandomState(99)
