@@ -57,7 +57,7 @@ def static_traffic(tag):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc summary of the SAME workload (profiles/<round>_<tag>_pmc.json,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE).  Counters cannot be read inside a timed
     run, so this is a STATIC figure from a separate profiled run -- labelled as such in the bench line."""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (rnd, tag))
         if os.path.exists(path):
             try:
@@ -452,6 +452,46 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
                                                 "peak": peak / 1e12, "unit": "TMAC32/s", "frac": nm * MAC32_MML_TERM / mdt / peak,
                                                 "traffic": static_traffic("mml")[0], "traffic_source": static_traffic("mml")[1], "algorithmic_bytes": nm * 288}}
     del d_g1m, d_g2m
+    # N independent multi_miller_loops of k = 3 terms + final exponentiation in ONE call: bulk signature verification
+    # (blsgpu_multi_miller_loop_many; pairings.rs:554-603 + :48-176 once per equation).  Canonical work: 3 Miller
+    # loops of 6 900 + one final exponentiation of 9 100 field multiplications = 29 800 x 300 MAC32 per equation.
+    ne, ke = 1 << 14, 3
+    d_off = torch.arange(0, (ne + 1) * ke, ke, dtype=torch.int64, device=dev)
+    d_eq = torch.zeros((ne, 72), dtype=torch.int64, device=dev)
+    eqms = median_ms(lambda: ctx.multi_miller_loop_many_device(d_g1.data_ptr(), d_g2.data_ptr(), d_off.data_ptr(), ne, ne * ke, d_eq.data_ptr(), max_seg_terms=ke), sync, warm=1, reps=5)
+    mac_eq = (ke * 6900 + 9100) * 300
+    eq = {"n": ne, "terms_per_equation": ke, "ms": eqms, "equations_per_s": ne / (eqms * 1e-3),
+          "note": "2^14 equations prod_{j<3} e(P_ij, Q_ij) in one blsgpu_multi_miller_loop_many_device call (Miller values of the 3 x 2^14 terms on the quad kernels, segmented "
+                  "Fp12 product, batched final exponentiation), inputs and outputs in HBM",
+          "roofline": {"bound": "int-valu", "kernel": "k_pairing_quad (Miller) + k_fp12_prod_seg_quad + k_final_exp_quad", "mac32_per_unit": mac_eq,
+                       "achieved": ne * mac_eq / (eqms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s", "frac": ne * mac_eq / (eqms * 1e-3) / peak,
+                       "algorithmic_bytes": ne * (ke * 288 + 576), "traffic": None}}
+    if not args.no_cpu_baseline:
+        from oracle import c_oracle
+        from oracle import bls12_381_ref as o_ref
+        ms_ = 1 << 11                                     # 2^11 equations = 6 144 Miller loops + 2 048 final exponentiations: a few seconds of CPU work
+        t1 = time.perf_counter()
+        cml, cused = c_oracle.pairing_batch(1, g1xy[:ms_ * ke], g1f[:ms_ * ke], g2xy[:ms_ * ke], g2f[:ms_ * ke], host_threads())
+        t_ml = time.perf_counter() - t1
+        # the two Fp12 products per equation are done here by the Python oracle on a 64-equation sample (checker only; ~1 % of an equation's work, not timed)
+        chk = 64
+        prods = np.zeros((chk, 72), dtype=np.uint64)
+        lim = lambda w: o_ref.fp12_unflatten([o_ref.fp_from_mont_limbs([int(x) for x in w[6 * i:6 * i + 6]]) for i in range(12)])
+        for s_ in range(chk):
+            acc = o_ref.fp12_mul(o_ref.fp12_mul(lim(cml[ke * s_]), lim(cml[ke * s_ + 1])), lim(cml[ke * s_ + 2]))
+            prods[s_] = np.concatenate([np.array(o_ref.fp_to_mont_limbs(c_), dtype=np.uint64) for c_ in o_ref.fp12_flatten(acc)])
+        t1 = time.perf_counter()
+        c_oracle.pairing_batch(2, cml[:ms_], None, None, None, host_threads())
+        t_fe = time.perf_counter() - t1
+        want_eq = c_oracle.pairing_batch(2, prods, None, None, None, 1)[0]
+        eq["gpu_result_matches"] = bool(np.array_equal(d_eq[:chk].cpu().numpy().view(np.uint64), want_eq))
+        eq["cpu_baseline"] = {"value": ms_ / (t_ml + t_fe), "unit": "equations/s", "cores": cused, "kind": "port",
+                              "sample": f"first 2^11 equations: 3 x 2^11 Miller loops + 2^11 final exponentiations of the C restatement (oracle/bls_oracle.c), OpenMP over {cused} threads; "
+                                        "the two Fp12 products per equation (~1 % of its work) are not in the CPU figure"}
+        if not eq["gpu_result_matches"]:
+            raise SystemExit("bench: GPU multi_miller_loop_many differs from the CPU oracle on the sample")
+    extras["verification_equations"] = eq
+    del d_off, d_eq
     # Fr transform of the MSM's scalar vector
     if n & (n - 1) == 0:
         log_n = int(np.log2(n))
@@ -551,6 +591,14 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
                               "roofline": {"bound": "int-valu", "kernel": "k_mul_batch<G2, lane pair>", "mac32_per_unit": MAC32_G2_MUL, "achieved": n2m * MAC32_G2_MUL / (mb2ms * 1e-3) / 1e12,
                                            "peak": peak / 1e12, "unit": "TMAC32/s", "frac": n2m * MAC32_G2_MUL / (mb2ms * 1e-3) / peak,
                                            "reference_algorithm_mac32_per_unit": MAC32_G2_MUL_REF}}
+    if not args.no_cpu_baseline:
+        from oracle import c_oracle
+        mm2 = 1 << 10
+        want_xy2, want_inf2 = c_oracle.mul_batch_affine(2, xy2m[:mm2], None, sb[:mm2], host_threads())
+        got_xy2, got_inf2 = ctx.batch_normalize(2, d_mo2[:mm2].cpu().numpy().view(np.uint64))
+        extras["g2_mul_batch"]["gpu_result_matches"] = bool(np.array_equal(got_xy2, want_xy2) and np.array_equal(got_inf2, want_inf2))
+        if not extras["g2_mul_batch"]["gpu_result_matches"]:
+            raise SystemExit("bench: GPU G2 mul_batch differs from the CPU oracle on the sample")
     del d_xy1, d_mo, d_xy2, d_mo2
     # fixed-base mode: resident window-shifted tables (13 windows of 20 bits, one bucket set, no window combine)
     t1 = time.perf_counter()

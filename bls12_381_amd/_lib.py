@@ -79,6 +79,23 @@ SIGNATURES = {
     "blsgpu_miller_loop_batch": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_multi_miller_loop": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_final_exponentiation_batch": (c_int, [c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_multi_miller_loop_many": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
+    "blsgpu_multi_miller_loop_many_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_sz, c_sz, c_int, c_vp]),
+    "blsgpu_wide_status": (ctypes.c_char_p, [c_vp]),
+    "blsgpu_group_create": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp)]),
+    "blsgpu_group_destroy": (None, [c_vp]),
+    "blsgpu_group_size": (c_int, [c_vp]),
+    "blsgpu_group_ctx": (c_vp, [c_vp, c_int]),
+    "blsgpu_group_bases_upload": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
+    "blsgpu_group_bases_from_scalars": (c_int, [c_vp, c_int, c_vp, c_sz, ctypes.POINTER(c_vp)]),
+    "blsgpu_group_bases_len": (c_sz, [c_vp]),
+    "blsgpu_group_bases_free": (None, [c_vp]),
+    "blsgpu_g1_msm_sharded": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_g2_msm_sharded": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_pairing_batch_sharded": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_miller_loop_batch_sharded": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_multi_miller_loop_sharded": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
+    "blsgpu_multi_miller_loop_many_sharded": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
     "blsgpu_fp12_product": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_pairing_batch_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_multi_miller_loop_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),

@@ -449,6 +449,28 @@ class Context:
         check(self.lib.blsgpu_multi_miller_loop(self.h, _ptr(g1), _ptr(f1), _ptr(g2), _ptr(f2), n, _ptr(out)), "multi_miller_loop")
         return out
 
+    def multi_miller_loop_many(self, g1_xy, g1_inf, g2_xy, g2_inf, offsets, final_exp=True):
+        """N independent `multi_miller_loop`s (CSR offsets over the terms) -> (N, 72): `MillerLoopResult`s, or -- final_exp --
+        `Gt`s (`blsgpu_multi_miller_loop_many`; pairings.rs:554-603 once per segment)"""
+        g1, f1, g2, f2, n = self._pair_args(g1_xy, g1_inf, g2_xy, g2_inf)
+        off = np.ascontiguousarray(np.asarray(offsets, dtype=np.uint64))
+        if off.ndim != 1 or off.shape[0] < 1 or int(off[-1]) != n:
+            raise ValueError("multi_miller_loop_many: offsets must be nseg + 1 values ending at the number of terms")
+        nseg = off.shape[0] - 1
+        out = np.zeros((nseg, 72), dtype=np.uint64)
+        check(self.lib.blsgpu_multi_miller_loop_many(self.h, _ptr(g1), _ptr(f1), _ptr(g2), _ptr(f2), _ptr(off), nseg, 1 if final_exp else 0, _ptr(out)),
+              "multi_miller_loop_many")
+        return out
+
+    def multi_miller_loop_many_device(self, d_g1, d_g2, d_offsets, nseg, total_terms, d_out, max_seg_terms=0, final_exp=True, d_g1_inf=None, d_g2_inf=None):
+        check(self.lib.blsgpu_multi_miller_loop_many_device(self.h, ctypes.c_void_p(d_g1), ctypes.c_void_p(d_g1_inf), ctypes.c_void_p(d_g2), ctypes.c_void_p(d_g2_inf),
+                                                            ctypes.c_void_p(d_offsets), nseg, total_terms, max_seg_terms, 1 if final_exp else 0, ctypes.c_void_p(d_out)),
+              "multi_miller_loop_many_device")
+
+    def wide_status(self):
+        """'' when the small-batch (wide) pairing programs are loaded, otherwise the reason they are not"""
+        return (self.lib.blsgpu_wide_status(self.h) or b"").decode()
+
     def final_exponentiation_batch(self, f):
         f = _u64(f, (-1, 72))
         out = np.zeros_like(f)
@@ -488,6 +510,111 @@ class Context:
         f = _u64(f, (-1, 72))
         out = np.zeros(72, dtype=np.uint64)
         check(self.lib.blsgpu_fp12_product(self.h, _ptr(f), f.shape[0], _ptr(out)), "fp12_product")
+        return out
+
+
+class GroupBases:
+    """Resident bases sharded over the members of a Group (`blsgpu_group_bases`): member k holds a contiguous slice."""
+
+    def __init__(self, group, handle, gid):
+        self.group, self.handle, self.gid = group, handle, gid
+
+    def __len__(self):
+        return int(_lib.load().blsgpu_group_bases_len(self.handle))
+
+    def free(self):
+        if self.handle:
+            _lib.load().blsgpu_group_bases_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Group:
+    """The hot path sharded over several GPUs of one node from ONE process (`blsgpu_group`, include/bls12_381_hip.h): one
+    context and one host thread per listed device; partial results (one group element per member) are folded with `Sum`
+    (g1.rs:161-171) / `MillerLoopResult + MillerLoopResult` (pairings.rs:179-186).  A device may be listed more than once."""
+
+    def __init__(self, devices):
+        self.lib = _lib.load()
+        devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        h = ctypes.c_void_p()
+        check(self.lib.blsgpu_group_create(devs, len(devices), ctypes.byref(h)), "group_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.blsgpu_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(self.lib.blsgpu_group_size(self.h))
+
+    def set_assume_subgroup(self, on):
+        for k in range(len(self)):
+            check(self.lib.blsgpu_set_assume_subgroup(ctypes.c_void_p(self.lib.blsgpu_group_ctx(self.h, k)), 1 if on else 0), "set_assume_subgroup")
+
+    def upload_bases(self, group, xy, infinity=None):
+        w = 12 if group == 1 else 24
+        xy = _u64(xy, (-1, w))
+        n = xy.shape[0]
+        inf = _flags(infinity, n)
+        h = ctypes.c_void_p()
+        check(self.lib.blsgpu_group_bases_upload(self.h, group, _ptr(xy), _ptr(inf), n, ctypes.byref(h)), "group_bases_upload")
+        return GroupBases(self, h, group)
+
+    def bases_from_scalars(self, group, scalars):
+        sb = scalars_to_bytes(scalars)
+        h = ctypes.c_void_p()
+        check(self.lib.blsgpu_group_bases_from_scalars(self.h, group, _ptr(sb), sb.shape[0], ctypes.byref(h)), "group_bases_from_scalars")
+        return GroupBases(self, h, group)
+
+    def msm(self, bases, scalars):
+        sb = scalars_to_bytes(scalars)
+        out = np.zeros(18 if bases.gid == 1 else 36, dtype=np.uint64)
+        fn = self.lib.blsgpu_g1_msm_sharded if bases.gid == 1 else self.lib.blsgpu_g2_msm_sharded
+        check(fn(self.h, bases.handle, _ptr(sb), sb.shape[0], _ptr(out)), "msm_sharded")
+        return out
+
+    _pair_args = Context._pair_args
+
+    def pairing_batch(self, g1_xy, g1_inf, g2_xy, g2_inf):
+        g1, f1, g2, f2, n = self._pair_args(g1_xy, g1_inf, g2_xy, g2_inf)
+        out = np.zeros((n, 72), dtype=np.uint64)
+        check(self.lib.blsgpu_pairing_batch_sharded(self.h, _ptr(g1), _ptr(f1), _ptr(g2), _ptr(f2), n, _ptr(out)), "pairing_batch_sharded")
+        return out
+
+    def miller_loop_batch(self, g1_xy, g1_inf, g2_xy, g2_inf):
+        g1, f1, g2, f2, n = self._pair_args(g1_xy, g1_inf, g2_xy, g2_inf)
+        out = np.zeros((n, 72), dtype=np.uint64)
+        check(self.lib.blsgpu_miller_loop_batch_sharded(self.h, _ptr(g1), _ptr(f1), _ptr(g2), _ptr(f2), n, _ptr(out)), "miller_loop_batch_sharded")
+        return out
+
+    def multi_miller_loop(self, g1_xy, g1_inf, g2_xy, g2_inf, final_exp=False):
+        g1, f1, g2, f2, n = self._pair_args(g1_xy, g1_inf, g2_xy, g2_inf)
+        out = np.zeros(72, dtype=np.uint64)
+        check(self.lib.blsgpu_multi_miller_loop_sharded(self.h, _ptr(g1), _ptr(f1), _ptr(g2), _ptr(f2), n, 1 if final_exp else 0, _ptr(out)), "multi_miller_loop_sharded")
+        return out
+
+    def multi_miller_loop_many(self, g1_xy, g1_inf, g2_xy, g2_inf, offsets, final_exp=True):
+        g1, f1, g2, f2, n = self._pair_args(g1_xy, g1_inf, g2_xy, g2_inf)
+        off = np.ascontiguousarray(np.asarray(offsets, dtype=np.uint64))
+        if off.ndim != 1 or off.shape[0] < 1 or int(off[-1]) != n:
+            raise ValueError("multi_miller_loop_many: offsets must be nseg + 1 values ending at the number of terms")
+        nseg = off.shape[0] - 1
+        out = np.zeros((nseg, 72), dtype=np.uint64)
+        check(self.lib.blsgpu_multi_miller_loop_many_sharded(self.h, _ptr(g1), _ptr(f1), _ptr(g2), _ptr(f2), _ptr(off), nseg, 1 if final_exp else 0, _ptr(out)),
+              "multi_miller_loop_many_sharded")
         return out
 
 
@@ -864,6 +991,27 @@ def multi_miller_loop(terms):
     for i, (p, prep) in enumerate(terms):
         g1[i], f1[i], g2[i], f2[i] = p.xy, p.infinity, prep.q.xy, prep.q.infinity
     return MillerLoopResult(default_context().multi_miller_loop(g1, f1, g2, f2))
+
+
+def multi_miller_loop_many(equations, final_exp=True):
+    """One `multi_miller_loop` per equation (a list of lists of `(&G1Affine, &G2Prepared)` terms) in ONE device call: the bulk
+    form of the pattern `E::multi_miller_loop(&terms).final_exponentiation()` of signature verification (pairings.rs:554-603,
+    817-824).  Returns a list of `Gt` (final_exp) or `MillerLoopResult`."""
+    eqs = [list(e) for e in equations]
+    n = sum(len(e) for e in eqs)
+    g1 = np.zeros((n, 12), dtype=np.uint64)
+    g2 = np.zeros((n, 24), dtype=np.uint64)
+    f1 = np.zeros(n, dtype=np.uint8)
+    f2 = np.zeros(n, dtype=np.uint8)
+    off = np.zeros(len(eqs) + 1, dtype=np.uint64)
+    i = 0
+    for s, e in enumerate(eqs):
+        for p, prep in e:
+            g1[i], f1[i], g2[i], f2[i] = p.xy, p.infinity, prep.q.xy, prep.q.infinity
+            i += 1
+        off[s + 1] = i
+    out = default_context().multi_miller_loop_many(g1, f1, g2, f2, off, final_exp)
+    return [Gt(v) if final_exp else MillerLoopResult(v) for v in out]
 
 
 def _msm(group, bases, scalars):

@@ -93,12 +93,14 @@ struct blsgpu_ctx {
   u32* d_wide = nullptr;               // the wide programs (bls12_381_amd/wide_prog.bin, generated at build time by tools/gen_wide_prog.py) in device memory
   size_t wide_off[4] = {0, 0, 0, 0};   // word offsets of the Miller-loop / final-exponentiation programs: [0..1] 1024 lanes x 4 limbs, [2..3] 512 lanes x 8 limbs
   int wide_state = 0;                  // 0 = not tried, 1 = loaded, -1 = unavailable (the quad kernels take every size then)
+  std::string wide_why;                // ... and why (blsgpu_wide_status)
   bool assume_subgroup = false;        // blsgpu_set_assume_subgroup: skip the subgroup check of uploaded bases (the caller vouches for them)
   bool no_glv = false;                 // A/B hook (env BLSGPU_NO_GLV at create): plain 256-bit windows (no GLV for G1, no psi decomposition for G2)
   bool force_slow_sort = false;        // test hook (env BLSGPU_FORCE_SLOW_SORT at create): the global-atomic sort used beyond 2^24 points
   hipStream_t acc_stream = nullptr;     // bucket accumulation of pipelined calls (the caller's stream is never blocked)
   hipEvent_t ev[9] = {};
-  u32* d_status = nullptr;              // [0]: sticky "a scalar was not canonical (>= r)" flag of the ASYNCHRONOUS (device-pointer) calls, reported by blsgpu_synchronize / blsgpu_join;
+  u32* d_status = nullptr;              // [0]: sticky "a scalar was not canonical (>= r)" flag of the ASYNCHRONOUS (device-pointer) calls, reported and cleared by blsgpu_synchronize
+                                        // (blsgpu_join is a stream-level wait without a host round trip and reports nothing);
                                         // [1]: scratch of the subgroup check; [2]: the flag of the synchronous call in progress (cleared before it, fetched with its result)
   std::atomic<size_t> owner_thread{0};  // CtxClaim: the host thread inside an entry point (0 = none)
   int owner_depth = 0;
@@ -124,7 +126,7 @@ struct blsgpu_ctx {
   } slot[NSLOT];
   int next_slot = 0;
   unsigned long long msm_calls = 0;
-  DevBuf result, io_a, io_b, io_c, io_d, io_out, flags_a, flags_b;
+  DevBuf result, io_a, io_b, io_c, io_d, io_e, io_f, io_out, flags_a, flags_b;
   DevBuf fr_tw[2], fr_tmp, fr_ninv;     // Fr transform: twiddle tables (forward / inverse), permutation target, n^-1
   int fr_tw_log[2] = {-1, -1};
   int fr_ninv_log = -1;
@@ -142,7 +144,7 @@ struct blsgpu_bases {
   // there and nowhere else on the curve, while the reference's `multiply` (g1.rs:754-774) is defined for every curve
   // point.  subgroup: 1 = every base passed is_torsion_free on the device (or was built as [k]G), 2 = the caller vouched
   // for the set (blsgpu_set_assume_subgroup), 0 = at least one base is outside the subgroup -> plain windows, no images,
-  // 3 = not tested because the set is too large for the split anyway (plain windows).
+  // 3 = not tested: a one-shot upload (the test would cost more than the split saves) or a set too large for the split anyway (plain windows).
   int subgroup = 0;
   // optional window-shifted tables: table[w * n + i] = [2^(table_c * w)] P_i   (blsgpu_bases_precompute)
   u32* table = nullptr; int table_c = 0, table_w = 0;
@@ -440,7 +442,15 @@ extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
   c->device = device;
   c->force_slow_sort = getenv("BLSGPU_FORCE_SLOW_SORT") != nullptr;
   c->no_glv = getenv("BLSGPU_NO_GLV") != nullptr;
-  if (const char* v = getenv("BLSGPU_PAIRING_LAYOUT")) c->pairing_layout = (v[0] == 'q' || v[0] == '4') ? 4 : (v[0] == 'w') ? 256 : (v[0] == 'a') ? 0 : 2;
+  if (const char* v = getenv("BLSGPU_PAIRING_LAYOUT")) {
+    // exact names only: a typo must not silently select the slowest kernels
+    const std::string s(v);
+    if (s == "auto" || s == "0" || s.empty()) c->pairing_layout = 0;
+    else if (s == "pair" || s == "2") c->pairing_layout = 2;
+    else if (s == "quad" || s == "4") c->pairing_layout = 4;
+    else if (s == "wide" || s == "256") c->pairing_layout = 256;
+    else { delete c; return bad("blsgpu_create: BLSGPU_PAIRING_LAYOUT must be one of auto, pair, quad, wide"); }
+  }
   if (const char* v = getenv("BLSGPU_ITEM_CAP")) { long k = atol(v); if (k >= 8 && k <= ITEM_CAP_MAX) c->item_cap = (u32)k; }
   int rc = ctx_init(c);
   if (rc != BLSGPU_OK) { blsgpu_destroy(c); return rc; }       // destroy tolerates the half-built context (null handles are skipped)
@@ -453,7 +463,7 @@ extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
   hipDeviceSynchronize();
   if (c->d_status) hipFree(c->d_status);
   if (c->d_wide) hipFree(c->d_wide);
-  DevBuf* bufs[] = {&c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_out, &c->flags_a, &c->flags_b, &c->fr_tw[0], &c->fr_tw[1], &c->fr_tmp, &c->fr_ninv};
+  DevBuf* bufs[] = {&c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->io_f, &c->io_out, &c->flags_a, &c->flags_b, &c->fr_tw[0], &c->fr_tw[1], &c->fr_tmp, &c->fr_ninv};
   for (auto b : bufs) b->release();
   for (auto& sl : c->slot) {
     DevBuf* sb[] = {&sl.ent, &sl.sorted, &sl.hist, &sl.offs, &sl.cursor, &sl.bsum, &sl.items, &sl.heavy, &sl.ctrl, &sl.glv,
@@ -591,8 +601,12 @@ static int bases_make_endo(blsgpu_ctx* c, blsgpu_bases* b, bool trusted) {
   if (e != hipSuccess) { hipFree(b->endo); b->endo = nullptr; return fail("k_bases_endo", e, __LINE__); }
   return BLSGPU_OK;
 }
+// oneshot: the set serves exactly one MSM (blsgpu_g{1,2}_msm_host / *_msm_bytes).  The subgroup test costs ~2 k (G1) / ~6 k (G2)
+// field multiplications per point -- several times the MSM it would speed up (2^20 G1 points: 23 ms of test for a 3 ms MSM) -- so
+// unless the caller vouches for the set it is NOT tested and keeps no images: the call runs on plain 256-bit windows, which are the
+// complete-formula bucket method and exact for every curve point (state 3).  Resident uploads amortise the test over their MSMs.
 template <class F>
-static int bases_import(blsgpu_ctx* c, const void* d_xy, const void* d_inf, size_t n, blsgpu_bases** out) {
+static int bases_import(blsgpu_ctx* c, const void* d_xy, const void* d_inf, size_t n, blsgpu_bases** out, bool oneshot = false) {
   blsgpu_bases* b = new blsgpu_bases();
   b->group = GroupTag<F>::id; b->n = n; b->device = c->device;
   size_t bytes = (n ? n : 1) * Store<F>::AFF_WORDS * 4;
@@ -604,19 +618,20 @@ static int bases_import(blsgpu_ctx* c, const void* d_xy, const void* d_inf, size
     if (e == hipSuccess) e = hipEventRecord(b->ev_ready, c->stream);
     if (e != hipSuccess) { bases_drop(b); return fail("k_bases_import", e, __LINE__); }
   }
+  if (oneshot && !c->assume_subgroup) { b->subgroup = 3; *out = b; return BLSGPU_OK; }
   if (int rc = bases_make_endo(c, b, false)) { bases_drop(b); return rc; }
   *out = b;
   return BLSGPU_OK;
 }
 template <class F>
-static int bases_upload(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, blsgpu_bases** out) {
+static int bases_upload(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, blsgpu_bases** out, bool oneshot = false) {
   if (!c || !out || (n && !xy)) return bad("bases_upload: NULL argument");
   HIPCHK(hipSetDevice(c->device));
   size_t xb = n * 2 * Wire<F>::WORDS * 4;
   if (c->io_a.reserve(xb ? xb : 16) || c->flags_a.reserve(n ? n : 16)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
   if (n) HIPCHK(hipMemcpyAsync(c->io_a.p, xy, xb, hipMemcpyHostToDevice, c->stream));
   if (n && inf) HIPCHK(hipMemcpyAsync(c->flags_a.p, inf, n, hipMemcpyHostToDevice, c->stream));
-  int rc = bases_import<F>(c, c->io_a.p, inf ? c->flags_a.p : nullptr, n, out);
+  int rc = bases_import<F>(c, c->io_a.p, inf ? c->flags_a.p : nullptr, n, out, oneshot);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
   return BLSGPU_OK;
@@ -1098,7 +1113,7 @@ extern "C" int blsgpu_g2_msm_many(blsgpu_ctx* c, const blsgpu_bases* b, size_t f
 template <class F>
 static int msm_oneshot(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) {
   blsgpu_bases* b = nullptr;
-  int rc = bases_upload<F>(c, xy, inf, n, &b);
+  int rc = bases_upload<F>(c, xy, inf, n, &b, true);
   if (rc) return rc;
   rc = msm_host<F>(c, b, 0, s, n, out);
   blsgpu_bases_free(b);
@@ -1497,6 +1512,15 @@ extern "C" int blsgpu_fr_ntt(blsgpu_ctx* c, uint64_t* data, int log_n, int inver
 // quad kernels' flat ~6.1 ms
 constexpr size_t WIDE_ONE_PER_CU = 256;
 constexpr size_t WIDE_AUTO_MAX = 1536;
+static int wide_unavailable(blsgpu_ctx* c, const std::string& why) {
+  c->wide_why = why;
+  // with the default `auto` layout the quad kernels take small batches too (correct, but ~6 ms instead of ~1.1 ms for one pairing):
+  // say so once per process instead of degrading in silence
+  static std::atomic<bool> told{false};
+  if (c->pairing_layout == 0 && !told.exchange(true))
+    fprintf(stderr, "libblsgpu: the wide (small-batch) pairing path is unavailable -- %s; batches of <= %zu pairings run on the quad kernels\n", why.c_str(), WIDE_AUTO_MAX);
+  return -1;
+}
 static int wide_load(blsgpu_ctx* c) {
   if (c->wide_state) return c->wide_state;
   c->wide_state = -1;
@@ -1504,31 +1528,36 @@ static int wide_load(blsgpu_ctx* c) {
   if (const char* e = getenv("BLSGPU_WIDE_PROG")) path = e;
   else {
     Dl_info info;
-    if (!dladdr((const void*)&blsgpu_create, &info) || !info.dli_fname) return -1;
+    if (!dladdr((const void*)&blsgpu_create, &info) || !info.dli_fname) return wide_unavailable(c, "the library's own path is unknown (static link?): set BLSGPU_WIDE_PROG to wide_prog.bin");
     path = info.dli_fname;
     const size_t slash = path.find_last_of('/');
     path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/wide_prog.bin";
   }
   FILE* fh = fopen(path.c_str(), "rb");
-  if (!fh) return -1;
+  if (!fh) return wide_unavailable(c, path + " cannot be opened (generate it: tools/gen_wide_prog.py, or __graft_entry__.build())");
   std::vector<u32> w;
   u32 buf[4096]; size_t got;
   while ((got = fread(buf, 4, 4096, fh)) > 0) w.insert(w.end(), buf, buf + got);
   fclose(fh);
-  if (w.size() < 32 || w[0] != WIDE_BLOB_MAGIC || w[1] != 4) return -1;
+  if (w.size() < 32 || w[0] != WIDE_BLOB_MAGIC || w[1] != 4) return wide_unavailable(c, path + " is not a wide program file (truncated or foreign)");
+  if (w[15] != WIDE_FORMAT_VERSION) return wide_unavailable(c, path + " has another format version than this library (stale file: regenerate it)");
   static const u32 cfg[4][2] = {{1024, 4}, {1024, 4}, {512, 8}, {512, 8}};
   for (int k = 0; k < 4; k++) {
     const size_t off = w[2 + 2 * k], len = w[3 + 2 * k];
     // a program is only usable by the kernel it was generated for: same lanes per workgroup and limbs per product lane, slots and accumulators within the LDS arrays
     if (off + len > w.size() || len < 16 || (off & 3) || w[off] != WIDE_PROG_MAGIC || w[off + 2] > (u32)WIDE_MAX_SLOTS || w[off + 10] != cfg[k][0] ||
         w[off + 11] != cfg[k][1] || w[off + 12] >= (u32)WIDE_MAX_SLOTS || w[off + 13] > (u32)WIDE_MAX_ACC || (w[off + 7] & 3) || (w[off + 8] & 3) || (w[off + 9] & 1))
-      return -1;
+      return wide_unavailable(c, path + " was generated for another kernel configuration");
     c->wide_off[k] = off;
   }
-  if (hipMalloc((void**)&c->d_wide, w.size() * 4) != hipSuccess) { (void)hipGetLastError(); c->d_wide = nullptr; return -1; }
-  if (hipMemcpy(c->d_wide, w.data(), w.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); hipFree(c->d_wide); c->d_wide = nullptr; return -1; }
+  if (hipMalloc((void**)&c->d_wide, w.size() * 4) != hipSuccess) { (void)hipGetLastError(); c->d_wide = nullptr; return wide_unavailable(c, "hipMalloc for the wide programs failed"); }
+  if (hipMemcpy(c->d_wide, w.data(), w.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); hipFree(c->d_wide); c->d_wide = nullptr; return wide_unavailable(c, "hipMemcpy of the wide programs failed"); }
   c->wide_state = 1;
   return 1;
+}
+static int wide_missing(blsgpu_ctx* c) {
+  g_err = "pairing: BLSGPU_PAIRING_LAYOUT=wide but the wide programs are unavailable: " + c->wide_why;
+  return BLSGPU_ERR_ARG;
 }
 // which kernels take a batch of n pairings / Miller loops / final exponentiations: 256 = wide, 4 = quad, 2 = lane pair
 static int pairing_layout_for(blsgpu_ctx* c, size_t n) {
@@ -1540,7 +1569,13 @@ extern "C" int blsgpu_pairing_layout(blsgpu_ctx* c, size_t n) { CTX_CLAIM(c);
   if (!c) return bad("pairing_layout: NULL context");
   if (hipSetDevice(c->device) != hipSuccess) { (void)hipGetLastError(); return bad("pairing_layout: hipSetDevice failed"); }
   const int l = pairing_layout_for(c, n);
-  return l < 0 ? bad("pairing_layout: BLSGPU_PAIRING_LAYOUT=wide but wide_prog.bin is missing or was generated for another kernel configuration") : l;
+  return l < 0 ? wide_missing(c) : l;
+}
+// "" when the wide programs are loaded, otherwise the reason they are not (also tried now if no pairing call has tried yet)
+extern "C" const char* blsgpu_wide_status(blsgpu_ctx* c) {
+  if (!c) return "NULL context";
+  if (hipSetDevice(c->device) != hipSuccess) { (void)hipGetLastError(); return "hipSetDevice failed"; }
+  return wide_load(c) == 1 ? "" : c->wide_why.c_str();
 }
 static void wide_launch(blsgpu_ctx* c, int mode, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) {
   if (n <= WIDE_ONE_PER_CU)
@@ -1553,7 +1588,7 @@ static void wide_launch(blsgpu_ctx* c, int mode, const void* g1, const void* g1i
 static int pairing_launch(blsgpu_ctx* c, int mode, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) {
   // mode 0: full pairing, 1: Miller loop only
   const int layout = pairing_layout_for(c, n);
-  if (layout < 0) return bad("pairing: BLSGPU_PAIRING_LAYOUT=wide but wide_prog.bin is missing or was generated for another kernel configuration");
+  if (layout < 0) return wide_missing(c);
   if (layout == 256) { wide_launch(c, mode, g1, g1inf, g2, g2inf, n, out); LAUNCHCHK(); return BLSGPU_OK; }
   if (layout == 4) {
     hipLaunchKernelGGL(k_pairing_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, mode, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2,
@@ -1607,7 +1642,7 @@ extern "C" int blsgpu_final_exponentiation_device(blsgpu_ctx* c, const void* in,
   if (!n) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
   const int layout = pairing_layout_for(c, n);
-  if (layout < 0) return bad("pairing: BLSGPU_PAIRING_LAYOUT=wide but wide_prog.bin is missing or was generated for another kernel configuration");
+  if (layout < 0) return wide_missing(c);
   if (layout == 256) wide_launch(c, 2, in, nullptr, nullptr, nullptr, n, out);
   else if (layout == 4) hipLaunchKernelGGL(k_final_exp_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, (const u32*)in, (u32*)out, n);
   else hipLaunchKernelGGL(k_final_exp, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)in, (u32*)out, n);
@@ -1682,6 +1717,70 @@ extern "C" int blsgpu_multi_miller_loop(blsgpu_ctx* c, const uint64_t* g1, const
   HIPCHK(hipStreamSynchronize(c->stream));
   return BLSGPU_OK;
 }
+// ---- N independent multi_miller_loops in one call (bulk signature verification: N equations of k pairings each) -------------------
+// Segment s = terms [off[s], off[s + 1]).  Miller values per term on the throughput kernels (or the wide path when there are few),
+// one segmented Fp12 product, one batched final exponentiation.  The product of independently squared per-term values is the
+// reference's shared-accumulator value exactly (Fp12 is a field: same element, canonical limbs).
+static int final_exp_launch(blsgpu_ctx* c, const void* in, size_t n, void* out) {
+  const int layout = pairing_layout_for(c, n);
+  if (layout < 0) return wide_missing(c);
+  if (layout == 256) wide_launch(c, 2, in, nullptr, nullptr, nullptr, n, out);
+  else if (layout == 4) hipLaunchKernelGGL(k_final_exp_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, (const u32*)in, (u32*)out, n);
+  else hipLaunchKernelGGL(k_final_exp, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)in, (u32*)out, n);
+  LAUNCHCHK();
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_multi_miller_loop_many_device(blsgpu_ctx* c, const void* g1, const void* g1inf, const void* g2, const void* g2inf, const void* d_offsets, size_t nseg,
+                                                    size_t total, size_t max_seg_terms, int final_exp, void* out) { CTX_CLAIM(c);
+  if (!c || (nseg && (!d_offsets || !out)) || (total && (!g1 || !g2))) return bad("multi_miller_loop_many: NULL argument");
+  if (!nseg) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  const int parts = (max_seg_terms == 0 || max_seg_terms > 32) ? 32 : 1;
+  if (c->io_out.reserve((total ? total : 1) * 576) || (parts > 1 && c->io_c.reserve(nseg * parts * 576)) || (final_exp && c->io_d.reserve(nseg * 576))) {
+    g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP;
+  }
+  if (total) { int rc = pairing_launch(c, 1, g1, g1inf, g2, g2inf, total, c->io_out.p); if (rc) return rc; }
+  u32* prod = final_exp ? c->io_d.as<u32>() : (u32*)out;
+  hipLaunchKernelGGL(k_fp12_prod_seg_quad, dim3(nblk(nseg * parts * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, c->io_out.as<u32>(), (const unsigned long long*)d_offsets,
+                     nseg, total, parts, parts > 1 ? c->io_c.as<u32>() : prod);
+  LAUNCHCHK();
+  if (parts > 1) {
+    hipLaunchKernelGGL(k_fp12_prod_quad, dim3(nblk(nseg * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, c->io_c.as<u32>(), prod, nseg * parts, nseg, parts);
+    LAUNCHCHK();
+  }
+  return final_exp ? final_exp_launch(c, prod, nseg, out) : BLSGPU_OK;
+}
+extern "C" int blsgpu_multi_miller_loop_many(blsgpu_ctx* c, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, const uint64_t* offsets, size_t nseg,
+                                             int final_exp, uint64_t* out) { CTX_CLAIM(c);
+  if (!c || (nseg && (!offsets || !out))) return bad("multi_miller_loop_many: NULL argument");
+  if (!nseg) return BLSGPU_OK;
+  if (offsets[0] != 0) return bad("multi_miller_loop_many: offsets[0] must be 0");
+  size_t max_k = 0;
+  for (size_t i = 0; i < nseg; i++) {
+    if (offsets[i] > offsets[i + 1]) return bad("multi_miller_loop_many: offsets must be non-decreasing");
+    if (offsets[i + 1] - offsets[i] > max_k) max_k = (size_t)(offsets[i + 1] - offsets[i]);
+  }
+  const size_t n = (size_t)offsets[nseg];
+  if (n && (!g1 || !g2)) return bad("multi_miller_loop_many: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->io_a.reserve(n ? n * 96 : 16) || c->io_b.reserve(n ? n * 192 : 16) || c->flags_a.reserve(n ? n : 16) || c->flags_b.reserve(n ? n : 16) || c->io_e.reserve((nseg + 1) * 8) ||
+      c->io_f.reserve(nseg * 576)) {
+    g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP;
+  }
+  if (n) {
+    HIPCHK(hipMemcpyAsync(c->io_a.p, g1, n * 96, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->io_b.p, g2, n * 192, hipMemcpyHostToDevice, c->stream));
+    if (g1inf) HIPCHK(hipMemcpyAsync(c->flags_a.p, g1inf, n, hipMemcpyHostToDevice, c->stream));
+    if (g2inf) HIPCHK(hipMemcpyAsync(c->flags_b.p, g2inf, n, hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCHK(hipMemcpyAsync(c->io_e.p, offsets, (nseg + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  int rc = blsgpu_multi_miller_loop_many_device(c, c->io_a.p, g1inf ? c->flags_a.p : nullptr, c->io_b.p, g2inf ? c->flags_b.p : nullptr, c->io_e.p, nseg, n, max_k ? max_k : 1, final_exp,
+                                                c->io_f.p);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(out, c->io_f.p, nseg * 576, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
 extern "C" int blsgpu_final_exponentiation_batch(blsgpu_ctx* c, const uint64_t* in, size_t n, uint64_t* out) { CTX_CLAIM(c);
   if (!c || (n && (!in || !out))) return bad("final_exponentiation: NULL argument");
   if (!n) return BLSGPU_OK;
@@ -1689,7 +1788,7 @@ extern "C" int blsgpu_final_exponentiation_batch(blsgpu_ctx* c, const uint64_t* 
   if (c->io_a.reserve(n * 576) || c->io_out.reserve(n * 576)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
   HIPCHK(hipMemcpyAsync(c->io_a.p, in, n * 576, hipMemcpyHostToDevice, c->stream));
   const int layout = pairing_layout_for(c, n);
-  if (layout < 0) return bad("pairing: BLSGPU_PAIRING_LAYOUT=wide but wide_prog.bin is missing or was generated for another kernel configuration");
+  if (layout < 0) return wide_missing(c);
   if (layout == 256) wide_launch(c, 2, c->io_a.p, nullptr, nullptr, nullptr, n, c->io_out.p);
   else if (layout == 4) hipLaunchKernelGGL(k_final_exp_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, c->io_a.as<u32>(), c->io_out.as<u32>(), n);
   else hipLaunchKernelGGL(k_final_exp, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, c->io_a.as<u32>(), c->io_out.as<u32>(), n);
@@ -1772,4 +1871,166 @@ extern "C" int blsgpu_g1_to_bytes_batch(blsgpu_ctx* c, const uint64_t* xy, const
 }
 extern "C" int blsgpu_g2_to_bytes_batch(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, int compressed, uint8_t* out) { CTX_CLAIM(c);
   return point_encode<Fp2Policy>(c, xy, inf, n, compressed, out);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// device groups: the hot path sharded over the GPUs of ONE node from ONE process
+// ---------------------------------------------------------------------------------------------------
+// MSMs, batches of pairings and multi_miller_loops shard over their independent terms in contiguous slices; every
+// member reduces its slice to ONE group element (144 B G1 / 288 B G2 / 576 B Fp12) and the members' partial results are folded with
+// the reference's own operators -- `Sum for G1Projective` (g1.rs:161-171, g2.rs:162-172), `MillerLoopResult + MillerLoopResult`
+// (pairings.rs:179-186) -- followed by ONE final exponentiation (:48-176).  Inside one process the exchange needs no collective
+// library: each member hands its few hundred bytes back through host memory and member 0 folds them on its device.  One context and
+// one host thread per member (a context is single-threaded by contract); a device may be listed more than once (logical members on
+// one GPU: how the single-GPU tests exercise the 8-member code path).
+struct blsgpu_group { std::vector<blsgpu_ctx*> ctx; };
+struct blsgpu_group_bases { int group = 1; size_t n = 0; std::vector<blsgpu_bases*> part; };
+
+// contiguous slice [lo, hi) of n items owned by member k of w (sizes differ by at most one; the same rule as distributed.shard_range)
+static void group_range(size_t n, size_t k, size_t w, size_t& lo, size_t& hi) {
+  const size_t q = n / w, r = n % w;
+  lo = k * q + (k < r ? k : r);
+  hi = lo + q + (k < r ? 1 : 0);
+}
+// fn(member, context) on one host thread per member (member 0 on the caller's); the first failing member's code and message win
+template <class Fn> static int group_run(blsgpu_group* g, Fn fn) {
+  const size_t w = g->ctx.size();
+  std::vector<int> rc(w, BLSGPU_OK);
+  std::vector<std::string> msg(w);
+  auto body = [&](size_t i) { rc[i] = fn(i, g->ctx[i]); if (rc[i]) msg[i] = g_err; };
+  std::vector<std::thread> th;
+  th.reserve(w);
+  for (size_t i = 1; i < w; i++) th.emplace_back(body, i);
+  body(0);
+  for (auto& t : th) t.join();
+  for (size_t i = 0; i < w; i++)
+    if (rc[i]) { g_err = "group member " + std::to_string(i) + ": " + msg[i]; return rc[i]; }
+  return BLSGPU_OK;
+}
+extern "C" void blsgpu_group_destroy(blsgpu_group* g) {
+  if (!g) return;
+  for (auto c : g->ctx) blsgpu_destroy(c);
+  delete g;
+}
+extern "C" int blsgpu_group_create(const int* devices, int ndev, blsgpu_group** out) {
+  if (!out || !devices || ndev <= 0 || ndev > 64) return bad("group_create: bad argument (1..64 members)");
+  blsgpu_group* g = new blsgpu_group();
+  for (int i = 0; i < ndev; i++) {
+    blsgpu_ctx* c = nullptr;
+    int rc = blsgpu_create(devices[i], &c);
+    if (rc) { const std::string keep = g_err; blsgpu_group_destroy(g); g_err = "group_create: member " + std::to_string(i) + ": " + keep; return rc; }
+    g->ctx.push_back(c);
+  }
+  *out = g;
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_group_size(const blsgpu_group* g) { return g ? (int)g->ctx.size() : 0; }
+extern "C" blsgpu_ctx* blsgpu_group_ctx(blsgpu_group* g, int member) { return (g && member >= 0 && (size_t)member < g->ctx.size()) ? g->ctx[(size_t)member] : nullptr; }
+extern "C" void blsgpu_group_bases_free(blsgpu_group_bases* b) {
+  if (!b) return;
+  for (auto p : b->part) blsgpu_bases_free(p);
+  delete b;
+}
+extern "C" size_t blsgpu_group_bases_len(const blsgpu_group_bases* b) { return b ? b->n : 0; }
+// member k keeps points [lo_k, hi_k) resident on its device
+extern "C" int blsgpu_group_bases_upload(blsgpu_group* g, int group, const uint64_t* xy, const uint8_t* inf, size_t n, blsgpu_group_bases** out) {
+  if (!g || !out || (n && !xy) || (group != 1 && group != 2)) return bad("group_bases_upload: bad argument");
+  blsgpu_group_bases* b = new blsgpu_group_bases();
+  b->group = group; b->n = n; b->part.assign(g->ctx.size(), nullptr);
+  const size_t w = g->ctx.size(), words = group == 1 ? 12 : 24;
+  int rc = group_run(g, [&](size_t k, blsgpu_ctx* c) {
+    size_t lo, hi; group_range(n, k, w, lo, hi);
+    return group == 1 ? blsgpu_g1_bases_upload(c, xy + lo * words, inf ? inf + lo : nullptr, hi - lo, &b->part[k])
+                      : blsgpu_g2_bases_upload(c, xy + lo * words, inf ? inf + lo : nullptr, hi - lo, &b->part[k]);
+  });
+  if (rc) { const std::string keep = g_err; blsgpu_group_bases_free(b); g_err = keep; return rc; }
+  *out = b;
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_group_bases_from_scalars(blsgpu_group* g, int group, const uint8_t* scalars, size_t n, blsgpu_group_bases** out) {
+  if (!g || !out || (n && !scalars) || (group != 1 && group != 2)) return bad("group_bases_from_scalars: bad argument");
+  blsgpu_group_bases* b = new blsgpu_group_bases();
+  b->group = group; b->n = n; b->part.assign(g->ctx.size(), nullptr);
+  const size_t w = g->ctx.size();
+  int rc = group_run(g, [&](size_t k, blsgpu_ctx* c) {
+    size_t lo, hi; group_range(n, k, w, lo, hi);
+    return blsgpu_bases_from_scalars(c, group, scalars + lo * 32, hi - lo, &b->part[k]);
+  });
+  if (rc) { const std::string keep = g_err; blsgpu_group_bases_free(b); g_err = keep; return rc; }
+  *out = b;
+  return BLSGPU_OK;
+}
+// sum_{i < n} scalars[i] * bases[i]: member k multiplies the part of [0, n) that lies in ITS resident slice, member 0 folds the w partial sums
+template <int G>
+static int msm_sharded(blsgpu_group* g, const blsgpu_group_bases* b, const uint8_t* scalars, size_t n, uint64_t* out) {
+  constexpr size_t PW = G == 1 ? 18 : 36;
+  if (!g || !b || !out || (n && !scalars)) return bad("msm_sharded: NULL argument");
+  if (b->group != G) return bad("msm_sharded: bases belong to the other group");
+  if (b->part.size() != g->ctx.size()) return bad("msm_sharded: the bases were sharded over another group");
+  if (n > b->n) return bad("msm_sharded: more scalars than resident bases");
+  const size_t w = g->ctx.size();
+  std::vector<uint64_t> parts(w * PW);
+  int rc = group_run(g, [&](size_t k, blsgpu_ctx* c) {
+    size_t lo, hi; group_range(b->n, k, w, lo, hi);
+    const size_t end = hi < n ? hi : n, cnt = end > lo ? end - lo : 0;
+    const uint8_t* s = scalars + (cnt ? lo * 32 : 0);
+    return G == 1 ? blsgpu_g1_msm(c, b->part[k], 0, s, cnt, parts.data() + k * PW) : blsgpu_g2_msm(c, b->part[k], 0, s, cnt, parts.data() + k * PW);
+  });
+  if (rc) return rc;
+  return G == 1 ? blsgpu_g1_sum(g->ctx[0], parts.data(), w, out) : blsgpu_g2_sum(g->ctx[0], parts.data(), w, out);
+}
+extern "C" int blsgpu_g1_msm_sharded(blsgpu_group* g, const blsgpu_group_bases* b, const uint8_t* scalars, size_t n, uint64_t out[18]) { return msm_sharded<1>(g, b, scalars, n, out); }
+extern "C" int blsgpu_g2_msm_sharded(blsgpu_group* g, const blsgpu_group_bases* b, const uint8_t* scalars, size_t n, uint64_t out[36]) { return msm_sharded<2>(g, b, scalars, n, out); }
+// n independent pairings (mode 0) or raw Miller values (mode 1): index slices, every member writes its slice of `out`; no fold
+static int pairings_sharded(blsgpu_group* g, int mode, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, size_t n, uint64_t* out) {
+  if (!g || (n && (!g1 || !g2 || !out))) return bad("pairing_batch_sharded: NULL argument");
+  const size_t w = g->ctx.size();
+  return group_run(g, [&](size_t k, blsgpu_ctx* c) {
+    size_t lo, hi; group_range(n, k, w, lo, hi);
+    if (lo == hi) return (int)BLSGPU_OK;
+    return mode == 0 ? blsgpu_pairing_batch(c, g1 + lo * 12, g1inf ? g1inf + lo : nullptr, g2 + lo * 24, g2inf ? g2inf + lo : nullptr, hi - lo, out + lo * 72)
+                     : blsgpu_miller_loop_batch(c, g1 + lo * 12, g1inf ? g1inf + lo : nullptr, g2 + lo * 24, g2inf ? g2inf + lo : nullptr, hi - lo, out + lo * 72);
+  });
+}
+extern "C" int blsgpu_pairing_batch_sharded(blsgpu_group* g, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, size_t n, uint64_t* out) {
+  return pairings_sharded(g, 0, g1, g1inf, g2, g2inf, n, out);
+}
+extern "C" int blsgpu_miller_loop_batch_sharded(blsgpu_group* g, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, size_t n, uint64_t* out) {
+  return pairings_sharded(g, 1, g1, g1inf, g2, g2inf, n, out);
+}
+// prod_i ML(g1[i], g2[i]): member-local products of index slices, folded by member 0; final_exp != 0: followed by ONE final exponentiation
+extern "C" int blsgpu_multi_miller_loop_sharded(blsgpu_group* g, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, size_t n, int final_exp,
+                                                uint64_t out[72]) {
+  if (!g || !out || (n && (!g1 || !g2))) return bad("multi_miller_loop_sharded: NULL argument");
+  const size_t w = g->ctx.size();
+  std::vector<uint64_t> parts(w * 72);
+  int rc = group_run(g, [&](size_t k, blsgpu_ctx* c) {
+    size_t lo, hi; group_range(n, k, w, lo, hi);
+    return blsgpu_multi_miller_loop(c, n ? g1 + lo * 12 : g1, g1inf ? g1inf + lo : nullptr, n ? g2 + lo * 24 : g2, g2inf ? g2inf + lo : nullptr, hi - lo, parts.data() + k * 72);
+  });
+  if (rc) return rc;
+  if (!final_exp) return blsgpu_fp12_product(g->ctx[0], parts.data(), w, out);
+  uint64_t f[72];
+  rc = blsgpu_fp12_product(g->ctx[0], parts.data(), w, f);
+  if (rc) return rc;
+  return blsgpu_final_exponentiation_batch(g->ctx[0], f, 1, out);
+}
+// N independent multi_miller_loops (blsgpu_multi_miller_loop_many): the SEGMENTS are dealt in contiguous slices, nothing to fold
+extern "C" int blsgpu_multi_miller_loop_many_sharded(blsgpu_group* g, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, const uint64_t* offsets,
+                                                     size_t nseg, int final_exp, uint64_t* out) {
+  if (!g || (nseg && (!offsets || !out))) return bad("multi_miller_loop_many_sharded: NULL argument");
+  if (!nseg) return BLSGPU_OK;
+  if (offsets[0] != 0) return bad("multi_miller_loop_many: offsets[0] must be 0");
+  for (size_t i = 0; i < nseg; i++) if (offsets[i] > offsets[i + 1]) return bad("multi_miller_loop_many: offsets must be non-decreasing");
+  if (offsets[nseg] && (!g1 || !g2)) return bad("multi_miller_loop_many_sharded: NULL argument");
+  const size_t w = g->ctx.size();
+  return group_run(g, [&](size_t k, blsgpu_ctx* c) {
+    size_t lo, hi; group_range(nseg, k, w, lo, hi);
+    if (lo == hi) return (int)BLSGPU_OK;
+    const size_t t0 = (size_t)offsets[lo];
+    std::vector<uint64_t> off(hi - lo + 1);
+    for (size_t i = lo; i <= hi; i++) off[i - lo] = offsets[i] - t0;
+    return blsgpu_multi_miller_loop_many(c, g1 ? g1 + t0 * 12 : g1, g1inf ? g1inf + t0 : nullptr, g2 ? g2 + t0 * 24 : g2, g2inf ? g2inf + t0 : nullptr, off.data(), hi - lo, final_exp,
+                                         out + lo * 72);
+  });
 }

@@ -643,6 +643,34 @@ QUAD_KERNEL k_fp12_prod_quad(const u32* __restrict__ in, u32* __restrict__ out, 
   }
   qc_save(acc, out + j * 144);
 }
+// N independent products (`multi_miller_loop` once per CSR segment, pairings.rs:554-603: the accumulator of segment s is the product of
+// its terms' Miller values; an empty segment gives `MillerLoopResult::default()` = one, :28-32).  Segment s = values
+// [off[s], off[s + 1]) of `in`, cut into `parts` runs of equal length: quad (s, c) multiplies run c and writes out[s * parts + c].
+// parts = 1 for short segments (one quad walks the segment); parts = 32 when segments may be long, followed by k_fp12_prod_quad with
+// fan = 32 over the partial products.  Offsets beyond `total` are clamped (the device-pointer entry point cannot validate them).
+QUAD_KERNEL k_fp12_prod_seg_quad(const u32* __restrict__ in, const unsigned long long* __restrict__ off, size_t nseg, size_t total, int parts,
+                                 u32* __restrict__ out) {
+  const size_t q = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / QL;
+  if (q >= nseg * (size_t)parts) return;
+  const size_t sgm = q / (size_t)parts, c = q % (size_t)parts;
+  size_t beg = (size_t)off[sgm], end = (size_t)off[sgm + 1];
+  if (end > total) end = total;
+  if (beg > end) beg = end;
+  const size_t run = (end - beg + (size_t)parts - 1) / (size_t)parts;
+  size_t pb = beg + c * run, pe = pb + run;
+  if (pb > end) pb = end;
+  if (pe > end) pe = end;
+  QC12 acc;
+  if (pb == pe) acc = q12_to_cold(q12_one());
+  else {
+    acc = qc_load(in + pb * 144);
+    for (size_t i = pb + 1; i < pe; i++) {
+      QC12 x = qc_load(in + i * 144), t;
+      qc_mul(t, acc, x); acc = t;
+    }
+  }
+  qc_save(acc, out + q * 144);
+}
 // parity hook: op 0 mul, 4 invert, 7 frobenius_map, 8 conjugate, 9 cyclotomic_square, 10 cyclotomic exponentiation (f^|x| conjugated)
 QUAD_KERNEL k_fp12_op_quad(int op, const u32* __restrict__ a, const u32* __restrict__ b, u32* __restrict__ out, size_t n) {
   __shared__ u32 park_lds[QPARK_WORDS * QUAD_BLOCK];

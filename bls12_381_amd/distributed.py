@@ -23,18 +23,28 @@ def shard_range(n, rank, world):
 
 
 def all_gather_partials(partial, world, dist=None, device=None):
-    """partial: 1-D np.uint64 array (wire limbs of this rank's partial result) -> (world, len) array on every rank."""
+    """This rank's partial result -> the (world, len) block of every rank's, on every rank.
+
+    `partial` is either a 1-D np.uint64 array (host limbs: what the synchronous entry points return) or a 1-D int64 torch tensor
+    that already lives on the GPU (what the `*_device` entry points write).  A tensor never leaves its device: the rows are
+    gathered in place into ONE (world, len) tensor (`all_gather_rows`) which is returned as it is, ready for the device-side
+    fold (`blsgpu_g1_sum_device` / `blsgpu_fp12_product_device`).  A numpy partial is staged through `device` (the RCCL backend
+    moves device memory only; gloo takes it from the host) and comes back as numpy."""
+    is_np = isinstance(partial, np.ndarray)
     if world == 1:
-        return partial[None, :].copy()
+        return partial[None, :].copy() if is_np else partial[None, :].clone()
     import torch
     if dist is None:
         import torch.distributed as dist
+    if not is_np:
+        gathered = torch.empty((world, partial.shape[0]), dtype=partial.dtype, device=partial.device)
+        return all_gather_rows(gathered, partial.contiguous(), dist)
     t = torch.from_numpy(partial.view(np.int64).copy())
     if device is not None:
         t = t.to(device)
-    out = [torch.zeros_like(t) for _ in range(world)]
-    dist.all_gather(out, t)
-    return torch.stack(out).cpu().numpy().view(np.uint64)
+    gathered = torch.empty((world, t.shape[0]), dtype=t.dtype, device=t.device)
+    all_gather_rows(gathered, t, dist)
+    return gathered.cpu().numpy().view(np.uint64)
 
 
 def all_gather_rows(gathered, row, dist=None):

@@ -212,6 +212,24 @@ inline MillerLoopResult multi_miller_loop(const std::vector<std::pair<G1Affine, 
   check(blsgpu_multi_miller_loop(Context::instance().handle(), a.data(), fa.data(), b.data(), fb.data(), n, m.f.data()), "multi_miller_loop");
   return m;
 }
+// N independent `multi_miller_loop(..).final_exponentiation()` in one device call: the bulk form of signature verification
+// (src/pairings.rs:554-603, 817-824; blsgpu_multi_miller_loop_many)
+inline std::vector<Gt> multi_miller_loop_many(const std::vector<std::vector<std::pair<G1Affine, G2Prepared>>>& equations) {
+  size_t n = 0;
+  std::vector<uint64_t> off(equations.size() + 1, 0);
+  for (size_t s = 0; s < equations.size(); s++) { n += equations[s].size(); off[s + 1] = n; }
+  std::vector<uint64_t> a(n * 12 + 1), b(n * 24 + 1), o(equations.size() * 72 + 1); std::vector<uint8_t> fa(n + 1), fb(n + 1);
+  size_t i = 0;
+  for (const auto& e : equations)
+    for (const auto& t : e) {
+      std::memcpy(a.data() + 12 * i, t.first.xy.data(), 96); std::memcpy(b.data() + 24 * i, t.second.q.xy.data(), 192);
+      fa[i] = t.first.infinity; fb[i] = t.second.q.infinity; i++;
+    }
+  check(blsgpu_multi_miller_loop_many(Context::instance().handle(), a.data(), fa.data(), b.data(), fb.data(), off.data(), equations.size(), 1, o.data()), "multi_miller_loop_many");
+  std::vector<Gt> out(equations.size());
+  for (size_t s = 0; s < equations.size(); s++) std::memcpy(out[s].f.data(), o.data() + 72 * s, 576);
+  return out;
+}
 inline Gt Gt::generator() { return pairing(G1Affine::generator(), G2Affine::generator()); }            // src/pairings.rs:359-475
 
 // src/hash_to_curve/mod.rs:86-108 with ExpandMsgXmd<Sha256>: `G::hash_to_curve(msg, dst)` / `G::encode_to_curve(msg, dst)` for a batch
@@ -242,6 +260,56 @@ inline void fr_ntt(std::vector<FrLimbs>& v, bool inverse = false) {         // n
   int log_n = 0; while (((size_t)1 << log_n) < v.size()) log_n++;
   check(blsgpu_fr_ntt(Context::instance().handle(), v[0].data(), log_n, inverse ? 1 : 0), "fr_ntt");
 }
+
+// The same operations sharded over several GPUs of one node from this process (blsgpu_group: one context + one host thread per
+// listed device; partial results folded with `Sum` / `MillerLoopResult + MillerLoopResult`, src/g1.rs:161-171, src/pairings.rs:179-186)
+class Group {
+ public:
+  explicit Group(const std::vector<int>& devices) { check(blsgpu_group_create(devices.data(), (int)devices.size(), &h_), "blsgpu_group_create"); }
+  ~Group() { blsgpu_group_destroy(h_); }
+  Group(const Group&) = delete;
+  Group& operator=(const Group&) = delete;
+  blsgpu_group* handle() const { return h_; }
+  int size() const { return blsgpu_group_size(h_); }
+  // sum_i scalars[i] * bases[i] with bases and scalars dealt to the members in contiguous slices
+  template <int G> Projective<G> msm(const std::vector<Affine<G>>& bases, const std::vector<Scalar>& scalars) const {
+    if (bases.size() != scalars.size()) throw std::invalid_argument("msm: length mismatch");
+    const size_t n = bases.size();
+    std::vector<uint64_t> xy(n * Affine<G>::W + 1); std::vector<uint8_t> inf(n + 1), sb(n * 32 + 1);
+    for (size_t i = 0; i < n; i++) { std::memcpy(xy.data() + i * Affine<G>::W, bases[i].xy.data(), Affine<G>::W * 8); inf[i] = bases[i].infinity; std::memcpy(sb.data() + 32 * i, scalars[i].bytes.data(), 32); }
+    blsgpu_group_bases* b = nullptr;
+    check(blsgpu_group_bases_upload(h_, G, xy.data(), inf.data(), n, &b), "group_bases_upload");
+    Projective<G> r;
+    int rc = G == 1 ? blsgpu_g1_msm_sharded(h_, b, sb.data(), n, r.xyz.data()) : blsgpu_g2_msm_sharded(h_, b, sb.data(), n, r.xyz.data());
+    blsgpu_group_bases_free(b);
+    check(rc, "msm_sharded");
+    return r;
+  }
+  // multi_miller_loop(terms).final_exponentiation() with the terms dealt to the members and ONE final exponentiation
+  Gt multi_miller_loop_final_exp(const std::vector<std::pair<G1Affine, G2Prepared>>& terms) const {
+    const size_t n = terms.size();
+    std::vector<uint64_t> a(n * 12 + 1), b(n * 24 + 1); std::vector<uint8_t> fa(n + 1), fb(n + 1);
+    for (size_t i = 0; i < n; i++) {
+      std::memcpy(a.data() + 12 * i, terms[i].first.xy.data(), 96); std::memcpy(b.data() + 24 * i, terms[i].second.q.xy.data(), 192);
+      fa[i] = terms[i].first.infinity; fb[i] = terms[i].second.q.infinity;
+    }
+    Gt g;
+    check(blsgpu_multi_miller_loop_sharded(h_, a.data(), fa.data(), b.data(), fb.data(), n, 1, g.f.data()), "multi_miller_loop_sharded");
+    return g;
+  }
+  std::vector<Gt> pairing_batch(const std::vector<G1Affine>& p, const std::vector<G2Affine>& q) const {
+    if (p.size() != q.size()) throw std::invalid_argument("pairing_batch: length mismatch");
+    const size_t n = p.size(); std::vector<Gt> out(n);
+    if (!n) return out;
+    std::vector<uint64_t> a(n * 12), b(n * 24), o(n * 72); std::vector<uint8_t> fa(n), fb(n);
+    for (size_t i = 0; i < n; i++) { std::memcpy(a.data() + 12 * i, p[i].xy.data(), 96); std::memcpy(b.data() + 24 * i, q[i].xy.data(), 192); fa[i] = p[i].infinity; fb[i] = q[i].infinity; }
+    check(blsgpu_pairing_batch_sharded(h_, a.data(), fa.data(), b.data(), fb.data(), n, o.data()), "pairing_batch_sharded");
+    for (size_t i = 0; i < n; i++) std::memcpy(out[i].f.data(), o.data() + 72 * i, 576);
+    return out;
+  }
+ private:
+  blsgpu_group* h_ = nullptr;
+};
 
 struct Bls12 {                                              // `pairing::Engine` / `MultiMillerLoop`, src/pairings.rs:790-824
   static Gt pairing(const G1Affine& p, const G2Affine& q) { return bls::pairing(p, q); }

@@ -101,7 +101,14 @@ size_t blsgpu_bases_len(const blsgpu_bases* b);
  * results for off-subgroup inputs are unspecified.  Default: 0 (test every upload).
  * blsgpu_bases_subgroup_state: 1 = verified (or built as [k]G), 2 = assumed by the caller, 0 = at least one point is
  * outside the subgroup (plain windows), 3 = not tested: the set is beyond the size the split supports (G2: more than 2^22
- * points) and runs on plain windows in any case. */
+ * points) and runs on plain windows in any case.
+ * The ONE-SHOT entry points (blsgpu_g{1,2}_msm_host, blsgpu_g{1,2}_msm_bytes) upload a set for a single MSM: the test would
+ * cost several times the MSM it speeds up, so they skip it and run on plain windows (exact for every curve point, state 3)
+ * unless blsgpu_set_assume_subgroup(ctx, 1) is set, in which case they take the fast path untested.
+ * Synchronisation: an upload that runs the test (`*_bases_upload`, `*_bases_from_device` with the default
+ * assume_subgroup = 0) reads the verdict back and therefore SYNCHRONISES the context's stream (blsgpu_set_stream: the
+ * caller's stream) -- it blocks the host and cannot be captured into a graph.  With blsgpu_set_assume_subgroup(ctx, 1)
+ * `*_bases_from_device` only enqueues work and returns. */
 int blsgpu_set_assume_subgroup(blsgpu_ctx* ctx, int enabled);
 int blsgpu_bases_subgroup_state(const blsgpu_bases* b);
 /* Read points [first, first+count) back in wire format (xy: count*12 or count*24 u64; infinity: count bytes). */
@@ -127,7 +134,9 @@ int blsgpu_g1_msm_many(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first,
 int blsgpu_g2_msm_many(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const uint8_t* scalars, size_t n, size_t k, uint64_t* out_xyz);
 int blsgpu_g1_msm_many_device(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const void* d_scalars, size_t n, size_t k, void* d_out_xyz);
 int blsgpu_g2_msm_many_device(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const void* d_scalars, size_t n, size_t k, void* d_out_xyz);
-/* One-shot convenience: upload, multiply, free. */
+/* One-shot convenience: upload, multiply, free.  No subgroup test and no endomorphism split (plain windows: exact for every
+ * curve point) unless blsgpu_set_assume_subgroup(ctx, 1) -- see the subgroup contract above.  For a set used more than once
+ * upload it (blsgpu_g1_bases_upload) and call blsgpu_g1_msm. */
 int blsgpu_g1_msm_host(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, const uint8_t* scalars, size_t n, uint64_t out_xyz[18]);
 int blsgpu_g2_msm_host(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, const uint8_t* scalars, size_t n, uint64_t out_xyz[36]);
 /* The same on the reference's PUBLIC encodings, for a wrapper crate that cannot reach limbs (`pub(crate)`, src/g1.rs:28-32):
@@ -187,9 +196,13 @@ int blsgpu_g2_to_bytes_batch(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t*
  *     2 = lane pair (the layout of rounds 1-2, kept for A/B runs).
  * BLSGPU_PAIRING_LAYOUT=wide|quad|pair|auto in the environment at blsgpu_create fixes the choice; with "wide" a missing
  * or mismatching program file makes the pairing entry points FAIL (BLSGPU_ERR_ARG) instead of silently running another
- * kernel; with "auto" (the default) the quad kernels take every size then and this function says so.
- * All layouts return limb-identical results. */
+ * kernel; with "auto" (the default) the quad kernels take every size then, this function says so, and the library prints ONE
+ * line to stderr the first time it happens (a single pairing costs ~6 ms instead of ~1.1 ms then).  Any other value of the
+ * variable makes blsgpu_create fail with BLSGPU_ERR_ARG.  All layouts return limb-identical results. */
 int blsgpu_pairing_layout(blsgpu_ctx* ctx, size_t n);
+/* "" when the wide programs are loaded on this context, otherwise the reason they are not (file missing, stale format
+ * version, generated for another kernel configuration, library path unknown in a static link: set $BLSGPU_WIDE_PROG). */
+const char* blsgpu_wide_status(blsgpu_ctx* ctx);
 /* out[i] = pairing(g1[i], g2[i]) for n independent pairs (`pairing`, src/pairings.rs:607-653; 72 u64 each).
  * An identity on either side yields Gt::identity() = Fp12::one(), as the reference does. */
 int blsgpu_pairing_batch(blsgpu_ctx* ctx, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy, const uint8_t* g2_inf, size_t n, uint64_t* out_gt);
@@ -199,6 +212,22 @@ int blsgpu_miller_loop_batch(blsgpu_ctx* ctx, const uint64_t* g1_xy, const uint8
 /* out = prod_i ML(g1[i], g2[i])  (`multi_miller_loop`, src/pairings.rs:554-603; pairs with an identity are
  * skipped).  n = 0 yields Fp12::one() (`MillerLoopResult::default`, :28-32). */
 int blsgpu_multi_miller_loop(blsgpu_ctx* ctx, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy, const uint8_t* g2_inf, size_t n, uint64_t out_f[72]);
+/* N independent `multi_miller_loop`s in one call -- the shape of bulk signature verification, where generic `E: MultiMillerLoop`
+ * callers evaluate one product of k pairings per equation (src/pairings.rs:554-603, 817-824; the test pattern :871-921).
+ * Segment s = terms offsets[s] .. offsets[s+1] of the g1 / g2 arrays (CSR: nseg + 1 non-decreasing offsets, offsets[0] = 0).
+ *   final_exp = 0: out[s] = multi_miller_loop(terms of s)                        (a `MillerLoopResult`, 72 u64)
+ *   final_exp != 0: out[s] = multi_miller_loop(terms of s).final_exponentiation() (a `Gt`, 72 u64)
+ * Terms with an identity on either side are skipped as the reference does (:566-569); an empty segment yields
+ * `MillerLoopResult::default()` = Fp12::one() (:28-32), whose final exponentiation is `Gt::identity()`.  One batched Miller
+ * kernel over all terms, one segmented Fp12 product, one batched final exponentiation; few terms take the wide path.  For ONE
+ * product over very many terms blsgpu_multi_miller_loop (shared squarings) is the faster entry point. */
+int blsgpu_multi_miller_loop_many(blsgpu_ctx* ctx, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy, const uint8_t* g2_inf, const uint64_t* offsets,
+                                  size_t nseg, int final_exp, uint64_t* out);
+/* Device-pointer variant, asynchronous on the context's stream: points, flags, offsets (nseg + 1 u64) and the output in device
+ * memory.  `total_terms` = offsets[nseg] and `max_seg_terms` = an upper bound of the segment lengths (0 = unknown) are passed
+ * by value because the host cannot read the offsets without a synchronisation; offsets beyond total_terms are clamped. */
+int blsgpu_multi_miller_loop_many_device(blsgpu_ctx* ctx, const void* d_g1_xy, const void* d_g1_inf, const void* d_g2_xy, const void* d_g2_inf, const void* d_offsets,
+                                         size_t nseg, size_t total_terms, size_t max_seg_terms, int final_exp, void* d_out);
 /* out[i] = final_exponentiation(in[i])  (`MillerLoopResult::final_exponentiation`, src/pairings.rs:48-176). */
 int blsgpu_final_exponentiation_batch(blsgpu_ctx* ctx, const uint64_t* in_f, size_t n, uint64_t* out_gt);
 /* out = prod of n Fp12 values (`MillerLoopResult + MillerLoopResult`, src/pairings.rs:179-186; `Gt + Gt`). */
@@ -215,6 +244,43 @@ int blsgpu_multi_miller_loop_device(blsgpu_ctx* ctx, const void* d_g1_xy, const 
 int blsgpu_miller_loop_batch_device(blsgpu_ctx* ctx, const void* d_g1_xy, const void* d_g1_inf, const void* d_g2_xy, const void* d_g2_inf, size_t n, void* d_out_f);
 int blsgpu_final_exponentiation_device(blsgpu_ctx* ctx, const void* d_in_f, size_t n, void* d_out_gt);
 int blsgpu_fp12_product_device(blsgpu_ctx* ctx, const void* d_in_f, size_t n, void* d_out_f);
+
+/* ---- device groups: the path sharded over the GPUs of one node from ONE process ------------------------------------- */
+/* "Large MSMs and pairing batches shard embarrassingly across the 8 GPUs" (SURVEY.md 8e): a group is one context per listed
+ * device; every `*_sharded` call deals its independent terms to the members in contiguous slices (sizes differ by at most
+ * one), runs each member on its own host thread, and folds the members' partial results -- ONE group element each: 144 B
+ * G1, 288 B G2, 576 B Fp12 -- on member 0 with the reference's own operators: `Sum for G1Projective` (src/g1.rs:161-171,
+ * src/g2.rs:162-172) and `MillerLoopResult + MillerLoopResult` (src/pairings.rs:179-186), then ONE final exponentiation
+ * (:48-176).  Inside one process those few hundred bytes travel through host memory; no collective library is involved
+ * (one process per GPU over RCCL is bls12_381_amd/distributed.py + bench.py --gpus N).  Results are the same group / field
+ * elements as the single-context entry points'.  `devices` may name a device more than once (logical members on one GPU).
+ * A group is driven by one host thread at a time; blsgpu_group_ctx gives access to a member's context for the per-context
+ * settings (blsgpu_set_assume_subgroup, blsgpu_set_msm_window, ...). */
+typedef struct blsgpu_group blsgpu_group;
+typedef struct blsgpu_group_bases blsgpu_group_bases;   /* resident bases, member k holds points [lo_k, hi_k) on its device */
+int blsgpu_group_create(const int* devices, int ndev, blsgpu_group** out);
+void blsgpu_group_destroy(blsgpu_group* group);
+int blsgpu_group_size(const blsgpu_group* group);
+blsgpu_ctx* blsgpu_group_ctx(blsgpu_group* group, int member);
+/* Shard n affine points (wire format as blsgpu_g1_bases_upload; `group_id` = 1 | 2) / the multiples [k_i]G over the members. */
+int blsgpu_group_bases_upload(blsgpu_group* group, int group_id, const uint64_t* xy, const uint8_t* infinity, size_t n, blsgpu_group_bases** out);
+int blsgpu_group_bases_from_scalars(blsgpu_group* group, int group_id, const uint8_t* scalars, size_t n, blsgpu_group_bases** out);
+size_t blsgpu_group_bases_len(const blsgpu_group_bases* b);
+void blsgpu_group_bases_free(blsgpu_group_bases* b);
+/* out = sum_{i<n} scalars[i] * bases[i], n <= blsgpu_group_bases_len: every member runs a complete MSM over its slice,
+ * member 0 adds the partial sums (blsgpu_g1_msm / blsgpu_g1_sum per member; same contracts, incl. canonical scalars). */
+int blsgpu_g1_msm_sharded(blsgpu_group* group, const blsgpu_group_bases* bases, const uint8_t* scalars, size_t n, uint64_t out_xyz[18]);
+int blsgpu_g2_msm_sharded(blsgpu_group* group, const blsgpu_group_bases* bases, const uint8_t* scalars, size_t n, uint64_t out_xyz[36]);
+/* n independent pairings / raw Miller values: index slices, each member writes its slice of `out` (n x 72 u64); nothing to fold. */
+int blsgpu_pairing_batch_sharded(blsgpu_group* group, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy, const uint8_t* g2_inf, size_t n, uint64_t* out_gt);
+int blsgpu_miller_loop_batch_sharded(blsgpu_group* group, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy, const uint8_t* g2_inf, size_t n, uint64_t* out_f);
+/* `multi_miller_loop` over n terms: member-local products of index slices, folded by member 0; final_exp != 0 applies the ONE
+ * final exponentiation (out = a `Gt`), final_exp = 0 returns the `MillerLoopResult`. */
+int blsgpu_multi_miller_loop_sharded(blsgpu_group* group, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy, const uint8_t* g2_inf, size_t n, int final_exp,
+                                     uint64_t out[72]);
+/* blsgpu_multi_miller_loop_many with the SEGMENTS dealt to the members in contiguous slices. */
+int blsgpu_multi_miller_loop_many_sharded(blsgpu_group* group, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy, const uint8_t* g2_inf,
+                                          const uint64_t* offsets, size_t nseg, int final_exp, uint64_t* out);
 
 /* ---- field self-test hooks (parity tests of the arithmetic core against the oracle) ---------------------- */
 /* out[i] = a[i] op b[i] over n Fp elements in wire format; op: 0 mul, 1 add, 2 sub, 3 square(a), 4 invert(a), 5 neg(a). */

@@ -212,6 +212,102 @@ pub fn miller_product(parts: &[MillerLoopResult]) -> MillerLoopResult {
     gpu.unwrap_or_else(|| parts.iter().fold(MillerLoopResult::default(), |a, b| a + b))
 }
 
+/// One `multi_miller_loop(terms).final_exponentiation()` per equation in ONE device call -- the bulk form of what generic
+/// `E: MultiMillerLoop` verifiers do once per signature (src/pairings.rs:554-603, 817-824, 48-176).  Equations with no terms give
+/// `Gt::identity()`.
+pub fn multi_miller_loop_many(equations: &[&[(&G1Affine, &G2PreparedHip)]]) -> Vec<Gt> {
+    let cpu = || equations.iter().map(|e| crate::pairings::multi_miller_loop_cpu(e).final_exponentiation_cpu()).collect::<Vec<_>>();
+    if equations.len() < GPU_MIN_PAIRINGS { return cpu(); }
+    let gpu = with_ctx(|ctx| {
+        let p: Vec<G1Affine> = equations.iter().flat_map(|e| e.iter().map(|t| *t.0)).collect();
+        let q: Vec<G2Affine> = equations.iter().flat_map(|e| e.iter().map(|t| t.1.q)).collect();
+        let mut off = Vec::with_capacity(equations.len() + 1);
+        off.push(0u64);
+        for e in equations { off.push(off[off.len() - 1] + e.len() as u64); }
+        let ((g1, f1), (g2, f2)) = (g1_wire(&p), g2_wire(&q));
+        let mut out = alloc::vec![0u64; equations.len() * 72];
+        ok(unsafe { ffi::blsgpu_multi_miller_loop_many(ctx, g1.as_ptr(), f1.as_ptr(), g2.as_ptr(), f2.as_ptr(), off.as_ptr(), equations.len(), 1, out.as_mut_ptr()) })?;
+        Some(out.chunks_exact(72).map(|c| Gt(fp12(c))).collect::<Vec<_>>())
+    });
+    gpu.unwrap_or_else(cpu)
+}
+
+// ---- all GPUs of the node from this process ------------------------------------------------------------------------------
+/// One library context (and, inside the library, one host thread) per listed device.  MSMs, batches of pairings and
+/// `multi_miller_loop`s are dealt to the members in contiguous slices; the members' partial results -- one group element each
+/// -- are folded with the crate's own `Sum` (src/g1.rs:161-171) / `MillerLoopResult + MillerLoopResult` (src/pairings.rs:179-186),
+/// followed by ONE final exponentiation.  `None` from the constructors = no usable device: callers keep the CPU path.
+pub struct Group(*mut ffi::BlsgpuGroup);
+unsafe impl Send for Group {}
+impl Drop for Group { fn drop(&mut self) { unsafe { ffi::blsgpu_group_destroy(self.0) } } }
+impl Group {
+    pub fn new(devices: &[c_int]) -> Option<Group> {
+        let mut h = core::ptr::null_mut();
+        ok(unsafe { ffi::blsgpu_group_create(devices.as_ptr(), devices.len() as c_int, &mut h) })?;
+        Some(Group(h))
+    }
+    /// every device the HIP runtime shows
+    pub fn all_devices() -> Option<Group> {
+        let n = unsafe { ffi::blsgpu_device_count() };
+        if n <= 0 { return None; }
+        let d: Vec<c_int> = (0..n).collect();
+        Group::new(&d)
+    }
+    pub fn len(&self) -> usize { unsafe { ffi::blsgpu_group_size(self.0) as usize } }
+    /// `bases.iter().zip(scalars).map(|(p, s)| p * s).sum::<G1Projective>()` over all members
+    pub fn msm_g1(&self, bases: &[G1Affine], scalars: &[Scalar]) -> G1Projective {
+        assert_eq!(bases.len(), scalars.len());
+        let gpu = (|| {
+            let ((xy, inf), s) = (g1_wire(bases), scalar_bytes(scalars));
+            let mut b = core::ptr::null_mut();
+            ok(unsafe { ffi::blsgpu_group_bases_upload(self.0, 1, xy.as_ptr(), inf.as_ptr(), bases.len(), &mut b) })?;
+            let mut out = [0u64; 18];
+            let rc = unsafe { ffi::blsgpu_g1_msm_sharded(self.0, b, s.as_ptr(), bases.len(), out.as_mut_ptr()) };
+            unsafe { ffi::blsgpu_group_bases_free(b) };
+            ok(rc)?;
+            Some(G1Projective { x: fp(&out[0..6]), y: fp(&out[6..12]), z: fp(&out[12..18]) })
+        })();
+        gpu.unwrap_or_else(|| bases.iter().zip(scalars).map(|(p, s)| p * s).sum())
+    }
+    pub fn msm_g2(&self, bases: &[G2Affine], scalars: &[Scalar]) -> G2Projective {
+        assert_eq!(bases.len(), scalars.len());
+        let gpu = (|| {
+            let ((xy, inf), s) = (g2_wire(bases), scalar_bytes(scalars));
+            let mut b = core::ptr::null_mut();
+            ok(unsafe { ffi::blsgpu_group_bases_upload(self.0, 2, xy.as_ptr(), inf.as_ptr(), bases.len(), &mut b) })?;
+            let mut out = [0u64; 36];
+            let rc = unsafe { ffi::blsgpu_g2_msm_sharded(self.0, b, s.as_ptr(), bases.len(), out.as_mut_ptr()) };
+            unsafe { ffi::blsgpu_group_bases_free(b) };
+            ok(rc)?;
+            Some(G2Projective { x: fp2(&out[0..12]), y: fp2(&out[12..24]), z: fp2(&out[24..36]) })
+        })();
+        gpu.unwrap_or_else(|| bases.iter().zip(scalars).map(|(p, s)| p * s).sum())
+    }
+    /// out[i] = e(p[i], q[i]), index slices per member
+    pub fn pairing_batch(&self, p: &[G1Affine], q: &[G2Affine]) -> Vec<Gt> {
+        assert_eq!(p.len(), q.len());
+        let gpu = (|| {
+            let ((g1, f1), (g2, f2)) = (g1_wire(p), g2_wire(q));
+            let mut out = alloc::vec![0u64; p.len() * 72];
+            ok(unsafe { ffi::blsgpu_pairing_batch_sharded(self.0, g1.as_ptr(), f1.as_ptr(), g2.as_ptr(), f2.as_ptr(), p.len(), out.as_mut_ptr()) })?;
+            Some(out.chunks_exact(72).map(|c| Gt(fp12(c))).collect::<Vec<_>>())
+        })();
+        gpu.unwrap_or_else(|| p.iter().zip(q).map(|(a, b)| crate::pairings::pairing_cpu(a, b)).collect())
+    }
+    /// `multi_miller_loop(terms)` with the terms dealt to the members (raw `MillerLoopResult`: apply `final_exponentiation` once)
+    pub fn multi_miller_loop(&self, terms: &[(&G1Affine, &G2PreparedHip)]) -> MillerLoopResult {
+        let gpu = (|| {
+            let p: Vec<G1Affine> = terms.iter().map(|t| *t.0).collect();
+            let q: Vec<G2Affine> = terms.iter().map(|t| t.1.q).collect();
+            let ((g1, f1), (g2, f2)) = (g1_wire(&p), g2_wire(&q));
+            let mut out = [0u64; 72];
+            ok(unsafe { ffi::blsgpu_multi_miller_loop_sharded(self.0, g1.as_ptr(), f1.as_ptr(), g2.as_ptr(), f2.as_ptr(), terms.len(), 0, out.as_mut_ptr()) })?;
+            Some(MillerLoopResult(fp12(&out)))
+        })();
+        gpu.unwrap_or_else(|| crate::pairings::multi_miller_loop_cpu(terms))
+    }
+}
+
 // ---- trait forwarding (replaces the bodies at src/pairings.rs:795-824) --------------------------------------------------
 #[cfg(feature = "hip")]
 impl pairing::Engine for crate::Bls12 {

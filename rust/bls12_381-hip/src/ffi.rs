@@ -7,6 +7,10 @@ use core::ffi::{c_char, c_int, c_uint, c_void};
 #[repr(C)] pub struct BlsgpuCtx { _private: [u8; 0] }
 /// opaque: bases resident in HBM (blsgpu_g1_bases_upload & co. / blsgpu_bases_free)
 #[repr(C)] pub struct BlsgpuBases { _private: [u8; 0] }
+/// opaque: one context per listed device (blsgpu_group_create / blsgpu_group_destroy)
+#[repr(C)] pub struct BlsgpuGroup { _private: [u8; 0] }
+/// opaque: bases sharded over the members of a group (blsgpu_group_bases_upload / blsgpu_group_bases_free)
+#[repr(C)] pub struct BlsgpuGroupBases { _private: [u8; 0] }
 
 pub const BLSGPU_OK: c_int = 0;
 
@@ -60,9 +64,12 @@ extern "C" {
     pub fn blsgpu_g1_to_bytes_batch(ctx: *mut BlsgpuCtx, xy: *const u64, infinity: *const u8, n: usize, compressed: c_int, out: *mut u8) -> c_int;
     pub fn blsgpu_g2_to_bytes_batch(ctx: *mut BlsgpuCtx, xy: *const u64, infinity: *const u8, n: usize, compressed: c_int, out: *mut u8) -> c_int;
     pub fn blsgpu_pairing_layout(ctx: *mut BlsgpuCtx, n: usize) -> c_int;
+    pub fn blsgpu_wide_status(ctx: *mut BlsgpuCtx) -> *const c_char;
     pub fn blsgpu_pairing_batch(ctx: *mut BlsgpuCtx, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, n: usize, out_gt: *mut u64) -> c_int;
     pub fn blsgpu_miller_loop_batch(ctx: *mut BlsgpuCtx, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, n: usize, out_f: *mut u64) -> c_int;
     pub fn blsgpu_multi_miller_loop(ctx: *mut BlsgpuCtx, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, n: usize, out_f: *mut u64) -> c_int;
+    pub fn blsgpu_multi_miller_loop_many(ctx: *mut BlsgpuCtx, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, offsets: *const u64, nseg: usize, final_exp: c_int, out: *mut u64) -> c_int;
+    pub fn blsgpu_multi_miller_loop_many_device(ctx: *mut BlsgpuCtx, d_g1_xy: *const c_void, d_g1_inf: *const c_void, d_g2_xy: *const c_void, d_g2_inf: *const c_void, d_offsets: *const c_void, nseg: usize, total_terms: usize, max_seg_terms: usize, final_exp: c_int, d_out: *mut c_void) -> c_int;
     pub fn blsgpu_final_exponentiation_batch(ctx: *mut BlsgpuCtx, in_f: *const u64, n: usize, out_gt: *mut u64) -> c_int;
     pub fn blsgpu_fp12_product(ctx: *mut BlsgpuCtx, in_f: *const u64, n: usize, out_f: *mut u64) -> c_int;
     pub fn blsgpu_gt_mul_scalar_batch(ctx: *mut BlsgpuCtx, gt: *const u64, scalars: *const u8, n: usize, out: *mut u64) -> c_int;
@@ -71,6 +78,20 @@ extern "C" {
     pub fn blsgpu_miller_loop_batch_device(ctx: *mut BlsgpuCtx, d_g1_xy: *const c_void, d_g1_inf: *const c_void, d_g2_xy: *const c_void, d_g2_inf: *const c_void, n: usize, d_out_f: *mut c_void) -> c_int;
     pub fn blsgpu_final_exponentiation_device(ctx: *mut BlsgpuCtx, d_in_f: *const c_void, n: usize, d_out_gt: *mut c_void) -> c_int;
     pub fn blsgpu_fp12_product_device(ctx: *mut BlsgpuCtx, d_in_f: *const c_void, n: usize, d_out_f: *mut c_void) -> c_int;
+    pub fn blsgpu_group_create(devices: *const c_int, ndev: c_int, out: *mut *mut BlsgpuGroup) -> c_int;
+    pub fn blsgpu_group_destroy(group: *mut BlsgpuGroup);
+    pub fn blsgpu_group_size(group: *const BlsgpuGroup) -> c_int;
+    pub fn blsgpu_group_ctx(group: *mut BlsgpuGroup, member: c_int) -> *mut BlsgpuCtx;
+    pub fn blsgpu_group_bases_upload(group: *mut BlsgpuGroup, group_id: c_int, xy: *const u64, infinity: *const u8, n: usize, out: *mut *mut BlsgpuGroupBases) -> c_int;
+    pub fn blsgpu_group_bases_from_scalars(group: *mut BlsgpuGroup, group_id: c_int, scalars: *const u8, n: usize, out: *mut *mut BlsgpuGroupBases) -> c_int;
+    pub fn blsgpu_group_bases_len(b: *const BlsgpuGroupBases) -> usize;
+    pub fn blsgpu_group_bases_free(b: *mut BlsgpuGroupBases);
+    pub fn blsgpu_g1_msm_sharded(group: *mut BlsgpuGroup, bases: *const BlsgpuGroupBases, scalars: *const u8, n: usize, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_g2_msm_sharded(group: *mut BlsgpuGroup, bases: *const BlsgpuGroupBases, scalars: *const u8, n: usize, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_pairing_batch_sharded(group: *mut BlsgpuGroup, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, n: usize, out_gt: *mut u64) -> c_int;
+    pub fn blsgpu_miller_loop_batch_sharded(group: *mut BlsgpuGroup, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, n: usize, out_f: *mut u64) -> c_int;
+    pub fn blsgpu_multi_miller_loop_sharded(group: *mut BlsgpuGroup, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, n: usize, final_exp: c_int, out: *mut u64) -> c_int;
+    pub fn blsgpu_multi_miller_loop_many_sharded(group: *mut BlsgpuGroup, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, offsets: *const u64, nseg: usize, final_exp: c_int, out: *mut u64) -> c_int;
     pub fn blsgpu_fp_op(ctx: *mut BlsgpuCtx, op: c_int, a: *const u64, b: *const u64, n: usize, out: *mut u64) -> c_int;
     pub fn blsgpu_fp2_op(ctx: *mut BlsgpuCtx, op: c_int, a: *const u64, b: *const u64, n: usize, out: *mut u64) -> c_int;
     pub fn blsgpu_fp6_op(ctx: *mut BlsgpuCtx, op: c_int, a: *const u64, b: *const u64, n: usize, out: *mut u64) -> c_int;

@@ -291,16 +291,17 @@ def test_msm_medium(ctx, group, logn):
 
 def test_msm_full_size_2_20(ctx):
     """BASELINE config 2: 2^20-point G1 MSM, checked through the discrete-log identity."""
+    from bls12_381_amd import synthetic as sy
     n = 1 << 20
-    rs = np.random.RandomState(20)
-    kb = rs.randint(0, 256, size=(n, 32), dtype=np.uint8); kb[:, 31] &= 0x3F
-    sb = rs.randint(0, 256, size=(n, 32), dtype=np.uint8); sb[:, 31] &= 0x3F
-    ks = [int.from_bytes(kb[i].tobytes(), "little") for i in range(n)]
-    ss = [int.from_bytes(sb[i].tobytes(), "little") for i in range(n)]
+    # the headline distribution (SURVEY.md 8d): uniform in [0, r) by rejection, all 255 bits in play -- bench.py's own sampler and seed
+    kb = sy.scalars(n, sy.SEED + 1)
+    sb = sy.scalars(n, sy.SEED)
+    assert int(sb[:, 31].max()) >= 0x70 and int(kb[:, 31].max()) >= 0x70          # scalars above 2^254 are present
+    ss = sy.to_ints(sb)
     bases = ctx.bases_from_scalars(1, kb)
     out = ctx.msm(bases, sb)
     xy, inf = ctx.batch_normalize(1, out[None, :])
-    tot = sum(k * s for k, s in zip(ks, ss)) % o.R_ORDER
+    tot = sy.dot_mod_r(kb, sb)
     import bls12_381_amd as b
     assert b.G1Affine(xy[0], bool(inf[0])).to_uncompressed() == o.g1_to_uncompressed(o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, tot)))
     # linearity (size-independent property): MSM(2s) == 2 * MSM(s)
@@ -1603,3 +1604,174 @@ def test_one_context_from_two_host_threads_is_refused_not_corrupted(ctx):
     assert seen and all(b"another host thread" in m for m in seen), "the second thread was never refused"
     assert np.array_equal(res["gt"][:64], want)
     assert c.pairing_layout(1) == 256                           # and the context works as before afterwards
+
+
+# ---- round 4: segmented multi_miller_loop, device groups, diagnostics ---------------------------------------------------------
+def _terms_w(ps, qs):
+    G1 = np.stack([g1aff_w(p)[0] for p in ps]); F1 = np.array([g1aff_w(p)[1] for p in ps], dtype=np.uint8)
+    G2 = np.stack([g2aff_w(q)[0] for q in qs]); F2 = np.array([g2aff_w(q)[1] for q in qs], dtype=np.uint8)
+    return G1, F1, G2, F2
+
+
+def test_multi_miller_loop_many_segments_vs_oracle(ctx):
+    """N independent multi_miller_loops in one call: every segment against the oracle's `multi_miller_loop(terms)` (raw value)
+    and `.final_exponentiation()`, for k in {0, 1, 2, 3, 8} terms, identities on either side, an empty first / last segment --
+    pairings.rs:554-603 once per segment, `MillerLoopResult::default()` for no terms (:28-32)"""
+    import bls12_381_amd as b
+    ps, qs = _pair_inputs(15, 4242)
+    ps[4] = o.G1_IDENTITY_AFF; qs[9] = o.G2_IDENTITY_AFF
+    lens = [0, 1, 2, 3, 0, 8, 1, 0]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    assert int(off[-1]) == 15
+    G1, F1, G2, F2 = _terms_w(ps, qs)
+    raw = ctx.multi_miller_loop_many(G1, F1, G2, F2, off, final_exp=False)
+    gt = ctx.multi_miller_loop_many(G1, F1, G2, F2, off, final_exp=True)
+    for s, k in enumerate(lens):
+        lo = int(off[s])
+        want = o.multi_miller_loop([(p, o.g2_prepare(q)) for p, q in zip(ps[lo:lo + k], qs[lo:lo + k])])
+        assert np.array_equal(raw[s], fp12w(want)), f"segment {s} (k = {k}): raw Miller value"
+        assert np.array_equal(gt[s], fp12w(o.final_exponentiation(want))), f"segment {s} (k = {k}): Gt"
+    assert np.array_equal(gt[0], fp12w(o.FP12_ONE))                      # Gt::identity for an empty equation
+    # the mirrored API: one equation e(aG, bH) e(-abG, H) = 1 next to one that does not hold
+    a, c = b.Scalar(77), b.Scalar(1234567)
+    g, h = b.G1Affine.generator(), b.G2Affine.generator()
+    eq_ok = [((g * a).to_affine(), b.G2Prepared((h * c).to_affine())), (-(g * (a * c)).to_affine(), b.G2Prepared(h))]
+    eq_bad = [((g * a).to_affine(), b.G2Prepared((h * c).to_affine())), (-(g * a).to_affine(), b.G2Prepared(h))]
+    res = b.multi_miller_loop_many([eq_ok, eq_bad, []])
+    assert res[0] == b.Gt.identity() and res[1] != b.Gt.identity() and res[2] == b.Gt.identity()
+    assert res[1] == b.multi_miller_loop(eq_bad).final_exponentiation()
+    # nothing to do / malformed offsets
+    assert ctx.multi_miller_loop_many(G1[:0], F1[:0], G2[:0], F2[:0], np.zeros(1, dtype=np.uint64)).shape == (0, 72)
+    with pytest.raises(b.BlsGpuError):
+        ctx.multi_miller_loop_many(G1[:3], F1[:3], G2[:3], F2[:3], np.array([0, 2, 1, 3], dtype=np.uint64))
+
+
+def test_multi_miller_loop_many_2_12_equations_of_three_vs_c_oracle(ctx):
+    """2^12 signature-verification-shaped equations (k = 3) on the throughput kernels, limb for limb: the C oracle's raw Miller
+    values multiplied per segment by the Python oracle's Fp12 product, final exponentiation by the C oracle; plus long segments
+    (the 32-run form of the segmented product) against the single-product entry point and the oracle"""
+    from oracle import c_oracle
+    c_oracle.build()
+    nseg, k = 1 << 12, 3
+    n = nseg * k
+    ab, _ = _rand_scalars_np(n, 141)
+    bb, _ = _rand_scalars_np(n, 142)
+    g1, f1 = ctx.bases_from_scalars(1, ab).download()
+    g2, f2 = ctx.bases_from_scalars(2, bb).download()
+    f1 = f1.copy(); f2 = f2.copy(); f1[[5, 300]] = 1; f2[[301, 9000]] = 1
+    off = (np.arange(nseg + 1) * k).astype(np.uint64)
+    assert ctx.pairing_layout(n) == 4 and ctx.pairing_layout(nseg) == 4
+    ml, _ = c_oracle.pairing_batch(1, g1, f1, g2, f2)
+    prods = np.zeros((nseg, 72), dtype=np.uint64)
+    for s in range(nseg):
+        acc = wfp12(ml[3 * s])
+        acc = o.fp12_mul(o.fp12_mul(acc, wfp12(ml[3 * s + 1])), wfp12(ml[3 * s + 2]))
+        prods[s] = fp12w(acc)
+    assert np.array_equal(ctx.multi_miller_loop_many(g1, f1, g2, f2, off, final_exp=False), prods)
+    want = c_oracle.pairing_batch(2, prods, None, None, None)[0]
+    assert np.array_equal(ctx.multi_miller_loop_many(g1, f1, g2, f2, off, final_exp=True), want)
+    # ragged and long segments: lengths 1100 (beyond 32 x 32), 40, 0, 7 -- against blsgpu_multi_miller_loop per segment
+    lens = [1100, 40, 0, 7]
+    off2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    m = int(off2[-1])
+    got = ctx.multi_miller_loop_many(g1[:m], f1[:m], g2[:m], f2[:m], off2, final_exp=False)
+    for s, ln in enumerate(lens):
+        lo = int(off2[s])
+        assert np.array_equal(got[s], ctx.multi_miller_loop(g1[lo:lo + ln], f1[lo:lo + ln], g2[lo:lo + ln], f2[lo:lo + ln])), s
+    acc = o.FP12_ONE
+    for i in range(1100, 1140):
+        acc = o.fp12_mul(acc, wfp12(ml[i]))
+    assert np.array_equal(got[1], fp12w(acc))
+
+
+@pytest.mark.parametrize("members", [2, 8])
+def test_device_group_matches_single_context(ctx, members):
+    """blsgpu_group: the sharded entry points of the C library (one context + one host thread per member; here `members` logical
+    members on device 0, the code path of an 8-GPU node) against the single-context results -- MSMs as affine points, everything
+    in Fp12 limb for limb (a product of partial products is the same field element)"""
+    import bls12_381_amd as b
+    from bls12_381_amd import synthetic as sy
+    grp = b.Group([0] * members)
+    assert len(grp) == members
+    nrm = lambda g, x: ctx.batch_normalize(g, x[None, :])
+    for gid, n in ((1, 5003), (2, 1001)):
+        kb, sb = sy.scalars(n, 700 + gid), sy.scalars(n, 710 + gid)
+        gb = grp.bases_from_scalars(gid, kb)
+        assert len(gb) == n
+        rb = ctx.bases_from_scalars(gid, kb)
+        want = nrm(gid, ctx.msm(rb, sb))
+        got = nrm(gid, grp.msm(gb, sb))
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        # fewer scalars than resident bases (some members get nothing), one scalar, none
+        for m in (n // 2 + 1, 1, 0):
+            w2 = nrm(gid, ctx.msm(rb, sb[:m])); g2_ = nrm(gid, grp.msm(gb, sb[:m]))
+            assert np.array_equal(g2_[0], w2[0]) and np.array_equal(g2_[1], w2[1]), (gid, m)
+        # uploaded (not generated) bases incl. an identity: subgroup test per member
+        xy, inf = rb.download(0, 300)
+        inf = inf.copy(); inf[7] = 1
+        ub = grp.upload_bases(gid, xy, inf)
+        w3 = nrm(gid, ctx.msm(ctx.upload_bases(gid, xy, inf), sb[:300])); g3 = nrm(gid, grp.msm(ub, sb[:300]))
+        assert np.array_equal(g3[0], w3[0]) and np.array_equal(g3[1], w3[1])
+        gb.free(); ub.free()
+    n = 37
+    g1, f1 = ctx.bases_from_scalars(1, sy.scalars(n, 721)).download(); g2, f2 = ctx.bases_from_scalars(2, sy.scalars(n, 722)).download()
+    f1 = f1.copy(); f1[3] = 1
+    assert np.array_equal(grp.pairing_batch(g1, f1, g2, f2), ctx.pairing_batch(g1, f1, g2, f2))
+    assert np.array_equal(grp.miller_loop_batch(g1, f1, g2, f2), ctx.miller_loop_batch(g1, f1, g2, f2))
+    raw = ctx.multi_miller_loop(g1, f1, g2, f2)
+    assert np.array_equal(grp.multi_miller_loop(g1, f1, g2, f2), raw)
+    assert np.array_equal(grp.multi_miller_loop(g1, f1, g2, f2, final_exp=True), ctx.final_exponentiation_batch(raw[None, :])[0])
+    for m in (3, 0):                          # fewer terms than members; no terms: MillerLoopResult::default / Gt::identity
+        assert np.array_equal(grp.multi_miller_loop(g1[:m], f1[:m], g2[:m], f2[:m]), ctx.multi_miller_loop(g1[:m], f1[:m], g2[:m], f2[:m]))
+    assert np.array_equal(grp.multi_miller_loop(g1[:0], f1[:0], g2[:0], f2[:0], final_exp=True), fp12w(o.FP12_ONE))
+    off = np.array([0, 3, 3, 10, 11, 20, 37], dtype=np.uint64)
+    assert np.array_equal(grp.multi_miller_loop_many(g1, f1, g2, f2, off), ctx.multi_miller_loop_many(g1, f1, g2, f2, off))
+    # errors of a member surface with its index; the group stays usable
+    bad = sy.scalars(8, 730).copy(); bad[5] = 0xFF
+    gb = grp.bases_from_scalars(1, sy.scalars(8, 731))
+    import ctypes
+    out18 = np.zeros(18, dtype=np.uint64)
+    rc = grp.lib.blsgpu_g1_msm_sharded(grp.h, gb.handle, bad.ctypes.data_as(ctypes.c_void_p), 8, out18.ctypes.data_as(ctypes.c_void_p))
+    assert rc == -2 and b"group member" in grp.lib.blsgpu_last_error() and b"canonical" in grp.lib.blsgpu_last_error()
+    ok = sy.scalars(8, 732)
+    assert np.array_equal(nrm(1, grp.msm(gb, ok))[0], nrm(1, ctx.msm(ctx.bases_from_scalars(1, sy.scalars(8, 731)), ok))[0])
+    grp.close()
+
+
+def test_layout_variable_and_wide_program_diagnostics(monkeypatch, tmp_path):
+    """BLSGPU_PAIRING_LAYOUT takes exact names only (a typo fails blsgpu_create instead of selecting the slowest kernels); a missing /
+    stale wide program is reported by blsgpu_wide_status, and with the default layout small batches then run on the quad kernels"""
+    import bls12_381_amd as b
+    for bad in ("Quad", "WIDE", "wyde", "3"):
+        monkeypatch.setenv("BLSGPU_PAIRING_LAYOUT", bad)
+        with pytest.raises(b.BlsGpuError, match="BLSGPU_PAIRING_LAYOUT"):
+            b.Context(0)
+    for good, want in (("quad", 4), ("4", 4), ("pair", 2), ("auto", 256), ("wide", 256)):
+        monkeypatch.setenv("BLSGPU_PAIRING_LAYOUT", good)
+        c = b.Context(0)
+        assert c.pairing_layout(1) == want, good
+        c.close()
+    monkeypatch.delenv("BLSGPU_PAIRING_LAYOUT")
+    c = b.Context(0)
+    assert c.wide_status() == "" and c.pairing_layout(1) == 256
+    c.close()
+    # a stale file: the shipped blob with another format version
+    blob = bytearray(open(os.path.join(os.path.dirname(b.LIB_PATH), "wide_prog.bin"), "rb").read())
+    blob[60:64] = (99).to_bytes(4, "little")
+    stale = tmp_path / "stale.bin"
+    stale.write_bytes(bytes(blob))
+    for path, word in ((str(stale), "format version"), (str(tmp_path / "absent.bin"), "cannot be opened")):
+        monkeypatch.setenv("BLSGPU_WIDE_PROG", path)
+        c = b.Context(0)
+        assert word in c.wide_status(), c.wide_status()
+        assert c.pairing_layout(1) == 4
+        g = b.G1Affine.generator(); h = b.G2Affine.generator()
+        out = c.pairing_batch(g.xy[None, :], None, h.xy[None, :], None)
+        assert np.array_equal(out[0], b.Gt.generator().f)           # still the right value, on the quad kernels
+        c.close()
+        monkeypatch.setenv("BLSGPU_PAIRING_LAYOUT", "wide")
+        c = b.Context(0)
+        with pytest.raises(b.BlsGpuError, match=word):
+            c.pairing_layout(1)
+        c.close()
+        monkeypatch.delenv("BLSGPU_PAIRING_LAYOUT")

@@ -40,6 +40,41 @@ def test_no_silent_cpu_fallback():
     assert "import oracle" not in src and "from oracle" not in src, "the product must never import the oracle"
 
 
+def test_build_inputs_do_not_reach_the_oracle():
+    """oracle/ is test infrastructure: neither the run-time package nor anything build() executes may import, hash or read it.
+    (1) every generator build() runs (tools/gen_*.py) mentions the oracle only behind its optional --check flag, (2) build()'s own
+    source names oracle/ only where it builds the checker (c_oracle.build), (3) the wide-program generator, run in an isolated
+    interpreter with the `oracle` package made un-importable, writes a blob byte-identical to the checked run's."""
+    tools = os.path.join(ROOT, "tools")
+    for f in sorted(os.listdir(tools)):
+        if not (f.startswith("gen_") and f.endswith(".py")):
+            continue
+        lines = open(os.path.join(tools, f)).read().splitlines()
+        for i, l in enumerate(lines):
+            if re.search(r"^\s*(from|import)\s+oracle\b", l):
+                guard = [k for k in range(i - 1, -1, -1) if re.match(r"\s*(if|def|class)\b", lines[k])]
+                assert guard and re.match(r"\s*if check\b", lines[guard[0]]), "%s:%d imports the oracle outside `if check:`" % (f, i + 1)
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    build_src = entry[entry.index("def build("):entry.index("def check_isa(")]
+    assert "--check" not in build_src, "build() must not run a generator in its oracle-checking mode"
+    mentions = [l for l in build_src.splitlines() if re.search(r"\boracle\b", l) and not l.strip().startswith(("#", '"""'))]
+    assert all("c_oracle" in l for l in mentions), mentions          # only `from oracle import c_oracle; c_oracle.build(force)`: building the checker
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    blocked = os.path.join(ROOT, "build", "no_oracle_site")
+    os.makedirs(os.path.join(blocked, "oracle"), exist_ok=True)
+    with open(os.path.join(blocked, "oracle", "__init__.py"), "w") as fh:
+        fh.write("raise ImportError('the oracle is not a build input')\n")
+    gen = os.path.join(tools, "gen_wide_prog.py")
+    a, b_ = os.path.join(ROOT, "build", "wide_prog_no_oracle.bin"), os.path.join(ROOT, "build", "wide_prog_checked.bin")
+    env = dict(os.environ, PYTHONPATH=blocked)
+    subprocess.check_call([sys.executable, gen, "--out", a], env=env, cwd=blocked, stderr=subprocess.DEVNULL)
+    subprocess.check_call([sys.executable, gen, "--check", "--out", b_], stderr=subprocess.DEVNULL)
+    assert open(a, "rb").read() == open(b_, "rb").read()
+    shipped = os.path.join(ROOT, "bls12_381_amd", "wide_prog.bin")
+    if os.path.exists(shipped):
+        assert open(shipped, "rb").read() == open(a, "rb").read(), "bls12_381_amd/wide_prog.bin is stale: run __graft_entry__.build()"
+
+
 def test_host_encodings_match_golden(golden_dir):
     """G1Affine / G2Affine (de)serialisation of the host mirror against src/tests/*.dat and the oracle."""
     import bls12_381_amd as b
@@ -132,6 +167,15 @@ for words in (18, 36, 72):
     assert g.data_ptr() == gathered.data_ptr() and g.is_contiguous()
     for rk in range(world):
         assert torch.equal(g[rk], torch.arange(words, dtype=torch.int64) + 1000 * (rk + 1))
+# all_gather_partials: a tensor partial stays a tensor on its device (no host round trip), a numpy partial comes back as numpy
+from bls12_381_amd.distributed import all_gather_partials
+tp = torch.arange(18, dtype=torch.int64) + 7000 * (rank + 1)
+gt_ = all_gather_partials(tp, world, dist)
+assert isinstance(gt_, torch.Tensor) and gt_.shape == (world, 18) and gt_.device == tp.device and gt_.is_contiguous()
+npart = all_gather_partials(tp.numpy().view(np.uint64), world, dist)
+assert isinstance(npart, np.ndarray) and npart.dtype == np.uint64
+for rk in range(world):
+    assert torch.equal(gt_[rk], torch.arange(18, dtype=torch.int64) + 7000 * (rk + 1)) and np.array_equal(npart[rk].view(np.int64), gt_[rk].numpy())
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
@@ -228,7 +272,9 @@ _RUST_TYPES = {"c_int": "int", "usize": "size_t", "c_uint": "unsigned", "*mut Bl
                "*mut BlsgpuBases": "blsgpu_bases*", "*const BlsgpuBases": "const blsgpu_bases*", "*mut *mut BlsgpuBases": "blsgpu_bases**",
                "*const u64": "const uint64_t*", "*mut u64": "uint64_t*", "*const u8": "const uint8_t*", "*mut u8": "uint8_t*",
                "*const c_void": "const void*", "*mut c_void": "void*", "*mut f64": "double*", "*mut f32": "float*", "*mut c_uint": "unsigned*",
-               "*const c_char": "const char*"}
+               "*const c_char": "const char*", "*const c_int": "const int*",
+               "*mut BlsgpuGroup": "blsgpu_group*", "*const BlsgpuGroup": "const blsgpu_group*", "*mut *mut BlsgpuGroup": "blsgpu_group**",
+               "*mut BlsgpuGroupBases": "blsgpu_group_bases*", "*const BlsgpuGroupBases": "const blsgpu_group_bases*", "*mut *mut BlsgpuGroupBases": "blsgpu_group_bases**"}
 
 
 def _parse_rust_extern(path):
@@ -279,7 +325,8 @@ def test_rust_sources_are_complete():
     hip = open(os.path.join(base, "in-tree", "hip.rs")).read()
     for needle in ("impl pairing::Engine for crate::Bls12", "impl pairing::MultiMillerLoop for crate::Bls12", "impl pairing::MillerLoopResult for MillerLoopResult",
                    "pub fn msm_g1", "pub fn msm_g2", "pub fn pairing_batch", "pub fn multi_miller_loop", "pub fn final_exponentiation", "pub fn batch_normalize_g1",
-                   "pub fn sum_g1", "pub fn mul_batch_g1", "pub fn mul_batch_g2", "pub const GPU_MIN_PAIRINGS", "impl From<G2Affine> for G2PreparedHip"):
+                   "pub fn sum_g1", "pub fn mul_batch_g1", "pub fn mul_batch_g2", "pub const GPU_MIN_PAIRINGS", "impl From<G2Affine> for G2PreparedHip",
+                   "pub fn multi_miller_loop_many", "pub struct Group", "impl Drop for Group", "blsgpu_g1_msm_sharded", "blsgpu_multi_miller_loop_sharded", "blsgpu_pairing_batch_sharded"):
         assert needle in hip, needle
     assert os.path.exists(os.path.join(base, "Cargo.toml")) and os.path.exists(os.path.join(base, "build.rs"))
 

@@ -20,7 +20,9 @@ C_TO_RUST = {
     "blsgpu_bases*": "*mut BlsgpuBases", "const blsgpu_bases*": "*const BlsgpuBases", "blsgpu_bases**": "*mut *mut BlsgpuBases",
     "const uint64_t*": "*const u64", "uint64_t*": "*mut u64", "const uint8_t*": "*const u8", "uint8_t*": "*mut u8",
     "const void*": "*const c_void", "void*": "*mut c_void", "double*": "*mut f64", "float*": "*mut f32", "unsigned*": "*mut c_uint",
-    "const char*": "*const c_char",
+    "const char*": "*const c_char", "const int*": "*const c_int",
+    "blsgpu_group*": "*mut BlsgpuGroup", "const blsgpu_group*": "*const BlsgpuGroup", "blsgpu_group**": "*mut *mut BlsgpuGroup",
+    "blsgpu_group_bases*": "*mut BlsgpuGroupBases", "const blsgpu_group_bases*": "*const BlsgpuGroupBases", "blsgpu_group_bases**": "*mut *mut BlsgpuGroupBases",
 }
 
 
@@ -64,6 +66,10 @@ def rust_source():
              "#[repr(C)] pub struct BlsgpuCtx { _private: [u8; 0] }",
              "/// opaque: bases resident in HBM (blsgpu_g1_bases_upload & co. / blsgpu_bases_free)",
              "#[repr(C)] pub struct BlsgpuBases { _private: [u8; 0] }",
+             "/// opaque: one context per listed device (blsgpu_group_create / blsgpu_group_destroy)",
+             "#[repr(C)] pub struct BlsgpuGroup { _private: [u8; 0] }",
+             "/// opaque: bases sharded over the members of a group (blsgpu_group_bases_upload / blsgpu_group_bases_free)",
+             "#[repr(C)] pub struct BlsgpuGroupBases { _private: [u8; 0] }",
              "",
              "pub const BLSGPU_OK: c_int = 0;",
              "",

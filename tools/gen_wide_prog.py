@@ -387,13 +387,24 @@ def f12_store(f):
     return [c.stored() for c in f]
 
 
+def _fp2_pow(a, e):
+    """a^e in Fp[u]/(u^2 + 1) on Python integers: the generator owns the arithmetic behind the constants it bakes into the program
+    (the Frobenius coefficients of fp12.rs:149-168 / fp6.rs:159-185 are (u + 1)^(k (p^i - 1) / 6)); tests/ pin them to the oracle"""
+    r = (1, 0)
+    while e:
+        if e & 1:
+            r = ((r[0] * a[0] - r[1] * a[1]) % P, (r[0] * a[1] + r[1] * a[0]) % P)
+        a = ((a[0] * a[0] - a[1] * a[1]) % P, 2 * a[0] * a[1] % P)
+        e >>= 1
+    return r
+
+
 def f12_frobenius(f, power):
     """f^(p^power): conjugate the coefficients (odd powers) and scale e_k by (u + 1)^(k (p^power - 1) / 6)  (fp12.rs:145-171)"""
-    from oracle import bls12_381_ref as o
     out = []
     for k in range(6):
         c = f[k].conj() if power % 2 else f[k]
-        g = o.fp2_pow((1, 1), k * (P ** power - 1) // 6)
+        g = _fp2_pow((1, 1), k * (P ** power - 1) // 6)
         out.append(c * f2_const(g) if k else c)
     return out
 
@@ -773,13 +784,21 @@ def encode(g, rounds, consts, nslots, n_in, n_out):
 
 
 def build_programs(check=False):
-    """(miller, final_exp) encoded programs; with check, compare the symbolic values with the oracle on a test input"""
+    """(miller, final_exp) encoded programs.  The symbolic nodes carry their value for ONE sample input (SAMPLE_P, SAMPLE_Q below: the
+    generator's own literals) so that constant folding and the bound bookkeeping can be asserted while the program is built; with
+    check=True (tests/ only: the product build never passes it) the values are also compared with oracle/bls12_381_ref.py"""
     global G
-    sys.path.insert(0, ROOT)
-    from oracle import bls12_381_ref as o
-    r = o.SplitMix64(2026)
-    Pa = o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, r.scalar()))
-    Qa = o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, r.scalar()))
+    Pa, Qa = SAMPLE_P, SAMPLE_Q
+    assert (Pa[1] * Pa[1] - Pa[0] ** 3 - 4) % P == 0, "SAMPLE_P is not on y^2 = x^3 + 4"
+    if check:
+        sys.path.insert(0, ROOT)
+        from oracle import bls12_381_ref as o         # test infrastructure: reached only through --check
+        r = o.SplitMix64(2026)
+        assert o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, r.scalar()))[:2] == SAMPLE_P, "SAMPLE_P is not [k]G1 of the oracle's stream"
+        assert o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, r.scalar()))[:2] == SAMPLE_Q, "SAMPLE_Q is not [k]G2 of the oracle's stream"
+        for k in range(6):
+            for power in (1, 2, 3):
+                assert _fp2_pow((1, 1), k * (P ** power - 1) // 6) == tuple(c % P for c in o.fp2_pow((1, 1), k * (P ** power - 1) // 6))
     progs = {}
     # Miller loop: inputs px py qx.re qx.im qy.re qy.im in slots 12..17, outputs (tower order c0.c0.re ... c1.c2.im) in slots 0..11
     G = Graph()
@@ -791,7 +810,7 @@ def build_programs(check=False):
     for i, c in enumerate(flat):
         G.output(c, i)
     if check:
-        want = o.fp12_flatten(o.miller_loop(Pa, Qa))
+        want = o.fp12_flatten(o.miller_loop(Pa + (False,), Qa + (False,)))
         assert [n.val for n in G.outputs] == [w % P for w in want], "Miller program differs from the oracle"
     ml_val = [n.val for n in G.outputs]
     rounds, consts, nslots = schedule(G, 18)
@@ -806,12 +825,22 @@ def build_programs(check=False):
     for i, c in enumerate(flat):
         G.output(c, i)
     if check:
-        want = o.fp12_flatten(o.pairing(Pa, Qa))
+        want = o.fp12_flatten(o.pairing(Pa + (False,), Qa + (False,)))
         assert [n.val for n in G.outputs] == [w % P for w in want], "final exponentiation program differs from the oracle"
     rounds, consts, nslots = schedule(G, 12)
     progs["final_exp"] = (encode(G, rounds, consts, nslots, 12, 12), len(rounds), nslots, len(G.nodes))
     return progs
 
+
+# the sample input the node values are carried for: affine coordinates of one point of G1 and one of G2 (subgroup points, so that
+# the checked run can compare with the pairing of the oracle); literals, so that the generator needs nothing outside this file
+SAMPLE_P = (2953704839879994580174565036682715916180523479062088721756859108067000074983573215055813609902719574827537402469893,
+            2899222940235106533380767082349259515979568556411165493167315793440371091908654876618364418118559910748204779541058)
+SAMPLE_Q = ((731565187646367782085872659530889344490627462904754225030790530923945044183985844094010590147024639760215747998007,
+             3945096305268708607333280870131116412615992429647936549067354213625000321693642968900745670590454298583381806024262),
+            (2142671969214379813623204901809485091240339275669814619282785327695981863376685360930435794692371520888022959880221,
+             786019518877564554804028913490236040290455969355151147466247272841717321863948206830577347573464900792183413848521))
+FORMAT_VERSION = 4                        # word 15 of the blob header; wide.hip.h WIDE_FORMAT_VERSION must agree (bump with any change of the encoding)
 
 CONFIGS = [(1024, 4), (512, 8)]           # (lanes, limbs of x per product lane) built into the library: lowest latency / two workgroups per CU
 
@@ -839,10 +868,13 @@ def main():
             off += len(data)
             blob += data
             print("%4d x %d  %-10s %5d rounds, %4d slots, %6d nodes, %7d bytes" % (LANES, CHUNK, name, nr, ns, nn, len(data)), file=sys.stderr)
-    assert len(index) <= 14
-    head = struct.pack("<16I", 0x57504752, len(index) // 2, *index, *([0] * (14 - len(index))))
-    with open(out, "wb") as fh:
+    assert len(index) <= 13
+    head = struct.pack("<16I", 0x57504752, len(index) // 2, *index, *([0] * (13 - len(index))), FORMAT_VERSION)
+    tmp = "%s.tmp.%d" % (out, os.getpid())        # several ranks may build at once: a reader never sees a half-written file
+    with open(tmp, "wb") as fh:
         fh.write(head + blob)
+    os.replace(tmp, out)
+    assert "--check" in sys.argv or not any(m == "oracle" or m.startswith("oracle.") for m in sys.modules), "the generator reached the oracle without --check"
     print("wrote", out, len(head) + len(blob), "bytes", file=sys.stderr)
 
 
