@@ -507,7 +507,8 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
                             "note": "radix-2 NTT over the scalar field, in place, natural order; 5 radix-4 passes over the data + one LDS pass at 2^20",
                             "roofline": {"bound": "int-valu", "kernel": "k_fr_stage2 x 5 + k_fr_tile", "mac32_per_unit": (log_n * 136) // 2,
                                          "achieved": ntt_mac / (nms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s", "frac": ntt_mac / (nms * 1e-3) / peak,
-                                         "algorithmic_bytes": ntt_bytes, "hbm_frac_of_8TBs": ntt_bytes / (nms * 1e-3) / 8e12, "traffic": None}}
+                                         "algorithmic_bytes": ntt_bytes, "hbm_frac_of_8TBs": ntt_bytes / (nms * 1e-3) / 8e12,
+                                         "traffic": static_traffic("ntt")[0], "traffic_source": static_traffic("ntt")[1]}}
         del d_fr
     # hash-to-curve in front of the pairings: 2^16 32-byte messages -> G2
     rs = np.random.RandomState(99)
@@ -520,7 +521,16 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
     def h2c():
         bls._lib.check(ctx.lib.blsgpu_hash_to_curve_device(ctx.h, 2, hm.data_ptr(), ho.data_ptr(), np_, hd.data_ptr(), len(hdst), 0, hout.data_ptr()), "hash_to_curve_device")
     hms = median_ms(h2c, sync, warm=1, reps=3)
-    extras["hash_to_g2"] = {"n": np_, "ms": hms, "hashes_per_s": np_ / (hms * 1e-3), "note": "hash_to_curve (XMD:SHA-256, SSWU, RO) of 32-byte messages to G2"}
+    # work per hash in the units of SURVEY.md 8d (one Fp multiplication = 300 MAC32; an Fp2 product counts 3, an Fp2 square 2): two
+    # square-root-ratio powers a^((p^2-9)/16) of the simplified SWU map (762 squarings + 204 products in Fp2 each: 2 x 2 136), the two
+    # multiplications by |x| of the cofactor clearing (63 doublings + 5 additions on the twist each: 2 x ~1 900), isogeny, point
+    # additions, psi maps, sgn0 / exceptional-case selects ~600: ~8 700 field multiplications (an estimate of the algorithm's count,
+    # not an instruction count of the kernel)
+    mac_h2c = 8700 * 300
+    extras["hash_to_g2"] = {"n": np_, "ms": hms, "hashes_per_s": np_ / (hms * 1e-3), "note": "hash_to_curve (XMD:SHA-256, SSWU, RO) of 32-byte messages to G2",
+                            "roofline": {"bound": "int-valu", "kernel": "k_hash_to_curve<G2, lane pair>", "mac32_per_unit": mac_h2c, "mac32_per_unit_is": "estimate (see bench.py)",
+                                         "achieved": np_ * mac_h2c / (hms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s", "frac": np_ * mac_h2c / (hms * 1e-3) / peak,
+                                         "algorithmic_bytes": np_ * (32 + 288), "traffic": None}}
     del hm, ho, hout
     # 2^20-point G2 MSM (BASELINE configs[2]), pipelined like the headline
     n2 = min(1 << 20, n)

@@ -35,7 +35,9 @@ typedef uint64_t u64;
 typedef u32 v16 __attribute__((ext_vector_type(16)));   // ABI carrier: passes in 16 VGPRs across calls
 
 #define DEV __device__ __forceinline__
+#ifndef DEVNI                     // a translation unit built for another occupancy gives its out-of-line routines the matching register budget
 #define DEVNI __device__ __noinline__
+#endif
 
 constexpr int NL = 14;
 constexpr int LW = 28;

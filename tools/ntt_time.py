@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fr NTT timing: python tools/ntt_time.py  (2^16, 2^20, 2^24 elements in HBM, in place; median of 20)"""
+"""Fr NTT timing: python tools/ntt_time.py [log_n ...]  (default 2^10, 2^16, 2^20, 2^24 elements in HBM, in place; median of 20)"""
 import hashlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,7 +8,7 @@ import torch
 import bls12_381_amd as bls
 ctx = bls.Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-for log_n in (10, 16, 20, 24):
+for log_n in ([int(a) for a in sys.argv[1:]] or (10, 16, 20, 24)):
     n = 1 << log_n
     rs = np.random.RandomState(log_n)
     a = rs.randint(0, 2**62, size=(n, 4), dtype=np.int64).astype(np.uint64)
