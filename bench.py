@@ -591,6 +591,24 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
         mb["gpu_result_matches"] = bool(np.array_equal(got_xy, want_xy) and np.array_equal(got_inf, want_inf))
         if not mb["gpu_result_matches"]:
             raise SystemExit("bench: GPU mul_batch differs from the CPU oracle on the sample")
+    # the same pairs with the caller vouching for the subgroup (blsgpu_set_assume_subgroup): endomorphism split, 32 windows of two additions
+    fctx = bls.Context(torch.cuda.current_device())
+    fctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    fctx.set_assume_subgroup(True)
+    d_mo_f = torch.zeros((n, 18), dtype=torch.int64, device=dev)
+    mbf = median_ms(lambda: fctx.mul_batch_device(1, d_xy1.data_ptr(), 0, d_scalars.data_ptr(), n, d_mo_f.data_ptr()), sync, warm=1, reps=3)
+    MAC32_G1_MUL_GLV = 1860 * 300
+    mb["vouched_subgroup"] = {"ms": mbf, "scalar_muls_per_s": n / (mbf * 1e-3),
+                              "note": "k_mul_batch_glv: scalars split with the endomorphism, 128 doublings x 8 + 67 additions x 12 + 32 = 1 860 field multiplications per unit",
+                              "roofline": {"bound": "int-valu", "kernel": "k_mul_batch_glv", "mac32_per_unit": MAC32_G1_MUL_GLV, "achieved": n * MAC32_G1_MUL_GLV / (mbf * 1e-3) / 1e12,
+                                           "peak": peak / 1e12, "unit": "TMAC32/s", "frac": n * MAC32_G1_MUL_GLV / (mbf * 1e-3) / peak}}
+    if not args.no_cpu_baseline:
+        fa_xy, fa_inf = ctx.batch_normalize(1, d_mo_f[:mm].cpu().numpy().view(np.uint64))
+        mb["vouched_subgroup"]["gpu_result_matches"] = bool(np.array_equal(fa_xy, want_xy) and np.array_equal(fa_inf, want_inf))
+        if not mb["vouched_subgroup"]["gpu_result_matches"]:
+            raise SystemExit("bench: GPU mul_batch (endomorphism path) differs from the CPU oracle on the sample")
+    fctx.close()
+    del d_mo_f
     extras["g1_mul_batch"] = mb
     n2m = min(1 << 18, n2)
     xy2m, _ = b2.download(0, n2m)

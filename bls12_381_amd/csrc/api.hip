@@ -816,20 +816,21 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   if (c->item_cap) cap = c->item_cap;
   const size_t max_items = total / cap + nb + 1;                // every bucket has >= 1 item
   const size_t max_records = nb + max_items;                    // bucket sums + partial sums of heavy buckets
-  bad_alloc |= sl.items.reserve(max_items * sizeof(ItemDesc));
-  bad_alloc |= sl.heavy.reserve(nb * sizeof(uint4));
-  bad_alloc |= sl.ctrl.reserve((4 + 2 * ITEM_BINS) * 4);
   {
+    blsgpu_ctx::Slot* g = &sl;
+    bad_alloc |= g->items.reserve(max_items * sizeof(ItemDesc));
+    bad_alloc |= g->heavy.reserve(nb * sizeof(uint4));
+    bad_alloc |= g->ctrl.reserve((4 + 2 * ITEM_BINS) * 4);
     // (re)allocation frees memory: make sure nothing of this slot is in flight
     size_t lvl = (nb / 2 + 1) * PW * 4;
-    bool grow = sl.buckets.cap < max_records * PW * 4 || sl.lvlR[0].cap < lvl || sl.lvlT.cap < 2 * lvl || sl.wacc[0].cap < (size_t)nwin * 32 * PW * 4 || sl.wsums.cap < (size_t)nwin * PW * 4;
-    if (grow) { HIPCHK(hipStreamSynchronize(sl.tail)); HIPCHK(hipStreamSynchronize(st)); }
-    bad_alloc |= sl.buckets.reserve(max_records * PW * 4);
-    bad_alloc |= sl.lvlR[0].reserve(lvl); bad_alloc |= sl.lvlR[1].reserve(lvl); bad_alloc |= sl.lvlT.reserve(2 * lvl);     // every level's T records side by side
-    bad_alloc |= sl.tsum[0].reserve(lvl); bad_alloc |= sl.tsum[1].reserve(lvl);
-    bad_alloc |= sl.wacc[0].reserve((size_t)nwin * 32 * PW * 4); bad_alloc |= sl.wacc[1].reserve((size_t)nwin * 32 * PW * 4);
-    bad_alloc |= sl.wsums.reserve((size_t)nwin * PW * 4);
-    bad_alloc |= sl.result.reserve(PW * 4);
+    bool grow = g->buckets.cap < max_records * PW * 4 || g->lvlR[0].cap < lvl || g->lvlT.cap < 2 * lvl || g->wacc[0].cap < (size_t)nwin * 32 * PW * 4 || g->wsums.cap < (size_t)nwin * PW * 4;
+    if (grow) { HIPCHK(hipStreamSynchronize(g->tail)); HIPCHK(hipStreamSynchronize(g->tail2)); HIPCHK(hipStreamSynchronize(st)); }
+    bad_alloc |= g->buckets.reserve(max_records * PW * 4);
+    bad_alloc |= g->lvlR[0].reserve(lvl); bad_alloc |= g->lvlR[1].reserve(lvl); bad_alloc |= g->lvlT.reserve(2 * lvl);     // every level's T records side by side
+    bad_alloc |= g->tsum[0].reserve(lvl); bad_alloc |= g->tsum[1].reserve(lvl);
+    bad_alloc |= g->wacc[0].reserve((size_t)nwin * 32 * PW * 4); bad_alloc |= g->wacc[1].reserve((size_t)nwin * 32 * PW * 4);
+    bad_alloc |= g->wsums.reserve((size_t)nwin * PW * 4);
+    bad_alloc |= g->result.reserve(PW * 4);
   }
   if (bad_alloc) { g_err = "hipMalloc(msm scratch) failed"; return BLSGPU_ERR_HIP; }
   const bool prof = c->profiling;
@@ -894,53 +895,64 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     LAUNCHCHK();
     mark(3);
   }
+  // 4.-7. for the windows [g0, g0 + ng) (the whole call: cutting a single call into a high and a low window group whose tails overlap
+  // was measured in round 4 and is slower, tools/experiments/msm_window_groups.patch): work items, accumulation, bucket reduction,
+  // window combine.  gs = the slot whose buffers, side streams and events are used; gft / gas / gtt / gt2 = front, accumulation, tail
+  // and tree streams
+  auto run_group = [&](blsgpu_ctx::Slot& gs, int g0, int ng, hipStream_t gft, hipStream_t gas, hipStream_t gtt, hipStream_t gt2, bool last) -> int {
+  const size_t gnb = (size_t)ng * nbw;
+  const size_t gmax_items = (size_t)ng * ns / cap + gnb + 1;
+  const u32* goffs = sl.offs.as<u32>() + (size_t)g0 * nbw;
   // 4. work items
-  u32* ctrl = sl.ctrl.as<u32>();
+  u32* ctrl = gs.ctrl.as<u32>();
   u32* bins = ctrl + 4;
   u32* bcur = ctrl + 4 + ITEM_BINS;
-  hipLaunchKernelGGL(k_item_count, dim3(nblk(nb, ITEM_BLOCK_BUCKETS)), dim3(256), 0, ft, sl.offs.as<u32>(), bins, ctrl, (int)nb, cap);
-  hipLaunchKernelGGL(k_item_scan, dim3(1), dim3(256), 0, ft, bins, ctrl, cap);
-  hipLaunchKernelGGL(k_item_fill, dim3(nblk(nb, ITEM_BLOCK_BUCKETS)), dim3(256), 0, ft, sl.offs.as<u32>(), bins, bcur, ctrl, sl.items.as<ItemDesc>(),
-                     sl.heavy.as<uint4>(), (int)nb, cap);
-  LAUNCHCHK();
-  mark(4);
-  // pipelined calls accumulate on the library's own stream: front(i+1) must not queue behind accumulate(i)
-  hipStream_t as = c->pipelining ? c->acc_stream : st;
-  if (as != ft) { HIPCHK(hipEventRecord(sl.ev_front, ft)); HIPCHK(hipStreamWaitEvent(as, sl.ev_front, 0)); }
+  {
+    hipLaunchKernelGGL(k_item_count, dim3(nblk(gnb, ITEM_BLOCK_BUCKETS)), dim3(256), 0, gft, goffs, bins, ctrl, (int)gnb, cap);
+    hipLaunchKernelGGL(k_item_scan, dim3(1), dim3(256), 0, gft, bins, ctrl, cap);
+    hipLaunchKernelGGL(k_item_fill, dim3(nblk(gnb, ITEM_BLOCK_BUCKETS)), dim3(256), 0, gft, goffs, bins, bcur, ctrl, gs.items.as<ItemDesc>(),
+                       gs.heavy.as<uint4>(), (int)gnb, cap);
+    LAUNCHCHK();
+    if (last) mark(4);
+    if (gas != gft) { HIPCHK(hipEventRecord(gs.ev_front, gft)); HIPCHK(hipStreamWaitEvent(gas, gs.ev_front, 0)); }
+  }
   // the records (and images) may have been written on another stream than this call's (blsgpu_set_stream after the upload)
   if (!bases->ready_seen) {
     if (hipEventQuery(bases->ev_ready) == hipSuccess) bases->ready_seen = true;
-    else HIPCHK(hipStreamWaitEvent(as, bases->ev_ready, 0));
+    else HIPCHK(hipStreamWaitEvent(gas, bases->ev_ready, 0));
   }
   // 5. accumulate (grid covers the worst-case item count; surplus lanes exit on ctrl[2])
   // timing events are not free in a pipelined run (two records cost ~0.05-0.1 ms of queue time per MSM): sample every N-th launch
   const bool time_this = c->acc_timing && (c->acc_tick++ % (unsigned)c->acc_timing) == 0;
-  if (time_this) { acc_harvest(c, false); if (sl.k_pending) { hipEventSynchronize(sl.ev_k1); acc_harvest(c, false); } hipEventRecord(sl.ev_k0, as); }
-  u32* records = sl.buckets.as<u32>();
+  if (time_this) { acc_harvest(c, false); if (gs.k_pending) { hipEventSynchronize(gs.ev_k1); acc_harvest(c, false); } hipEventRecord(gs.ev_k0, gas); }
+  u32* records = gs.buckets.as<u32>();
   const u32* base_rec = (merged ? bases->table : bases->rec) + first * Store<F>::AFF_WORDS;
   if constexpr (GroupTag<F>::id == 2)
-    hipLaunchKernelGGL(k_msm_accumulate_g2pair, dim3(nblk(2 * max_items, BLS_G2ACC_BLOCK)), dim3(BLS_G2ACC_BLOCK), 0, as, gls ? bases->endo + 4 * first * Store<F>::AFF_WORDS : base_rec,
-                       sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
+    hipLaunchKernelGGL(k_msm_accumulate_g2pair, dim3(nblk(2 * gmax_items, BLS_G2ACC_BLOCK)), dim3(BLS_G2ACC_BLOCK), 0, gas, gls ? bases->endo + 4 * first * Store<F>::AFF_WORDS : base_rec,
+                       sl.sorted.as<u32>(), gs.items.as<ItemDesc>(), ctrl, records);
   else
-    hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(max_items, BLS_ACC_BLOCK)), dim3(BLS_ACC_BLOCK), 0, as, base_rec, glv ? bases->endo + first * Store<F>::AFF_WORDS : (const u32*)nullptr,
-                       glv ? (u32)n : 0xffffffffu, sl.sorted.as<u32>(), sl.items.as<ItemDesc>(), ctrl, records);
-  if (time_this) { hipEventRecord(sl.ev_k1, as); sl.k_pending = true; }
+    hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(gmax_items, BLS_ACC_BLOCK)), dim3(BLS_ACC_BLOCK), 0, gas, base_rec, glv ? bases->endo + first * Store<F>::AFF_WORDS : (const u32*)nullptr,
+                       glv ? (u32)n : 0xffffffffu, sl.sorted.as<u32>(), gs.items.as<ItemDesc>(), ctrl, records);
+  if (time_this) { hipEventRecord(gs.ev_k1, gas); gs.k_pending = true; }
   // the fold of cut buckets (almost always a no-op) stays on the accumulation stream: as the first kernel of the tail it made
   // the next accumulation start ~90 us earlier, inside the previous call's bottom reduction level, and the pipelined rate FELL
   // by 2.6 % (A/B on one box, twice: 3.57 vs 3.66*10^8 scalar-muls/s)
-  hipLaunchKernelGGL(k_msm_heavy<F>, dim3(HEAVY_SMALL_BLOCKS + 512), dim3(256), 0, as, sl.heavy.as<uint4>(), ctrl, records);
+  hipLaunchKernelGGL(k_msm_heavy<F>, dim3(HEAVY_SMALL_BLOCKS + 512), dim3(256), 0, gas, gs.heavy.as<uint4>(), ctrl, records);
   LAUNCHCHK();
-  if (prof) hipEventRecord(c->ev[5], as);
-  // ---- tail on the slot's own stream ---------------------------------------------------------------
-  if (tt != as) { HIPCHK(hipEventRecord(sl.ev_acc, as)); HIPCHK(hipStreamWaitEvent(tt, sl.ev_acc, 0)); }
+  if (prof) hipEventRecord(c->ev[5], gas);
+  // ---- tail ------------------------------------------------------------------------------------------------------
+  if (gtt != gas) { HIPCHK(hipEventRecord(gs.ev_acc, gas)); HIPCHK(hipStreamWaitEvent(gtt, gs.ev_acc, 0)); }
   // 6. per-window weighted sums:  wsum = sum_g T_g + M * wsum0(R)
   {
+    const int nseg = ng;                                // (shadows the call's window count: everything below is per group)
+    hipStream_t tt = gtt;
+    blsgpu_ctx::Slot& sl = gs;
     std::vector<int> Ms;
     const u32* E = records;
     int nn = (int)nbw, off = 1, cur = 0, level = 0;
     // level T sums are stored consecutively in wacc[0]: level l at offset l * nseg
-    u32* tstore = sl.wacc[0].as<u32>();
-    hipStream_t t2 = sl.tail2;
+    u32* tstore = sl.wacc[0].template as<u32>();
+    hipStream_t t2 = gt2;
     size_t toff = 0;                                    // offset (records) of this level's T block inside lvlT
     struct Tree { const u32* in; int n, pp, level; size_t off; };
     std::vector<Tree> trees;                            // T trees with passes left
@@ -967,8 +979,8 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     while (nn > 1) {
       int M = nn >= 8 ? 8 : nn;
       int G = nn / M;
-      u32* Rout = sl.lvlR[cur].as<u32>();
-      u32* Tout = sl.lvlT.as<u32>() + toff * PW;
+      u32* Rout = sl.lvlR[cur].template as<u32>();
+      u32* Tout = sl.lvlT.template as<u32>() + toff * PW;
       // a level with a single group writes its T straight into the Horner table
       if (G == 1) Tout = tstore + (size_t)level * nseg * PW;
       // the two running sums of a chain (R and T) advance on two teams / two lanes, T one step behind R: M + 1 dependent
@@ -995,7 +1007,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
           const u32* Tin = Tout; int tn = G, tc = 0;
           while (tn > 1) {
             int TM = tn >= 8 ? 8 : tn; int TG = (tn + TM - 1) / TM;
-            u32* o = TG == 1 ? tstore + (size_t)level * nseg * PW : sl.tsum[tc].as<u32>() + toff * PW;
+            u32* o = TG == 1 ? tstore + (size_t)level * nseg * PW : sl.tsum[tc].template as<u32>() + toff * PW;
             hipLaunchKernelGGL(k_tree_sum<F>, dim3(nblk((size_t)nseg * TG, 256)), dim3(256), 0, tt, Tin, o, nseg, tn, TM);
             LAUNCHCHK();
             Tin = o; tn = TG; tc ^= 1;
@@ -1019,7 +1031,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
       HIPCHK(hipMemcpyAsync(sl.wsums.p, records, (size_t)nseg * PW * 4, hipMemcpyDeviceToDevice, tt));
     } else {
       // Horner over the levels: acc_L = T_L ; acc_l = T_l + M_l * acc_{l+1}
-      u32* accbuf = sl.wacc[1].as<u32>();
+      u32* accbuf = sl.wacc[1].template as<u32>();
       HIPCHK(hipMemcpyAsync(accbuf, tstore + (size_t)(level - 1) * nseg * PW, (size_t)nseg * PW * 4, hipMemcpyDeviceToDevice, tt));
       for (int l = level - 2; l >= 0; l--) {
         int k = 0; while ((1 << k) < Ms[l]) k++;
@@ -1029,16 +1041,27 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
       HIPCHK(hipMemcpyAsync(sl.wsums.p, accbuf, (size_t)nseg * PW * 4, hipMemcpyDeviceToDevice, tt));
     }
   }
-  if (prof) hipEventRecord(c->ev[6], tt);
+  if (prof) hipEventRecord(c->ev[6], gtt);
   // 7. combine windows
-  hipLaunchKernelGGL(k_msm_combine_team<F>, dim3(1), dim3(TEAM), TEAM_LDS(TEAM), tt, sl.wsums.as<u32>(), sl.result.as<u32>(), nseg, cw);
+  hipLaunchKernelGGL(k_msm_combine_team<F>, dim3(1), dim3(TEAM), TEAM_LDS(TEAM), gtt, gs.wsums.as<u32>(), gs.result.as<u32>(), ng, cw);
   LAUNCHCHK();
-  hipLaunchKernelGGL(k_proj_export<F>, dim3(1), dim3(256), 0, tt, sl.result.as<u32>(), (u32*)d_out_wire, (size_t)1);
-  LAUNCHCHK();
-  if (prof) hipEventRecord(c->ev[7], tt);
-  HIPCHK(hipEventRecord(sl.ev_tail, tt));
-  sl.tail_pending = true;
-  sl.seq = ++c->msm_calls;
+  if (last) {
+    hipLaunchKernelGGL(k_proj_export<F>, dim3(1), dim3(256), 0, gtt, gs.result.as<u32>(), (u32*)d_out_wire, (size_t)1);
+    LAUNCHCHK();
+  }
+  if (prof) hipEventRecord(c->ev[7], gtt);
+  HIPCHK(hipEventRecord(gs.ev_tail, gtt));
+  gs.tail_pending = true;
+  gs.seq = c->msm_calls + 1;
+  return BLSGPU_OK;
+  };
+  // pipelined calls accumulate on the library's own stream: front(i+1) must not queue behind accumulate(i)
+  hipStream_t as = c->pipelining ? c->acc_stream : st;
+  {
+    int rc = run_group(sl, 0, nseg, ft, as, tt, sl.tail2, true);
+    if (rc) return rc;
+  }
+  ++c->msm_calls;
   if (!c->pipelining && tt != st) HIPCHK(hipStreamWaitEvent(st, sl.ev_tail, 0));    // in-order semantics on the caller's stream
   if (prof) {
     HIPCHK(hipStreamSynchronize(tt));
@@ -1130,6 +1153,14 @@ static int mul_batch_device(blsgpu_ctx* c, const void* d_xy, const void* d_inf, 
   if (!c || (n && (!d_xy || !d_scalars || !d_out))) return bad("mul_batch: NULL argument");
   if (!n) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
+  if constexpr (MbIO<F>::LANES == 1) {
+    // G1 points the caller vouches for (blsgpu_set_assume_subgroup): the endomorphism split halves the doublings, as in the MSM
+    if (c->assume_subgroup && !c->no_glv) {
+      hipLaunchKernelGGL(k_mul_batch_glv, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (const u32*)d_xy, (const uint8_t*)d_inf, (const u32*)d_scalars, (u32*)d_out, n, c->status_word);
+      LAUNCHCHK();
+      return BLSGPU_OK;
+    }
+  }
   hipLaunchKernelGGL(k_mul_batch<F>, dim3(nblk(n * MbIO<F>::LANES, 256)), dim3(256), 0, c->stream, (const u32*)d_xy, (const uint8_t*)d_inf, (const u32*)d_scalars,
                      (u32*)d_out, n, c->status_word);
   LAUNCHCHK();

@@ -267,15 +267,10 @@ template <int WORDS> struct DigitIter {
 // scalars: the same number of bucket additions, but HALF the windows -- half the buckets to reduce and half the doublings
 // in the window combine.  out[i] = |k1|, out[n + i] = |k2| as four words each; bit 127 = 1 if the term is SUBTRACTED.
 typedef unsigned __int128 u128;
-__global__ void __launch_bounds__(256) k_glv_decompose(const u32* __restrict__ scalars, u32* __restrict__ out, int n, u32* __restrict__ status) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// k (eight words, canonical) -> |k1|, |k2| as four words each; bit 127 of k1 = 1 if the P term is SUBTRACTED, bit 127 of k2 = 1 if the
+// phi(P) term is SUBTRACTED
+DEV void glv_split(const u32* k, u32* k1o, u32* k2o) {
   constexpr u32 Lw[4] = BLS_GLV_L_W, Mw[5] = BLS_GLV_M_W, Hw[4] = BLS_GLV_H_W;
-  u32 k[8];
-  const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
-  uint4 a = sp[0], b = sp[1];
-  k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
-  if (!scalar_is_canonical(k)) atomicOr(status, 1u);
   // q = floor(k M / 2^256) in {floor(k / L) - 1, floor(k / L)}   (M = floor(2^256 / L))
   u32 q[5];
   u128 acc = 0;
@@ -319,9 +314,22 @@ __global__ void __launch_bounds__(256) k_glv_decompose(const u32* __restrict__ s
   }
   // k P = (neg1 ? -1 : 1) |k1| P  +  k2 (-phi(P)):  the phi term is subtracted when k2 > 0
   u32 sub2 = neg2 ? 0u : 1u;
+  k1o[0] = k1[0]; k1o[1] = k1[1]; k1o[2] = k1[2]; k1o[3] = k1[3] | (neg1 << 31);
+  k2o[0] = k2[0]; k2o[1] = k2[1]; k2o[2] = k2[2]; k2o[3] = k2[3] | (sub2 << 31);
+}
+__global__ void __launch_bounds__(256) k_glv_decompose(const u32* __restrict__ scalars, u32* __restrict__ out, int n, u32* __restrict__ status) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 k[8];
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+  uint4 a = sp[0], b = sp[1];
+  k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
+  if (!scalar_is_canonical(k)) atomicOr(status, 1u);
+  u32 k1[4], k2[4];
+  glv_split(k, k1, k2);
   uint4* o = reinterpret_cast<uint4*>(out);
-  o[i] = make_uint4(k1[0], k1[1], k1[2], k1[3] | (neg1 << 31));
-  o[(size_t)n + i] = make_uint4(k2[0], k2[1], k2[2], k2[3] | (sub2 << 31));
+  o[i] = make_uint4(k1[0], k1[1], k1[2], k1[3]);
+  o[(size_t)n + i] = make_uint4(k2[0], k2[1], k2[2], k2[3]);
 }
 // the images under phi of resident G1 bases: (BETA x, y), same flag
 __global__ void __launch_bounds__(256) k_bases_endo(const u32* __restrict__ rec, u32* __restrict__ endo, size_t n) {

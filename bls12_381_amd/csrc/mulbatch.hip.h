@@ -89,4 +89,77 @@ k_mul_batch(const u32* __restrict__ xy, const uint8_t* __restrict__ inf, const u
   MbIO<F>::save(acc.x, o); MbIO<F>::save(acc.y, o + WW); MbIO<F>::save(acc.z, o + 2 * WW);
 }
 
+// G1 fast path for points the caller vouches for (prime-order subgroup: blsgpu_set_assume_subgroup): the GLV split of the MSM
+// (msm.hip.h glv_split: k P = +-|k1| P -+ |k2| phi(P) with 127-bit halves, phi(X : Y : Z) = (BETA X : Y : Z), g1.rs:421-437) turns
+// the 64 windows into 32 with TWO additions each over ONE table -- the image of a table entry is one multiplication by BETA:
+// 128 doublings x 8 + 67 additions x 12 + 32 = 1 860 field multiplications against 2 852.  Outside the subgroup phi(P) is not
+// -[z^2] P, so unverified inputs keep the kernel above.
+__global__ void __launch_bounds__(256, 2)
+k_mul_batch_glv(const u32* __restrict__ xy, const uint8_t* __restrict__ inf, const u32* __restrict__ scalars, u32* __restrict__ out, size_t n,
+                u32* __restrict__ status) {
+  typedef FpPolicy F;
+  constexpr int WW = 12;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 s[8];
+  {
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
+    uint4 a = sp[0], b = sp[1];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+  }
+  if (!scalar_is_canonical(s)) atomicOr(status, 1u);
+  u32 h[2][4];
+  glv_split(s, h[0], h[1]);
+  const u32 flip[2] = {h[0][3] >> 31, h[1][3] >> 31};        // the whole term is subtracted
+  h[0][3] &= 0x7fffffffu; h[1][3] &= 0x7fffffffu;
+  // signed digits in [-8, 8] of both halves; |k_j| < 2^126.5 leaves the top window at most 5 + carry: no 33rd window
+  u32 mag[2][4], sgn[2] = {0, 0};
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    u32 carry = 0;
+#pragma unroll
+    for (int w = 0; w < 32; w++) {
+      u32 d = ((h[j][w >> 3] >> ((w & 7) * 4)) & 15u) + carry;
+      const u32 over = d > 8u ? 1u : 0u;
+      d = over ? 16u - d : d;
+      carry = over;
+      if ((w & 7) == 0) mag[j][w >> 3] = 0;
+      mag[j][w >> 3] |= d << ((w & 7) * 4);
+      sgn[j] |= over << w;
+    }
+  }
+  Proj<F> tab[8];
+  {
+    Proj<F> p;
+    p.x = MbIO<F>::load(xy + i * 2 * WW); p.y = MbIO<F>::load(xy + i * 2 * WW + WW);
+    p.z = (inf && inf[i]) ? F::zero() : F::one();
+    tab[0] = p;
+    tab[1] = pt_double<F>(p);
+    tab[2] = pt_add<F>(tab[1], p);
+    tab[3] = pt_double<F>(tab[1]);
+    tab[4] = pt_add<F>(tab[3], p);
+    tab[5] = pt_double<F>(tab[2]);
+    tab[6] = pt_add<F>(tab[5], p);
+    tab[7] = pt_double<F>(tab[3]);
+  }
+  constexpr PLimbs kb = {BLS_BETA};
+  Proj<F> acc = pt_identity<F>();
+#pragma nounroll
+  for (int w = 31; w >= 0; w--) {
+    if (w != 31) { acc = pt_double<F>(acc); acc = pt_double<F>(acc); acc = pt_double<F>(acc); acc = pt_double<F>(acc); }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const u32 d = (mag[j][w >> 3] >> ((w & 7) * 4)) & 15u;
+      const bool neg_d = (((sgn[j] >> w) & 1u) ^ flip[j]) != 0;
+      Proj<F> t = tab[d ? d - 1 : 0];
+      if (!d) t = pt_identity<F>();
+      if (j) t.x = F::st(mul(t.x, fe1_const(kb)));
+      t.y = select(neg_d, F::st(neg(t.y)), t.y);
+      acc = pt_add<F>(acc, t);
+    }
+  }
+  u32* o = out + i * 3 * WW;
+  MbIO<F>::save(acc.x, o); MbIO<F>::save(acc.y, o + WW); MbIO<F>::save(acc.z, o + 2 * WW);
+}
+
 }  // namespace bls

@@ -156,7 +156,10 @@ int blsgpu_set_msm_window(blsgpu_ctx* ctx, int c);
  * `multiply` :754-774; src/g2.rs:609-647, 825-845; the "scalar multiplication" points of benches/groups.rs:44,89,113,158).
  * Signed 4-bit windows over complete addition formulas: exact for every curve point (identity, scalars 0 and r - 1, points
  * outside the prime-order subgroup) -- no subgroup precondition.  The projective representative differs from the one the
- * reference's double-and-add produces; the group element (affine coordinates) is the same.  `infinity` may be NULL. */
+ * reference's double-and-add produces; the group element (affine coordinates) is the same.  `infinity` may be NULL.
+ * With blsgpu_set_assume_subgroup(ctx, 1) -- the caller vouches that every point lies in the prime-order subgroup, e.g. values
+ * from the checked decoders -- the G1 entry points split the scalars with the endomorphism (half the doublings, ~1.5x the rate);
+ * results for off-subgroup points are then unspecified, as for the MSM. */
 int blsgpu_g1_mul_batch(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, const uint8_t* scalars, size_t n, uint64_t* out_xyz);
 int blsgpu_g2_mul_batch(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, const uint8_t* scalars, size_t n, uint64_t* out_xyz);
 /* Same with device pointers, asynchronous on the context's stream. */
