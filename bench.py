@@ -627,7 +627,24 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
         extras["g2_mul_batch"]["gpu_result_matches"] = bool(np.array_equal(got_xy2, want_xy2) and np.array_equal(got_inf2, want_inf2))
         if not extras["g2_mul_batch"]["gpu_result_matches"]:
             raise SystemExit("bench: GPU G2 mul_batch differs from the CPU oracle on the sample")
-    del d_xy1, d_mo, d_xy2, d_mo2
+    fctx2 = bls.Context(torch.cuda.current_device())
+    fctx2.set_stream(torch.cuda.current_stream().cuda_stream)
+    fctx2.set_assume_subgroup(True)
+    d_mo2f = torch.zeros((n2m, 36), dtype=torch.int64, device=dev)
+    mb2f = median_ms(lambda: fctx2.mul_batch_device(2, d_xy2.data_ptr(), 0, d_s2.data_ptr(), n2m, d_mo2f.data_ptr()), sync, warm=1, reps=3)
+    MAC32_G2_MUL_GLS = int(MAC32_G2_MUL * (64 * 8 + 71 * 12 + 48) / 2852)      # 64 doublings + 71 additions + the psi images, in the units of MAC32_G2_MUL
+    extras["g2_mul_batch"]["vouched_subgroup"] = {
+        "ms": mb2f, "scalar_muls_per_s": n2m / (mb2f * 1e-3),
+        "note": "k_mul_batch_gls: four 63-bit digits over psi, 16 windows of four additions (64 doublings + 71 additions per unit)",
+        "roofline": {"bound": "int-valu", "kernel": "k_mul_batch_gls", "mac32_per_unit": MAC32_G2_MUL_GLS, "achieved": n2m * MAC32_G2_MUL_GLS / (mb2f * 1e-3) / 1e12,
+                     "peak": peak / 1e12, "unit": "TMAC32/s", "frac": n2m * MAC32_G2_MUL_GLS / (mb2f * 1e-3) / peak}}
+    if not args.no_cpu_baseline:
+        fa2_xy, fa2_inf = ctx.batch_normalize(2, d_mo2f[:mm2].cpu().numpy().view(np.uint64))
+        extras["g2_mul_batch"]["vouched_subgroup"]["gpu_result_matches"] = bool(np.array_equal(fa2_xy, want_xy2) and np.array_equal(fa2_inf, want_inf2))
+        if not extras["g2_mul_batch"]["vouched_subgroup"]["gpu_result_matches"]:
+            raise SystemExit("bench: GPU G2 mul_batch (psi path) differs from the CPU oracle on the sample")
+    fctx2.close()
+    del d_xy1, d_mo, d_xy2, d_mo2, d_mo2f
     # fixed-base mode: resident window-shifted tables (13 windows of 20 bits, one bucket set, no window combine)
     t1 = time.perf_counter()
     bases.precompute(0)

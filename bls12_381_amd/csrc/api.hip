@@ -1161,6 +1161,13 @@ static int mul_batch_device(blsgpu_ctx* c, const void* d_xy, const void* d_inf, 
       return BLSGPU_OK;
     }
   }
+  if constexpr (MbIO<F>::LANES == 2) {
+    if (c->assume_subgroup && !c->no_glv) {         // G2 points the caller vouches for: the four-dimensional psi split
+      hipLaunchKernelGGL(k_mul_batch_gls, dim3(nblk(n * 2, 256)), dim3(256), 0, c->stream, (const u32*)d_xy, (const uint8_t*)d_inf, (const u32*)d_scalars, (u32*)d_out, n, c->status_word);
+      LAUNCHCHK();
+      return BLSGPU_OK;
+    }
+  }
   hipLaunchKernelGGL(k_mul_batch<F>, dim3(nblk(n * MbIO<F>::LANES, 256)), dim3(256), 0, c->stream, (const u32*)d_xy, (const uint8_t*)d_inf, (const u32*)d_scalars,
                      (u32*)d_out, n, c->status_word);
   LAUNCHCHK();

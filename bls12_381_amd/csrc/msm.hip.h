@@ -369,15 +369,10 @@ DEV void gls_divmod_x(u32* u, int m, u32* q) {        // u: m + 2 words (top wor
     u[j] = (u32)(u64)t; u[j + 1] = (u32)((u64)t >> 32); u[j + 2] = 0;
   }
 }
-__global__ void __launch_bounds__(256) k_gls_decompose(const u32* __restrict__ scalars, u32* __restrict__ out, int n, u32* __restrict__ status) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// k (TEN words: the canonical scalar in k[0..7], k[8] = k[9] = 0; clobbered) -> the four digits |d_j| < 2^63 and, in sub[j], whether the
+// term d_j psi^j(P) is SUBTRACTED
+DEV void gls_split(u32* k, u64* d_out, u32* sub) {
   constexpr u64 X = 0xd201000000010000ull, H = X >> 1;
-  u32 k[10];
-  const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
-  uint4 a = sp[0], b = sp[1];
-  k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w; k[8] = 0; k[9] = 0;
-  if (!scalar_is_canonical(k)) atomicOr(status, 1u);
   u64 d[5];
   u32 q0[8], q1[6];
   gls_divmod_x(k, 7, q0);                       // k = q0 X + d0,  q0 < 2^192
@@ -409,10 +404,22 @@ __global__ void __launch_bounds__(256) k_gls_decompose(const u32* __restrict__ s
     if (neg[0]) d[0] += 1; else if (d[0] == 0) { d[0] = 1; neg[0] = 1; } else d[0] -= 1;
   }
   // k P = d0 P - d1 psi(P) + d2 psi^2(P) - d3 psi^3(P):  odd terms are subtracted when their digit is positive
+  sub[0] = neg[0]; sub[1] = neg[1] ^ 1u; sub[2] = neg[2]; sub[3] = neg[3] ^ 1u;
+  d_out[0] = d[0]; d_out[1] = d[1]; d_out[2] = d[2]; d_out[3] = d[3];
+}
+__global__ void __launch_bounds__(256) k_gls_decompose(const u32* __restrict__ scalars, u32* __restrict__ out, int n, u32* __restrict__ status) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 k[10];
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+  uint4 a = sp[0], b = sp[1];
+  k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w; k[8] = 0; k[9] = 0;
+  if (!scalar_is_canonical(k)) atomicOr(status, 1u);
+  u64 d[4]; u32 sb[4];
+  gls_split(k, d, sb);
   uint4* o = reinterpret_cast<uint4*>(out + (size_t)i * 8);
-  u32 s0 = neg[0], s1 = neg[1] ^ 1u, s2 = neg[2], s3 = neg[3] ^ 1u;
-  o[0] = make_uint4((u32)d[0], (u32)(d[0] >> 32) | (s0 << 31), (u32)d[1], (u32)(d[1] >> 32) | (s1 << 31));
-  o[1] = make_uint4((u32)d[2], (u32)(d[2] >> 32) | (s2 << 31), (u32)d[3], (u32)(d[3] >> 32) | (s3 << 31));
+  o[0] = make_uint4((u32)d[0], (u32)(d[0] >> 32) | (sb[0] << 31), (u32)d[1], (u32)(d[1] >> 32) | (sb[1] << 31));
+  o[1] = make_uint4((u32)d[2], (u32)(d[2] >> 32) | (sb[2] << 31), (u32)d[3], (u32)(d[3] >> 32) | (sb[3] << 31));
 }
 // the images psi^j(P), j = 0..3, of resident G2 bases, interleaved (four 256-byte records per point):
 // psi(x, y) = (conj(x) cx, conj(y) cy) (g2.rs:847-890), psi^2(x, y) = (x k2, -y) (:891-912), psi^3 = psi o psi^2

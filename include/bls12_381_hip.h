@@ -158,8 +158,9 @@ int blsgpu_set_msm_window(blsgpu_ctx* ctx, int c);
  * outside the prime-order subgroup) -- no subgroup precondition.  The projective representative differs from the one the
  * reference's double-and-add produces; the group element (affine coordinates) is the same.  `infinity` may be NULL.
  * With blsgpu_set_assume_subgroup(ctx, 1) -- the caller vouches that every point lies in the prime-order subgroup, e.g. values
- * from the checked decoders -- the G1 entry points split the scalars with the endomorphism (half the doublings, ~1.5x the rate);
- * results for off-subgroup points are then unspecified, as for the MSM. */
+ * from the checked decoders -- the scalars are split with the endomorphisms as in the MSM (G1: two 127-bit halves, half the
+ * doublings; G2: four 63-bit digits over psi, a quarter of the doublings); results for off-subgroup points are then
+ * unspecified, as for the MSM. */
 int blsgpu_g1_mul_batch(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, const uint8_t* scalars, size_t n, uint64_t* out_xyz);
 int blsgpu_g2_mul_batch(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, const uint8_t* scalars, size_t n, uint64_t* out_xyz);
 /* Same with device pointers, asynchronous on the context's stream. */

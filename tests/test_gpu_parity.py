@@ -1777,38 +1777,40 @@ def test_layout_variable_and_wide_program_diagnostics(monkeypatch, tmp_path):
         monkeypatch.delenv("BLSGPU_PAIRING_LAYOUT")
 
 
-def test_mul_batch_endomorphism_fast_path_for_vouched_points():
-    """blsgpu_set_assume_subgroup(1): G1 mul_batch splits the scalars with the endomorphism (k_mul_batch_glv: 32 windows, two
-    additions each) -- every output against the tier-1 C restatement of `multiply` (g1.rs:754-774) after affine conversion, on
-    random pairs, on every branch boundary of the decomposition (tests/decomp_model.glv_candidates), identities and s in {0, 1, r - 1};
-    and equal to the complete-formula kernel a context without the flag runs"""
+@pytest.mark.parametrize("group", [1, 2])
+def test_mul_batch_endomorphism_fast_path_for_vouched_points(group):
+    """blsgpu_set_assume_subgroup(1): mul_batch splits the scalars with the endomorphisms (G1: k_mul_batch_glv, 32 windows of two
+    additions; G2: k_mul_batch_gls, 16 windows of four over psi) -- every output against the tier-1 C restatement of `multiply`
+    (g1.rs:754-774, g2.rs:825-845) after affine conversion, on random pairs, on every branch boundary of the decomposition
+    (tests/decomp_model), identities and s in {0, 1, r - 1}; and equal to the complete-formula kernel a context without the flag runs"""
     import bls12_381_amd as b
     from oracle import c_oracle
     from bls12_381_amd import synthetic as sy
     from tests import decomp_model as dm
     c_oracle.build()
-    cands = dm.glv_candidates()
-    n = (1 << 13) + len(cands)
-    kb = sy.scalars(n, sy.SEED + 81)
-    sb = np.array(sy.scalars(n, sy.SEED + 82), dtype=np.uint8).reshape(n, 32).copy()
+    cands = dm.glv_candidates() if group == 1 else dm.gls_candidates()
+    n = (1 << (13 if group == 1 else 11)) + len(cands)
+    kb = sy.scalars(n, sy.SEED + 81 + group)
+    sb = np.array(sy.scalars(n, sy.SEED + 83 + group), dtype=np.uint8).reshape(n, 32).copy()
     for j, s in enumerate(cands):
         sb[j] = np.frombuffer(int(s).to_bytes(32, "little"), dtype=np.uint8)
     fast = b.Context(0); fast.set_assume_subgroup(True)
     plain = b.Context(0)
-    xy, inf = plain.bases_from_scalars(1, kb).download()
+    xy, inf = plain.bases_from_scalars(group, kb).download()
     xy = xy.copy(); inf = inf.copy()
-    inf[len(cands) + 3] = 1; xy[len(cands) + 3] = g1aff_w(o.G1_IDENTITY_AFF)[0]
-    want_xy, want_inf = c_oracle.mul_batch_affine(1, xy, inf, sb)
-    got = fast.mul_batch(1, xy, inf, sb)
-    axy, ainf = fast.batch_normalize(1, got)
+    inf[len(cands) + 3] = 1; xy[len(cands) + 3] = g1aff_w(o.G1_IDENTITY_AFF)[0] if group == 1 else g2aff_w(o.G2_IDENTITY_AFF)[0]
+    want_xy, want_inf = c_oracle.mul_batch_affine(group, xy, inf, sb)
+    got = fast.mul_batch(group, xy, inf, sb)
+    axy, ainf = fast.batch_normalize(group, got)
     assert np.array_equal(ainf, want_inf)
     assert np.array_equal(axy[ainf == 0], want_xy[want_inf == 0])
-    pxy, pinf = plain.batch_normalize(1, plain.mul_batch(1, xy, inf, sb))
+    pxy, pinf = plain.batch_normalize(group, plain.mul_batch(group, xy, inf, sb))
     assert np.array_equal(pinf, ainf) and np.array_equal(pxy[pinf == 0], axy[ainf == 0])
     # a non-canonical scalar is reported by the fast path too
     import ctypes
     bad = sb[:4].copy(); bad[2] = 0xFF
-    o18 = np.zeros((4, 18), dtype=np.uint64)
+    o18 = np.zeros((4, 18 * group), dtype=np.uint64)
     P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    assert fast.lib.blsgpu_g1_mul_batch(fast.h, P(np.ascontiguousarray(xy[:4])), None, P(bad), 4, P(o18)) == -2
+    fn = fast.lib.blsgpu_g1_mul_batch if group == 1 else fast.lib.blsgpu_g2_mul_batch
+    assert fn(fast.h, P(np.ascontiguousarray(xy[:4])), None, P(bad), 4, P(o18)) == -2
     fast.close(); plain.close()
