@@ -40,6 +40,17 @@ int main(int argc, char** argv) {
   auto xi = fr_op(FrOp::Invert, x);
   REQUIRE(fr_op(FrOp::Mul, x, xi)[0] == one && fr_op(FrOp::Mul, x, xi)[3] == one);
   auto y = x; fr_ntt(y); REQUIRE(!(y == x)); fr_ntt(y, true); REQUIRE(y == x);
+  // round 4: N equations in one call; the same operations over a device group (two logical members on device 0)
+  auto eqs = multi_miller_loop_many({{{ga, G2Prepared(hb)}, {G1Affine::generator(), G2Prepared(G2Affine::generator())}}, {}, {{ga, G2Prepared(hb)}}});
+  REQUIRE(eqs.size() == 3 && eqs[0] == p + g && eqs[1] == Gt::identity() && eqs[2] == p);
+  {
+    Group grp({0, 0});
+    REQUIRE(grp.size() == 2);
+    REQUIRE(grp.msm<1>({G1Affine::generator(), ga, ga}, {b, Scalar::from_u64(1), Scalar::from_u64(2)}) == gp * b + G1Projective{(G1Affine::generator() * a).xyz} + (G1Projective{(G1Affine::generator() * a).xyz}).dbl());
+    REQUIRE(grp.multi_miller_loop_final_exp({{ga, G2Prepared(hb)}, {G1Affine::identity(), G2Prepared(hb)}, {G1Affine::generator(), G2Prepared(G2Affine::generator())}}) == p + g);
+    auto pb = grp.pairing_batch({ga, G1Affine::generator(), G1Affine::identity()}, {hb, G2Affine::generator(), hb});
+    REQUIRE(pb[0] == p && pb[1] == g && pb[2] == Gt::identity());
+  }
   std::printf("host mirror ok\n");
   return 0;
 }
