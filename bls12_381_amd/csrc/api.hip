@@ -127,6 +127,9 @@ struct blsgpu_ctx {
   int next_slot = 0;
   unsigned long long msm_calls = 0;
   DevBuf result, io_a, io_b, io_c, io_d, io_e, io_f, io_out, flags_a, flags_b;
+  DevBuf fb_table[2];                   // fixed-base comb tables of the generators (k_fixed_base): 32 x 256 affine records each, built at first use
+  hipEvent_t ev_fb[2] = {};             // recorded where a table was built; awaited by every user (the caller may switch streams)
+  bool fb_ready[2] = {false, false};
   DevBuf fr_tw[2], fr_tmp, fr_ninv;     // Fr transform: twiddle tables (forward / inverse), permutation target, n^-1
   int fr_tw_log[2] = {-1, -1};
   int fr_ninv_log = -1;
@@ -311,6 +314,40 @@ __global__ void __launch_bounds__(256) k_bases_from_scalars(const u32* __restric
   for (int j = 2 * EL + 1; j < Store<F>::AFF_WORDS; j++) r[j] = 0;
 }
 
+// The same multiples from a resident table (fixed-base comb, the `WnafGroup`-style use of a fixed generator: g1.rs:988-1005,
+// g2.rs:1133-1149): table[w * 256 + d] = affine([d * 2^(8 w)] G) for the 32 bytes of a scalar -- built once per context by the kernel
+// above from 8 192 one-byte scalars -- so a multiple is 32 complete mixed additions (352 field multiplications + the affine
+// conversion) instead of 255 doublings and additions (4 845): rec[i] = affine([k_i] G), any 256-bit k_i, the same canonical record.
+template <class F>
+__global__ void __launch_bounds__(256) k_fixed_base(const u32* __restrict__ scalars, const u32* __restrict__ table, u32* __restrict__ rec, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int EL = Store<F>::EL, AW = Store<F>::AFF_WORDS;
+  u32 s[8];
+  {
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
+    uint4 a = sp[0], b = sp[1];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+  }
+  Proj<F> acc = pt_identity<F>();
+#pragma nounroll
+  for (int w = 0; w < 32; w++) {
+    const u32 d = (s[w >> 2] >> ((w & 3) * 8)) & 255u;
+    Aff<F> q; bool inf;
+    load_aff<F>(table + ((size_t)w * 256 + d) * AW, q, inf);
+    acc = pt_add_mixed<F>(acc, q, inf);
+  }
+  bool zz = is_zero(acc.z);
+  auto zi = inv(acc.z);
+  auto x = canon_any(mul(acc.x, zi));
+  auto y = canon_any(mul(acc.y, zi));
+  if (zz) { x = canon_any(F::zero()); y = canon_any(F::one()); }
+  u32* r = rec + i * AW;
+  Store<F>::st(r, x); Store<F>::st(r + EL, y);
+  r[2 * EL] = zz ? 1 : 0;
+  for (int j = 2 * EL + 1; j < AW; j++) r[j] = 0;
+}
+
 template <class F>
 __global__ void k_store_identity(u32* out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) store_proj<F>(out, pt_identity<F>());
@@ -405,6 +442,7 @@ static int ctx_init(blsgpu_ctx* c) {
   c->stream = c->own_stream;
   for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
   for (auto& e : c->ev_fr) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto& e : c->ev_fb) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   int prio_lo = 0, prio_hi = 0;
   HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
   // A/B hooks for the stream priorities: BLSGPU_PRIO = three characters for accumulation / tail / front, each h, n or l
@@ -463,7 +501,7 @@ extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
   hipDeviceSynchronize();
   if (c->d_status) hipFree(c->d_status);
   if (c->d_wide) hipFree(c->d_wide);
-  DevBuf* bufs[] = {&c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->io_f, &c->io_out, &c->flags_a, &c->flags_b, &c->fr_tw[0], &c->fr_tw[1], &c->fr_tmp, &c->fr_ninv};
+  DevBuf* bufs[] = {&c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->io_f, &c->io_out, &c->flags_a, &c->flags_b, &c->fr_tw[0], &c->fr_tw[1], &c->fr_tmp, &c->fr_ninv, &c->fb_table[0], &c->fb_table[1]};
   for (auto b : bufs) b->release();
   for (auto& sl : c->slot) {
     DevBuf* sb[] = {&sl.ent, &sl.sorted, &sl.hist, &sl.offs, &sl.cursor, &sl.bsum, &sl.items, &sl.heavy, &sl.ctrl, &sl.glv,
@@ -477,6 +515,7 @@ extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
   }
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
   for (auto& e : c->ev_fr) if (e) hipEventDestroy(e);
+  for (auto& e : c->ev_fb) if (e) hipEventDestroy(e);
   if (c->acc_stream) hipStreamDestroy(c->acc_stream);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
@@ -659,7 +698,30 @@ extern "C" int blsgpu_bases_from_scalars(blsgpu_ctx* c, int group, const uint8_t
   if (hipEventCreateWithFlags(&b->ev_ready, hipEventDisableTiming) != hipSuccess) { delete b; g_err = "hipEventCreate(bases) failed"; return BLSGPU_ERR_HIP; }
   if (hipMalloc((void**)&b->rec, (n ? n : 1) * words * 4) != hipSuccess) { bases_drop(b); g_err = "hipMalloc(bases) failed"; return BLSGPU_ERR_HIP; }
   if (n) {
-    if (group == 1) hipLaunchKernelGGL(k_bases_from_scalars<FpPolicy>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), b->rec, n);
+    // below a few thousand multiples the double-and-add kernel is as fast as building the comb table would be
+    const bool comb = n >= 4096 || c->fb_ready[group - 1];
+    if (comb && !c->fb_ready[group - 1]) {
+      // table[w * 256 + d] = [d * 2^(8 w)] G: 8 192 scalars with one non-zero byte each, through the double-and-add kernel, once per context
+      DevBuf& tb = c->fb_table[group - 1];
+      std::vector<uint8_t> one_byte((size_t)8192 * 32, 0);
+      for (int w = 0; w < 32; w++) for (int d = 0; d < 256; d++) one_byte[((size_t)w * 256 + d) * 32 + w] = (uint8_t)d;
+      if (tb.reserve((size_t)8192 * words * 4) || c->io_c.reserve((size_t)8192 * 32)) { bases_drop(b); g_err = "hipMalloc(fixed-base table) failed"; return BLSGPU_ERR_HIP; }
+      hipError_t e = hipMemcpyAsync(c->io_c.p, one_byte.data(), one_byte.size(), hipMemcpyHostToDevice, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);                 // `one_byte` lives on this frame
+      if (e != hipSuccess) { bases_drop(b); return fail("fixed-base table upload", e, __LINE__); }
+      if (group == 1) hipLaunchKernelGGL(k_bases_from_scalars<FpPolicy>, dim3(nblk(8192, 256)), dim3(256), 0, c->stream, c->io_c.as<u32>(), tb.as<u32>(), (size_t)8192);
+      else hipLaunchKernelGGL(k_bases_from_scalars<Fp2Policy>, dim3(nblk(8192, 256)), dim3(256), 0, c->stream, c->io_c.as<u32>(), tb.as<u32>(), (size_t)8192);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipEventRecord(c->ev_fb[group - 1], c->stream);
+      if (e != hipSuccess) { bases_drop(b); return fail("fixed-base table build", e, __LINE__); }
+      c->fb_ready[group - 1] = true;
+    }
+    if (comb) {
+      hipError_t e = hipStreamWaitEvent(c->stream, c->ev_fb[group - 1], 0);
+      if (e != hipSuccess) { bases_drop(b); return fail("fixed-base table wait", e, __LINE__); }
+      if (group == 1) hipLaunchKernelGGL(k_fixed_base<FpPolicy>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), c->fb_table[0].as<u32>(), b->rec, n);
+      else hipLaunchKernelGGL(k_fixed_base<Fp2Policy>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), c->fb_table[1].as<u32>(), b->rec, n);
+    } else if (group == 1) hipLaunchKernelGGL(k_bases_from_scalars<FpPolicy>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), b->rec, n);
     else hipLaunchKernelGGL(k_bases_from_scalars<Fp2Policy>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), b->rec, n);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipEventRecord(b->ev_ready, c->stream);

@@ -1814,3 +1814,44 @@ def test_mul_batch_endomorphism_fast_path_for_vouched_points(group):
     fn = fast.lib.blsgpu_g1_mul_batch if group == 1 else fast.lib.blsgpu_g2_mul_batch
     assert fn(fast.h, P(np.ascontiguousarray(xy[:4])), None, P(bad), 4, P(o18)) == -2
     fast.close(); plain.close()
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_fixed_base_comb_table_matches_double_and_add_and_golden(group, golden_dir):
+    """blsgpu_bases_from_scalars on >= 4096 scalars takes the fixed-base comb (k_fixed_base: 32 table lookups + complete mixed
+    additions): the same canonical records as the double-and-add kernel small calls run, the golden k*G files for k = 0..999, and
+    plain 256-bit integers beyond r (no reduction: [k]G for the integer k, as before)"""
+    import bls12_381_amd as b
+    n = 4096 + 64
+    ks = list(range(1000)) + [o.R_ORDER - 1, o.R_ORDER, o.R_ORDER + 5, (1 << 255) - 19, (1 << 256) - 1, 1 << 248, 255 << 248, 0x0100010001000100]
+    r = o.SplitMix64(77 + group)
+    while len(ks) < n:
+        ks.append(r.next() | (r.next() << 64) | (r.next() << 128) | (r.next() << 192))
+    kb = np.zeros((n, 32), dtype=np.uint8)
+    for i, k in enumerate(ks):
+        kb[i] = np.frombuffer(int(k).to_bytes(32, "little"), dtype=np.uint8)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    import ctypes
+    big, small = b.Context(0), b.Context(0)
+
+    def from_raw(c, rows):
+        h = ctypes.c_void_p()
+        rows = np.ascontiguousarray(rows)
+        assert c.lib.blsgpu_bases_from_scalars(c.h, group, rows.ctypes.data_as(ctypes.c_void_p), rows.shape[0], ctypes.byref(h)) == 0
+        return b.ResidentBases(c, h, group)
+    xy, inf = from_raw(big, kb).download()                       # one call of 4160: the comb
+    want_xy = np.zeros_like(xy); want_inf = np.zeros_like(inf)
+    for lo in range(0, n, 1024):                                 # five calls of <= 1024: double-and-add (no table in this context)
+        wx, wi = from_raw(small, kb[lo:lo + 1024]).download()
+        want_xy[lo:lo + 1024] = wx; want_inf[lo:lo + 1024] = wi
+    assert np.array_equal(inf, want_inf) and np.array_equal(xy, want_xy)
+    assert inf[0] == 1 and inf[1001] == 1 and inf.sum() == 2     # k = 0 and k = r
+    usz = 96 if group == 1 else 192
+    unc = open(os.path.join(golden_dir, f"g{group}_uncompressed_valid_test_vectors.dat"), "rb").read()
+    cls = b.G1Affine if group == 1 else b.G2Affine
+    for k in list(range(0, 1000, 53)) + [1, 2, 999]:
+        assert cls(xy[k], bool(inf[k])).to_uncompressed() == unc[usz * k:usz * (k + 1)], k
+    # once the table exists, small calls use it too
+    x2, i2 = from_raw(big, kb[:7]).download()
+    assert np.array_equal(x2, want_xy[:7]) and np.array_equal(i2, want_inf[:7])
+    big.close(); small.close()
