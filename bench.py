@@ -490,8 +490,20 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
                                         "the two Fp12 products per equation (~1 % of its work) are not in the CPU figure"}
         if not eq["gpu_result_matches"]:
             raise SystemExit("bench: GPU multi_miller_loop_many differs from the CPU oracle on the sample")
+    # the same shape at 2^16 equations (the 2^16 pairs tiled three times): from 49 152 segments on the library shares the squarings inside a
+    # segment (one lane pair per equation, k_multi_miller_seg); max_seg_terms = 0 forces the per-term path for comparison
+    ne2 = 1 << 16
+    d_g1e, d_g2e = d_g1.repeat(ke, 1), d_g2.repeat(ke, 1)
+    d_off2 = torch.arange(0, (ne2 + 1) * ke, ke, dtype=torch.int64, device=dev)
+    d_eq2 = torch.zeros((ne2, 72), dtype=torch.int64, device=dev)
+    eq2 = median_ms(lambda: ctx.multi_miller_loop_many_device(d_g1e.data_ptr(), d_g2e.data_ptr(), d_off2.data_ptr(), ne2, ne2 * ke, d_eq2.data_ptr(), max_seg_terms=ke), sync, warm=1, reps=3)
+    keep = d_eq2[:256].clone()
+    eq2p = median_ms(lambda: ctx.multi_miller_loop_many_device(d_g1e.data_ptr(), d_g2e.data_ptr(), d_off2.data_ptr(), ne2, ne2 * ke, d_eq2.data_ptr(), max_seg_terms=0), sync, warm=1, reps=3)
+    eq["n65536"] = {"ms": eq2, "equations_per_s": ne2 / (eq2 * 1e-3), "frac": ne2 * mac_eq / (eq2 * 1e-3) / peak, "per_term_path_ms": eq2p,
+                    "paths_agree": bool(torch.equal(keep, d_eq2[:256])),
+                    "note": "2^16 equations: shared accumulator per equation (k_multi_miller_seg) + batched final exponentiation; per_term_path_ms = the same call on the per-term quads"}
     extras["verification_equations"] = eq
-    del d_off, d_eq
+    del d_off, d_eq, d_g1e, d_g2e, d_off2, d_eq2
     # Fr transform of the MSM's scalar vector
     if n & (n - 1) == 0:
         log_n = int(np.log2(n))

@@ -1821,6 +1821,7 @@ extern "C" int blsgpu_multi_miller_loop(blsgpu_ctx* c, const uint64_t* g1, const
 // Segment s = terms [off[s], off[s + 1]).  Miller values per term on the throughput kernels (or the wide path when there are few),
 // one segmented Fp12 product, one batched final exponentiation.  The product of independently squared per-term values is the
 // reference's shared-accumulator value exactly (Fp12 is a field: same element, canonical limbs).
+constexpr size_t MML_SEG_SHARED_MIN = 49152;      // segments from which blsgpu_multi_miller_loop_many shares squarings inside a segment
 static int final_exp_launch(blsgpu_ctx* c, const void* in, size_t n, void* out) {
   const int layout = pairing_layout_for(c, n);
   if (layout < 0) return wide_missing(c);
@@ -1839,8 +1840,17 @@ extern "C" int blsgpu_multi_miller_loop_many_device(blsgpu_ctx* c, const void* g
   if (c->io_out.reserve((total ? total : 1) * 576) || (parts > 1 && c->io_c.reserve(nseg * parts * 576)) || (final_exp && c->io_d.reserve(nseg * 576))) {
     g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP;
   }
-  if (total) { int rc = pairing_launch(c, 1, g1, g1inf, g2, g2inf, total, c->io_out.p); if (rc) return rc; }
   u32* prod = final_exp ? c->io_d.as<u32>() : (u32*)out;
+  // MANY short segments: one lane pair per segment with a shared accumulator (the reference's own schedule: (k - 1) / k of the 62
+  // squarings per term disappear); it needs >= 2^16 lanes' worth of segments to beat the per-term quads (a quarter-filled chip runs
+  // at the latency of one shared loop: ~13 ms for k = 3)
+  if (total && max_seg_terms >= 2 && max_seg_terms <= (size_t)MML_MAX_K && nseg >= MML_SEG_SHARED_MIN && c->pairing_layout != 256) {
+    hipLaunchKernelGGL(k_multi_miller_seg, dim3(nblk(nseg * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2,
+                       (const uint8_t*)g2inf, (const unsigned long long*)d_offsets, nseg, total, prod);
+    LAUNCHCHK();
+    return final_exp ? final_exp_launch(c, prod, nseg, out) : BLSGPU_OK;
+  }
+  if (total) { int rc = pairing_launch(c, 1, g1, g1inf, g2, g2inf, total, c->io_out.p); if (rc) return rc; }
   hipLaunchKernelGGL(k_fp12_prod_seg_quad, dim3(nblk(nseg * parts * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, c->io_out.as<u32>(), (const unsigned long long*)d_offsets,
                      nseg, total, parts, parts > 1 ? c->io_c.as<u32>() : prod);
   LAUNCHCHK();

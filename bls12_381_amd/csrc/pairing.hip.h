@@ -600,6 +600,31 @@ PAIR_KERNEL k_multi_miller_shared(const u32* __restrict__ g1, const uint8_t* __r
   multi_miller_shared(f, t, K);
   fp12_save(f, out + j * 144);
 }
+// out[s] = multi_miller_loop(terms off[s] .. off[s + 1]) with ONE shared accumulator per segment (the reference's own schedule,
+// pairings.rs:554-603: per bit every term adds its line, one squaring for all): segments of at most MML_MAX_K terms (longer ones are
+// clamped: the host dispatches here only when its bound holds), empty segments give one.  Used by blsgpu_multi_miller_loop_many for
+// MANY short segments, where a lane pair per segment fills the chip and (k - 1) / k of the 62 squarings per term disappear.
+PAIR_KERNEL k_multi_miller_seg(const u32* __restrict__ g1, const uint8_t* __restrict__ g1inf, const u32* __restrict__ g2, const uint8_t* __restrict__ g2inf,
+                               const unsigned long long* __restrict__ off, size_t nseg, size_t total, u32* __restrict__ out) {
+  size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / PL;
+  if (j >= nseg) return;
+  size_t beg = (size_t)off[j], end = (size_t)off[j + 1];
+  if (end > total) end = total;
+  if (beg > end) beg = end;
+  int K = (int)(end - beg < (size_t)MML_MAX_K ? end - beg : (size_t)MML_MAX_K);
+  MmlTerm<PE> t[MML_MAX_K];
+  for (int k = 0; k < K; k++) {
+    const size_t i = beg + k;
+    t[k].skip = (g1inf && g1inf[i]) || (g2inf && g2inf[i]);
+    if (t[k].skip) continue;
+    t[k].px = fe_from_ref(g1 + i * 24); t[k].py = fe_from_ref(g1 + i * 24 + 12);
+    t[k].qx = E2<PE>::load(g2 + i * 48); t[k].qy = E2<PE>::load(g2 + i * 48 + 24);
+    t[k].r.x = t[k].qx; t[k].r.y = t[k].qy; t[k].r.z = E2<PE>::one();
+  }
+  Fp12T<PE> f;
+  multi_miller_shared(f, t, K);
+  fp12_save(f, out + j * 144);
+}
 PAIR_KERNEL k_final_exp(const u32* __restrict__ in, u32* __restrict__ out, size_t n) {
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / PL;
   if (i >= n) return;

@@ -1855,3 +1855,41 @@ def test_fixed_base_comb_table_matches_double_and_add_and_golden(group, golden_d
     x2, i2 = from_raw(big, kb[:7]).download()
     assert np.array_equal(x2, want_xy[:7]) and np.array_equal(i2, want_inf[:7])
     big.close(); small.close()
+
+
+def test_multi_miller_loop_many_shared_squarings_for_many_short_segments(ctx):
+    """from 49 152 segments of at most 8 terms blsgpu_multi_miller_loop_many runs one lane pair per segment with a shared accumulator
+    (k_multi_miller_seg, the reference's own schedule): the same Miller values, limb for limb, as the per-term path (forced by
+    max_seg_terms = 0) -- ragged lengths 0..4 and identities included -- and as the oracle on sampled segments"""
+    import torch
+    from bls12_381_amd import synthetic as sy
+    nseg = 49152 + 7
+    rs = np.random.RandomState(5)
+    lens = rs.randint(0, 5, size=nseg)
+    lens[:4] = [0, 1, 4, 3]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    total = int(off[-1])
+    m = 1 << 12                                                    # 2^12 distinct pairs, tiled
+    g1, f1 = ctx.bases_from_scalars(1, sy.scalars(m, 801)).download(); g2, f2 = ctx.bases_from_scalars(2, sy.scalars(m, 802)).download()
+    f1 = f1.copy(); f2 = f2.copy(); f1[5] = 1; f2[9] = 1
+    reps = -(-total // m)
+    G1 = np.tile(g1, (reps, 1))[:total]; F1 = np.tile(f1, reps)[:total]; G2 = np.tile(g2, (reps, 1))[:total]; F2 = np.tile(f2, reps)[:total]
+    dev = torch.device("cuda", 0)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64 if a.dtype == np.uint64 else np.uint8)).to(dev)
+    dG1, dG2, dF1, dF2, dOff = d(G1), d(G2), d(F1), d(F2), torch.from_numpy(off).to(dev)
+    outs = []
+    for max_k in (4, 0):                                           # shared accumulator / per-term quads + segmented product
+        o_ = torch.zeros((nseg, 72), dtype=torch.int64, device=dev)
+        ctx.multi_miller_loop_many_device(dG1.data_ptr(), dG2.data_ptr(), dOff.data_ptr(), nseg, total, o_.data_ptr(), max_seg_terms=max_k, final_exp=False,
+                                          d_g1_inf=dF1.data_ptr(), d_g2_inf=dF2.data_ptr())
+        ctx.synchronize()
+        outs.append(o_.cpu().numpy().view(np.uint64))
+    assert np.array_equal(outs[0], outs[1])
+    pt1 = lambda i: (wfp(G1[i][0:6]), wfp(G1[i][6:12]), bool(F1[i]))
+    pt2 = lambda i: (wfp2(G2[i][0:12]), wfp2(G2[i][12:24]), bool(F2[i]))
+    for s in (0, 1, 2, 3, nseg - 1):
+        terms = [(pt1(i), o.g2_prepare(pt2(i))) for i in range(int(off[s]), int(off[s + 1]))]
+        assert np.array_equal(outs[0][s], fp12w(o.multi_miller_loop(terms))), s
+    # the host entry point takes the same route (its bound is exact) and finishes with the batched final exponentiation
+    gt = ctx.multi_miller_loop_many(G1, F1, G2, F2, off.astype(np.uint64), final_exp=True)
+    assert np.array_equal(gt[:64], ctx.final_exponentiation_batch(outs[0][:64]))
