@@ -223,8 +223,9 @@ int blsgpu_multi_miller_loop(blsgpu_ctx* ctx, const uint64_t* g1_xy, const uint8
  *   final_exp != 0: out[s] = multi_miller_loop(terms of s).final_exponentiation() (a `Gt`, 72 u64)
  * Terms with an identity on either side are skipped as the reference does (:566-569); an empty segment yields
  * `MillerLoopResult::default()` = Fp12::one() (:28-32), whose final exponentiation is `Gt::identity()`.  One batched Miller
- * kernel over all terms, one segmented Fp12 product, one batched final exponentiation; few terms take the wide path.  For ONE
- * product over very many terms blsgpu_multi_miller_loop (shared squarings) is the faster entry point. */
+ * kernel over all terms, one segmented Fp12 product, one batched final exponentiation; few terms take the wide path; from
+ * 49 152 segments of at most 8 terms on, every segment shares one accumulator (the reference's own schedule) instead.  For
+ * ONE product over very many terms blsgpu_multi_miller_loop is the faster entry point. */
 int blsgpu_multi_miller_loop_many(blsgpu_ctx* ctx, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy, const uint8_t* g2_inf, const uint64_t* offsets,
                                   size_t nseg, int final_exp, uint64_t* out);
 /* Device-pointer variant, asynchronous on the context's stream: points, flags, offsets (nseg + 1 u64) and the output in device
