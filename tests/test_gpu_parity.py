@@ -1893,3 +1893,48 @@ def test_multi_miller_loop_many_shared_squarings_for_many_short_segments(ctx):
     # the host entry point takes the same route (its bound is exact) and finishes with the batched final exponentiation
     gt = ctx.multi_miller_loop_many(G1, F1, G2, F2, off.astype(np.uint64), final_exp=True)
     assert np.array_equal(gt[:64], ctx.final_exponentiation_batch(outs[0][:64]))
+
+
+def test_round4_entry_points_edge_cases_and_argument_errors(ctx):
+    """new entry points: degenerate sizes are values (a group of one member, fewer points than members, segments that are all empty,
+    no segments), bad arguments are status codes with a message, and the objects stay usable"""
+    import ctypes
+    import bls12_381_amd as b
+    from bls12_381_amd import synthetic as sy
+    lib = ctx.lib
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    ERR_ARG = -2
+    # multi_miller_loop_many: all-empty segments, zero segments, NULL / malformed arguments
+    z12, z24 = np.zeros((0, 12), dtype=np.uint64), np.zeros((0, 24), dtype=np.uint64)
+    out = ctx.multi_miller_loop_many(z12, None, z24, None, np.zeros(4, dtype=np.uint64), final_exp=True)
+    assert out.shape == (3, 72) and all(np.array_equal(v, fp12w(o.FP12_ONE)) for v in out)
+    assert np.array_equal(ctx.multi_miller_loop_many(z12, None, z24, None, np.zeros(4, dtype=np.uint64), final_exp=False)[1], fp12w(o.FP12_ONE))
+    off = np.array([0, 1], dtype=np.uint64); o72 = np.zeros(72, dtype=np.uint64)
+    g1 = np.zeros(12, dtype=np.uint64); g2 = np.zeros(24, dtype=np.uint64)
+    assert lib.blsgpu_multi_miller_loop_many(ctx.h, P(g1), None, P(g2), None, None, 1, 1, P(o72)) == ERR_ARG          # no offsets
+    assert lib.blsgpu_multi_miller_loop_many(ctx.h, None, None, P(g2), None, P(off), 1, 1, P(o72)) == ERR_ARG         # terms but no points
+    assert lib.blsgpu_multi_miller_loop_many(ctx.h, P(g1), None, P(g2), None, P(np.array([1, 1], dtype=np.uint64)), 1, 1, P(o72)) == ERR_ARG   # offsets[0] != 0
+    assert b"offsets" in lib.blsgpu_last_error()
+    assert lib.blsgpu_multi_miller_loop_many(ctx.h, None, None, None, None, None, 0, 1, None) == 0                    # nothing to do
+    # groups: creation errors, one member, fewer points than members
+    h = ctypes.c_void_p()
+    assert lib.blsgpu_group_create(None, 2, ctypes.byref(h)) == ERR_ARG
+    assert lib.blsgpu_group_create((ctypes.c_int * 1)(0), 0, ctypes.byref(h)) == ERR_ARG
+    assert lib.blsgpu_group_create((ctypes.c_int * 2)(0, 4096), 2, ctypes.byref(h)) != 0 and b"member 1" in lib.blsgpu_last_error()
+    assert lib.blsgpu_group_size(None) == 0 and lib.blsgpu_group_ctx(None, 0) is None
+    one = b.Group([0])
+    kb, sb = sy.scalars(3, 950), sy.scalars(3, 951)
+    nrm = lambda x: ctx.batch_normalize(1, x[None, :])[0][0]
+    want = nrm(ctx.msm(ctx.bases_from_scalars(1, kb), sb))
+    assert np.array_equal(nrm(one.msm(one.bases_from_scalars(1, kb), sb)), want)
+    eight = b.Group([0] * 8)
+    gb = eight.bases_from_scalars(1, kb)                              # three points over eight members: five members hold nothing
+    assert np.array_equal(nrm(eight.msm(gb, sb)), want)
+    assert lib.blsgpu_group_ctx(eight.h, 7) is not None and lib.blsgpu_group_ctx(eight.h, 8) is None
+    o18 = np.zeros(18, dtype=np.uint64)
+    assert lib.blsgpu_g2_msm_sharded(eight.h, gb.handle, P(sb), 3, P(o18)) == ERR_ARG and b"other group" in lib.blsgpu_last_error()
+    assert lib.blsgpu_g1_msm_sharded(eight.h, gb.handle, P(sb), 4, P(o18)) == ERR_ARG                                 # more scalars than bases
+    assert lib.blsgpu_g1_msm_sharded(one.h, gb.handle, P(sb), 3, P(o18)) == ERR_ARG and b"another group" in lib.blsgpu_last_error()
+    assert lib.blsgpu_pairing_batch_sharded(eight.h, None, None, None, None, 2, P(o72)) == ERR_ARG
+    assert np.array_equal(nrm(eight.msm(gb, sb)), want)               # still usable
+    one.close(); eight.close()
