@@ -532,6 +532,7 @@ static int take_status(blsgpu_ctx* c) {
   HIPCHK(hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost));
   if (st) {
     HIPCHK(hipMemset(c->d_status, 0, 4));
+    if (st & 2u) return bad("multi_miller_loop_many_device: a segment is longer than the max_seg_terms the caller passed (its value is unspecified)");
     return bad("msm: a scalar is not canonical (>= r); Scalar::to_bytes never produces such bytes (scalar.rs:284-296)");
   }
   return BLSGPU_OK;
@@ -1846,7 +1847,7 @@ extern "C" int blsgpu_multi_miller_loop_many_device(blsgpu_ctx* c, const void* g
   // at the latency of one shared loop: ~13 ms for k = 3)
   if (total && max_seg_terms >= 2 && max_seg_terms <= (size_t)MML_MAX_K && nseg >= MML_SEG_SHARED_MIN && c->pairing_layout != 256) {
     hipLaunchKernelGGL(k_multi_miller_seg, dim3(nblk(nseg * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2,
-                       (const uint8_t*)g2inf, (const unsigned long long*)d_offsets, nseg, total, prod);
+                       (const uint8_t*)g2inf, (const unsigned long long*)d_offsets, nseg, total, prod, c->d_status);
     LAUNCHCHK();
     return final_exp ? final_exp_launch(c, prod, nseg, out) : BLSGPU_OK;
   }

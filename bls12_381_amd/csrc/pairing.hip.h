@@ -605,12 +605,13 @@ PAIR_KERNEL k_multi_miller_shared(const u32* __restrict__ g1, const uint8_t* __r
 // clamped: the host dispatches here only when its bound holds), empty segments give one.  Used by blsgpu_multi_miller_loop_many for
 // MANY short segments, where a lane pair per segment fills the chip and (k - 1) / k of the 62 squarings per term disappear.
 PAIR_KERNEL k_multi_miller_seg(const u32* __restrict__ g1, const uint8_t* __restrict__ g1inf, const u32* __restrict__ g2, const uint8_t* __restrict__ g2inf,
-                               const unsigned long long* __restrict__ off, size_t nseg, size_t total, u32* __restrict__ out) {
+                               const unsigned long long* __restrict__ off, size_t nseg, size_t total, u32* __restrict__ out, u32* __restrict__ status) {
   size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / PL;
   if (j >= nseg) return;
   size_t beg = (size_t)off[j], end = (size_t)off[j + 1];
   if (end > total) end = total;
   if (beg > end) beg = end;
+  if (end - beg > (size_t)MML_MAX_K) atomicOr(status, 2u);          // the caller's bound on the segment length does not hold: reported, that segment's value is unspecified
   int K = (int)(end - beg < (size_t)MML_MAX_K ? end - beg : (size_t)MML_MAX_K);
   MmlTerm<PE> t[MML_MAX_K];
   for (int k = 0; k < K; k++) {

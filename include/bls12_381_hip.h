@@ -230,7 +230,9 @@ int blsgpu_multi_miller_loop_many(blsgpu_ctx* ctx, const uint64_t* g1_xy, const 
                                   size_t nseg, int final_exp, uint64_t* out);
 /* Device-pointer variant, asynchronous on the context's stream: points, flags, offsets (nseg + 1 u64) and the output in device
  * memory.  `total_terms` = offsets[nseg] and `max_seg_terms` = an upper bound of the segment lengths (0 = unknown) are passed
- * by value because the host cannot read the offsets without a synchronisation; offsets beyond total_terms are clamped. */
+ * by value because the host cannot read the offsets without a synchronisation; offsets beyond total_terms are clamped, and a
+ * segment longer than a max_seg_terms <= 8 the caller passed is reported by the next blsgpu_synchronize (BLSGPU_ERR_ARG; the
+ * value of that segment is unspecified) -- the sticky flag of the asynchronous entry points, see blsgpu_synchronize. */
 int blsgpu_multi_miller_loop_many_device(blsgpu_ctx* ctx, const void* d_g1_xy, const void* d_g1_inf, const void* d_g2_xy, const void* d_g2_inf, const void* d_offsets,
                                          size_t nseg, size_t total_terms, size_t max_seg_terms, int final_exp, void* d_out);
 /* out[i] = final_exponentiation(in[i])  (`MillerLoopResult::final_exponentiation`, src/pairings.rs:48-176). */
@@ -260,7 +262,9 @@ int blsgpu_fp12_product_device(blsgpu_ctx* ctx, const void* d_in_f, size_t n, vo
  * (one process per GPU over RCCL is bls12_381_amd/distributed.py + bench.py --gpus N).  Results are the same group / field
  * elements as the single-context entry points'.  `devices` may name a device more than once (logical members on one GPU).
  * A group is driven by one host thread at a time; blsgpu_group_ctx gives access to a member's context for the per-context
- * settings (blsgpu_set_assume_subgroup, blsgpu_set_msm_window, ...). */
+ * settings (blsgpu_set_assume_subgroup, blsgpu_set_msm_window, ...) and for work the group calls do not cover: the sharded
+ * calls are synchronous and take host buffers; a caller that wants pipelined / device-pointer MSMs on every GPU drives the
+ * members' contexts itself (one host thread per context) and folds with blsgpu_g1_sum / blsgpu_fp12_product. */
 typedef struct blsgpu_group blsgpu_group;
 typedef struct blsgpu_group_bases blsgpu_group_bases;   /* resident bases, member k holds points [lo_k, hi_k) on its device */
 int blsgpu_group_create(const int* devices, int ndev, blsgpu_group** out);

@@ -1890,6 +1890,15 @@ def test_multi_miller_loop_many_shared_squarings_for_many_short_segments(ctx):
     for s in (0, 1, 2, 3, nseg - 1):
         terms = [(pt1(i), o.g2_prepare(pt2(i))) for i in range(int(off[s]), int(off[s + 1]))]
         assert np.array_equal(outs[0][s], fp12w(o.multi_miller_loop(terms))), s
+    # a bound that does not hold (a 9-term segment behind max_seg_terms = 8) is reported by the next synchronize, not computed wrong in silence
+    import bls12_381_amd as b
+    lens9 = np.full(nseg, 1, dtype=np.int64); lens9[100] = 9
+    off9 = torch.from_numpy(np.concatenate([[0], np.cumsum(lens9)]).astype(np.int64)).to(dev)
+    o9 = torch.zeros((nseg, 72), dtype=torch.int64, device=dev)
+    ctx.multi_miller_loop_many_device(dG1.data_ptr(), dG2.data_ptr(), off9.data_ptr(), nseg, int(lens9.sum()), o9.data_ptr(), max_seg_terms=8, final_exp=False)
+    with pytest.raises(b.BlsGpuError, match="max_seg_terms"):
+        ctx.synchronize()
+    ctx.synchronize()                                              # the flag is cleared by the report
     # the host entry point takes the same route (its bound is exact) and finishes with the batched final exponentiation
     gt = ctx.multi_miller_loop_many(G1, F1, G2, F2, off.astype(np.uint64), final_exp=True)
     assert np.array_equal(gt[:64], ctx.final_exponentiation_batch(outs[0][:64]))
