@@ -75,6 +75,8 @@ static inline int emu_update_dpp(int /*old*/, int src, int ctrl, int /*row_mask*
 // LDS atomics of the wide kernel (ds_add_u64 / ds_wrxchg_rtn_b64)
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned long long atomicExch(unsigned long long* p, unsigned long long v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
+// status-word flags (global memory)
+static inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 template <class T> static inline T min(T a, T b) { return a < b ? a : b; }
 // wave vote: every emulated lane decides for itself (only used for an early loop exit whose extra iterations are identities)
 static inline int __all(int p) { return p; }
