@@ -13,6 +13,8 @@
 //!   multi_miller_loop         multi_miller_loop(&[(p_i, prepared q_i)])                 src/pairings.rs:554-603
 //!   final_exponentiation      MillerLoopResult::final_exponentiation                    src/pairings.rs:48-176
 //!   batch_normalize_g1        G1Projective::batch_normalize                             src/g1.rs:806-839
+//!   multi_miller_loop_many    multi_miller_loop(terms_s).final_exponentiation() for every equation s    src/pairings.rs:554-603, 48-176
+//!   GpuGroup::*               the same operations sharded over the GPUs of the node (folds: `Sum`, `MillerLoopResult +`)
 //! Hot-path functions of the reference are infallible; here a HIP failure or a bad argument is an `Err(Error)` and the
 //! caller decides (fall back to the CPU expression above, or propagate).  The library itself never computes on the CPU.
 #![allow(clippy::missing_safety_doc)]
@@ -166,6 +168,21 @@ pub fn multi_miller_loop(gpu: &Gpu, terms: &[(&G1Affine, &G2Affine)]) -> Result<
     Ok(GtLimbs(out))
 }
 
+/// N independent `multi_miller_loop(terms).final_exponentiation()` in ONE device call (bulk signature verification: one product of
+/// k pairings per equation, src/pairings.rs:554-603, 817-824, 48-176): the `Gt` limbs of every equation; `final_exp = false` returns
+/// the raw `MillerLoopResult` limbs.  An equation without terms gives `Gt::identity()` / `MillerLoopResult::default()`.
+pub fn multi_miller_loop_many(gpu: &Gpu, equations: &[&[(&G1Affine, &G2Affine)]], final_exp: bool) -> Result<Vec<GtLimbs>, Error> {
+    let p: Vec<G1Affine> = equations.iter().flat_map(|e| e.iter().map(|t| *t.0)).collect();
+    let q: Vec<G2Affine> = equations.iter().flat_map(|e| e.iter().map(|t| *t.1)).collect();
+    let mut off = Vec::with_capacity(equations.len() + 1);
+    off.push(0u64);
+    for e in equations { off.push(off[off.len() - 1] + e.len() as u64); }
+    let ((g1, f1), (g2, f2)) = (g1_wire(gpu, &p)?, g2_wire(gpu, &q)?);
+    let mut out = vec![0u64; equations.len() * 72];
+    check(unsafe { ffi::blsgpu_multi_miller_loop_many(gpu.ctx, g1.as_ptr(), f1.as_ptr(), g2.as_ptr(), f2.as_ptr(), off.as_ptr(), equations.len(), final_exp as c_int, out.as_mut_ptr()) })?;
+    Ok(split72(out))
+}
+
 /// `MillerLoopResult::final_exponentiation` (src/pairings.rs:48-176) for a batch of raw Miller values.
 pub fn final_exponentiation(gpu: &Gpu, f: &[GtLimbs]) -> Result<Vec<GtLimbs>, Error> {
     let flat: Vec<u64> = f.iter().flat_map(|g| g.0).collect();
@@ -226,6 +243,63 @@ impl<'a> ResidentG1<'a> {
     }
 }
 impl Drop for ResidentG1<'_> { fn drop(&mut self) { unsafe { ffi::blsgpu_bases_free(self.handle) } } }
+
+/// Every listed GPU of the node behind one handle (`blsgpu_group_*`): MSMs, batches of pairings and `multi_miller_loop`s are dealt to
+/// the members in contiguous slices -- one context and one host thread per member inside the library -- and the members' partial results
+/// (one group element each) are folded with the reference's own operators, `Sum` (src/g1.rs:161-171) and `MillerLoopResult +
+/// MillerLoopResult` (src/pairings.rs:179-186), followed by ONE final exponentiation.  The decoders run on member 0's context.
+pub struct GpuGroup { group: *mut ffi::BlsgpuGroup, first: Gpu }
+unsafe impl Send for GpuGroup {}
+impl Drop for GpuGroup { fn drop(&mut self) { unsafe { ffi::blsgpu_group_destroy(self.group) } } }
+impl GpuGroup {
+    pub fn new(devices: &[i32]) -> Result<GpuGroup, Error> {
+        let mut group = core::ptr::null_mut();
+        check(unsafe { ffi::blsgpu_group_create(devices.as_ptr(), devices.len() as c_int, &mut group) })?;
+        // a context of its own for the byte decoders (the members' contexts belong to the group's worker threads during a call)
+        match Gpu::new(devices[0]) {
+            Ok(first) => Ok(GpuGroup { group, first }),
+            Err(e) => { unsafe { ffi::blsgpu_group_destroy(group) }; Err(e) }
+        }
+    }
+    pub fn all_devices() -> Result<GpuGroup, Error> {
+        let d: Vec<i32> = (0..Gpu::device_count().max(1)).collect();
+        GpuGroup::new(&d)
+    }
+    pub fn len(&self) -> usize { unsafe { ffi::blsgpu_group_size(self.group) as usize } }
+    pub fn is_empty(&self) -> bool { self.len() == 0 }
+    /// `bases.iter().zip(scalars).map(|(p, s)| p * s).sum::<G1Projective>()` sharded over the members
+    pub fn msm_g1(&self, bases: &[G1Affine], scalars: &[Scalar]) -> Result<G1Projective, Error> {
+        assert_eq!(bases.len(), scalars.len());
+        let ((xy, inf), s) = (g1_wire(&self.first, bases)?, scalar_bytes(scalars));
+        let mut gb = core::ptr::null_mut();
+        check(unsafe { ffi::blsgpu_group_bases_upload(self.group, 1, xy.as_ptr(), inf.as_ptr(), bases.len(), &mut gb) })?;
+        let mut xyz = [0u64; 18];
+        let rc = unsafe { ffi::blsgpu_g1_msm_sharded(self.group, gb, s.as_ptr(), bases.len(), xyz.as_mut_ptr()) };
+        unsafe { ffi::blsgpu_group_bases_free(gb) };
+        check(rc)?;
+        let (mut axy, mut ainf, mut enc) = ([0u64; 12], [0u8; 1], [0u8; 96]);
+        check(unsafe { ffi::blsgpu_g1_batch_normalize(self.first.ctx, xyz.as_ptr(), 1, axy.as_mut_ptr(), ainf.as_mut_ptr()) })?;
+        check(unsafe { ffi::blsgpu_g1_to_bytes_batch(self.first.ctx, axy.as_ptr(), ainf.as_ptr(), 1, 0, enc.as_mut_ptr()) })?;
+        Ok(G1Projective::from(Option::<G1Affine>::from(G1Affine::from_uncompressed_unchecked(&enc)).expect("libblsgpu returned an invalid G1 encoding")))
+    }
+    /// out[i] = e(p[i], q[i]), index slices per member
+    pub fn pairing_batch(&self, p: &[G1Affine], q: &[G2Affine]) -> Result<Vec<GtLimbs>, Error> {
+        assert_eq!(p.len(), q.len());
+        let ((g1, f1), (g2, f2)) = (g1_wire(&self.first, p)?, g2_wire(&self.first, q)?);
+        let mut out = vec![0u64; p.len() * 72];
+        check(unsafe { ffi::blsgpu_pairing_batch_sharded(self.group, g1.as_ptr(), f1.as_ptr(), g2.as_ptr(), f2.as_ptr(), p.len(), out.as_mut_ptr()) })?;
+        Ok(split72(out))
+    }
+    /// `multi_miller_loop(terms).final_exponentiation()`: member-local products, one fold, ONE final exponentiation
+    pub fn multi_miller_loop_final_exp(&self, terms: &[(&G1Affine, &G2Affine)]) -> Result<GtLimbs, Error> {
+        let p: Vec<G1Affine> = terms.iter().map(|t| *t.0).collect();
+        let q: Vec<G2Affine> = terms.iter().map(|t| *t.1).collect();
+        let ((g1, f1), (g2, f2)) = (g1_wire(&self.first, &p)?, g2_wire(&self.first, &q)?);
+        let mut out = [0u64; 72];
+        check(unsafe { ffi::blsgpu_multi_miller_loop_sharded(self.group, g1.as_ptr(), f1.as_ptr(), g2.as_ptr(), f2.as_ptr(), terms.len(), 1, out.as_mut_ptr()) })?;
+        Ok(GtLimbs(out))
+    }
+}
 
 /// `Curve::to_affine` convenience for callers that want affine results.
 pub fn to_affine_g1(p: &G1Projective) -> G1Affine { p.to_affine() }

@@ -319,9 +319,9 @@ def test_rust_sources_are_complete():
             assert sym in ffi, (rel, sym)
         assert src.count("{") == src.count("}") and src.count("(") == src.count(")"), rel
     lib = open(os.path.join(base, "src", "lib.rs")).read()
-    for fn in ("msm_g1", "msm_g2", "mul_batch_g1", "mul_batch_g2", "pairing_batch", "multi_miller_loop", "final_exponentiation", "batch_normalize_g1", "fp12_product", "gt_mul_scalar"):
+    for fn in ("msm_g1", "msm_g2", "mul_batch_g1", "mul_batch_g2", "pairing_batch", "multi_miller_loop", "final_exponentiation", "batch_normalize_g1", "fp12_product", "gt_mul_scalar", "multi_miller_loop_many"):
         assert re.search(r"pub fn %s\b" % fn, lib), fn
-    assert "blsgpu_g1_msm_bytes" in lib and "blsgpu_g2_msm_bytes" in lib
+    assert "blsgpu_g1_msm_bytes" in lib and "blsgpu_g2_msm_bytes" in lib and "pub struct GpuGroup" in lib and "blsgpu_multi_miller_loop_sharded" in lib
     hip = open(os.path.join(base, "in-tree", "hip.rs")).read()
     for needle in ("impl pairing::Engine for crate::Bls12", "impl pairing::MultiMillerLoop for crate::Bls12", "impl pairing::MillerLoopResult for MillerLoopResult",
                    "pub fn msm_g1", "pub fn msm_g2", "pub fn pairing_batch", "pub fn multi_miller_loop", "pub fn final_exponentiation", "pub fn batch_normalize_g1",
