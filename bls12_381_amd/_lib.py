@@ -82,6 +82,15 @@ SIGNATURES = {
     "blsgpu_multi_miller_loop_many": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
     "blsgpu_multi_miller_loop_many_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_sz, c_sz, c_int, c_vp]),
     "blsgpu_wide_status": (ctypes.c_char_p, [c_vp]),
+    "blsgpu_g2_prepare": (c_int, [c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
+    "blsgpu_g2_prepare_device": (c_int, [c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
+    "blsgpu_g2_prepared_len": (c_sz, [c_vp]),
+    "blsgpu_g2_prepared_free": (None, [c_vp]),
+    "blsgpu_g2_prepared_coeffs": (c_int, [c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "blsgpu_multi_miller_loop_prepared": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_multi_miller_loop_prepared_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_multi_miller_loop_prepared_many": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
+    "blsgpu_multi_miller_loop_prepared_many_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_sz, c_sz, c_int, c_vp]),
     "blsgpu_group_create": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp)]),
     "blsgpu_group_destroy": (None, [c_vp]),
     "blsgpu_group_size": (c_int, [c_vp]),

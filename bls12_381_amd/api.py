@@ -130,6 +130,38 @@ class ResidentBases:
             pass
 
 
+class PreparedG2Table:
+    """m `G2Prepared` values resident on the device (`blsgpu_g2_prepared`): the 68 line-coefficient triples of each point
+    (pairings.rs:487-546), named by index in the `*_prepared` Miller loops."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.handle = ctx, handle
+
+    def __len__(self):
+        return int(self.ctx.lib.blsgpu_g2_prepared_len(self.handle)) if self.handle else 0
+
+    def coeffs(self, index):
+        """(infinity, (68, 3, 12) u64): `G2Prepared { infinity, coeffs }` of point `index` in the reference's value format"""
+        out = np.zeros((68, 3, 12), dtype=np.uint64)
+        inf = np.zeros(1, dtype=np.uint8)
+        check(self.ctx.lib.blsgpu_g2_prepared_coeffs(self.ctx.h, self.handle, index, _ptr(out), _ptr(inf)), "g2_prepared_coeffs")
+        return bool(inf[0]), out
+
+    def free(self):
+        if self.handle:
+            self.ctx.lib.blsgpu_g2_prepared_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+UNPREPARED = 0xffffffff
+
+
 class Context:
     """One device + one HIP stream + scratch memory (`blsgpu_ctx`).  Not re-entrant."""
 
@@ -466,6 +498,68 @@ class Context:
         check(self.lib.blsgpu_multi_miller_loop_many_device(self.h, ctypes.c_void_p(d_g1), ctypes.c_void_p(d_g1_inf), ctypes.c_void_p(d_g2), ctypes.c_void_p(d_g2_inf),
                                                             ctypes.c_void_p(d_offsets), nseg, total_terms, max_seg_terms, 1 if final_exp else 0, ctypes.c_void_p(d_out)),
               "multi_miller_loop_many_device")
+
+    # -- G2Prepared resident on the device (pairings.rs:487-546) and its consumers (:554-603) -----------------------
+    def g2_prepare(self, g2_xy, g2_inf=None):
+        g2 = _u64(g2_xy, (-1, 24))
+        m = g2.shape[0]
+        h = ctypes.c_void_p()
+        check(self.lib.blsgpu_g2_prepare(self.h, _ptr(g2), _ptr(_flags(g2_inf, m)) if g2_inf is not None else None, m, ctypes.byref(h)), "g2_prepare")
+        return PreparedG2Table(self, h)
+
+    def g2_prepare_device(self, d_g2, d_inf, m):
+        h = ctypes.c_void_p()
+        check(self.lib.blsgpu_g2_prepare_device(self.h, ctypes.c_void_p(d_g2), ctypes.c_void_p(d_inf), m, ctypes.byref(h)), "g2_prepare_device")
+        return PreparedG2Table(self, h)
+
+    def _prepared_args(self, g1_xy, g1_inf, q_index, g2_xy, g2_inf):
+        g1 = _u64(g1_xy, (-1, 12))
+        n = g1.shape[0]
+        qi = None
+        if q_index is not None:
+            qi = np.ascontiguousarray(np.asarray(q_index, dtype=np.uint32))
+            if qi.shape != (n,):
+                raise ValueError("q_index must name one table entry (or UNPREPARED) per term")
+        g2 = None
+        if g2_xy is not None:
+            g2 = _u64(g2_xy, (-1, 24))
+            if g2.shape[0] != n:
+                raise ValueError("G1 and G2 inputs differ in length")
+        f2 = _flags(g2_inf, n) if (g2 is not None and g2_inf is not None) else None
+        return g1, _flags(g1_inf, n), g2, f2, qi, n
+
+    def multi_miller_loop_prepared(self, g1_xy, g1_inf, table, q_index, g2_xy=None, g2_inf=None):
+        """prod_i ML(g1[i], Q_i) with Q_i = table[q_index[i]] or -- q_index[i] = UNPREPARED -- g2[i] (pairings.rs:554-603)"""
+        g1, f1, g2, f2, qi, n = self._prepared_args(g1_xy, g1_inf, q_index, g2_xy, g2_inf)
+        out = np.zeros(72, dtype=np.uint64)
+        check(self.lib.blsgpu_multi_miller_loop_prepared(self.h, _ptr(g1), _ptr(f1), _ptr(g2) if g2 is not None else None, _ptr(f2) if f2 is not None else None,
+                                                         _ptr(qi) if qi is not None else None, table.handle if table is not None else None, n, _ptr(out)),
+              "multi_miller_loop_prepared")
+        return out
+
+    def multi_miller_loop_prepared_many(self, g1_xy, g1_inf, table, q_index, offsets, g2_xy=None, g2_inf=None, final_exp=True):
+        g1, f1, g2, f2, qi, n = self._prepared_args(g1_xy, g1_inf, q_index, g2_xy, g2_inf)
+        off = np.ascontiguousarray(np.asarray(offsets, dtype=np.uint64))
+        if off.ndim != 1 or off.shape[0] < 1 or int(off[-1]) != n:
+            raise ValueError("multi_miller_loop_prepared_many: offsets must be nseg + 1 values ending at the number of terms")
+        nseg = off.shape[0] - 1
+        out = np.zeros((nseg, 72), dtype=np.uint64)
+        check(self.lib.blsgpu_multi_miller_loop_prepared_many(self.h, _ptr(g1), _ptr(f1), _ptr(g2) if g2 is not None else None, _ptr(f2) if f2 is not None else None,
+                                                              _ptr(qi) if qi is not None else None, table.handle if table is not None else None, _ptr(off), nseg,
+                                                              1 if final_exp else 0, _ptr(out)), "multi_miller_loop_prepared_many")
+        return out
+
+    def multi_miller_loop_prepared_device(self, d_g1, table, d_q_index, n, d_out, d_g2=None, d_g1_inf=None, d_g2_inf=None):
+        check(self.lib.blsgpu_multi_miller_loop_prepared_device(self.h, ctypes.c_void_p(d_g1), ctypes.c_void_p(d_g1_inf), ctypes.c_void_p(d_g2), ctypes.c_void_p(d_g2_inf),
+                                                                ctypes.c_void_p(d_q_index), table.handle if table is not None else None, n, ctypes.c_void_p(d_out)),
+              "multi_miller_loop_prepared_device")
+
+    def multi_miller_loop_prepared_many_device(self, d_g1, table, d_q_index, d_offsets, nseg, total_terms, d_out, max_seg_terms=0, final_exp=True, d_g2=None, d_g1_inf=None,
+                                               d_g2_inf=None):
+        check(self.lib.blsgpu_multi_miller_loop_prepared_many_device(self.h, ctypes.c_void_p(d_g1), ctypes.c_void_p(d_g1_inf), ctypes.c_void_p(d_g2), ctypes.c_void_p(d_g2_inf),
+                                                                     ctypes.c_void_p(d_q_index), table.handle if table is not None else None, ctypes.c_void_p(d_offsets), nseg,
+                                                                     total_terms, max_seg_terms, 1 if final_exp else 0, ctypes.c_void_p(d_out)),
+              "multi_miller_loop_prepared_many_device")
 
     def wide_status(self):
         """'' when the small-batch (wide) pairing programs are loaded, otherwise the reason they are not"""
@@ -964,13 +1058,32 @@ class MillerLoopResult:
 
 
 class G2Prepared:
-    """src/pairings.rs:498-546.  Opaque in the reference (private fields); here it keeps the affine point --
-    the GPU recomputes the 68 line coefficients on the fly instead of storing 19 584 B per point."""
+    """src/pairings.rs:487-546.  Opaque in the reference (private fields).  `G2Prepared(q)` keeps the affine point (its lines are
+    then computed on the fly in every Miller loop, as in rounds 1-4); `G2Prepared.resident(q)` / `G2Prepared.resident_many(points)`
+    do what `From<G2Affine>` does in the reference: the 68 coefficient triples are computed ONCE, into a device-resident table
+    (`blsgpu_g2_prepare`), and every later `multi_miller_loop` only evaluates them."""
 
-    def __init__(self, q):
+    def __init__(self, q, table=None, index=None):
         if not isinstance(q, G2Affine):
             raise TypeError("G2Prepared::from expects a G2Affine")
-        self.q = q
+        self.q, self.table, self.index = q, table, index
+
+    @classmethod
+    def resident_many(cls, points):
+        points = list(points)
+        xy = np.stack([q.xy for q in points]) if points else np.zeros((0, 24), dtype=np.uint64)
+        table = default_context().g2_prepare(xy, np.array([q.infinity for q in points], dtype=np.uint8))
+        return [cls(q, table, i) for i, q in enumerate(points)]
+
+    @classmethod
+    def resident(cls, q):
+        return cls.resident_many([q])[0]
+
+    def coeffs(self):
+        """(infinity, (68, 3, 12) u64) of a resident value"""
+        if self.table is None:
+            raise ValueError("G2Prepared.coeffs: not resident (use G2Prepared.resident)")
+        return self.table.coeffs(self.index)
 
 
 def pairing(p, q):
@@ -990,7 +1103,19 @@ def multi_miller_loop(terms):
     f2 = np.zeros(n, dtype=np.uint8)
     for i, (p, prep) in enumerate(terms):
         g1[i], f1[i], g2[i], f2[i] = p.xy, p.infinity, prep.q.xy, prep.q.infinity
+    table, qi = _resident_indices([prep for _, prep in terms])
+    if table is not None:
+        return MillerLoopResult(default_context().multi_miller_loop_prepared(g1, f1, table, qi, g2, f2))
     return MillerLoopResult(default_context().multi_miller_loop(g1, f1, g2, f2))
+
+
+def _resident_indices(preps):
+    """the table shared by the resident `G2Prepared` values among `preps` and the per-term indices (terms of another table, or not
+    resident, are UNPREPARED: their lines are computed on the fly from the affine point they also hold); (None, None) if none is resident"""
+    table = next((p.table for p in preps if p.table is not None), None)
+    if table is None:
+        return None, None
+    return table, np.array([p.index if p.table is table else UNPREPARED for p in preps], dtype=np.uint32)
 
 
 def multi_miller_loop_many(equations, final_exp=True):
@@ -1010,7 +1135,11 @@ def multi_miller_loop_many(equations, final_exp=True):
             g1[i], f1[i], g2[i], f2[i] = p.xy, p.infinity, prep.q.xy, prep.q.infinity
             i += 1
         off[s + 1] = i
-    out = default_context().multi_miller_loop_many(g1, f1, g2, f2, off, final_exp)
+    table, qi = _resident_indices([prep for e in eqs for _, prep in e])
+    if table is not None:
+        out = default_context().multi_miller_loop_prepared_many(g1, f1, table, qi, off, g2, f2, final_exp)
+    else:
+        out = default_context().multi_miller_loop_many(g1, f1, g2, f2, off, final_exp)
     return [Gt(v) if final_exp else MillerLoopResult(v) for v in out]
 
 

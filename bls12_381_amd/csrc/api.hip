@@ -16,6 +16,7 @@
 #include "msm.hip.h"
 #include "pairing.hip.h"
 #include "quad.hip.h"
+#include "prep.hip.h"
 #include "mulbatch.hip.h"
 #include "wide.hip.h"
 #include <dlfcn.h>
@@ -127,6 +128,8 @@ struct blsgpu_ctx {
   int next_slot = 0;
   unsigned long long msm_calls = 0;
   DevBuf result, io_a, io_b, io_c, io_d, io_e, io_f, io_out, flags_a, flags_b;
+  DevBuf mmlp_work, mmlp_out;           // prepared Miller loops (prep.hip.h): per-quad work area, partial products of one long product
+  DevBuf fb_stage;                      // staging of the one-byte scalars the tables are built from
   DevBuf fb_table[2];                   // fixed-base comb tables of the generators (k_fixed_base): 32 x 256 affine records each, built at first use
   hipEvent_t ev_fb[2] = {};             // recorded where a table was built; awaited by every user (the caller may switch streams)
   bool fb_ready[2] = {false, false};
@@ -501,7 +504,7 @@ extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
   hipDeviceSynchronize();
   if (c->d_status) hipFree(c->d_status);
   if (c->d_wide) hipFree(c->d_wide);
-  DevBuf* bufs[] = {&c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->io_f, &c->io_out, &c->flags_a, &c->flags_b, &c->fr_tw[0], &c->fr_tw[1], &c->fr_tmp, &c->fr_ninv, &c->fb_table[0], &c->fb_table[1]};
+  DevBuf* bufs[] = {&c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->io_f, &c->io_out, &c->flags_a, &c->flags_b, &c->fr_tw[0], &c->fr_tw[1], &c->fr_tmp, &c->fr_ninv, &c->fb_table[0], &c->fb_table[1], &c->fb_stage, &c->mmlp_work, &c->mmlp_out};
   for (auto b : bufs) b->release();
   for (auto& sl : c->slot) {
     DevBuf* sb[] = {&sl.ent, &sl.sorted, &sl.hist, &sl.offs, &sl.cursor, &sl.bsum, &sl.items, &sl.heavy, &sl.ctrl, &sl.glv,
@@ -533,6 +536,7 @@ static int take_status(blsgpu_ctx* c) {
   if (st) {
     HIPCHK(hipMemset(c->d_status, 0, 4));
     if (st & 2u) return bad("multi_miller_loop_many_device: a segment is longer than the max_seg_terms the caller passed (its value is unspecified)");
+    if (st & 4u) return bad("multi_miller_loop_prepared: a q_index lies outside the prepared table (the term was skipped)");
     return bad("msm: a scalar is not canonical (>= r); Scalar::to_bytes never produces such bytes (scalar.rs:284-296)");
   }
   return BLSGPU_OK;
@@ -698,6 +702,7 @@ extern "C" int blsgpu_bases_from_scalars(blsgpu_ctx* c, int group, const uint8_t
   size_t words = group == 1 ? Store<FpPolicy>::AFF_WORDS : Store<Fp2Policy>::AFF_WORDS;
   if (hipEventCreateWithFlags(&b->ev_ready, hipEventDisableTiming) != hipSuccess) { delete b; g_err = "hipEventCreate(bases) failed"; return BLSGPU_ERR_HIP; }
   if (hipMalloc((void**)&b->rec, (n ? n : 1) * words * 4) != hipSuccess) { bases_drop(b); g_err = "hipMalloc(bases) failed"; return BLSGPU_ERR_HIP; }
+  bool fb_built_now = false;
   if (n) {
     // below a few thousand multiples the double-and-add kernel is as fast as building the comb table would be
     const bool comb = n >= 4096 || c->fb_ready[group - 1];
@@ -706,16 +711,18 @@ extern "C" int blsgpu_bases_from_scalars(blsgpu_ctx* c, int group, const uint8_t
       DevBuf& tb = c->fb_table[group - 1];
       std::vector<uint8_t> one_byte((size_t)8192 * 32, 0);
       for (int w = 0; w < 32; w++) for (int d = 0; d < 256; d++) one_byte[((size_t)w * 256 + d) * 32 + w] = (uint8_t)d;
-      if (tb.reserve((size_t)8192 * words * 4) || c->io_c.reserve((size_t)8192 * 32)) { bases_drop(b); g_err = "hipMalloc(fixed-base table) failed"; return BLSGPU_ERR_HIP; }
-      hipError_t e = hipMemcpyAsync(c->io_c.p, one_byte.data(), one_byte.size(), hipMemcpyHostToDevice, c->stream);
+      // staged through a buffer of its own: io_c is the scratch of the asynchronous multi_miller_loop_many_device, whose partial products
+      // may still be in flight on another stream (blsgpu_set_stream)
+      if (tb.reserve((size_t)8192 * words * 4) || c->fb_stage.reserve((size_t)8192 * 32)) { bases_drop(b); g_err = "hipMalloc(fixed-base table) failed"; return BLSGPU_ERR_HIP; }
+      hipError_t e = hipMemcpyAsync(c->fb_stage.p, one_byte.data(), one_byte.size(), hipMemcpyHostToDevice, c->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(c->stream);                 // `one_byte` lives on this frame
       if (e != hipSuccess) { bases_drop(b); return fail("fixed-base table upload", e, __LINE__); }
-      if (group == 1) hipLaunchKernelGGL(k_bases_from_scalars<FpPolicy>, dim3(nblk(8192, 256)), dim3(256), 0, c->stream, c->io_c.as<u32>(), tb.as<u32>(), (size_t)8192);
-      else hipLaunchKernelGGL(k_bases_from_scalars<Fp2Policy>, dim3(nblk(8192, 256)), dim3(256), 0, c->stream, c->io_c.as<u32>(), tb.as<u32>(), (size_t)8192);
+      if (group == 1) hipLaunchKernelGGL(k_bases_from_scalars<FpPolicy>, dim3(nblk(8192, 256)), dim3(256), 0, c->stream, c->fb_stage.as<u32>(), tb.as<u32>(), (size_t)8192);
+      else hipLaunchKernelGGL(k_bases_from_scalars<Fp2Policy>, dim3(nblk(8192, 256)), dim3(256), 0, c->stream, c->fb_stage.as<u32>(), tb.as<u32>(), (size_t)8192);
       e = hipGetLastError();
       if (e == hipSuccess) e = hipEventRecord(c->ev_fb[group - 1], c->stream);
       if (e != hipSuccess) { bases_drop(b); return fail("fixed-base table build", e, __LINE__); }
-      c->fb_ready[group - 1] = true;
+      fb_built_now = true;                 // marked ready only once the build is known to have run (the synchronisation at the end of this call)
     }
     if (comb) {
       hipError_t e = hipStreamWaitEvent(c->stream, c->ev_fb[group - 1], 0);
@@ -729,7 +736,11 @@ extern "C" int blsgpu_bases_from_scalars(blsgpu_ctx* c, int group, const uint8_t
     if (e != hipSuccess) { bases_drop(b); return fail("k_bases_from_scalars", e, __LINE__); }
   }
   if (int rc = bases_make_endo(c, b, true)) { bases_drop(b); return rc; }      // [k]G lies in the subgroup by construction
-  HIPCHK(hipStreamSynchronize(c->stream));
+  {
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { bases_drop(b); return fail("bases_from_scalars", e, __LINE__); }     // (a table built in this call stays unmarked: rebuilt next time)
+  }
+  if (fb_built_now) c->fb_ready[group - 1] = true;
   *out = b;
   return BLSGPU_OK;
 }
@@ -964,7 +975,9 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   // and tree streams
   auto run_group = [&](blsgpu_ctx::Slot& gs, int g0, int ng, hipStream_t gft, hipStream_t gas, hipStream_t gtt, hipStream_t gt2, bool last) -> int {
   const size_t gnb = (size_t)ng * nbw;
-  const size_t gmax_items = (size_t)ng * ns / cap + gnb + 1;
+  // entries in THIS group's bucket sets / cap + one item per bucket: with resident tables (merged) the single bucket set holds the
+  // entries of ALL nwin windows (the accumulation kernels run one lane per item without a grid stride, so the grid must cover them)
+  const size_t gmax_items = (size_t)(merged ? nwin : ng) * ns / cap + gnb + 1;
   const u32* goffs = sl.offs.as<u32>() + (size_t)g0 * nbw;
   // 4. work items
   u32* ctrl = gs.ctrl.as<u32>();
@@ -1837,15 +1850,27 @@ extern "C" int blsgpu_multi_miller_loop_many_device(blsgpu_ctx* c, const void* g
   if (!c || (nseg && (!d_offsets || !out)) || (total && (!g1 || !g2))) return bad("multi_miller_loop_many: NULL argument");
   if (!nseg) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
-  const int parts = (max_seg_terms == 0 || max_seg_terms > 32) ? 32 : 1;
-  if (c->io_out.reserve((total ? total : 1) * 576) || (parts > 1 && c->io_c.reserve(nseg * parts * 576)) || (final_exp && c->io_d.reserve(nseg * 576))) {
+  // runs per segment of the segmented product: 1 when the caller bounds the segments by 32 terms; otherwise (bound unknown or larger)
+  // sized by the MEAN segment length -- ~8 values per run, at most 32 runs -- so that the partial products (576 B per run) stay
+  // proportional to the input whatever the number of segments (2^20 three-term segments with an unknown bound: 1 run each, not 32);
+  // a single long segment among many short ones is then walked by few quads: slower for that segment, never a failed allocation
+  int parts = 1;
+  if (max_seg_terms == 0 || max_seg_terms > 32) {
+    const size_t mean = (total + nseg - 1) / nseg;
+    parts = (int)((mean + 7) / 8);
+    if (parts < 1) parts = 1;
+    if (parts > 32) parts = 32;
+  }
+  // the shared-accumulator kernel is the lane-pair layout's: a context pinned to the quad (or wide) layout keeps the per-term path
+  const bool seg_shared = total && max_seg_terms >= 2 && max_seg_terms <= (size_t)MML_MAX_K && nseg >= MML_SEG_SHARED_MIN && (c->pairing_layout == 0 || c->pairing_layout == 2);
+  if ((!seg_shared && c->io_out.reserve((total ? total : 1) * 576)) || (!seg_shared && parts > 1 && c->io_c.reserve(nseg * parts * 576)) || (final_exp && c->io_d.reserve(nseg * 576))) {
     g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP;
   }
   u32* prod = final_exp ? c->io_d.as<u32>() : (u32*)out;
   // MANY short segments: one lane pair per segment with a shared accumulator (the reference's own schedule: (k - 1) / k of the 62
   // squarings per term disappear); it needs >= 2^16 lanes' worth of segments to beat the per-term quads (a quarter-filled chip runs
   // at the latency of one shared loop: ~13 ms for k = 3)
-  if (total && max_seg_terms >= 2 && max_seg_terms <= (size_t)MML_MAX_K && nseg >= MML_SEG_SHARED_MIN && c->pairing_layout != 256) {
+  if (seg_shared) {
     hipLaunchKernelGGL(k_multi_miller_seg, dim3(nblk(nseg * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2,
                        (const uint8_t*)g2inf, (const unsigned long long*)d_offsets, nseg, total, prod, c->d_status);
     LAUNCHCHK();
@@ -1887,6 +1912,174 @@ extern "C" int blsgpu_multi_miller_loop_many(blsgpu_ctx* c, const uint64_t* g1, 
   HIPCHK(hipMemcpyAsync(c->io_e.p, offsets, (nseg + 1) * 8, hipMemcpyHostToDevice, c->stream));
   int rc = blsgpu_multi_miller_loop_many_device(c, c->io_a.p, g1inf ? c->flags_a.p : nullptr, c->io_b.p, g2inf ? c->flags_b.p : nullptr, c->io_e.p, nseg, n, max_k ? max_k : 1, final_exp,
                                                 c->io_f.p);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(out, c->io_f.p, nseg * 576, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+// ---------------------------------------------------------------------------------------------------
+// G2Prepared resident on the device (prep.hip.h): pairings.rs:487-546 (the table), :554-603 (its consumers)
+// ---------------------------------------------------------------------------------------------------
+struct blsgpu_g2_prepared { int device = 0; size_t n = 0; u32* tab = nullptr; uint8_t* inf = nullptr; hipEvent_t ev_ready = nullptr; };
+static void prepared_drop(blsgpu_g2_prepared* p) {
+  if (p->tab) hipFree(p->tab);
+  if (p->inf) hipFree(p->inf);
+  if (p->ev_ready) hipEventDestroy(p->ev_ready);
+  delete p;
+}
+extern "C" int blsgpu_g2_prepare_device(blsgpu_ctx* c, const void* d_g2, const void* d_inf, size_t m, blsgpu_g2_prepared** out) { CTX_CLAIM(c);
+  if (!c || !out || (m && !d_g2)) return bad("g2_prepare: NULL argument");
+  if (m >= 0xfffffff0ull) return bad("g2_prepare: too many points for 32-bit table indices");
+  HIPCHK(hipSetDevice(c->device));
+  blsgpu_g2_prepared* p = new blsgpu_g2_prepared();
+  p->device = c->device; p->n = m;
+  if (hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming) != hipSuccess) { delete p; g_err = "hipEventCreate(g2_prepared) failed"; return BLSGPU_ERR_HIP; }
+  if (hipMalloc((void**)&p->tab, (m ? m : 1) * PREP_POINT_WORDS * 4) != hipSuccess || hipMalloc((void**)&p->inf, m ? m : 1) != hipSuccess) {
+    (void)hipGetLastError(); prepared_drop(p); g_err = "hipMalloc(g2_prepared) failed"; return BLSGPU_ERR_HIP;
+  }
+  if (m) hipLaunchKernelGGL(k_g2_prepare_quad, dim3(nblk(m * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, (const u32*)d_g2, (const uint8_t*)d_inf, m, p->tab, p->inf);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipEventRecord(p->ev_ready, c->stream);          // consumers on another stream (blsgpu_set_stream) wait for the table
+  if (e != hipSuccess) { prepared_drop(p); return fail("k_g2_prepare_quad", e, __LINE__); }
+  *out = p;
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_g2_prepare(blsgpu_ctx* c, const uint64_t* g2, const uint8_t* inf, size_t m, blsgpu_g2_prepared** out) { CTX_CLAIM(c);
+  if (!c || !out || (m && !g2)) return bad("g2_prepare: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->io_b.reserve(m ? m * 192 : 16) || c->flags_b.reserve(m ? m : 16)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  if (m) HIPCHK(hipMemcpyAsync(c->io_b.p, g2, m * 192, hipMemcpyHostToDevice, c->stream));
+  if (m && inf) HIPCHK(hipMemcpyAsync(c->flags_b.p, inf, m, hipMemcpyHostToDevice, c->stream));
+  blsgpu_g2_prepared* p = nullptr;
+  int rc = blsgpu_g2_prepare_device(c, c->io_b.p, inf ? c->flags_b.p : nullptr, m, &p);
+  if (rc) return rc;
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) { prepared_drop(p); return fail("g2_prepare", e, __LINE__); }
+  *out = p;
+  return BLSGPU_OK;
+}
+extern "C" size_t blsgpu_g2_prepared_len(const blsgpu_g2_prepared* p) { return p ? p->n : 0; }
+extern "C" void blsgpu_g2_prepared_free(blsgpu_g2_prepared* p) {
+  if (!p) return;
+  hipSetDevice(p->device);
+  hipDeviceSynchronize();                  // an asynchronous Miller loop may still be reading the table
+  prepared_drop(p);
+}
+extern "C" int blsgpu_g2_prepared_coeffs(blsgpu_ctx* c, const blsgpu_g2_prepared* p, size_t index, uint64_t* out, uint8_t* out_inf) { CTX_CLAIM(c);
+  if (!c || !p || !out || index >= p->n) return bad("g2_prepared_coeffs: bad argument");
+  if (p->device != c->device) return bad("g2_prepared_coeffs: the table lives on another device than the context");
+  HIPCHK(hipSetDevice(c->device));
+  const size_t bytes = (size_t)PREP_STEPS * 3 * 24 * 4;
+  if (c->io_out.reserve(bytes)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  HIPCHK(hipStreamWaitEvent(c->stream, p->ev_ready, 0));
+  hipLaunchKernelGGL(k_g2_prepared_export, dim3(1), dim3(256), 0, c->stream, p->tab, index, c->io_out.as<u32>());
+  LAUNCHCHK();
+  HIPCHK(hipMemcpyAsync(out, c->io_out.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  if (out_inf) HIPCHK(hipMemcpyAsync(out_inf, p->inf + index, 1, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+// one launch of k_mml_prep_quad: nseg quads, work area sized for kmax term slots per quad
+static int mmlp_launch(blsgpu_ctx* c, const void* g1, const void* g1inf, const void* g2, const void* g2inf, const void* qidx, const blsgpu_g2_prepared* p, const void* d_off,
+                       size_t nseg, size_t total, int kuni, int kmax, void* out) {
+  if (p && p->device != c->device) return bad("multi_miller_loop_prepared: the table lives on another device than the context");
+  if (kmax < 1) kmax = 1;
+  if (kmax > MMLP_MAX_K) kmax = MMLP_MAX_K;
+  const unsigned blocks = nblk(nseg * QL, QUAD_BLOCK);
+  const size_t threads = (size_t)blocks * QUAD_BLOCK;
+  // [kmax][threads] u32 meta | [kmax][4][threads] uint4 pp | [kmax][12][threads] uint4 running points
+  const size_t meta_b = (size_t)kmax * threads * 4, pp_b = (size_t)kmax * 4 * threads * 16, rr_b = (size_t)kmax * 12 * threads * 16;
+  if (c->mmlp_work.reserve(meta_b + pp_b + rr_b)) { g_err = "hipMalloc(prepared Miller work area) failed"; return BLSGPU_ERR_HIP; }
+  uint8_t* w = c->mmlp_work.as<uint8_t>();
+  if (p) HIPCHK(hipStreamWaitEvent(c->stream, p->ev_ready, 0));
+  hipLaunchKernelGGL(k_mml_prep_quad, dim3(blocks), dim3(QUAD_BLOCK), 0, c->stream, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2, (const uint8_t*)g2inf,
+                     (const u32*)(p ? qidx : nullptr), p ? p->tab : (const u32*)nullptr, p ? p->inf : (const uint8_t*)nullptr, (u32)(p ? p->n : 0),
+                     (const unsigned long long*)d_off, nseg, total, kuni, kmax, (u32*)w, (uint4*)(w + meta_b), (uint4*)(w + meta_b + pp_b), (u32*)out, c->d_status);
+  LAUNCHCHK();
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_multi_miller_loop_prepared_device(blsgpu_ctx* c, const void* g1, const void* g1inf, const void* g2, const void* g2inf, const void* qidx,
+                                                        const blsgpu_g2_prepared* p, size_t n, void* out) { CTX_CLAIM(c);
+  if (!c || !out || (n && !g1) || (n && qidx && !p) || (n && !qidx && !g2)) return bad("multi_miller_loop_prepared: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (!n) return fp12_product_device(c, nullptr, 0, (u32*)out);
+  // terms per accumulator: as many as still leave two wavefronts per SIMD busy (2^15 quads)
+  int K = 1;
+  while (K < MMLP_MAX_K && n / (2 * (size_t)K) >= 32768) K *= 2;
+  const size_t groups = (n + K - 1) / K;
+  if (c->mmlp_out.reserve(groups * 576)) { g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP; }
+  int rc = mmlp_launch(c, g1, g1inf, g2, g2inf, qidx, p, nullptr, groups, n, K, K, c->mmlp_out.p);
+  if (rc) return rc;
+  return fp12_product_device(c, c->mmlp_out.as<u32>(), groups, (u32*)out);
+}
+static int check_qidx(const uint32_t* qidx, size_t n, const blsgpu_g2_prepared* p, const uint64_t* g2) {
+  if (!qidx) return (n && !g2) ? bad("multi_miller_loop_prepared: g2 is NULL and no term is prepared") : BLSGPU_OK;
+  if (!p) return bad("multi_miller_loop_prepared: q_index without a prepared table");
+  for (size_t i = 0; i < n; i++) {
+    if (qidx[i] == BLSGPU_UNPREPARED) { if (!g2) return bad("multi_miller_loop_prepared: an unprepared term needs g2"); }
+    else if (qidx[i] >= p->n) return bad("multi_miller_loop_prepared: q_index outside the prepared table");
+  }
+  return BLSGPU_OK;
+}
+// host-pointer staging shared by the two prepared entry points: g1 -> io_a, g2 -> io_b, flags -> flags_a/b, indices -> io_e
+static int mmlp_stage(blsgpu_ctx* c, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, const uint32_t* qidx, size_t n) {
+  if (c->io_a.reserve(n ? n * 96 : 16) || c->io_b.reserve(n ? n * 192 : 16) || c->flags_a.reserve(n ? n : 16) || c->flags_b.reserve(n ? n : 16) || c->io_e.reserve(n ? n * 4 : 16)) {
+    g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP;
+  }
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipMemcpyAsync(c->io_a.p, g1, n * 96, hipMemcpyHostToDevice, c->stream));
+  if (g2) HIPCHK(hipMemcpyAsync(c->io_b.p, g2, n * 192, hipMemcpyHostToDevice, c->stream));
+  if (g1inf) HIPCHK(hipMemcpyAsync(c->flags_a.p, g1inf, n, hipMemcpyHostToDevice, c->stream));
+  if (g2 && g2inf) HIPCHK(hipMemcpyAsync(c->flags_b.p, g2inf, n, hipMemcpyHostToDevice, c->stream));
+  if (qidx) HIPCHK(hipMemcpyAsync(c->io_e.p, qidx, n * 4, hipMemcpyHostToDevice, c->stream));
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_multi_miller_loop_prepared(blsgpu_ctx* c, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, const uint32_t* qidx,
+                                                 const blsgpu_g2_prepared* p, size_t n, uint64_t* out) { CTX_CLAIM(c);
+  if (!c || !out || (n && !g1)) return bad("multi_miller_loop_prepared: NULL argument");
+  if (int rc = check_qidx(qidx, n, p, g2)) return rc;
+  HIPCHK(hipSetDevice(c->device));
+  if (c->result.reserve(576)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  if (int rc = mmlp_stage(c, g1, g1inf, g2, g2inf, qidx, n)) return rc;
+  int rc = blsgpu_multi_miller_loop_prepared_device(c, c->io_a.p, g1inf ? c->flags_a.p : nullptr, g2 ? c->io_b.p : nullptr, (g2 && g2inf) ? c->flags_b.p : nullptr,
+                                                    qidx ? c->io_e.p : nullptr, p, n, c->result.p);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(out, c->result.p, 576, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_multi_miller_loop_prepared_many_device(blsgpu_ctx* c, const void* g1, const void* g1inf, const void* g2, const void* g2inf, const void* qidx,
+                                                             const blsgpu_g2_prepared* p, const void* d_off, size_t nseg, size_t total, size_t max_seg_terms, int final_exp,
+                                                             void* out) { CTX_CLAIM(c);
+  if (!c || (nseg && (!d_off || !out)) || (total && !g1) || (total && qidx && !p) || (total && !qidx && !g2)) return bad("multi_miller_loop_prepared_many: NULL argument");
+  if (!nseg) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  if (final_exp && c->io_d.reserve(nseg * 576)) { g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP; }
+  u32* prod = final_exp ? c->io_d.as<u32>() : (u32*)out;
+  const int kmax = (max_seg_terms == 0 || max_seg_terms > (size_t)MMLP_MAX_K) ? MMLP_MAX_K : (int)max_seg_terms;
+  int rc = mmlp_launch(c, g1, g1inf, g2, g2inf, qidx, p, d_off, nseg, total, 0, kmax, prod);
+  if (rc) return rc;
+  return final_exp ? final_exp_launch(c, prod, nseg, out) : BLSGPU_OK;
+}
+extern "C" int blsgpu_multi_miller_loop_prepared_many(blsgpu_ctx* c, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, const uint32_t* qidx,
+                                                      const blsgpu_g2_prepared* p, const uint64_t* offsets, size_t nseg, int final_exp, uint64_t* out) { CTX_CLAIM(c);
+  if (!c || (nseg && (!offsets || !out))) return bad("multi_miller_loop_prepared_many: NULL argument");
+  if (!nseg) return BLSGPU_OK;
+  if (offsets[0] != 0) return bad("multi_miller_loop_prepared_many: offsets[0] must be 0");
+  size_t max_k = 0;
+  for (size_t i = 0; i < nseg; i++) {
+    if (offsets[i] > offsets[i + 1]) return bad("multi_miller_loop_prepared_many: offsets must be non-decreasing");
+    if (offsets[i + 1] - offsets[i] > max_k) max_k = (size_t)(offsets[i + 1] - offsets[i]);
+  }
+  const size_t n = (size_t)offsets[nseg];
+  if (n && !g1) return bad("multi_miller_loop_prepared_many: NULL argument");
+  if (int rc = check_qidx(qidx, n, p, g2)) return rc;
+  HIPCHK(hipSetDevice(c->device));
+  if (c->io_f.reserve(nseg * 576) || c->io_c.reserve((nseg + 1) * 8)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  if (int rc = mmlp_stage(c, g1, g1inf, g2, g2inf, qidx, n)) return rc;
+  HIPCHK(hipMemcpyAsync(c->io_c.p, offsets, (nseg + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  int rc = blsgpu_multi_miller_loop_prepared_many_device(c, c->io_a.p, g1inf ? c->flags_a.p : nullptr, g2 ? c->io_b.p : nullptr, (g2 && g2inf) ? c->flags_b.p : nullptr,
+                                                         qidx ? c->io_e.p : nullptr, p, c->io_c.p, nseg, n, max_k ? max_k : 1, final_exp, c->io_f.p);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(out, c->io_f.p, nseg * 576, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));

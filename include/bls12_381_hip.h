@@ -252,6 +252,45 @@ int blsgpu_miller_loop_batch_device(blsgpu_ctx* ctx, const void* d_g1_xy, const 
 int blsgpu_final_exponentiation_device(blsgpu_ctx* ctx, const void* d_in_f, size_t n, void* d_out_gt);
 int blsgpu_fp12_product_device(blsgpu_ctx* ctx, const void* d_in_f, size_t n, void* d_out_f);
 
+/* ---- G2Prepared: line coefficients of FIXED G2 arguments resident on the device ----------------------------------------- */
+/* `G2Prepared` (src/pairings.rs:487-502) holds the 68 coefficient triples of a point's doubling / addition steps, computed once
+ * (`From<G2Affine> for G2Prepared`, :504-546), so that every later `multi_miller_loop` only EVALUATES them at P (:554-603 with
+ * `ell`, :696-707): ~2.9 k field multiplications per term instead of ~6.9 k.  A `blsgpu_g2_prepared` is a device-resident table
+ * of m such points in the library's limb form (26 112 B per point); verification keys (Groth16: three of four G2 arguments fixed)
+ * and fixed generators (BLS) are prepared once and named by index afterwards.  The identity keeps its flag and is skipped by the
+ * consumers as the reference skips it (:566-569).  The handle belongs to the context's device and outlives the context's calls;
+ * free it with blsgpu_g2_prepared_free (after the work that reads it has completed). */
+typedef struct blsgpu_g2_prepared blsgpu_g2_prepared;
+int blsgpu_g2_prepare(blsgpu_ctx* ctx, const uint64_t* g2_xy, const uint8_t* g2_inf, size_t m, blsgpu_g2_prepared** out);
+/* the same with the points (24 u64 each) and flags in device memory; asynchronous on the context's stream */
+int blsgpu_g2_prepare_device(blsgpu_ctx* ctx, const void* d_g2_xy, const void* d_g2_inf, size_t m, blsgpu_g2_prepared** out);
+size_t blsgpu_g2_prepared_len(const blsgpu_g2_prepared* p);
+void blsgpu_g2_prepared_free(blsgpu_g2_prepared* p);
+/* The stored coefficients of point `index` in the reference's own value format -- `coeffs: Vec<(Fp2, Fp2, Fp2)>`, 68 triples of
+ * 3 x 12 u64 canonical Montgomery limbs (2 448 u64) -- and its `infinity` flag: what an in-tree `G2Prepared` would hold, and the
+ * parity hook against the oracle's `G2Prepared::from`. */
+int blsgpu_g2_prepared_coeffs(blsgpu_ctx* ctx, const blsgpu_g2_prepared* p, size_t index, uint64_t* out_coeffs, uint8_t* out_inf);
+/* `multi_miller_loop(&[(&G1Affine, &G2Prepared)])` (src/pairings.rs:554-603) with prepared and unprepared terms mixed: term i pairs
+ * g1[i] with table point q_index[i], or -- q_index[i] = BLSGPU_UNPREPARED (or q_index = NULL: every term) -- with g2[i], whose
+ * lines are computed on the fly as in blsgpu_multi_miller_loop (g2 may be NULL when every term is prepared).  out = the raw
+ * `MillerLoopResult`, limb-identical to the unprepared entry points' and to the reference's.  An index outside the table is an
+ * argument error (host-pointer forms) / reported by the next blsgpu_synchronize (device-pointer forms, where the term is skipped). */
+#define BLSGPU_UNPREPARED 0xffffffffu
+int blsgpu_multi_miller_loop_prepared(blsgpu_ctx* ctx, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy, const uint8_t* g2_inf, const uint32_t* q_index,
+                                      const blsgpu_g2_prepared* prepared, size_t n, uint64_t out_f[72]);
+int blsgpu_multi_miller_loop_prepared_device(blsgpu_ctx* ctx, const void* d_g1_xy, const void* d_g1_inf, const void* d_g2_xy, const void* d_g2_inf, const void* d_q_index,
+                                             const blsgpu_g2_prepared* prepared, size_t n, void* d_out_f);
+/* N independent products in one call (blsgpu_multi_miller_loop_many with prepared terms): segment s = terms offsets[s] ..
+ * offsets[s+1]; every segment runs the reference's own schedule on one accumulator -- per step each term multiplies its line in,
+ * one squaring for all -- so a verification equation with k terms pays 62 squarings, not 62 k, and a prepared term only its
+ * `ell`s.  final_exp as in blsgpu_multi_miller_loop_many.  Segments of any length are accepted (more than 8 terms: several passes,
+ * multiplied together); for ONE long product use blsgpu_multi_miller_loop_prepared. */
+int blsgpu_multi_miller_loop_prepared_many(blsgpu_ctx* ctx, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy, const uint8_t* g2_inf, const uint32_t* q_index,
+                                           const blsgpu_g2_prepared* prepared, const uint64_t* offsets, size_t nseg, int final_exp, uint64_t* out);
+int blsgpu_multi_miller_loop_prepared_many_device(blsgpu_ctx* ctx, const void* d_g1_xy, const void* d_g1_inf, const void* d_g2_xy, const void* d_g2_inf, const void* d_q_index,
+                                                  const blsgpu_g2_prepared* prepared, const void* d_offsets, size_t nseg, size_t total_terms, size_t max_seg_terms,
+                                                  int final_exp, void* d_out);
+
 /* ---- device groups: the path sharded over the GPUs of one node from ONE process ------------------------------------- */
 /* "Large MSMs and pairing batches shard embarrassingly across the 8 GPUs" (SURVEY.md 8e): a group is one context per listed
  * device; every `*_sharded` call deals its independent terms to the members in contiguous slices (sizes differ by at most

@@ -11,6 +11,8 @@ use core::ffi::{c_char, c_int, c_uint, c_void};
 #[repr(C)] pub struct BlsgpuGroup { _private: [u8; 0] }
 /// opaque: bases sharded over the members of a group (blsgpu_group_bases_upload / blsgpu_group_bases_free)
 #[repr(C)] pub struct BlsgpuGroupBases { _private: [u8; 0] }
+/// opaque: `G2Prepared` values resident in HBM (blsgpu_g2_prepare / blsgpu_g2_prepared_free)
+#[repr(C)] pub struct BlsgpuG2Prepared { _private: [u8; 0] }
 
 pub const BLSGPU_OK: c_int = 0;
 
@@ -78,6 +80,15 @@ extern "C" {
     pub fn blsgpu_miller_loop_batch_device(ctx: *mut BlsgpuCtx, d_g1_xy: *const c_void, d_g1_inf: *const c_void, d_g2_xy: *const c_void, d_g2_inf: *const c_void, n: usize, d_out_f: *mut c_void) -> c_int;
     pub fn blsgpu_final_exponentiation_device(ctx: *mut BlsgpuCtx, d_in_f: *const c_void, n: usize, d_out_gt: *mut c_void) -> c_int;
     pub fn blsgpu_fp12_product_device(ctx: *mut BlsgpuCtx, d_in_f: *const c_void, n: usize, d_out_f: *mut c_void) -> c_int;
+    pub fn blsgpu_g2_prepare(ctx: *mut BlsgpuCtx, g2_xy: *const u64, g2_inf: *const u8, m: usize, out: *mut *mut BlsgpuG2Prepared) -> c_int;
+    pub fn blsgpu_g2_prepare_device(ctx: *mut BlsgpuCtx, d_g2_xy: *const c_void, d_g2_inf: *const c_void, m: usize, out: *mut *mut BlsgpuG2Prepared) -> c_int;
+    pub fn blsgpu_g2_prepared_len(p: *const BlsgpuG2Prepared) -> usize;
+    pub fn blsgpu_g2_prepared_free(p: *mut BlsgpuG2Prepared);
+    pub fn blsgpu_g2_prepared_coeffs(ctx: *mut BlsgpuCtx, p: *const BlsgpuG2Prepared, index: usize, out_coeffs: *mut u64, out_inf: *mut u8) -> c_int;
+    pub fn blsgpu_multi_miller_loop_prepared(ctx: *mut BlsgpuCtx, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, q_index: *const u32, prepared: *const BlsgpuG2Prepared, n: usize, out_f: *mut u64) -> c_int;
+    pub fn blsgpu_multi_miller_loop_prepared_device(ctx: *mut BlsgpuCtx, d_g1_xy: *const c_void, d_g1_inf: *const c_void, d_g2_xy: *const c_void, d_g2_inf: *const c_void, d_q_index: *const c_void, prepared: *const BlsgpuG2Prepared, n: usize, d_out_f: *mut c_void) -> c_int;
+    pub fn blsgpu_multi_miller_loop_prepared_many(ctx: *mut BlsgpuCtx, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, q_index: *const u32, prepared: *const BlsgpuG2Prepared, offsets: *const u64, nseg: usize, final_exp: c_int, out: *mut u64) -> c_int;
+    pub fn blsgpu_multi_miller_loop_prepared_many_device(ctx: *mut BlsgpuCtx, d_g1_xy: *const c_void, d_g1_inf: *const c_void, d_g2_xy: *const c_void, d_g2_inf: *const c_void, d_q_index: *const c_void, prepared: *const BlsgpuG2Prepared, d_offsets: *const c_void, nseg: usize, total_terms: usize, max_seg_terms: usize, final_exp: c_int, d_out: *mut c_void) -> c_int;
     pub fn blsgpu_group_create(devices: *const c_int, ndev: c_int, out: *mut *mut BlsgpuGroup) -> c_int;
     pub fn blsgpu_group_destroy(group: *mut BlsgpuGroup);
     pub fn blsgpu_group_size(group: *const BlsgpuGroup) -> c_int;

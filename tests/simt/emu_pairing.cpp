@@ -15,6 +15,7 @@ EmuQuadBarriers g_emu_quads;
 #include "pairing.hip.h"
 #ifdef EMU_WITH_QUAD
 #include "quad.hip.h"
+#include "prep.hip.h"
 #endif
 #ifdef EMU_WITH_WIDE
 #define WIDE_STANDALONE
@@ -57,6 +58,27 @@ void emu_quad_final_exp(const u32* in, u32* out, size_t n) {
 }
 void emu_quad_fp12_op(int op, const u32* a, const u32* b, u32* out, size_t n) {
   run_quad([=] { k_fp12_op_quad(op, a, b, out, n); });
+}
+// prep.hip.h: the table of ONE point (tab: PREP_POINT_WORDS words), its coefficients in wire form (68 x 3 x 24 words), and the
+// shared-accumulator loop of ONE segment (off -> the segment's two offsets, or nullptr with kuni: the run [0, kuni) of one long product);
+// work = kmax * 65 * 4 words
+void emu_g2_prepare(const u32* g2, const uint8_t* g2inf, u32* tab, uint8_t* tab_inf) {
+  run_quad([=] { k_g2_prepare_quad(g2, g2inf, 1, tab, tab_inf); });
+}
+void emu_g2_prepared_export(const u32* tab, u32* out) {
+  for (unsigned blk = 0; blk < (2 * PREP_STEPS + 3) / 4; blk++) {
+    std::vector<std::thread> th;
+    for (unsigned l = 0; l < 4; l++)
+      th.emplace_back([=] { threadIdx.x = l; blockDim.x = 4; blockIdx.x = blk; gridDim.x = (2 * PREP_STEPS + 3) / 4; k_g2_prepared_export(tab, 0, out); });
+    for (auto& t : th) t.join();
+  }
+}
+void emu_mml_prep(const u32* g1, const uint8_t* g1inf, const u32* g2, const uint8_t* g2inf, const u32* qidx, const u32* tab, const uint8_t* tab_inf, u32 tab_n,
+                  const unsigned long long* off, size_t total, int kuni, int kmax, u32* work, u32* out, u32* status) {
+  u32* wmeta = work;
+  uint4* wpp = reinterpret_cast<uint4*>(work + (size_t)kmax * 4);
+  uint4* wrr = wpp + (size_t)kmax * 4 * 4;
+  run_quad([=] { k_mml_prep_quad(g1, g1inf, g2, g2inf, qidx, tab, tab_inf, tab_n, off, 1, total, kuni, kmax, wmeta, wpp, wrr, out, status); });
 }
 #endif
 #endif

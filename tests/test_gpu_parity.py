@@ -514,6 +514,32 @@ def test_msm_precomputed_tables(ctx, group, window):
     assert np.array_equal(sx[0], ex) and si[0] == ei
 
 
+def test_msm_precomputed_tables_with_cut_buckets(ctx):
+    """Resident tables put the entries of ALL windows into one bucket set, so its buckets are routinely cut into many work items: a
+    small window with many points (2^17 points, 9-bit window: ~7 items per bucket) and the default window with heavily repeated
+    scalars.  The accumulation grid must cover every item (round-4 review: it was sized for one window's entries) -- compared with
+    the plain path and the discrete-log identity."""
+    n = 1 << 17
+    kb, ks = _rand_scalars_np(n, 4401)
+    sb, ss = _rand_scalars_np(n, 4402)
+    bases = ctx.bases_from_scalars(1, kb)
+    plain = ctx.batch_normalize(1, ctx.msm(bases, sb)[None, :])
+    tot = sum(k * s for k, s in zip(ks, ss)) % o.R_ORDER
+    ex, ei = g1aff_w(o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, tot)))
+    assert np.array_equal(plain[0][0], ex) and plain[1][0] == ei
+    rep = sb.copy(); rep[:] = sb[7]                                   # one scalar everywhere: 13 buckets hold everything
+    rep[::1000] = sb[::1000]
+    rs = [int.from_bytes(rep[i].tobytes(), "little") for i in range(n)]
+    tot_rep = sum(k * s for k, s in zip(ks, rs)) % o.R_ORDER
+    rx, ri = g1aff_w(o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, tot_rep)))
+    for window in (9, 12, 0):
+        bases.precompute(window)
+        got = ctx.batch_normalize(1, ctx.msm(bases, sb)[None, :])
+        assert np.array_equal(got[0], plain[0]) and np.array_equal(got[1], plain[1]), window
+        got = ctx.batch_normalize(1, ctx.msm(bases, rep)[None, :])
+        assert np.array_equal(got[0][0], rx) and got[1][0] == ri, window
+
+
 @pytest.mark.parametrize("group", [1, 2])
 def test_batch_normalize_large(ctx, group):
     """`batch_normalize` over 10 000 points (the reference's 'batch to affine n=10000' bench point) incl. identities:
@@ -1947,3 +1973,156 @@ def test_round4_entry_points_edge_cases_and_argument_errors(ctx):
     assert lib.blsgpu_pairing_batch_sharded(eight.h, None, None, None, None, 2, P(o72)) == ERR_ARG
     assert np.array_equal(nrm(eight.msm(gb, sb)), want)               # still usable
     one.close(); eight.close()
+
+
+# ---- round 5: G2Prepared resident on the device ----------------------------------------------------------------------------------
+def _coeffs_w(prep):
+    """oracle `G2Prepared` -> (68, 3, 12) u64 in the reference's value format"""
+    return np.array([[np.concatenate([fpw(c[0]), fpw(c[1])]) for c in tri] for tri in prep[1]], dtype=np.uint64)
+
+
+def test_g2_prepared_table_holds_the_reference_coefficients(ctx):
+    """`From<G2Affine> for G2Prepared` (pairings.rs:504-546): the device table of 1, 3 and 2^10 points holds the oracle's 68 coefficient
+    triples limb for limb (sampled for the large table), the identity keeps its flag and the generator's coefficients (:506-509)"""
+    ps, qs = _pair_inputs(3, 515)
+    for pts in ([qs[0]], [qs[0], o.G2_IDENTITY_AFF, qs[2]]):
+        G2 = np.stack([g2aff_w(q)[0] for q in pts]); F2 = np.array([g2aff_w(q)[1] for q in pts], dtype=np.uint8)
+        t = ctx.g2_prepare(G2, F2)
+        assert len(t) == len(pts)
+        for i, q in enumerate(pts):
+            inf, co = t.coeffs(i)
+            want = o.g2_prepare(q)
+            assert inf == bool(want[0]) and np.array_equal(co, _coeffs_w(want)), i
+        t.free()
+    kb, ks = _rand_scalars_np(1 << 10, 516)
+    g2, f2 = ctx.bases_from_scalars(2, kb).download()
+    t = ctx.g2_prepare(g2, None)
+    assert len(t) == 1 << 10
+    for i in (0, 1, 511, 1023):
+        q = o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, ks[i]))
+        inf, co = t.coeffs(i)
+        assert not inf and np.array_equal(co, _coeffs_w(o.g2_prepare(q))), i
+    import bls12_381_amd as b
+    with pytest.raises(b.BlsGpuError):
+        t.coeffs(1 << 10)
+    assert len(ctx.g2_prepare(g2[:0], None)) == 0
+
+
+def test_multi_miller_loop_prepared_matches_unprepared_and_oracle(ctx):
+    """`multi_miller_loop(&[(&G1Affine, &G2Prepared)])` (pairings.rs:554-603) with prepared, unprepared and identity terms mixed: raw
+    Miller values limb-identical to the oracle's multi_miller_loop over `g2_prepare`d points and to the unprepared entry points, for one
+    product and for segments of 0, 1, 2, 3, 8 and 11 terms (more than one pass); argument errors; the mirrored `G2Prepared.resident`"""
+    import bls12_381_amd as b
+    ps, qs = _pair_inputs(25, 5151)
+    ps[4] = o.G1_IDENTITY_AFF; qs[9] = o.G2_IDENTITY_AFF
+    fixed = [qs[20], o.G2_IDENTITY_AFF, qs[21], qs[22]]                       # the "verification key": table entries 0..3 (1 = identity)
+    TG = np.stack([g2aff_w(q)[0] for q in fixed]); TF = np.array([g2aff_w(q)[1] for q in fixed], dtype=np.uint8)
+    table = ctx.g2_prepare(TG, TF)
+    n = 15
+    qi = np.full(n, b.UNPREPARED, dtype=np.uint32)
+    qi[[1, 2, 5, 6, 7, 10, 14]] = [0, 2, 3, 1, 0, 2, 3]
+    eff_q = [fixed[int(k)] if k != b.UNPREPARED else qs[i] for i, k in enumerate(qi)]
+    G1, F1, G2, F2 = _terms_w(ps[:n], qs[:n])
+    # one product
+    want = o.multi_miller_loop([(p, o.g2_prepare(q)) for p, q in zip(ps[:n], eff_q)])
+    got = ctx.multi_miller_loop_prepared(G1, F1, table, qi, G2, F2)
+    assert np.array_equal(got, fp12w(want))
+    EG2, EF2 = np.stack([g2aff_w(q)[0] for q in eff_q]), np.array([g2aff_w(q)[1] for q in eff_q], dtype=np.uint8)
+    assert np.array_equal(got, ctx.multi_miller_loop(G1, F1, EG2, EF2))
+    # all prepared, no g2 array at all; all unprepared through the same kernel (q_index = None)
+    allp = np.array([0, 2, 3, 0, 2], dtype=np.uint32)
+    w2 = o.multi_miller_loop([(p, o.g2_prepare(fixed[int(k)])) for p, k in zip(ps[:5], allp)])
+    assert np.array_equal(ctx.multi_miller_loop_prepared(G1[:5], F1[:5], table, allp), fp12w(w2))
+    assert np.array_equal(ctx.multi_miller_loop_prepared(G1, F1, None, None, G2, F2), ctx.multi_miller_loop(G1, F1, G2, F2))
+    assert np.array_equal(ctx.multi_miller_loop_prepared(G1[:0], F1[:0], table, qi[:0]), fp12w(o.FP12_ONE))
+    # segments
+    lens = [0, 1, 2, 3, 0, 8, 1, 0]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    raw = ctx.multi_miller_loop_prepared_many(G1, F1, table, qi, off, G2, F2, final_exp=False)
+    gt = ctx.multi_miller_loop_prepared_many(G1, F1, table, qi, off, G2, F2, final_exp=True)
+    assert np.array_equal(raw, ctx.multi_miller_loop_many(G1, F1, EG2, EF2, off, final_exp=False))
+    for s, k in enumerate(lens):
+        lo = int(off[s])
+        w = o.multi_miller_loop([(p, o.g2_prepare(q)) for p, q in zip(ps[lo:lo + k], eff_q[lo:lo + k])])
+        assert np.array_equal(raw[s], fp12w(w)), s
+        assert np.array_equal(gt[s], fp12w(o.final_exponentiation(w))), s
+    off11 = np.array([0, 11, 15], dtype=np.uint64)                           # 11 terms: two passes of the shared loop, multiplied in the kernel
+    raw11 = ctx.multi_miller_loop_prepared_many(G1, F1, table, qi, off11, G2, F2, final_exp=False)
+    assert np.array_equal(raw11, ctx.multi_miller_loop_many(G1, F1, EG2, EF2, off11, final_exp=False))
+    # argument errors: index outside the table, an unprepared term without g2, indices without a table
+    bad = qi.copy(); bad[3] = 4
+    for args in ((G1, F1, table, bad, G2, F2), (G1, F1, table, qi, None, None), (G1, F1, None, qi, G2, F2)):
+        with pytest.raises(b.BlsGpuError):
+            ctx.multi_miller_loop_prepared(*args)
+    # the mirror: e(aG, bH) e(-abG, H) = 1 with H resident
+    a, c = b.Scalar(77), b.Scalar(1234567)
+    g, h = b.G1Affine.generator(), b.G2Affine.generator()
+    hp, hcp = b.G2Prepared.resident_many([h, (h * c).to_affine()])
+    assert np.array_equal(hp.coeffs()[1], _coeffs_w(o.g2_prepare(o.G2_GEN)))
+    eq_ok = [((g * a).to_affine(), hcp), (-(g * (a * c)).to_affine(), hp)]
+    eq_mixed = [((g * a).to_affine(), b.G2Prepared((h * c).to_affine())), (-(g * a).to_affine(), hp)]
+    assert b.multi_miller_loop(eq_ok).final_exponentiation() == b.Gt.identity()
+    res = b.multi_miller_loop_many([eq_ok, eq_mixed, []])
+    assert res[0] == b.Gt.identity() and res[1] != b.Gt.identity() and res[2] == b.Gt.identity()
+    plain = [(p, b.G2Prepared(pr.q)) for p, pr in eq_mixed]
+    assert res[1] == b.multi_miller_loop(plain).final_exponentiation()
+    table.free()
+
+
+def test_prepared_equations_2_12_vs_c_oracle_and_device_pointers(ctx):
+    """2^12 verification-shaped equations e(A_i, B_i) e(C_i, K0) e(D_i, K1) with K0, K1 prepared, on the throughput kernel through the
+    device-pointer entry point: equal to the unprepared path limb for limb and to the C oracle's Miller values multiplied per segment;
+    2^15 terms of one long product (K > 1 runs + product tree) against the unprepared product; a bad index is reported by synchronize"""
+    import torch
+    import bls12_381_amd as b
+    from oracle import c_oracle
+    c_oracle.build()
+    dev = torch.device("cuda", 0)
+    nseg, k = 1 << 12, 3
+    n = nseg * k
+    ab, _ = _rand_scalars_np(n, 551)
+    bb, _ = _rand_scalars_np(n, 552)
+    g1, f1 = ctx.bases_from_scalars(1, ab).download()
+    g2, f2 = ctx.bases_from_scalars(2, bb).download()
+    kk, _ = _rand_scalars_np(2, 553)
+    key, _ = ctx.bases_from_scalars(2, kk).download()
+    qi = np.full(n, b.UNPREPARED, dtype=np.uint32); qi[1::3] = 0; qi[2::3] = 1
+    eff = g2.copy(); eff[1::3] = key[0]; eff[2::3] = key[1]
+    off = (np.arange(nseg + 1) * k).astype(np.uint64)
+    table = ctx.g2_prepare(key, None)
+    t = lambda a: torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).to(dev)
+    d_g1, d_g2, d_qi, d_off = t(g1), t(g2), t(qi.view(np.int32)), t(off)
+    d_out = torch.zeros((nseg, 72), dtype=torch.int64, device=dev)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.multi_miller_loop_prepared_many_device(d_g1.data_ptr(), table, d_qi.data_ptr(), d_off.data_ptr(), nseg, n, d_out.data_ptr(), max_seg_terms=k, final_exp=False,
+                                                   d_g2=d_g2.data_ptr())
+        ctx.synchronize()
+        raw = d_out.cpu().numpy().view(np.uint64)
+        ml, _ = c_oracle.pairing_batch(1, g1, np.zeros(n, dtype=np.uint8), eff, np.zeros(n, dtype=np.uint8))
+        for s in (0, 1, 777, nseg - 1):
+            acc = o.fp12_mul(o.fp12_mul(wfp12(ml[3 * s]), wfp12(ml[3 * s + 1])), wfp12(ml[3 * s + 2]))
+            assert np.array_equal(raw[s], fp12w(acc)), s
+        assert np.array_equal(raw, ctx.multi_miller_loop_many(g1, None, eff, None, off, final_exp=False))
+        ctx.multi_miller_loop_prepared_many_device(d_g1.data_ptr(), table, d_qi.data_ptr(), d_off.data_ptr(), nseg, n, d_out.data_ptr(), max_seg_terms=k, final_exp=True,
+                                                   d_g2=d_g2.data_ptr())
+        ctx.synchronize()
+        want = c_oracle.pairing_batch(2, raw, None, None, None)[0]
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want)
+        # one long product: 2^15 terms (12 288 of ours tiled) -> K = 1 quads ... force K > 1 with 2^17 terms
+        reps = 11
+        big1, big2, bigq = np.tile(g1, (reps, 1)), np.tile(g2, (reps, 1)), np.tile(qi, reps)
+        bige = np.tile(eff, (reps, 1))
+        got = ctx.multi_miller_loop_prepared(big1, None, table, bigq, big2, None)
+        assert np.array_equal(got, ctx.multi_miller_loop(big1, None, bige, None))
+        # a bad index on the device-pointer path: skipped term, sticky flag
+        badq = qi.copy(); badq[4] = 7
+        d_bq = t(badq.view(np.int32))
+        ctx.multi_miller_loop_prepared_many_device(d_g1.data_ptr(), table, d_bq.data_ptr(), d_off.data_ptr(), nseg, n, d_out.data_ptr(), max_seg_terms=k, final_exp=False,
+                                                   d_g2=d_g2.data_ptr())
+        with pytest.raises(b.BlsGpuError):
+            ctx.synchronize()
+        ctx.synchronize()                                                    # cleared
+    finally:
+        ctx.set_stream(None)
+        table.free()

@@ -148,3 +148,57 @@ def test_emulated_wide_kernel_matches_oracle():
     mlw = fp12w(ml)
     lib.emu_wide(2, vp(mlw), None, vp(out), pm, pf)
     assert np.array_equal(out, fp12w(o.final_exponentiation(ml)))
+
+
+def _g2w(q):
+    return np.concatenate([fpw(q[0][0]), fpw(q[0][1]), fpw(q[1][0]), fpw(q[1][1])])
+
+
+PREP_POINT_WORDS = 68 * 3 * 2 * 16
+
+
+def test_emulated_g2_prepared_table_and_shared_prepared_loop_match_oracle(emu):
+    """prep.hip.h: (i) the device table of a point holds the reference's 68 coefficient triples (`G2Prepared::from`, pairings.rs:504-546)
+    limb for limb; (ii) the shared-accumulator loop over a segment of prepared and unprepared terms (incl. a skipped identity term) gives
+    the reference's multi_miller_loop value (pairings.rs:554-603); (iii) a segment longer than one pass (kmax = 2) and the uniform-run
+    mode of one long product agree with it."""
+    r = o.SplitMix64(4242)
+    Q = [o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, r.scalar())) for _ in range(3)]
+    P = [o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, r.scalar())) for _ in range(4)]
+    # (i) tables of Q[1], Q[2] (index 0, 1)
+    tab = np.zeros(2 * PREP_POINT_WORDS // 2, dtype=np.uint64)          # u32 words, 8-byte aligned by numpy (>= 16 in practice)
+    assert tab.ctypes.data % 16 == 0
+    tab_inf = np.zeros(2, dtype=np.uint8)
+    for j, q in enumerate(Q[1:]):
+        qw = _g2w(q)
+        emu.emu_g2_prepare(vp(qw), None, ctypes.c_void_p(tab.ctypes.data + 4 * PREP_POINT_WORDS * j), ctypes.c_void_p(tab_inf.ctypes.data + j))
+        co = np.zeros(68 * 3 * 12, dtype=np.uint64)
+        emu.emu_g2_prepared_export(ctypes.c_void_p(tab.ctypes.data + 4 * PREP_POINT_WORDS * j), vp(co))
+        want = np.concatenate([np.concatenate([fpw(c[0]), fpw(c[1])]) for tri in o.g2_prepare(q)[1] for c in tri])
+        assert np.array_equal(co, want), "prepared coefficients of point %d" % j
+    assert not tab_inf.any()
+    # (ii) segment: P0 with Q0 unprepared, P1 with table 0, P2 = identity with table 1 (skipped), P3 with table 1
+    terms_p = [P[0], P[1], (0, 1, True), P[3]]
+    g1 = np.concatenate([np.concatenate([fpw(p[0]), fpw(p[1])]) for p in terms_p])
+    g1inf = np.array([0, 0, 1, 0], dtype=np.uint8)
+    g2 = np.concatenate([_g2w(Q[0])] + [np.zeros(24, dtype=np.uint64)] * 3)
+    qidx = np.array([0xffffffff, 0, 1, 1], dtype=np.uint32)
+    want = o.multi_miller_loop([(P[0], o.g2_prepare(Q[0])), (P[1], o.g2_prepare(Q[1])), (P[3], o.g2_prepare(Q[2]))])
+
+    def run(off, total, kuni, kmax):
+        work = np.zeros(kmax * 65 * 4 // 2 + 2, dtype=np.uint64)
+        out = np.zeros(72, dtype=np.uint64)
+        status = np.zeros(1, dtype=np.uint32)
+        offp = vp(off) if off is not None else None
+        emu.emu_mml_prep(vp(g1), vp(g1inf), vp(g2), None, vp(qidx), vp(tab), vp(tab_inf), ctypes.c_uint32(2), offp, ctypes.c_size_t(total), kuni, kmax, vp(work), vp(out), vp(status))
+        assert status[0] == 0
+        return out
+
+    off = np.array([0, 4], dtype=np.uint64)
+    assert np.array_equal(run(off, 4, 0, 4), fp12w(want))
+    # (iii) two passes of two terms each, multiplied in the kernel; and the uniform-run mode
+    assert np.array_equal(run(off, 4, 0, 2), fp12w(want))
+    assert np.array_equal(run(None, 4, 4, 4), fp12w(want))
+    # an empty segment is one; an all-unprepared single term equals the plain Miller loop
+    assert np.array_equal(run(np.array([2, 2], dtype=np.uint64), 4, 0, 4), fp12w(o.FP12_ONE))
+    assert np.array_equal(run(np.array([0, 1], dtype=np.uint64), 4, 0, 1), fp12w(o.miller_loop(P[0], Q[0])))

@@ -22,6 +22,8 @@ C_TO_RUST = {
     "const void*": "*const c_void", "void*": "*mut c_void", "double*": "*mut f64", "float*": "*mut f32", "unsigned*": "*mut c_uint",
     "const char*": "*const c_char", "const int*": "*const c_int",
     "blsgpu_group*": "*mut BlsgpuGroup", "const blsgpu_group*": "*const BlsgpuGroup", "blsgpu_group**": "*mut *mut BlsgpuGroup",
+    "blsgpu_g2_prepared*": "*mut BlsgpuG2Prepared", "const blsgpu_g2_prepared*": "*const BlsgpuG2Prepared", "blsgpu_g2_prepared**": "*mut *mut BlsgpuG2Prepared",
+    "const uint32_t*": "*const u32", "uint32_t*": "*mut u32", "const void* const*": "*const *const c_void", "void* const*": "*const *mut c_void", "const size_t*": "*const usize",
     "blsgpu_group_bases*": "*mut BlsgpuGroupBases", "const blsgpu_group_bases*": "*const BlsgpuGroupBases", "blsgpu_group_bases**": "*mut *mut BlsgpuGroupBases",
 }
 
@@ -70,6 +72,8 @@ def rust_source():
              "#[repr(C)] pub struct BlsgpuGroup { _private: [u8; 0] }",
              "/// opaque: bases sharded over the members of a group (blsgpu_group_bases_upload / blsgpu_group_bases_free)",
              "#[repr(C)] pub struct BlsgpuGroupBases { _private: [u8; 0] }",
+             "/// opaque: `G2Prepared` values resident in HBM (blsgpu_g2_prepare / blsgpu_g2_prepared_free)",
+             "#[repr(C)] pub struct BlsgpuG2Prepared { _private: [u8; 0] }",
              "",
              "pub const BLSGPU_OK: c_int = 0;",
              "",
