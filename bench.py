@@ -57,7 +57,7 @@ def static_traffic(tag):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc summary of the SAME workload (profiles/<round>_<tag>_pmc.json,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE).  Counters cannot be read inside a timed
     run, so this is a STATIC figure from a separate profiled run -- labelled as such in the bench line."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (rnd, tag))
         if os.path.exists(path):
             try:
@@ -65,6 +65,106 @@ def static_traffic(tag):
             except Exception:
                 pass
     return None, None
+
+
+# ---- the ONE JSON line ----------------------------------------------------------------------------------------------------------
+# The driver keeps the last ~8 000 characters of stdout.  The full record (every note, per-op table and latency probe) goes to stderr
+# and, when the directory exists, to gpurun_out/bench_detail.json; stdout carries a compact line (< 6 000 characters) whose LAST keys
+# are the second half of BASELINE's metric -- batched pairings/sec -- so that they survive any truncation from the front.
+_DROP = {"note", "traffic_source", "launch_sampling", "sample_detail", "per_op_ns", "host", "mac32_per_launch", "reference_algorithm_mac32_per_unit",
+         "executed_mac_per_unit", "executed_frac_of_peak", "mac32_per_unit_is", "launch_ms_isolated", "hbm_frac_of_8TBs", "table_build_s", "resident_bytes",
+         "single_thread_value", "parallel_speedup", "algorithmic_bytes", "scalars", "single_call_scalar_muls_per_s", "end_to_end_scalar_muls_per_s",
+         "with_final_exponentiation_ms", "window_bits", "per_term_path_ms", "launches_timed", "peak", "unit", "bound", "kernel", "mac32_per_unit"}
+_KEEP_SMALL = ("pairing_n1_ms", "pairing_n1024_ms", "final_exponentiation_n1_ms", "multi_miller_loop_n3_plus_final_exponentiation_ms")
+
+
+def _num(x):
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    return float("%.5g" % x)
+
+
+def _slim(v, top=False):
+    if isinstance(v, dict):
+        return {k: _slim(x) for k, x in v.items() if (top or k not in _DROP) and x is not None}
+    if isinstance(v, (list, tuple)):
+        return [_slim(x) for x in v]
+    if isinstance(v, str):
+        return v if len(v) <= 200 else v[:197] + "..."
+    return _num(v)
+
+
+def slim_line(line):
+    """the compact stdout form of a full bench record: required keys first, every block reduced to its numbers, the pairing half of the
+    metric as top-level scalars at the very end"""
+    out = {}
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        out[k] = _num(line.get(k))
+    cfg = line.get("config") or {}
+    out["config"] = {k: (v if not isinstance(v, str) or len(v) <= 240 else v[:237] + "...") for k, v in cfg.items() if k != "scalars"}
+    roof = line.get("roofline")
+    if roof:
+        r = {k: _num(roof.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_isolated", "launch_ms", "whole_msm_frac_pipelined", "whole_msm_frac_single_call")}
+        out["roofline"] = r
+    cpu = line.get("cpu_baseline")
+    if cpu:
+        out["cpu_baseline"] = {k: _slim(cpu.get(k)) for k in ("value", "unit", "cores", "kind", "sample", "gpu_result_matches") if cpu.get(k) is not None}
+    for k in ("single_call_ms", "end_to_end_h2d_ms", "group_path"):
+        if line.get(k) is not None:
+            out[k] = _slim(line[k])
+    ex = line.get("extras")
+    tail = {}
+    if ex:
+        e2 = {}
+        for k, v in ex.items():
+            if k == "pairing_small_batches":
+                e2[k] = {kk: _num(v[kk]) for kk in _KEEP_SMALL if kk in v}
+            elif k in ("pairing_batch", "cpu_baseline_pairing", "pairings_per_s"):
+                continue                                   # emitted LAST, below
+            else:
+                e2[k] = _slim(v)
+        out["extras"] = e2
+        pb, mm, eq = ex.get("pairing_batch") or {}, ex.get("multi_miller_loop") or {}, ex.get("verification_equations") or {}
+        if pb:
+            # the second half of BASELINE's metric, with its roofline block and CPU baseline intact
+            rf = pb.get("roofline") or {}
+            tail["pairing_batch"] = {"n": pb.get("n"), "ms": _num(pb.get("ms")),
+                                     "roofline": {k: _num(rf.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "mac32_per_unit")}}
+            cp = ex.get("cpu_baseline_pairing")
+            if cp:
+                tail["cpu_baseline_pairing"] = {k: _slim(cp.get(k)) for k in ("value", "unit", "cores", "kind", "sample", "gpu_result_matches") if cp.get(k) is not None}
+            tail["pairings_per_s"] = _num(ex.get("pairings_per_s"))
+            tail["pairing_ms"] = _num(pb.get("ms"))
+            tail["pairing_frac"] = _num(rf.get("frac"))
+        if mm:
+            tail["mml_terms_per_s"] = _num(ex.get("multi_miller_loop_terms_per_s"))
+            tail["mml_ms"] = _num(mm.get("ms"))
+            tail["mml_frac"] = _num((mm.get("roofline") or {}).get("frac"))
+        if eq:
+            tail["equations_per_s"] = _num(eq.get("equations_per_s"))
+            tail["equations_frac"] = _num((eq.get("roofline") or {}).get("frac"))
+            pq = eq.get("prepared") or {}
+            if pq:
+                tail["prepared_equations_per_s"] = _num(pq.get("equations_per_s"))
+                tail["prepared_equations_speedup"] = _num(pq.get("speedup_over_unprepared"))
+    out.update(tail)
+    return out
+
+
+def emit(line):
+    """full record -> stderr (+ gpurun_out/bench_detail.json); compact line -> stdout"""
+    full = json.dumps(line)
+    sys.stderr.write("bench-detail: " + full + "\n")
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(d):
+            with open(os.path.join(d, "bench_detail.json"), "w") as fh:
+                fh.write(full + "\n")
+    except OSError:
+        pass
+    sys.stderr.flush()
+    print(json.dumps(slim_line(line)))
+    sys.stdout.flush()
 
 
 def parse():
@@ -316,7 +416,7 @@ def run_msm(args, e):
         }
         if latency:
             line["single_call_ms"] = latency["single_call_ms"]; line["end_to_end_h2d_ms"] = latency["end_to_end_h2d_ms"]
-        print(json.dumps(line))
+        emit(line)
     if multi:
         dist.barrier()
         dist.destroy_process_group()
@@ -366,9 +466,10 @@ def cpu_baseline_g1(ctx, bases, sb, n):
     if not same:
         raise SystemExit("bench: GPU MSM over the CPU sample differs from the oracle")
     return {"value": m / cdt, "unit": "scalar-muls/s", "cores": used, "kind": "port",
-            "sample": f"first 2^{int(np.log2(m))} (point, scalar) pairs of the same workload: sum(P_i*s_i) by 255-step double-and-add + Sum, "
-                      f"C restatement of the reference algorithm (oracle/bls_oracle.c), OpenMP dynamic schedule over {used} threads (= the CPUs the cgroup quota / affinity grants this process) after a warm-up; "
-                      f"single thread (4096-pair sample): {one:.0f}/s",
+            "sample": f"first 2^{int(np.log2(m))} (point, scalar) pairs of the workload: sum(P_i*s_i) by the reference's double-and-add + Sum (C port, OpenMP x{used}); 1 thread: {one:.0f}/s",
+            "sample_detail": f"first 2^{int(np.log2(m))} (point, scalar) pairs of the same workload: sum(P_i*s_i) by 255-step double-and-add + Sum, "
+                             f"C restatement of the reference algorithm (oracle/bls_oracle.c), OpenMP dynamic schedule over {used} threads (= the CPUs the cgroup quota / affinity grants this process) after a warm-up; "
+                             f"single thread (4096-pair sample): {one:.0f}/s",
             "single_thread_value": one, "parallel_speedup": (m / cdt) / one, "gpu_result_matches": same, "per_op_ns": per_op,
             "host": host_cpu_allotment()}
 
@@ -430,8 +531,7 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
         same_p = bool(np.array_equal(d_gt[:mp].cpu().numpy().view(np.uint64), cref))
         one_p = 1e9 / per_op["full_pairing_ns"]
         extras["cpu_baseline_pairing"] = {"value": mp / cpdt, "unit": "pairings/s", "cores": cused, "kind": "port",
-                                          "sample": f"first 2^14 of the same pairs, C restatement of pairings.rs (Miller loop + final exponentiation), "
-                                                    f"OpenMP over {cused} threads after a warm-up; single thread (512-pair sample): {one_p:.0f}/s",
+                                          "sample": f"first 2^14 of the same pairs: pairing() of pairings.rs (C port, OpenMP x{cused}); 1 thread: {one_p:.0f}/s",
                                           "single_thread_value": one_p, "parallel_speedup": (mp / cpdt) / one_p, "gpu_result_matches": same_p, "per_op_ns": per_op}
         if not same_p:
             raise SystemExit("bench: GPU pairings differ from the CPU oracle on the sample")
@@ -502,6 +602,59 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
     eq["n65536"] = {"ms": eq2, "equations_per_s": ne2 / (eq2 * 1e-3), "frac": ne2 * mac_eq / (eq2 * 1e-3) / peak, "per_term_path_ms": eq2p,
                     "paths_agree": bool(torch.equal(keep, d_eq2[:256])),
                     "note": "2^16 equations: shared accumulator per equation (k_multi_miller_seg) + batched final exponentiation; per_term_path_ms = the same call on the per-term quads"}
+    # The same shape with two of the three G2 arguments FIXED (a verification key: Groth16 has three of four fixed, BLS a fixed
+    # generator) and prepared once (blsgpu_g2_prepare: `G2Prepared::from`, pairings.rs:504-546): the prepared terms only evaluate their
+    # stored lines and every equation shares ONE accumulator (blsgpu_multi_miller_loop_prepared_many_device).  Canonical work per
+    # equation as the REFERENCE does it with prepared arguments: one unprepared term 6 900 + two prepared terms 2 900 each
+    # + one final exponentiation 9 100 field multiplications.
+    kkey = synthetic.scalars(2, 977)
+    key_xy, _ = ctx.bases_from_scalars(2, kkey).download()
+    table = ctx.g2_prepare(key_xy)
+    mac_eq_prep = (6900 + 2 * 2900 + 9100) * 300
+    prep = {"fixed_g2_arguments": 2, "terms_per_equation": ke, "table_bytes": 2 * 26112}
+    for nn, d_o, d_e in ((ne, d_off, d_eq), (ne2, d_off2, d_eq2)):
+        qi_np = np.full(nn * ke, bls.UNPREPARED, dtype=np.uint32); qi_np[1::3] = 0; qi_np[2::3] = 1
+        d_qi = torch.from_numpy(qi_np.view(np.int32)).to(dev)
+        d_gq = (d_g2e if nn == ne2 else d_g2)[:nn * ke].clone()
+        d_gp = (d_g1e if nn == ne2 else d_g1)[:nn * ke]
+        kt = torch.from_numpy(key_xy.view(np.int64)).to(dev)
+        d_gq[1::3] = kt[0]; d_gq[2::3] = kt[1]                  # the same equations for the unprepared path: the fixed points written out per term
+        tp = median_ms(lambda: ctx.multi_miller_loop_prepared_many_device(d_gp.data_ptr(), table, d_qi.data_ptr(), d_o.data_ptr(), nn, nn * ke, d_e.data_ptr(), max_seg_terms=ke,
+                                                                          d_g2=d_gq.data_ptr()), sync, warm=1, reps=5 if nn == ne else 3)
+        got_p = d_e[:512].clone()
+        tu = median_ms(lambda: ctx.multi_miller_loop_many_device(d_gp.data_ptr(), d_gq.data_ptr(), d_o.data_ptr(), nn, nn * ke, d_e.data_ptr(), max_seg_terms=ke), sync, warm=1,
+                       reps=5 if nn == ne else 3)
+        rec = {"ms": tp, "equations_per_s": nn / (tp * 1e-3), "unprepared_same_equations_ms": tu, "speedup_over_unprepared": tu / tp,
+               "paths_agree": bool(torch.equal(got_p, d_e[:512])),
+               "roofline": {"bound": "int-valu", "kernel": "k_mml_prep_quad + k_final_exp_quad", "mac32_per_unit": mac_eq_prep, "achieved": nn * mac_eq_prep / (tp * 1e-3) / 1e12,
+                            "peak": peak / 1e12, "unit": "TMAC32/s", "frac": nn * mac_eq_prep / (tp * 1e-3) / peak, "algorithmic_bytes": nn * (ke * 96 + 192 + 576), "traffic": None}}
+        if nn == ne:
+            prep.update(rec); prep["n"] = nn
+            if not args.no_cpu_baseline:
+                # the reference's own schedule on the host cores: ONE accumulator per equation, the fixed arguments prepared once outside the
+                # timed region, the variable one prepared inside it (`G2Prepared::from` is part of every call for a fresh point)
+                from oracle import c_oracle
+                ms_ = 1 << 11
+                tabs = c_oracle.g2_prepare(key_xy)
+                hg1 = d_gp[:ms_ * ke].cpu().numpy().view(np.uint64); hg2 = d_gq[:ms_ * ke].cpu().numpy().view(np.uint64)
+                hoff = (np.arange(ms_ + 1) * ke).astype(np.uint64)
+                c_oracle.multi_miller_prepared_many(hg1[:64 * ke], None, hg2[:64 * ke], None, qi_np[:64 * ke], tabs, None, hoff[:65], True, host_threads())
+                t1 = time.perf_counter()
+                cw, cused = c_oracle.multi_miller_prepared_many(hg1, None, hg2, None, qi_np[:ms_ * ke], tabs, None, hoff, True, host_threads())
+                ct = time.perf_counter() - t1
+                ctx.multi_miller_loop_prepared_many_device(d_gp.data_ptr(), table, d_qi.data_ptr(), d_o.data_ptr(), nn, nn * ke, d_e.data_ptr(), max_seg_terms=ke, d_g2=d_gq.data_ptr()); sync()
+                prep["gpu_result_matches"] = bool(np.array_equal(d_e[:ms_].cpu().numpy().view(np.uint64), cw))
+                prep["cpu_baseline"] = {"value": ms_ / ct, "unit": "equations/s", "cores": cused, "kind": "port",
+                                        "sample": f"first 2^11 equations: multi_miller_loop over G2Prepared terms (pairings.rs:554-603 schedule, C port) + final exponentiation, OpenMP x{cused}"}
+                if not prep["gpu_result_matches"]:
+                    raise SystemExit("bench: GPU prepared multi_miller_loop_many differs from the CPU oracle on the sample")
+        else:
+            prep["n65536"] = rec
+        if not rec["paths_agree"]:
+            raise SystemExit("bench: prepared and unprepared Miller loops disagree")
+        del d_qi, d_gq
+    table.free()
+    eq["prepared"] = prep
     extras["verification_equations"] = eq
     del d_off, d_eq, d_g1e, d_g2e, d_off2, d_eq2
     # Fr transform of the MSM's scalar vector

@@ -16,6 +16,7 @@
  */
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -563,6 +564,86 @@ int ora_pairing_batch(int mode, const u64* g1, const uint8_t* g1inf, const u64* 
     memcpy(out + 72 * i, &f, 576);
   }
   (void)FP2_ZERO_C;
+  return used;
+}
+
+/* ---- `G2Prepared` and the reference's own `multi_miller_loop` schedule (pairings.rs:487-603) --------------------------------- */
+typedef struct { line3 l[68]; } g2prep;
+static void g2_prepare_c(const fp2* qx, const fp2* qy, g2prep* out) {                                                        /* :504-546 */
+  g2r r = {*qx, *qy, fp2_one()};
+  int n = 0, found = 0;
+  for (int b = 63; b >= 0; b--) {
+    int i = (int)(((BLS_X_C >> 1) >> b) & 1);
+    if (!found) { found = i; continue; }
+    out->l[n++] = doubling_step(&r);
+    if (i) out->l[n++] = addition_step(&r, qx, qy);
+  }
+  out->l[n++] = doubling_step(&r);
+}
+/* coefficients of m points (m x 24 limbs in), m x 68 x 36 limbs out: `G2Prepared::from(G2Affine)` per point (identity: the generator's
+ * coefficients are the caller's business -- pass the generator) */
+int ora_g2_prepare(const u64* g2, long m, int threads, u64* out) {
+  int used = 1;
+#ifdef _OPENMP
+  if (threads <= 0) threads = omp_get_max_threads();
+  used = threads;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 4)
+#endif
+  for (long i = 0; i < m; i++) {
+    fp2 qx, qy; memcpy(&qx, g2 + 24 * i, 96); memcpy(&qy, g2 + 24 * i + 12, 96);
+    g2prep t; g2_prepare_c(&qx, &qy, &t);
+    memcpy(out + (size_t)i * 68 * 36, &t, sizeof t);
+  }
+  return used;
+}
+/* N independent `multi_miller_loop(&[(&G1Affine, &G2Prepared)])` (pairings.rs:554-603: ONE accumulator per call, per step every
+ * term's `ell`, one squaring for all), optionally followed by `.final_exponentiation()`.  Term t of segment s = terms off[s] ..
+ * off[s+1]: qidx[t] names a prepared table (68 x 36 limbs each in `tabs`, flag in tabinf) or -- 0xffffffff -- the point g2[t], which
+ * is PREPARED HERE first, as a caller of the reference must (`G2Prepared::from`, inside the timed region of the CPU baseline). */
+int ora_multi_miller_prepared_many(const u64* g1, const uint8_t* g1inf, const u64* g2, const uint8_t* g2inf, const unsigned* qidx, const u64* tabs,
+                                   const uint8_t* tabinf, const u64* off, long nseg, int final_exp, int threads, u64* out) {
+  int used = 1;
+#ifdef _OPENMP
+  if (threads <= 0) threads = omp_get_max_threads();
+  used = threads;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 4)
+#endif
+  for (long s = 0; s < nseg; s++) {
+    const long lo = (long)off[s], k = (long)off[s + 1] - lo;
+    const g2prep** tab = (const g2prep**)malloc((size_t)(k ? k : 1) * sizeof(*tab));
+    g2prep* own = (g2prep*)malloc((size_t)(k ? k : 1) * sizeof(*own));
+    fp* px = (fp*)malloc((size_t)(k ? k : 1) * sizeof(fp)); fp* py = (fp*)malloc((size_t)(k ? k : 1) * sizeof(fp));
+    long live = 0;
+    for (long j = 0; j < k; j++) {
+      const long t = lo + j;
+      const unsigned qi = qidx ? qidx[t] : 0xffffffffu;
+      int skip = g1inf && g1inf[t];
+      if (qi == 0xffffffffu) skip = skip || (g2inf && g2inf[t]); else skip = skip || (tabinf && tabinf[qi]);
+      if (skip) continue;                                                                                                    /* :566-569 */
+      memcpy(&px[live], g1 + 12 * t, 48); memcpy(&py[live], g1 + 12 * t + 6, 48);
+      if (qi == 0xffffffffu) {
+        fp2 qx, qy; memcpy(&qx, g2 + 24 * t, 96); memcpy(&qy, g2 + 24 * t + 12, 96);
+        g2_prepare_c(&qx, &qy, &own[live]);
+        tab[live] = &own[live];
+      } else tab[live] = (const g2prep*)(tabs + (size_t)qi * 68 * 36);
+      live++;
+    }
+    fp12 f = fp12_one();
+    int idx = 0, found = 0;
+    for (int b = 63; b >= 0; b--) {
+      int i = (int)(((BLS_X_C >> 1) >> b) & 1);
+      if (!found) { found = i; continue; }
+      for (long j = 0; j < live; j++) f = ell(&f, &tab[j]->l[idx], &px[j], &py[j]);
+      idx++;
+      if (i) { for (long j = 0; j < live; j++) f = ell(&f, &tab[j]->l[idx], &px[j], &py[j]); idx++; }
+      f = fp12_sqr(&f);
+    }
+    for (long j = 0; j < live; j++) f = ell(&f, &tab[j]->l[idx], &px[j], &py[j]);
+    f = fp12_conj(&f);
+    if (final_exp) f = final_exponentiation_c(&f);
+    memcpy(out + 72 * s, &f, 576);
+    free(tab); free(own); free(px); free(py);
+  }
   return used;
 }
 

@@ -1,6 +1,7 @@
 """CPU-side tests (no GPU): the C ABI library loads and exports every declared symbol, the host-side mirror
 (encodings, Scalar) agrees with the golden vectors and the oracle, the product fails loudly without a device,
 and the multi-rank sharding/fold plumbing is correct under gloo with world_size 2."""
+import json
 import os
 import re
 import subprocess
@@ -374,3 +375,32 @@ def test_scalar_decompositions_against_big_integers():
         assert all((m >> 48) + 1 <= 1 << 15 for m, _ in t)
         folded += t[2][0] > XH
     assert folded >= 0
+
+
+def test_bench_line_is_compact_and_ends_with_the_pairing_half_of_the_metric():
+    """the driver keeps the last ~8 000 characters of stdout: the compact line built from a FULL record (round 4's, with every note and
+    table in it) stays under 6 000 characters, is valid JSON with the contract's keys, and its last 2 000 characters carry the
+    2^16-pairing figure, its roofline fraction and its CPU baseline (round-4 review: they had been pushed out of the record)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_default_n1.json")))
+    # the round-5 additions, with long notes, as bench.py now produces them
+    full["extras"]["verification_equations"]["prepared"] = {"n": 16384, "ms": 7.5, "equations_per_s": 2.2e6, "speedup_over_unprepared": 1.4, "unprepared_same_equations_ms": 10.5,
+                                                            "paths_agree": True, "gpu_result_matches": True, "note": "x" * 900,
+                                                            "roofline": {"bound": "int-valu", "kernel": "k", "achieved": 14.2, "peak": 37.0, "unit": "TMAC32/s", "frac": 0.38, "traffic": None},
+                                                            "cpu_baseline": {"value": 9000.0, "unit": "equations/s", "cores": 16, "kind": "port", "sample": "y" * 400},
+                                                            "n65536": {"ms": 27.0, "equations_per_s": 2.4e6, "speedup_over_unprepared": 1.37, "roofline": {"frac": 0.42}}}
+    full["group_path"] = {"members": 8, "ms_per_step": 6.0, "value": 2.8e9, "note": "z" * 500}
+    s = json.dumps(bench.slim_line(full))
+    assert len(s) < 6000, len(s)
+    back = json.loads(s)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in back, k
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(back["roofline"]) and back["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-4)
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(back["cpu_baseline"])
+    tail = s[-2000:]
+    for needle in ('"pairing_frac"', '"pairing_ms"', '"pairings_per_s"', '"cpu_baseline_pairing"', '"mml_frac"', '"equations_frac"', '"prepared_equations_speedup"'):
+        assert needle in tail, needle
+    assert back["pairing_ms"] == pytest.approx(full["extras"]["pairing_batch"]["ms"], rel=1e-4)
+    assert back["pairing_batch"]["roofline"]["frac"] == pytest.approx(full["extras"]["pairing_batch"]["roofline"]["frac"], rel=1e-4)
+    assert list(back)[-1] in ("prepared_equations_speedup", "equations_frac")

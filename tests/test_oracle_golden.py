@@ -440,3 +440,30 @@ def test_c_oracle_g2(golden_dir):
     xy, inf = c_oracle.g2_to_affine(out)
     tot = sum(k * s for k, s in zip(ks, ss)) % o.R_ORDER
     assert np.array_equal(xy, g2w(o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, tot)))) and not inf
+
+
+def test_c_oracle_prepared_path_matches_tier0():
+    import numpy as np
+    """tier 1's `G2Prepared::from` (68 coefficient triples) and its shared-accumulator multi_miller_loop over prepared terms
+    (pairings.rs:504-546, 554-603) against tier 0, incl. a term prepared on the fly, an identity, an empty segment and the final exponentiation"""
+    from oracle import c_oracle
+    c_oracle.build()
+    r = o.SplitMix64(5)
+    fpw = lambda x: np.array(o.fp_to_mont_limbs(x), dtype=np.uint64)
+    f12 = lambda f: np.concatenate([fpw(c) for c in o.fp12_flatten(f)])
+    Q = [o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, r.scalar())) for _ in range(3)]
+    P = [o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, r.scalar())) for _ in range(4)]
+    g2 = np.stack([np.concatenate([fpw(q[0][0]), fpw(q[0][1]), fpw(q[1][0]), fpw(q[1][1])]) for q in Q] + [np.zeros(24, dtype=np.uint64)])
+    g1 = np.stack([np.concatenate([fpw(p[0]), fpw(p[1])]) for p in P])
+    tabs = c_oracle.g2_prepare(g2[1:3])
+    for j in (0, 1):
+        want = np.array([[np.concatenate([fpw(c[0]), fpw(c[1])]) for c in tri] for tri in o.g2_prepare(Q[1 + j])[1]], dtype=np.uint64)
+        assert np.array_equal(tabs[j], want)
+    qi = np.array([0xffffffff, 0, 1, 1], dtype=np.uint32)
+    f1 = np.array([0, 0, 0, 1], dtype=np.uint8)                     # the last term's P is the identity: skipped
+    off = np.array([0, 4, 4], dtype=np.uint64)
+    w = o.multi_miller_loop([(p, o.g2_prepare(q)) for p, q in zip(P[:3], Q)])
+    out, _ = c_oracle.multi_miller_prepared_many(g1, f1, g2, None, qi, tabs, None, off, False, 1)
+    assert np.array_equal(out[0], f12(w)) and np.array_equal(out[1], f12(o.FP12_ONE))
+    out, _ = c_oracle.multi_miller_prepared_many(g1, f1, g2, None, qi, tabs, None, off, True, 2)
+    assert np.array_equal(out[0], f12(o.final_exponentiation(w)))
