@@ -82,6 +82,16 @@ SIGNATURES = {
     "blsgpu_multi_miller_loop_many": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
     "blsgpu_multi_miller_loop_many_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_sz, c_sz, c_int, c_vp]),
     "blsgpu_wide_status": (ctypes.c_char_p, [c_vp]),
+    "blsgpu_g1_batch_normalize_device": (c_int, [c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "blsgpu_g2_batch_normalize_device": (c_int, [c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "blsgpu_g1_from_bytes_batch_device": (c_int, [c_vp, c_vp, c_sz, c_int, c_int, c_vp, c_vp, c_vp]),
+    "blsgpu_g2_from_bytes_batch_device": (c_int, [c_vp, c_vp, c_sz, c_int, c_int, c_vp, c_vp, c_vp]),
+    "blsgpu_g1_to_bytes_batch_device": (c_int, [c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
+    "blsgpu_g2_to_bytes_batch_device": (c_int, [c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
+    "blsgpu_gt_mul_scalar_batch_device": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_gt_is_identity_device": (c_int, [c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_bls_verify_batch": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
+    "blsgpu_bls_verify_batch_device": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
     "blsgpu_g2_prepare": (c_int, [c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
     "blsgpu_g2_prepare_device": (c_int, [c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
     "blsgpu_g2_prepared_len": (c_sz, [c_vp]),

@@ -499,6 +499,46 @@ class Context:
                                                             ctypes.c_void_p(d_offsets), nseg, total_terms, max_seg_terms, 1 if final_exp else 0, ctypes.c_void_p(d_out)),
               "multi_miller_loop_many_device")
 
+    # -- the widened rows with device pointers (a chain that stays in HBM) and bulk signature verification -------------
+    def batch_normalize_device(self, group, d_xyz, n, d_xy, d_inf):
+        fn = self.lib.blsgpu_g1_batch_normalize_device if group == 1 else self.lib.blsgpu_g2_batch_normalize_device
+        check(fn(self.h, ctypes.c_void_p(d_xyz), n, ctypes.c_void_p(d_xy), ctypes.c_void_p(d_inf)), "batch_normalize_device")
+
+    def points_from_bytes_device(self, group, d_bytes, n, d_xy, d_inf, d_ok, compressed=True, checked=True):
+        fn = self.lib.blsgpu_g1_from_bytes_batch_device if group == 1 else self.lib.blsgpu_g2_from_bytes_batch_device
+        check(fn(self.h, ctypes.c_void_p(d_bytes), n, 1 if compressed else 0, 1 if checked else 0, ctypes.c_void_p(d_xy), ctypes.c_void_p(d_inf), ctypes.c_void_p(d_ok)),
+              "from_bytes_batch_device")
+
+    def points_to_bytes_device(self, group, d_xy, d_inf, n, d_out, compressed=True):
+        fn = self.lib.blsgpu_g1_to_bytes_batch_device if group == 1 else self.lib.blsgpu_g2_to_bytes_batch_device
+        check(fn(self.h, ctypes.c_void_p(d_xy), ctypes.c_void_p(d_inf), n, 1 if compressed else 0, ctypes.c_void_p(d_out)), "to_bytes_batch_device")
+
+    def gt_mul_scalar_batch_device(self, d_gt, d_scalars, n, d_out):
+        check(self.lib.blsgpu_gt_mul_scalar_batch_device(self.h, ctypes.c_void_p(d_gt), ctypes.c_void_p(d_scalars), n, ctypes.c_void_p(d_out)), "gt_mul_scalar_batch_device")
+
+    def gt_is_identity_device(self, d_gt, n, d_flags):
+        check(self.lib.blsgpu_gt_is_identity_device(self.h, ctypes.c_void_p(d_gt), n, ctypes.c_void_p(d_flags)), "gt_is_identity_device")
+
+    def bls_verify_batch(self, mode, pk_bytes, sig_bytes, msgs, dst):
+        """Bulk BLS verification from bytes (blsgpu_bls_verify_batch): mode 0 = public keys in G1 (48 B) / signatures in G2 (96 B),
+        mode 1 the other way round; msgs: list of bytes.  -> (n,) uint8: 1 valid, 0 invalid, 2 bad public key, 3 bad signature"""
+        n = len(msgs)
+        pk = np.ascontiguousarray(np.frombuffer(bytes(pk_bytes), dtype=np.uint8)) if not isinstance(pk_bytes, np.ndarray) else np.ascontiguousarray(pk_bytes, dtype=np.uint8).reshape(-1)
+        sg = np.ascontiguousarray(np.frombuffer(bytes(sig_bytes), dtype=np.uint8)) if not isinstance(sig_bytes, np.ndarray) else np.ascontiguousarray(sig_bytes, dtype=np.uint8).reshape(-1)
+        if pk.shape[0] != n * (48 if mode == 0 else 96) or sg.shape[0] != n * (96 if mode == 0 else 48):
+            raise ValueError("bls_verify_batch: key / signature bytes do not match the number of messages")
+        off = np.zeros(n + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(m) for m in msgs])
+        blob = np.frombuffer(b"".join(bytes(m) for m in msgs), dtype=np.uint8).copy() if int(off[-1]) else np.zeros(1, dtype=np.uint8)
+        d = np.frombuffer(bytes(dst), dtype=np.uint8).copy() if len(dst) else np.zeros(1, dtype=np.uint8)
+        out = np.zeros(n, dtype=np.uint8)
+        check(self.lib.blsgpu_bls_verify_batch(self.h, mode, _ptr(pk), _ptr(sg), _ptr(blob), _ptr(off), n, _ptr(d), len(dst), _ptr(out)), "bls_verify_batch")
+        return out
+
+    def bls_verify_batch_device(self, mode, d_pk, d_sig, d_msgs, d_offsets, n, d_dst, dst_len, d_verdict):
+        check(self.lib.blsgpu_bls_verify_batch_device(self.h, mode, ctypes.c_void_p(d_pk), ctypes.c_void_p(d_sig), ctypes.c_void_p(d_msgs), ctypes.c_void_p(d_offsets), n,
+                                                      ctypes.c_void_p(d_dst), dst_len, ctypes.c_void_p(d_verdict)), "bls_verify_batch_device")
+
     # -- G2Prepared resident on the device (pairings.rs:487-546) and its consumers (:554-603) -----------------------
     def g2_prepare(self, g2_xy, g2_inf=None):
         g2 = _u64(g2_xy, (-1, 24))

@@ -128,7 +128,14 @@ struct blsgpu_ctx {
   int next_slot = 0;
   unsigned long long msm_calls = 0;
   DevBuf result, io_a, io_b, io_c, io_d, io_e, io_f, io_out, flags_a, flags_b;
+  int mmlp_k = 0;                       // A/B hook (env BLSGPU_MMLP_K): terms per accumulator of ONE long product (0 = automatic)
+  int mml_impl = 0;                     // A/B hook (env BLSGPU_MML_IMPL): kernel behind blsgpu_multi_miller_loop_device with K > 1 -- 0 = automatic, 1 = k_multi_miller_shared
+                                        // (rounds 2-4), 4 = k_mml_prep_quad with no prepared term
   DevBuf mmlp_work, mmlp_out;           // prepared Miller loops (prep.hip.h): per-quad work area, partial products of one long product
+  DevBuf gt_one; bool gt_one_ready = false; hipEvent_t ev_gt_one = nullptr;      // the wire form of Fp12::one() (blsgpu_gt_is_identity_device, bulk verification)
+  DevBuf ver;                           // bulk verification (blsgpu_bls_verify_batch): every intermediate of the chain
+  blsgpu_g2_prepared* ver_table = nullptr;   // ... and the resident `G2Prepared` of -G2 for mode 1
+  bool ver_consts_ready = false; hipEvent_t ev_ver = nullptr;
   DevBuf fb_stage;                      // staging of the one-byte scalars the tables are built from
   DevBuf fb_table[2];                   // fixed-base comb tables of the generators (k_fixed_base): 32 x 256 affine records each, built at first use
   hipEvent_t ev_fb[2] = {};             // recorded where a table was built; awaited by every user (the caller may switch streams)
@@ -446,6 +453,8 @@ static int ctx_init(blsgpu_ctx* c) {
   for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
   for (auto& e : c->ev_fr) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : c->ev_fb) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_gt_one, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_ver, hipEventDisableTiming));
   int prio_lo = 0, prio_hi = 0;
   HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
   // A/B hooks for the stream priorities: BLSGPU_PRIO = three characters for accumulation / tail / front, each h, n or l
@@ -473,6 +482,7 @@ static int ctx_init(blsgpu_ctx* c) {
   return BLSGPU_OK;
 }
 extern "C" void blsgpu_destroy(blsgpu_ctx* c);
+extern "C" void blsgpu_g2_prepared_free(blsgpu_g2_prepared* p);
 extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
   if (!out) return bad("blsgpu_create: out is NULL");
   int n = 0;
@@ -492,6 +502,8 @@ extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
     else if (s == "wide" || s == "256") c->pairing_layout = 256;
     else { delete c; return bad("blsgpu_create: BLSGPU_PAIRING_LAYOUT must be one of auto, pair, quad, wide"); }
   }
+  if (const char* v = getenv("BLSGPU_MMLP_K")) { long k = atol(v); if (k >= 1 && k <= MMLP_MAX_K) c->mmlp_k = (int)k; }
+  if (const char* v = getenv("BLSGPU_MML_IMPL")) { long k = atol(v); if (k == 1 || k == 4) c->mml_impl = (int)k; }
   if (const char* v = getenv("BLSGPU_ITEM_CAP")) { long k = atol(v); if (k >= 8 && k <= ITEM_CAP_MAX) c->item_cap = (u32)k; }
   int rc = ctx_init(c);
   if (rc != BLSGPU_OK) { blsgpu_destroy(c); return rc; }       // destroy tolerates the half-built context (null handles are skipped)
@@ -504,7 +516,7 @@ extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
   hipDeviceSynchronize();
   if (c->d_status) hipFree(c->d_status);
   if (c->d_wide) hipFree(c->d_wide);
-  DevBuf* bufs[] = {&c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->io_f, &c->io_out, &c->flags_a, &c->flags_b, &c->fr_tw[0], &c->fr_tw[1], &c->fr_tmp, &c->fr_ninv, &c->fb_table[0], &c->fb_table[1], &c->fb_stage, &c->mmlp_work, &c->mmlp_out};
+  DevBuf* bufs[] = {&c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->io_f, &c->io_out, &c->flags_a, &c->flags_b, &c->fr_tw[0], &c->fr_tw[1], &c->fr_tmp, &c->fr_ninv, &c->fb_table[0], &c->fb_table[1], &c->fb_stage, &c->mmlp_work, &c->mmlp_out, &c->gt_one, &c->ver};
   for (auto b : bufs) b->release();
   for (auto& sl : c->slot) {
     DevBuf* sb[] = {&sl.ent, &sl.sorted, &sl.hist, &sl.offs, &sl.cursor, &sl.bsum, &sl.items, &sl.heavy, &sl.ctrl, &sl.glv,
@@ -519,6 +531,9 @@ extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
   for (auto& e : c->ev_fr) if (e) hipEventDestroy(e);
   for (auto& e : c->ev_fb) if (e) hipEventDestroy(e);
+  if (c->ev_gt_one) hipEventDestroy(c->ev_gt_one);
+  if (c->ev_ver) hipEventDestroy(c->ev_ver);
+  if (c->ver_table) blsgpu_g2_prepared_free(c->ver_table);
   if (c->acc_stream) hipStreamDestroy(c->acc_stream);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
@@ -1315,31 +1330,40 @@ extern "C" int blsgpu_g2_sum_device(blsgpu_ctx* c, const void* xyz, size_t n, vo
 extern "C" int blsgpu_g1_sum(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* out) { CTX_CLAIM(c); return proj_sum<FpPolicy>(c, xyz, n, out); }
 extern "C" int blsgpu_g2_sum(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* out) { CTX_CLAIM(c); return proj_sum<Fp2Policy>(c, xyz, n, out); }
 
+// device core: projective wire records in device memory -> affine wire coordinates + infinity bytes in device memory (asynchronous)
+template <class F>
+static int batch_normalize_device(blsgpu_ctx* c, const void* d_xyz, size_t n, void* d_xy, void* d_inf) {
+  if (!c || (n && (!d_xyz || !d_xy || !d_inf))) return bad("batch_normalize: NULL argument");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  constexpr int PW = Store<F>::PROJ_WORDS;
+  if (c->io_c.reserve(n * PW * 4) || c->io_d.reserve(n * Store<F>::EL * 4)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  hipLaunchKernelGGL(k_proj_import<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (const u32*)d_xyz, c->io_c.as<u32>(), n);
+  if (n >= 4096) {
+    size_t T = (n + NORMALIZE_K - 1) / NORMALIZE_K;
+    hipLaunchKernelGGL(k_batch_normalize<F>, dim3(nblk(T, 256)), dim3(256), 0, c->stream, c->io_c.as<u32>(), c->io_d.as<u32>(), (u32*)d_xy, (uint8_t*)d_inf, n, T);
+  } else {
+    hipLaunchKernelGGL(k_proj_to_affine<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_c.as<u32>(), (u32*)d_xy, (uint8_t*)d_inf, n);
+  }
+  LAUNCHCHK();
+  return BLSGPU_OK;
+}
 template <class F>
 static int batch_normalize(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* xy, uint8_t* inf) {
   if (!c || (n && (!xyz || !xy))) return bad("batch_normalize: NULL argument");
   if (!n) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
-  constexpr int WW = Wire<F>::WORDS, PW = Store<F>::PROJ_WORDS;
-  if (c->io_a.reserve(n * 3 * WW * 4) || c->io_c.reserve(n * PW * 4) || c->io_out.reserve(n * 2 * WW * 4) || c->flags_b.reserve(n) ||
-      c->io_d.reserve(n * Store<F>::EL * 4)) {
-    g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP;
-  }
+  constexpr int WW = Wire<F>::WORDS;
+  if (c->io_a.reserve(n * 3 * WW * 4) || c->io_out.reserve(n * 2 * WW * 4) || c->flags_b.reserve(n)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
   HIPCHK(hipMemcpyAsync(c->io_a.p, xyz, n * 3 * WW * 4, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_proj_import<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), c->io_c.as<u32>(), n);
-  if (n >= 4096) {
-    size_t T = (n + NORMALIZE_K - 1) / NORMALIZE_K;
-    hipLaunchKernelGGL(k_batch_normalize<F>, dim3(nblk(T, 256)), dim3(256), 0, c->stream, c->io_c.as<u32>(), c->io_d.as<u32>(), c->io_out.as<u32>(),
-                       c->flags_b.as<uint8_t>(), n, T);
-  } else {
-    hipLaunchKernelGGL(k_proj_to_affine<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_c.as<u32>(), c->io_out.as<u32>(), c->flags_b.as<uint8_t>(), n);
-  }
-  LAUNCHCHK();
+  if (int rc = batch_normalize_device<F>(c, c->io_a.p, n, c->io_out.p, c->flags_b.p)) return rc;
   HIPCHK(hipMemcpyAsync(xy, c->io_out.p, n * 2 * WW * 4, hipMemcpyDeviceToHost, c->stream));
   if (inf) HIPCHK(hipMemcpyAsync(inf, c->flags_b.p, n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return BLSGPU_OK;
 }
+extern "C" int blsgpu_g1_batch_normalize_device(blsgpu_ctx* c, const void* xyz, size_t n, void* xy, void* inf) { CTX_CLAIM(c); return batch_normalize_device<FpPolicy>(c, xyz, n, xy, inf); }
+extern "C" int blsgpu_g2_batch_normalize_device(blsgpu_ctx* c, const void* xyz, size_t n, void* xy, void* inf) { CTX_CLAIM(c); return batch_normalize_device<Fp2Policy>(c, xyz, n, xy, inf); }
 extern "C" int blsgpu_g1_batch_normalize(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* xy, uint8_t* inf) { CTX_CLAIM(c); return batch_normalize<FpPolicy>(c, xyz, n, xy, inf); }
 extern "C" int blsgpu_g2_batch_normalize(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* xy, uint8_t* inf) { CTX_CLAIM(c); return batch_normalize<Fp2Policy>(c, xyz, n, xy, inf); }
 
@@ -1796,6 +1820,10 @@ extern "C" int blsgpu_fp12_product_device(blsgpu_ctx* c, const void* in, size_t 
   HIPCHK(hipSetDevice(c->device));
   return fp12_product_device(c, (const u32*)in, n, (u32*)out);
 }
+// the kernel behind the K > 1 case below: 1 = k_multi_miller_shared (measured fastest for unprepared terms: tools/mml_time.py), 4 = k_mml_prep_quad (prep.hip.h)
+constexpr int MML_IMPL_DEFAULT = 1;
+static int mmlp_launch(blsgpu_ctx* c, const void* g1, const void* g1inf, const void* g2, const void* g2inf, const void* qidx, const blsgpu_g2_prepared* p, const void* d_off,
+                       size_t nseg, size_t total, int kuni, int kmax, void* out);
 extern "C" int blsgpu_multi_miller_loop_device(blsgpu_ctx* c, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) { CTX_CLAIM(c);
   if (!c || !out || (n && (!g1 || !g2))) return bad("multi_miller_loop: NULL argument");
   HIPCHK(hipSetDevice(c->device));
@@ -1807,10 +1835,17 @@ extern "C" int blsgpu_multi_miller_loop_device(blsgpu_ctx* c, const void* g1, co
     if (n) { int rc = pairing_launch(c, 1, g1, g1inf, g2, g2inf, n, c->io_out.p); if (rc) return rc; }
     return fp12_product_device(c, c->io_out.as<u32>(), n, (u32*)out);
   }
+  if (c->mmlp_k > 0) K = c->mmlp_k;
   const size_t groups = (n + K - 1) / K;
-  hipLaunchKernelGGL(k_multi_miller_shared, dim3(nblk(groups * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)g1, (const uint8_t*)g1inf,
-                     (const u32*)g2, (const uint8_t*)g2inf, c->io_out.as<u32>(), n, K);
-  LAUNCHCHK();
+  const int impl = c->mml_impl ? c->mml_impl : MML_IMPL_DEFAULT;
+  if (impl == 1) {
+    hipLaunchKernelGGL(k_multi_miller_shared, dim3(nblk(groups * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)g1, (const uint8_t*)g1inf,
+                       (const u32*)g2, (const uint8_t*)g2inf, c->io_out.as<u32>(), n, K);
+    LAUNCHCHK();
+  } else {
+    int rc = mmlp_launch(c, g1, g1inf, g2, g2inf, nullptr, nullptr, nullptr, groups, n, K, K, c->io_out.p);
+    if (rc) return rc;
+  }
   return fp12_product_device(c, c->io_out.as<u32>(), groups, (u32*)out);
 }
 extern "C" int blsgpu_multi_miller_loop(blsgpu_ctx* c, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, size_t n, uint64_t* out) { CTX_CLAIM(c);
@@ -1987,7 +2022,7 @@ static int mmlp_launch(blsgpu_ctx* c, const void* g1, const void* g1inf, const v
   if (kmax > MMLP_MAX_K) kmax = MMLP_MAX_K;
   const unsigned blocks = nblk(nseg * QL, QUAD_BLOCK);
   const size_t threads = (size_t)blocks * QUAD_BLOCK;
-  // [kmax][threads] u32 meta | [kmax][4][threads] uint4 pp | [kmax][12][threads] uint4 running points
+  // [kmax][threads] u32 meta | [kmax][4][threads] uint4 P | [kmax][12][threads] uint4 running points
   const size_t meta_b = (size_t)kmax * threads * 4, pp_b = (size_t)kmax * 4 * threads * 16, rr_b = (size_t)kmax * 12 * threads * 16;
   if (c->mmlp_work.reserve(meta_b + pp_b + rr_b)) { g_err = "hipMalloc(prepared Miller work area) failed"; return BLSGPU_ERR_HIP; }
   uint8_t* w = c->mmlp_work.as<uint8_t>();
@@ -2004,8 +2039,10 @@ extern "C" int blsgpu_multi_miller_loop_prepared_device(blsgpu_ctx* c, const voi
   HIPCHK(hipSetDevice(c->device));
   if (!n) return fp12_product_device(c, nullptr, 0, (u32*)out);
   // terms per accumulator: as many as still leave two wavefronts per SIMD busy (2^15 quads)
+  const size_t fill = 32768;                                          // quads that fill the chip at two wavefronts per SIMD
   int K = 1;
-  while (K < MMLP_MAX_K && n / (2 * (size_t)K) >= 32768) K *= 2;
+  while (K < MMLP_MAX_K && n / (2 * (size_t)K) >= fill) K *= 2;
+  if (c->mmlp_k > 0) K = c->mmlp_k;
   const size_t groups = (n + K - 1) / K;
   if (c->mmlp_out.reserve(groups * 576)) { g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP; }
   int rc = mmlp_launch(c, g1, g1inf, g2, g2inf, qidx, p, nullptr, groups, n, K, K, c->mmlp_out.p);
@@ -2101,6 +2138,43 @@ extern "C" int blsgpu_final_exponentiation_batch(blsgpu_ctx* c, const uint64_t* 
   HIPCHK(hipStreamSynchronize(c->stream));
   return BLSGPU_OK;
 }
+extern "C" int blsgpu_gt_mul_scalar_batch_device(blsgpu_ctx* c, const void* gt, const void* scalars, size_t n, void* out) { CTX_CLAIM(c);
+  if (!c || (n && (!gt || !scalars || !out))) return bad("gt_mul_scalar: NULL argument");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_gt_mul_scalar, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)gt, (const u32*)scalars, (u32*)out, n);
+  LAUNCHCHK();
+  return BLSGPU_OK;
+}
+// flags[i] = (gt[i] == Fp12::one()): word-wise comparison with the canonical wire form of one (written once per context by k_fp12_one)
+__global__ void __launch_bounds__(256) k_fp12_equals(const u32* __restrict__ gt, const u32* __restrict__ one, size_t n, uint8_t* __restrict__ flags) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4* a = reinterpret_cast<const uint4*>(gt + i * 144);
+  const uint4* b = reinterpret_cast<const uint4*>(one);
+  u32 diff = 0;
+  for (int k = 0; k < 36; k++) { const uint4 x = a[k], y = b[k]; diff |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w); }
+  flags[i] = diff == 0 ? 1 : 0;
+}
+static int gt_one_ready(blsgpu_ctx* c) {
+  if (c->gt_one_ready) return BLSGPU_OK;
+  if (c->gt_one.reserve(576)) { g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP; }
+  hipLaunchKernelGGL(k_fp12_one, dim3(1), dim3(64), 0, c->stream, c->gt_one.as<u32>());
+  LAUNCHCHK();
+  HIPCHK(hipEventRecord(c->ev_gt_one, c->stream));
+  c->gt_one_ready = true;
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_gt_is_identity_device(blsgpu_ctx* c, const void* gt, size_t n, void* flags) { CTX_CLAIM(c);
+  if (!c || (n && (!gt || !flags))) return bad("gt_is_identity: NULL argument");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  if (int rc = gt_one_ready(c)) return rc;
+  HIPCHK(hipStreamWaitEvent(c->stream, c->ev_gt_one, 0));
+  hipLaunchKernelGGL(k_fp12_equals, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (const u32*)gt, c->gt_one.as<u32>(), n, (uint8_t*)flags);
+  LAUNCHCHK();
+  return BLSGPU_OK;
+}
 extern "C" int blsgpu_gt_mul_scalar_batch(blsgpu_ctx* c, const uint64_t* gt, const uint8_t* scalars, size_t n, uint64_t* out) { CTX_CLAIM(c);
   if (!c || (n && (!gt || !scalars || !out))) return bad("gt_mul_scalar: NULL argument");
   if (!n) return BLSGPU_OK;
@@ -2130,6 +2204,25 @@ extern "C" int blsgpu_fp12_product(blsgpu_ctx* c, const uint64_t* in, size_t n, 
 // batched point (de)serialisation + validation  (codec.hip.h)
 // ---------------------------------------------------------------------------------------------------
 template <class F>
+static int point_decode_device(blsgpu_ctx* c, const void* d_bytes, size_t n, int compressed, int checked, void* d_xy, void* d_inf, void* d_ok) {
+  if (!c || (n && (!d_bytes || !d_xy || !d_inf || !d_ok))) return bad("decode: NULL argument");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_point_decode<F>, dim3(nblk(n, 128)), dim3(128), 0, c->stream, (const uint8_t*)d_bytes, n, (compressed ? 1 : 0) | (checked ? 2 : 0), (u32*)d_xy, (uint8_t*)d_inf,
+                     (uint8_t*)d_ok);
+  LAUNCHCHK();
+  return BLSGPU_OK;
+}
+template <class F>
+static int point_encode_device(blsgpu_ctx* c, const void* d_xy, const void* d_inf, size_t n, int compressed, void* d_out) {
+  if (!c || (n && (!d_xy || !d_out))) return bad("encode: NULL argument");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_point_encode<F>, dim3(nblk(n, 128)), dim3(128), 0, c->stream, (const u32*)d_xy, (const uint8_t*)d_inf, n, compressed, (uint8_t*)d_out);
+  LAUNCHCHK();
+  return BLSGPU_OK;
+}
+template <class F>
 static int point_decode(blsgpu_ctx* c, const uint8_t* bytes, size_t n, int compressed, int checked, uint64_t* xy, uint8_t* inf, uint8_t* ok) {
   if (!c || (n && (!bytes || !xy || !inf || !ok))) return bad("decode: NULL argument");
   if (!n) return BLSGPU_OK;
@@ -2138,9 +2231,7 @@ static int point_decode(blsgpu_ctx* c, const uint8_t* bytes, size_t n, int compr
   size_t ib = n * (compressed ? CB : 2 * CB), xb = n * 2 * WW * 4;
   if (c->io_a.reserve(ib) || c->io_out.reserve(xb) || c->flags_a.reserve(n) || c->flags_b.reserve(n)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
   HIPCHK(hipMemcpyAsync(c->io_a.p, bytes, ib, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_point_decode<F>, dim3(nblk(n, 128)), dim3(128), 0, c->stream, c->io_a.as<uint8_t>(), n, (compressed ? 1 : 0) | (checked ? 2 : 0),
-                     c->io_out.as<u32>(), c->flags_a.as<uint8_t>(), c->flags_b.as<uint8_t>());
-  LAUNCHCHK();
+  if (int rc = point_decode_device<F>(c, c->io_a.p, n, compressed, checked, c->io_out.p, c->flags_a.p, c->flags_b.p)) return rc;
   HIPCHK(hipMemcpyAsync(xy, c->io_out.p, xb, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(inf, c->flags_a.p, n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(ok, c->flags_b.p, n, hipMemcpyDeviceToHost, c->stream));
@@ -2157,12 +2248,22 @@ static int point_encode(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, s
   if (c->io_a.reserve(xb) || c->io_out.reserve(ob) || c->flags_a.reserve(n)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
   HIPCHK(hipMemcpyAsync(c->io_a.p, xy, xb, hipMemcpyHostToDevice, c->stream));
   if (inf) HIPCHK(hipMemcpyAsync(c->flags_a.p, inf, n, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_point_encode<F>, dim3(nblk(n, 128)), dim3(128), 0, c->stream, c->io_a.as<u32>(), inf ? c->flags_a.as<uint8_t>() : nullptr, n, compressed,
-                     c->io_out.as<uint8_t>());
-  LAUNCHCHK();
+  if (int rc = point_encode_device<F>(c, c->io_a.p, inf ? c->flags_a.p : nullptr, n, compressed, c->io_out.p)) return rc;
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, ob, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return BLSGPU_OK;
+}
+extern "C" int blsgpu_g1_from_bytes_batch_device(blsgpu_ctx* c, const void* b, size_t n, int compressed, int checked, void* xy, void* inf, void* ok) { CTX_CLAIM(c);
+  return point_decode_device<FpPolicy>(c, b, n, compressed, checked, xy, inf, ok);
+}
+extern "C" int blsgpu_g2_from_bytes_batch_device(blsgpu_ctx* c, const void* b, size_t n, int compressed, int checked, void* xy, void* inf, void* ok) { CTX_CLAIM(c);
+  return point_decode_device<Fp2Policy>(c, b, n, compressed, checked, xy, inf, ok);
+}
+extern "C" int blsgpu_g1_to_bytes_batch_device(blsgpu_ctx* c, const void* xy, const void* inf, size_t n, int compressed, void* out) { CTX_CLAIM(c);
+  return point_encode_device<FpPolicy>(c, xy, inf, n, compressed, out);
+}
+extern "C" int blsgpu_g2_to_bytes_batch_device(blsgpu_ctx* c, const void* xy, const void* inf, size_t n, int compressed, void* out) { CTX_CLAIM(c);
+  return point_encode_device<Fp2Policy>(c, xy, inf, n, compressed, out);
 }
 extern "C" int blsgpu_g1_from_bytes_batch(blsgpu_ctx* c, const uint8_t* b, size_t n, int compressed, int checked, uint64_t* xy, uint8_t* inf, uint8_t* ok) { CTX_CLAIM(c);
   return point_decode<FpPolicy>(c, b, n, compressed, checked, xy, inf, ok);
@@ -2175,6 +2276,164 @@ extern "C" int blsgpu_g1_to_bytes_batch(blsgpu_ctx* c, const uint64_t* xy, const
 }
 extern "C" int blsgpu_g2_to_bytes_batch(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, int compressed, uint8_t* out) { CTX_CLAIM(c);
   return point_encode<Fp2Policy>(c, xy, inf, n, compressed, out);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bulk BLS signature verification: compressed bytes in -> verdict bytes out, every stage on the device
+// ---------------------------------------------------------------------------------------------------
+// consts[0..24): the affine wire coordinates of -G1 (g1.rs:86-104 negated, :126-134); consts[24..72): of -G2 (g2.rs:103-140)
+__global__ void k_bls_consts(u32* __restrict__ consts) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const Aff<FpPolicy> g = generator<FpPolicy>();
+  Wire<FpPolicy>::save(g.x, consts); Wire<FpPolicy>::save(neg(g.y), consts + 12);
+  const Aff<Fp2Policy> h = generator<Fp2Policy>();
+  Wire<Fp2Policy>::save(h.x, consts + 24); Wire<Fp2Policy>::save(neg(h.y), consts + 48);
+}
+// the two terms of equation i (segment i = terms 2 i, 2 i + 1).  A point whose decoding failed is flagged as the identity so that
+// the Miller kernels never see unvalidated limbs; its verdict comes from the ok flags.
+//   mode 0:  (pk_i, H_i), (-G1, sig_i)                       mode 1:  (sig_i, table[0] = -G2), (H_i, pk_i)
+__global__ void __launch_bounds__(256) k_bls_assemble(int mode, const u32* __restrict__ pk, const uint8_t* __restrict__ pk_inf, const uint8_t* __restrict__ pk_ok,
+                                                      const u32* __restrict__ sig, const uint8_t* __restrict__ sig_inf, const uint8_t* __restrict__ sig_ok,
+                                                      const u32* __restrict__ h, const uint8_t* __restrict__ h_inf, const u32* __restrict__ consts, size_t n,
+                                                      u32* __restrict__ g1t, uint8_t* __restrict__ g1f, u32* __restrict__ g2t, uint8_t* __restrict__ g2f,
+                                                      u32* __restrict__ qidx, unsigned long long* __restrict__ off) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  off[i] = 2ull * i;
+  if (i == n) return;
+  const bool pbad = !pk_ok[i], sbad = !sig_ok[i];
+  u32* a0 = g1t + (2 * i) * 24; u32* a1 = a0 + 24;
+  u32* b0 = g2t + (2 * i) * 48; u32* b1 = b0 + 48;
+  if (mode == 0) {
+    for (int k = 0; k < 24; k++) { a0[k] = pk[i * 24 + k]; a1[k] = consts[k]; }
+    for (int k = 0; k < 48; k++) { b0[k] = h[i * 48 + k]; b1[k] = sig[i * 48 + k]; }
+    g1f[2 * i] = (pk_inf[i] || pbad) ? 1 : 0; g1f[2 * i + 1] = 0;
+    g2f[2 * i] = h_inf[i]; g2f[2 * i + 1] = (sig_inf[i] || sbad) ? 1 : 0;
+    qidx[2 * i] = PREP_NONE; qidx[2 * i + 1] = PREP_NONE;
+  } else {
+    for (int k = 0; k < 24; k++) { a0[k] = sig[i * 24 + k]; a1[k] = h[i * 24 + k]; }
+    for (int k = 0; k < 48; k++) { b0[k] = 0; b1[k] = pk[i * 48 + k]; }
+    g1f[2 * i] = (sig_inf[i] || sbad) ? 1 : 0; g1f[2 * i + 1] = h_inf[i];
+    g2f[2 * i] = 0; g2f[2 * i + 1] = (pk_inf[i] || pbad) ? 1 : 0;
+    qidx[2 * i] = 0; qidx[2 * i + 1] = PREP_NONE;
+  }
+}
+__global__ void __launch_bounds__(256) k_bls_verdict(const uint8_t* __restrict__ is_one, const uint8_t* __restrict__ pk_ok, const uint8_t* __restrict__ sig_ok, size_t n,
+                                                     uint8_t* __restrict__ verdict) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  verdict[i] = !pk_ok[i] ? 2 : !sig_ok[i] ? 3 : is_one[i] ? 1 : 0;
+}
+extern "C" int blsgpu_bls_verify_batch_device(blsgpu_ctx* c, int mode, const void* d_pk, const void* d_sig, const void* d_msgs, const void* d_offsets, size_t n, const void* d_dst,
+                                              size_t dst_len, void* d_verdict) { CTX_CLAIM(c);
+  if (!c || (n && (!d_pk || !d_sig || !d_offsets || !d_verdict)) || (dst_len && !d_dst)) return bad("bls_verify_batch: NULL argument");
+  if (mode != 0 && mode != 1) return bad("bls_verify_batch: mode must be 0 (public keys in G1) or 1 (public keys in G2)");
+  if (dst_len > 255) return bad("bls_verify_batch_device: reduce a DST longer than 255 bytes on the host first");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  // G1-side and G2-side points of the equation: mode 0 = (pk, sig), mode 1 = (sig, pk); the hash goes to the signature's group
+  const size_t a_xy = n * 96, b_xy = n * 192, h_xyz = n * (mode == 0 ? 288 : 144), h_xy = n * (mode == 0 ? 192 : 96);
+  const size_t al = 256;
+  auto up = [&](size_t x) { return (x + al - 1) / al * al; };
+  size_t o = 0;
+  const size_t o_consts = o; o += up(288);
+  const size_t o_a = o; o += up(a_xy);
+  const size_t o_b = o; o += up(b_xy);
+  const size_t o_hp = o; o += up(h_xyz);
+  const size_t o_h = o; o += up(h_xy);
+  const size_t o_fl = o; o += up(6 * n);                // a_inf a_ok b_inf b_ok h_inf is_one
+  const size_t o_g1t = o; o += up(2 * n * 96);
+  const size_t o_g2t = o; o += up(2 * n * 192);
+  const size_t o_tf = o; o += up(4 * n);                // g1f (2n) g2f (2n)
+  const size_t o_qi = o; o += up(2 * n * 4);
+  const size_t o_off = o; o += up((n + 1) * 8);
+  const size_t o_gt = o; o += up(n * 576);
+  const bool fresh = c->ver.cap < o;
+  if (c->ver.reserve(o)) { g_err = "hipMalloc(bulk verification) failed"; return BLSGPU_ERR_HIP; }
+  uint8_t* base = c->ver.as<uint8_t>();
+  if (fresh || !c->ver_consts_ready) {
+    hipLaunchKernelGGL(k_bls_consts, dim3(1), dim3(64), 0, c->stream, (u32*)(base + o_consts));
+    LAUNCHCHK();
+    HIPCHK(hipEventRecord(c->ev_ver, c->stream));
+    c->ver_consts_ready = true;
+  }
+  HIPCHK(hipStreamWaitEvent(c->stream, c->ev_ver, 0));
+  if (mode == 1 && !c->ver_table) {
+    // `G2Prepared::from(-G2Affine::generator())`, once per context (its own allocation: it outlives a regrown scratch block)
+    int rc = blsgpu_g2_prepare_device(c, base + o_consts + 96, nullptr, 1, &c->ver_table);
+    if (rc) return rc;
+  }
+  uint8_t* fl = base + o_fl;
+  uint8_t *a_inf = fl, *a_ok = fl + n, *b_inf = fl + 2 * n, *b_ok = fl + 3 * n, *h_inf = fl + 4 * n, *is_one = fl + 5 * n;
+  // 1. checked decoding (`from_compressed`: on the curve, in the subgroup)
+  int rc = point_decode_device<FpPolicy>(c, mode == 0 ? d_pk : d_sig, n, 1, 1, base + o_a, a_inf, a_ok);
+  if (rc) return rc;
+  rc = point_decode_device<Fp2Policy>(c, mode == 0 ? d_sig : d_pk, n, 1, 1, base + o_b, b_inf, b_ok);
+  if (rc) return rc;
+  // 2. hash the messages to the signature's group, 3. normalise
+  rc = blsgpu_hash_to_curve_device(c, mode == 0 ? 2 : 1, d_msgs, d_offsets, n, d_dst, dst_len, 0, base + o_hp);
+  if (rc) return rc;
+  rc = mode == 0 ? batch_normalize_device<Fp2Policy>(c, base + o_hp, n, base + o_h, h_inf) : batch_normalize_device<FpPolicy>(c, base + o_hp, n, base + o_h, h_inf);
+  if (rc) return rc;
+  // 4. the two terms of every equation
+  const uint8_t *pk_inf = mode == 0 ? a_inf : b_inf, *pk_ok = mode == 0 ? a_ok : b_ok, *sig_inf = mode == 0 ? b_inf : a_inf, *sig_ok = mode == 0 ? b_ok : a_ok;
+  hipLaunchKernelGGL(k_bls_assemble, dim3(nblk(n + 1, 256)), dim3(256), 0, c->stream, mode, (const u32*)(base + (mode == 0 ? o_a : o_b)), pk_inf, pk_ok,
+                     (const u32*)(base + (mode == 0 ? o_b : o_a)), sig_inf, sig_ok, (const u32*)(base + o_h), h_inf, (const u32*)(base + o_consts), n, (u32*)(base + o_g1t),
+                     base + o_tf, (u32*)(base + o_g2t), base + o_tf + 2 * n, (u32*)(base + o_qi), (unsigned long long*)(base + o_off));
+  LAUNCHCHK();
+  // 5. one multi_miller_loop + final exponentiation per equation
+  if (mode == 0)
+    rc = blsgpu_multi_miller_loop_many_device(c, base + o_g1t, base + o_tf, base + o_g2t, base + o_tf + 2 * n, base + o_off, n, 2 * n, 2, 1, base + o_gt);
+  else
+    rc = blsgpu_multi_miller_loop_prepared_many_device(c, base + o_g1t, base + o_tf, base + o_g2t, base + o_tf + 2 * n, base + o_qi, c->ver_table, base + o_off, n, 2 * n, 2, 1,
+                                                       base + o_gt);
+  if (rc) return rc;
+  // 6. == Gt::identity()?
+  rc = blsgpu_gt_is_identity_device(c, base + o_gt, n, is_one);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_bls_verdict, dim3(nblk(n, 256)), dim3(256), 0, c->stream, is_one, pk_ok, sig_ok, n, (uint8_t*)d_verdict);
+  LAUNCHCHK();
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_bls_verify_batch(blsgpu_ctx* c, int mode, const uint8_t* pk, const uint8_t* sig, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst,
+                                       size_t dst_len, uint8_t* verdict) { CTX_CLAIM(c);
+  if (!c || (n && (!pk || !sig || !offsets || !verdict)) || (dst_len && !dst)) return bad("bls_verify_batch: NULL argument");
+  if (mode != 0 && mode != 1) return bad("bls_verify_batch: mode must be 0 (public keys in G1) or 1 (public keys in G2)");
+  if (!n) return BLSGPU_OK;
+  for (size_t i = 0; i < n; i++) if (offsets[i] > offsets[i + 1]) return bad("bls_verify_batch: offsets must be non-decreasing");
+  const size_t total = (size_t)offsets[n];
+  if (total && !msgs) return bad("bls_verify_batch: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  uint8_t d[255]; u32 dlen;
+  if (dst_len > 255) {                    // a DST longer than 255 bytes is replaced by H("H2C-OVERSIZE-DST-" || DST)  (expand_msg.rs:74-95)
+    Sha256 sh; sha_init(sh);
+    const char* salt = "H2C-OVERSIZE-DST-";
+    for (int i = 0; salt[i]; i++) sha_put(sh, (uint8_t)salt[i]);
+    for (size_t i = 0; i < dst_len; i++) sha_put(sh, dst[i]);
+    u32 hw[8]; sha_finish(sh, hw);
+    for (int i = 0; i < 32; i++) d[i] = (uint8_t)(hw[i >> 2] >> (24 - 8 * (i & 3)));
+    dlen = 32;
+  } else {
+    for (size_t i = 0; i < dst_len; i++) d[i] = dst[i];
+    dlen = (u32)dst_len;
+  }
+  const size_t pkb = n * (mode == 0 ? 48 : 96), sgb = n * (mode == 0 ? 96 : 48);
+  // ONE staging block: pk | sig | msgs | offsets | dst | verdict
+  auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t o_pk = 0, o_sg = up(pkb), o_ms = o_sg + up(sgb), o_of = o_ms + up(total + 16), o_ds = o_of + up((n + 1) * 8), o_vd = o_ds + 256, bytes = o_vd + up(n);
+  if (c->io_a.reserve(bytes)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  uint8_t* b = c->io_a.as<uint8_t>();
+  HIPCHK(hipMemcpyAsync(b + o_pk, pk, pkb, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(b + o_sg, sig, sgb, hipMemcpyHostToDevice, c->stream));
+  if (total) HIPCHK(hipMemcpyAsync(b + o_ms, msgs, total, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(b + o_of, offsets, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  if (dlen) HIPCHK(hipMemcpyAsync(b + o_ds, d, dlen, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));                 // `d` lives on this stack frame
+  int rc = blsgpu_bls_verify_batch_device(c, mode, b + o_pk, b + o_sg, b + o_ms, b + o_of, n, b + o_ds, dlen, b + o_vd);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(verdict, b + o_vd, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -389,6 +389,42 @@ int blsgpu_g2_hash_to_curve_batch(blsgpu_ctx* ctx, const uint8_t* msgs, const ui
 int blsgpu_hash_to_curve_device(blsgpu_ctx* ctx, int group, const void* d_msgs, const void* d_offsets, size_t n, const void* d_dst, size_t dst_len,
                                 int encode_only, void* d_out_xyz);
 
+
+/* ---- the widened rows with inputs and outputs in device memory: a chain that stays on the GPU ---------------- */
+/* Device-pointer twins of blsgpu_g{1,2}_batch_normalize, *_from_bytes_batch, *_to_bytes_batch and blsgpu_gt_mul_scalar_batch:
+ * same kernels, same formats, asynchronous on the context's stream, nothing crosses PCIe.  With them the stages of bulk
+ * verification -- decode + subgroup check (src/g1.rs:273-416, src/g2.rs:330-489), hash-to-curve (map_g2.rs:374-504), normalise
+ * (g2.rs:951-984), multi_miller_loop (pairings.rs:554-603), compare with the identity -- hand their results to one another in
+ * HBM: blsgpu_hash_to_curve_device writes PROJECTIVE points, *_batch_normalize_device turns them into the AFFINE + infinity
+ * form the Miller entry points take.  `d_infinity` of *_batch_normalize_device and `d_ok` / `d_infinity` of *_from_bytes_batch_device
+ * are outputs (n bytes each, required). */
+int blsgpu_g1_batch_normalize_device(blsgpu_ctx* ctx, const void* d_xyz, size_t n, void* d_xy, void* d_infinity);
+int blsgpu_g2_batch_normalize_device(blsgpu_ctx* ctx, const void* d_xyz, size_t n, void* d_xy, void* d_infinity);
+int blsgpu_g1_from_bytes_batch_device(blsgpu_ctx* ctx, const void* d_bytes, size_t n, int compressed, int checked, void* d_xy, void* d_infinity, void* d_ok);
+int blsgpu_g2_from_bytes_batch_device(blsgpu_ctx* ctx, const void* d_bytes, size_t n, int compressed, int checked, void* d_xy, void* d_infinity, void* d_ok);
+int blsgpu_g1_to_bytes_batch_device(blsgpu_ctx* ctx, const void* d_xy, const void* d_infinity, size_t n, int compressed, void* d_out);
+int blsgpu_g2_to_bytes_batch_device(blsgpu_ctx* ctx, const void* d_xy, const void* d_infinity, size_t n, int compressed, void* d_out);
+int blsgpu_gt_mul_scalar_batch_device(blsgpu_ctx* ctx, const void* d_gt, const void* d_scalars, size_t n, void* d_out);
+/* d_flags[i] = 1 if gt[i] == Gt::identity() (= Fp12::one(), src/pairings.rs:211-218), else 0: the verdict of an equation
+ * prod e(P_j, Q_j) == 1 without bringing 576 B per equation to the host. */
+int blsgpu_gt_is_identity_device(blsgpu_ctx* ctx, const void* d_gt, size_t n, void* d_flags);
+/* Bulk BLS signature verification, bytes in -> verdict bytes out, every stage on the device (one upload, one download in the
+ * host-pointer form): checked decoding of the compressed public keys and signatures, hash_to_curve of the messages (message i =
+ * bytes offsets[i] .. offsets[i+1] of `msgs`; `dst` <= 255 bytes in the device form), normalisation, ONE multi_miller_loop +
+ * final exponentiation per signature, comparison with Gt::identity().
+ *   mode 0 (public keys in G1, 48 B; signatures in G2, 96 B):  e(pk, H(m)) * e(-G1, sig) == 1   <=>  e(pk, H(m)) == e(G1, sig)
+ *   mode 1 (signatures in G1, 48 B; public keys in G2, 96 B):  e(sig, -G2) * e(H(m), pk) == 1   <=>  e(sig, G2) == e(H(m), pk),
+ *           with -G2 a `G2Prepared` resident in the context (built at first use).
+ * verdict[i]: 1 = the equation holds, 0 = it does not, 2 = the public key is not a valid encoding of a subgroup point
+ * (`from_compressed` -> None), 3 = the signature is not.  Identity points decode successfully and take part as the reference's
+ * `pairing` treats them (an identity on either side contributes Gt::identity()); rejecting an identity public key is the caller's
+ * policy (`KeyValidate`).  This is the reference's own operations composed, not a new scheme: src/g1.rs:336-390, src/g2.rs:390-489,
+ * src/hash_to_curve/map_g2.rs:374-504 (map_g1.rs:513-638), src/g2.rs:951-984, src/pairings.rs:554-603, :48-176. */
+int blsgpu_bls_verify_batch(blsgpu_ctx* ctx, int mode, const uint8_t* pk_bytes, const uint8_t* sig_bytes, const uint8_t* msgs, const uint64_t* offsets, size_t n,
+                            const uint8_t* dst, size_t dst_len, uint8_t* verdict);
+int blsgpu_bls_verify_batch_device(blsgpu_ctx* ctx, int mode, const void* d_pk_bytes, const void* d_sig_bytes, const void* d_msgs, const void* d_offsets, size_t n,
+                                   const void* d_dst, size_t dst_len, void* d_verdict);
+
 #ifdef __cplusplus
 }
 #endif

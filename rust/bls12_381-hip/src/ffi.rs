@@ -120,4 +120,14 @@ extern "C" {
     pub fn blsgpu_g1_hash_to_curve_batch(ctx: *mut BlsgpuCtx, msgs: *const u8, offsets: *const u64, n: usize, dst: *const u8, dst_len: usize, encode_only: c_int, out_xyz: *mut u64) -> c_int;
     pub fn blsgpu_g2_hash_to_curve_batch(ctx: *mut BlsgpuCtx, msgs: *const u8, offsets: *const u64, n: usize, dst: *const u8, dst_len: usize, encode_only: c_int, out_xyz: *mut u64) -> c_int;
     pub fn blsgpu_hash_to_curve_device(ctx: *mut BlsgpuCtx, group: c_int, d_msgs: *const c_void, d_offsets: *const c_void, n: usize, d_dst: *const c_void, dst_len: usize, encode_only: c_int, d_out_xyz: *mut c_void) -> c_int;
+    pub fn blsgpu_g1_batch_normalize_device(ctx: *mut BlsgpuCtx, d_xyz: *const c_void, n: usize, d_xy: *mut c_void, d_infinity: *mut c_void) -> c_int;
+    pub fn blsgpu_g2_batch_normalize_device(ctx: *mut BlsgpuCtx, d_xyz: *const c_void, n: usize, d_xy: *mut c_void, d_infinity: *mut c_void) -> c_int;
+    pub fn blsgpu_g1_from_bytes_batch_device(ctx: *mut BlsgpuCtx, d_bytes: *const c_void, n: usize, compressed: c_int, checked: c_int, d_xy: *mut c_void, d_infinity: *mut c_void, d_ok: *mut c_void) -> c_int;
+    pub fn blsgpu_g2_from_bytes_batch_device(ctx: *mut BlsgpuCtx, d_bytes: *const c_void, n: usize, compressed: c_int, checked: c_int, d_xy: *mut c_void, d_infinity: *mut c_void, d_ok: *mut c_void) -> c_int;
+    pub fn blsgpu_g1_to_bytes_batch_device(ctx: *mut BlsgpuCtx, d_xy: *const c_void, d_infinity: *const c_void, n: usize, compressed: c_int, d_out: *mut c_void) -> c_int;
+    pub fn blsgpu_g2_to_bytes_batch_device(ctx: *mut BlsgpuCtx, d_xy: *const c_void, d_infinity: *const c_void, n: usize, compressed: c_int, d_out: *mut c_void) -> c_int;
+    pub fn blsgpu_gt_mul_scalar_batch_device(ctx: *mut BlsgpuCtx, d_gt: *const c_void, d_scalars: *const c_void, n: usize, d_out: *mut c_void) -> c_int;
+    pub fn blsgpu_gt_is_identity_device(ctx: *mut BlsgpuCtx, d_gt: *const c_void, n: usize, d_flags: *mut c_void) -> c_int;
+    pub fn blsgpu_bls_verify_batch(ctx: *mut BlsgpuCtx, mode: c_int, pk_bytes: *const u8, sig_bytes: *const u8, msgs: *const u8, offsets: *const u64, n: usize, dst: *const u8, dst_len: usize, verdict: *mut u8) -> c_int;
+    pub fn blsgpu_bls_verify_batch_device(ctx: *mut BlsgpuCtx, mode: c_int, d_pk_bytes: *const c_void, d_sig_bytes: *const c_void, d_msgs: *const c_void, d_offsets: *const c_void, n: usize, d_dst: *const c_void, dst_len: usize, d_verdict: *mut c_void) -> c_int;
 }

@@ -2126,3 +2126,135 @@ def test_prepared_equations_2_12_vs_c_oracle_and_device_pointers(ctx):
     finally:
         ctx.set_stream(None)
         table.free()
+
+
+
+# ---- round 5: the widened rows with device pointers, bulk verification from bytes -------------------------------------------------
+def test_device_twins_of_the_widened_rows_match_their_host_forms(ctx):
+    """blsgpu_g{1,2}_batch_normalize_device, *_from_bytes_batch_device, *_to_bytes_batch_device, blsgpu_gt_mul_scalar_batch_device and
+    blsgpu_gt_is_identity_device against their (oracle-checked) host-pointer twins: hash-to-curve -> normalise -> encode -> decode ->
+    Miller loop -> identity test without leaving the device"""
+    import torch
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).to(dev)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        for group in (1, 2):
+            n = 5000 if group == 1 else 300                                  # both normalisation kernels (Montgomery's trick from 4 096 points on)
+            kb, _ = _rand_scalars_np(n, 700 + group)
+            kb[3] = 0                                                        # an identity
+            xy, inf = ctx.bases_from_scalars(group, kb).download()
+            w = 6 if group == 1 else 12                                      # u64 per coordinate
+            xyz = np.zeros((n, 3 * w), dtype=np.uint64)                      # (x z : y z : z) with z = another point's y (never zero)
+            z = np.roll(xy[:, w:], 1, axis=0).copy()
+            mul = ctx.fp_op if group == 1 else ctx.fp2_op
+            xyz[:, :w] = mul(0, xy[:, :w].copy(), z); xyz[:, w:2 * w] = mul(0, xy[:, w:].copy(), z); xyz[:, 2 * w:] = z
+            xyz[inf != 0, 2 * w:] = 0
+            hx, hi = ctx.batch_normalize(group, xyz)
+            d_xy = torch.zeros((n, 2 * w), dtype=torch.int64, device=dev); d_inf = torch.zeros(n, dtype=torch.uint8, device=dev)
+            d_xyz = t(xyz)
+            ctx.batch_normalize_device(group, d_xyz.data_ptr(), n, d_xy.data_ptr(), d_inf.data_ptr())
+            ctx.synchronize()
+            assert np.array_equal(d_xy.cpu().numpy().view(np.uint64), hx) and np.array_equal(d_inf.cpu().numpy(), hi)
+            assert np.array_equal(hx, xy) and np.array_equal(hi, inf)
+            for compressed in (True, False):
+                cb = (48 if group == 1 else 96) * (1 if compressed else 2)
+                enc = ctx.points_to_bytes(group, xy, inf, compressed=compressed)
+                d_enc = torch.zeros((n, cb), dtype=torch.uint8, device=dev)
+                ctx.points_to_bytes_device(group, d_xy.data_ptr(), d_inf.data_ptr(), n, d_enc.data_ptr(), compressed=compressed)
+                ctx.synchronize()
+                assert np.array_equal(d_enc.cpu().numpy(), enc)
+                bad = enc.copy(); bad[7, 5] ^= 0x55                            # a corrupted record (rejected or another point: the twins must agree)
+                d_bad = t(bad)
+                d_x2 = torch.zeros((n, 2 * w), dtype=torch.int64, device=dev); d_i2 = torch.zeros(n, dtype=torch.uint8, device=dev); d_ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+                ctx.points_from_bytes_device(group, d_bad.data_ptr(), n, d_x2.data_ptr(), d_i2.data_ptr(), d_ok.data_ptr(), compressed=compressed, checked=True)
+                ctx.synchronize()
+                hx2, hi2, hok = ctx.points_from_bytes(group, bad, compressed=compressed, checked=True)
+                ok = d_ok.cpu().numpy()
+                assert np.array_equal(ok, hok) and np.array_equal(d_i2.cpu().numpy()[ok != 0], hi2[hok != 0])
+                assert np.array_equal(d_x2.cpu().numpy().view(np.uint64)[ok != 0], hx2[hok != 0])
+        # Gt: scalar multiples and the identity test on the device
+        gen = fp12w(o.pairing(o.G1_GEN, o.G2_GEN))
+        ss = [0, 1, o.R_ORDER - 1, 12345, o.R_ORDER]                         # g^0 = g^r = identity
+        sb = np.stack([np.frombuffer((s % (1 << 256)).to_bytes(32, "little"), dtype=np.uint8) for s in ss])
+        G = np.stack([gen] * len(ss))
+        d_o = torch.zeros((len(ss), 72), dtype=torch.int64, device=dev); d_f = torch.zeros(len(ss), dtype=torch.uint8, device=dev)
+        d_G, d_sb = t(G), t(sb)
+        ctx.gt_mul_scalar_batch_device(d_G.data_ptr(), d_sb.data_ptr(), len(ss), d_o.data_ptr())
+        ctx.gt_is_identity_device(d_o.data_ptr(), len(ss), d_f.data_ptr())
+        ctx.synchronize()
+        assert np.array_equal(d_o.cpu().numpy().view(np.uint64)[:4], ctx.gt_mul_scalar_batch(G[:4], ss[:4]))
+        assert d_f.cpu().numpy().tolist() == [1, 0, 0, 0, 1]
+    finally:
+        ctx.set_stream(None)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_bls_verify_batch_from_bytes_vs_oracle(ctx, mode):
+    """Bulk verification, bytes in -> verdict bytes out (blsgpu_bls_verify_batch): 257 signatures (mode 0: public keys in G1, mode 1: in
+    G2), a few tampered in every way the chain distinguishes -- wrong message, wrong key, a signature that is not a curve point, a key
+    outside the subgroup, identity key and signature -- against (i) verdicts computed by the ORACLE on a sample (hash_to_curve, decoders
+    and `pairing` of oracle/), (ii) the C oracle's pairings of the decoded points for every entry"""
+    from oracle import h2c_ref as h
+    from oracle import c_oracle
+    c_oracle.build()
+    n = 257
+    dst = b"BLS_SIG_BLS12381G%d_XMD:SHA-256_SSWU_RO_NUL_" % (2 if mode == 0 else 1)
+    rs = np.random.RandomState(900 + mode)
+    msgs = [bytes(rs.randint(0, 256, size=int(rs.randint(0, 80)), dtype=np.uint8)) for _ in range(n)]
+    skb, sks = _rand_scalars_np(n, 910 + mode)
+    gk, gs = (1, 2) if mode == 0 else (2, 1)                                 # group of the keys / of the signatures
+    pk_xy, pk_inf = ctx.bases_from_scalars(gk, skb).download()
+    hm = ctx.hash_to_curve(gs, msgs, dst)                                    # (oracle-checked in test_hash_to_curve_vs_oracle)
+    hxy, hinf = ctx.batch_normalize(gs, hm)
+    sig_xyz = ctx.mul_batch(gs, hxy, hinf, skb)                              # sig_i = sk_i * H(m_i)
+    sig_xy, sig_inf = ctx.batch_normalize(gs, sig_xyz)
+    pk_b = ctx.points_to_bytes(gk, pk_xy, pk_inf, compressed=True).copy()
+    sig_b = ctx.points_to_bytes(gs, sig_xy, sig_inf, compressed=True).copy()
+    msgs = list(msgs)
+    expect = np.ones(n, dtype=np.uint8)
+    msgs[5] = msgs[5] + b"!"; expect[5] = 0                                  # wrong message
+    pk_b[9] = pk_b[10]; expect[9] = 0                                        # someone else's key
+    sig_b[20] = sig_b[21]; expect[20] = 0                                    # someone else's signature
+    ident = lambda size: np.array([0xC0] + [0] * (size - 1), dtype=np.uint8)
+    pk_b[30] = ident(pk_b.shape[1]); expect[30] = 0                          # identity key with an honest signature: e(O, H) e(-G, sig) != 1
+    pk_b[31] = ident(pk_b.shape[1]); sig_b[31] = ident(sig_b.shape[1]); expect[31] = 1      # both identities: the equation holds (the caller's KeyValidate rejects it)
+    # a signature / key that is not a valid encoding: flip bits until the checked decoder of the HOST twin rejects it
+    for idx, arr, code, grp in ((40, sig_b, 3, gs), (41, pk_b, 2, gk)):
+        for bit in range(8, 64):
+            cand = arr[idx].copy(); cand[bit // 8 + 1] ^= 1 << (bit % 8)
+            if not ctx.points_from_bytes(grp, cand[None, :], compressed=True, checked=True)[2][0]:
+                arr[idx] = cand; expect[idx] = code
+                break
+        assert expect[idx] == code
+    got = ctx.bls_verify_batch(mode, pk_b, sig_b, msgs, dst)
+    assert got.tolist() == expect.tolist()
+    # (i) the oracle on a sample: decode, hash, pair
+    dec_g1 = o.g1_from_compressed; dec_g2 = o.g2_from_compressed
+    for i in (0, 5, 9, 30, 31, 40, 41, 256):
+        if mode == 0:
+            pk, sg = dec_g1(pk_b[i].tobytes()), dec_g2(sig_b[i].tobytes())
+        else:
+            pk, sg = dec_g2(pk_b[i].tobytes()), dec_g1(sig_b[i].tobytes())
+        if pk is None:
+            want = 2
+        elif sg is None:
+            want = 3
+        elif mode == 0:
+            want = int(o.pairing(pk, o.g2_to_affine(h.g2_hash_to_curve(msgs[i], dst))) == o.pairing(o.G1_GEN, sg))
+        else:
+            want = int(o.pairing(sg, o.G2_GEN) == o.pairing(o.g1_to_affine(h.g1_hash_to_curve(msgs[i], dst)), pk))
+        assert got[i] == want, (i, want)
+    # (ii) every entry with valid encodings: e(pk, H(m)) == e(G, sig) by the C oracle on the host twins' decoded points
+    pxy, pinf, pok = ctx.points_from_bytes(gk, pk_b, compressed=True, checked=True)
+    sxy, sinf, sok = ctx.points_from_bytes(gs, sig_b, compressed=True, checked=True)
+    hm2 = ctx.batch_normalize(gs, ctx.hash_to_curve(gs, msgs, dst))
+    gen1 = np.tile(g1aff_w(o.G1_GEN)[0], (n, 1)); gen2 = np.tile(g2aff_w(o.G2_GEN)[0], (n, 1)); z = np.zeros(n, dtype=np.uint8)
+    if mode == 0:
+        lhs = c_oracle.pairing_batch(0, pxy, pinf, hm2[0], hm2[1])[0]; rhs = c_oracle.pairing_batch(0, gen1, z, sxy, sinf)[0]
+    else:
+        lhs = c_oracle.pairing_batch(0, sxy, sinf, gen2, z)[0]; rhs = c_oracle.pairing_batch(0, hm2[0], hm2[1], pxy, pinf)[0]
+    valid = (pok != 0) & (sok != 0)
+    want_all = np.where(pok == 0, 2, np.where(sok == 0, 3, (lhs == rhs).all(axis=1).astype(np.uint8)))
+    assert np.array_equal(got, want_all.astype(np.uint8)) and valid.sum() == n - 2
+    assert ctx.bls_verify_batch(mode, pk_b[:0], sig_b[:0], [], dst).shape == (0,)
