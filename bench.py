@@ -180,6 +180,9 @@ def parse():
     ap.add_argument("--same-device", action="store_true", help="testing aid: all ranks use GPU 0 (needs --backend gloo)")
     ap.add_argument("--dist-single", action="store_true", help="testing aid: run the N>1 code path (process group over RCCL, all-gather of the partial "
                     "sums, fold, rank agreement) with ONE rank -- the only way to execute that path on a one-GPU box")
+    ap.add_argument("--group", type=int, default=0, metavar="N", help="ONE process driving N members of a device group of the C library (blsgpu_group_*: one context + one "
+                    "persistent host thread per member, asynchronous pipelined MSMs, partial sums folded on member 0) instead of one process per GPU over RCCL; "
+                    "members are GPUs 0..N-1, or N logical members on GPU 0 when fewer GPUs are visible (or with --same-device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (batched pairings, G2 MSM, latency probes)")
     ap.add_argument("--mixed-log", type=int, nargs=3, default=[22, 22, 18], metavar=("G1", "G2", "MML"),
@@ -398,6 +401,22 @@ def run_msm(args, e):
     if rank == 0 and not multi and not args.no_extras:
         extras = run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out0)
 
+    # ---- the same sharded MSM from ONE process (the C library's device group: what a Rust host uses), timed by rank 0 while the other
+    # ranks wait at a CPU-side barrier (gloo: an RCCL barrier would spin on their GPUs) ------------------------------------------------
+    group_path = None
+    if multi and world > 1 and args.backend == "nccl" and not args.no_extras and not args.same_device:
+        try:
+            cpu_pg = dist.new_group(backend="gloo")
+            torch.cuda.synchronize()
+            dist.barrier(group=cpu_pg)
+            if rank == 0:
+                try:
+                    group_path = group_measure(bls, torch, list(range(world)), total if strong else None, 10, 3, weak_n=None if strong else n)
+                except Exception as ex:           # never lose the headline over the secondary measurement
+                    group_path = {"error": str(ex)[:200]}
+            dist.barrier(group=cpu_pg)
+        except Exception as ex:
+            group_path = {"error": "no CPU-side process group: " + str(ex)[:160]}
     if rank == 0:
         if strong:
             workload = ("ONE 2^%d-point G1 MSM sharded over %d MI355X (%d points per GPU), bases and scalars resident in HBM; one result per step: "
@@ -412,7 +431,7 @@ def run_msm(args, e):
             "dtype": "u32 (14x28-bit limbs, 64-bit accumulators)", "data": "synthetic",
             "config": {"workload": workload, "points_per_gpu": n, "total_points": total, "parallelism": "shard%d" % world,
                        "scalars": "SplitMix64(0xB1512381 + 2*rank), uniform in [0, r) by rejection (SURVEY.md 8d)"},
-            "roofline": roof, "cpu_baseline": cpu, "latency": latency, "msm_phase_ms": phases, "extras": extras,
+            "roofline": roof, "cpu_baseline": cpu, "latency": latency, "msm_phase_ms": phases, "extras": extras, "group_path": group_path,
         }
         if latency:
             line["single_call_ms"] = latency["single_call_ms"]; line["end_to_end_h2d_ms"] = latency["end_to_end_h2d_ms"]
@@ -657,6 +676,51 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
     eq["prepared"] = prep
     extras["verification_equations"] = eq
     del d_off, d_eq, d_g1e, d_g2e, d_off2, d_eq2
+    # Bulk signature verification from bytes, every stage on the device (blsgpu_bls_verify_batch_device): 2^14 (public key in G1, signature in
+    # G2, 32-byte message) triples -> verdict bytes.  Work per signature in the units of SURVEY.md 8d, stage by stage: checked G1 decoding
+    # ~2 500 (square root + subgroup test), checked G2 decoding ~9 000, hash_to_curve to G2 ~8 700, one two-term multi_miller_loop 2 x 6 900
+    # + one final exponentiation 9 100 (the decoding / hashing counts are estimates of the algorithms' multiplication counts).
+    nv = 1 << 14
+    vdst = b"BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_"
+    skb = synthetic.scalars(nv, 4242)
+    vmsgs = np.random.RandomState(7).randint(0, 256, size=(nv, 32), dtype=np.uint8)
+    pkxy, pkinf = ctx.bases_from_scalars(1, skb).download()
+    hxy, hinf = ctx.batch_normalize(2, ctx.hash_to_curve(2, [m.tobytes() for m in vmsgs], vdst))
+    sgxy, sginf = ctx.batch_normalize(2, ctx.mul_batch(2, hxy, hinf, skb))
+    pk_b = ctx.points_to_bytes(1, pkxy, pkinf, compressed=True).copy()
+    sg_b = ctx.points_to_bytes(2, sgxy, sginf, compressed=True).copy()
+    sg_b[3] = sg_b[4]; sgxy = sgxy.copy(); sgxy[3] = sgxy[4]      # one forged entry (bytes for the device, affine limbs for the CPU check)
+    d_pk, d_sg, d_vm = torch.from_numpy(pk_b).to(dev), torch.from_numpy(sg_b).to(dev), torch.from_numpy(vmsgs).to(dev)
+    d_vo = torch.arange(0, (nv + 1) * 32, 32, dtype=torch.int64, device=dev)
+    d_vd = torch.from_numpy(np.frombuffer(vdst, dtype=np.uint8).copy()).to(dev)
+    d_vv = torch.zeros(nv, dtype=torch.uint8, device=dev)
+    vms = median_ms(lambda: ctx.bls_verify_batch_device(0, d_pk.data_ptr(), d_sg.data_ptr(), d_vm.data_ptr(), d_vo.data_ptr(), nv, d_vd.data_ptr(), len(vdst), d_vv.data_ptr()), sync, warm=1, reps=5)
+    verd = d_vv.cpu().numpy()
+    mac_ver = (2500 + 9000 + 8700 + 2 * 6900 + 9100) * 300
+    ver = {"n": nv, "ms": vms, "signatures_per_s": nv / (vms * 1e-3), "verdicts_as_expected": bool(verd[3] == 0 and verd.sum() == nv - 1),
+           "note": "compressed public keys (48 B) + signatures (96 B) + 32-byte messages in HBM -> verdict bytes in HBM: checked decoding, hash_to_curve, normalisation, "
+                   "multi_miller_loop + final exponentiation per signature, identity test (blsgpu_bls_verify_batch_device)",
+           "roofline": {"bound": "int-valu", "kernel": "k_point_decode x 2 + k_hash_to_curve<G2> + k_pairing_quad (Miller) + k_fp12_prod_seg_quad + k_final_exp_quad",
+                        "mac32_per_unit": mac_ver, "mac32_per_unit_is": "estimate for the decoding and hashing stages", "achieved": nv * mac_ver / (vms * 1e-3) / 1e12, "peak": peak / 1e12,
+                        "unit": "TMAC32/s", "frac": nv * mac_ver / (vms * 1e-3) / peak, "algorithmic_bytes": nv * (48 + 96 + 32 + 1), "traffic": None}}
+    if not ver["verdicts_as_expected"]:
+        raise SystemExit("bench: bulk verification verdicts are wrong")
+    if not args.no_cpu_baseline:
+        from oracle import c_oracle
+        mv = 1 << 10
+        gen1 = np.tile(np.array(bls.G1Affine.generator().xy, dtype=np.uint64), (mv, 1))
+        t1 = time.perf_counter()
+        lhs, cused = c_oracle.pairing_batch(0, pkxy[:mv], None, hxy[:mv], None, host_threads())
+        rhs, _ = c_oracle.pairing_batch(0, gen1, None, sgxy[:mv], None, host_threads())
+        cvt = time.perf_counter() - t1
+        want_v = (lhs == rhs).all(axis=1)
+        ver["gpu_result_matches"] = bool(np.array_equal(verd[:mv] == 1, want_v) and want_v.sum() == mv - 1)          # entry 3 is the forged one
+        ver["cpu_baseline"] = {"value": mv / cvt, "unit": "signatures/s", "cores": cused, "kind": "port",
+                               "sample": f"first 2^10 signatures, the PAIRING stage only (two pairings each, C port, OpenMP x{cused}); decoding and hash_to_curve are not in the CPU figure"}
+        if not ver["gpu_result_matches"]:
+            raise SystemExit("bench: bulk verification disagrees with the CPU oracle's pairings on the sample")
+    extras["bls_verify_from_bytes"] = ver
+    del d_pk, d_sg, d_vm, d_vo, d_vv
     # Fr transform of the MSM's scalar vector
     if n & (n - 1) == 0:
         log_n = int(np.log2(n))
@@ -967,8 +1031,109 @@ def run_mixed(args, e):
         dist.destroy_process_group()
 
 
+# =====================================================================================================================
+# the same workload from ONE process: a device group of the C library (what a Rust host without torch.distributed uses)
+# =====================================================================================================================
+def group_measure(bls, torch, devices, total, steps, warmup, weak_n=None, check=True):
+    """K pipelined sharded MSMs through blsgpu_g1_msm_sharded_device + blsgpu_g1_partials_fold ("enqueue MSM i, fold MSM i - 2"); returns the
+    record of the run.  total = points of the ONE MSM split over the members (strong), or weak_n points per member."""
+    import ctypes
+    from bls12_381_amd import synthetic
+    N = len(devices)
+    g = bls.Group(devices)
+    g.set_pipelining(True)
+    n_all = weak_n * N if weak_n else total
+    sizes = g.shard_sizes(n_all)
+    kbs = [synthetic.scalars(sizes[k], synthetic.SEED + 2 * k + 1) for k in range(N)]
+    sbs = [synthetic.scalars(sizes[k], synthetic.SEED + 2 * k) for k in range(N)]
+    bases = g.bases_from_scalars(1, np.concatenate(kbs))
+    d_s = [torch.from_numpy(sbs[k]).to(torch.device("cuda", devices[k])) for k in range(N)]
+    d_o = [[torch.zeros(18, dtype=torch.int64, device=torch.device("cuda", devices[k])) for _ in range(4)] for k in range(N)]
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    sp = [t.data_ptr() for t in d_s]
+    d_fold = [torch.zeros(18, dtype=torch.int64, device=torch.device("cuda", devices[0])) for _ in range(4)]
+    state = {"i": 0, "last": None}
+
+    def step():
+        i = state["i"]; state["i"] = i + 1
+        g.msm_sharded_device(bases, sp, [d_o[k][i & 3].data_ptr() for k in range(N)])
+        if i >= 2:           # the fold of MSM i - 2 is queued behind it on the members' streams: no host synchronisation in the step
+            g.partials_fold_device(1, [d_o[k][(i - 2) & 3].data_ptr() for k in range(N)], d_fold[(i - 2) & 3].data_ptr(), lag=2)
+
+    def drain():
+        i = state["i"]
+        for j in range(max(0, i - 2), i):
+            g.partials_fold_device(1, [d_o[k][j & 3].data_ptr() for k in range(N)], d_fold[j & 3].data_ptr(), lag=i - 1 - j)
+        g.synchronize()
+        if i:
+            state["last"] = d_fold[(i - 1) & 3].cpu().numpy().view(np.uint64).copy()
+        state["i"] = 0
+
+    for _ in range(warmup):
+        step()
+    drain()
+    lib = g.lib
+    avg, cnt = ctypes.c_double(), ctypes.c_uint()
+    bls._lib.check(lib.blsgpu_msm_accumulate_stats(g.member_ctx(0), 3, ctypes.byref(avg), ctypes.byref(cnt)), "msm_accumulate_stats")
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    drain()
+    dt = time.perf_counter() - t0
+    bls._lib.check(lib.blsgpu_msm_accumulate_stats(g.member_ctx(0), 0, ctypes.byref(avg), ctypes.byref(cnt)), "msm_accumulate_stats")
+    rec = {"members": N, "devices": list(devices), "distinct_gpus": len(set(devices)), "total_points": n_all, "points_per_member": sizes[0], "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * dt / steps, "value": float(n_all) * steps / dt, "member0_accumulate_launch_ms": avg.value, "member0_launches_timed": int(cnt.value)}
+    if check:
+        # discrete-log identity: sum_i s_i [k_i]G = [sum_i s_i k_i] G
+        tot = sum(synthetic.dot_mod_r(kbs[k], sbs[k]) for k in range(N)) % synthetic.R_ORDER
+        c0 = bls.Context(devices[0])
+        want = c0.bases_from_scalars(1, [tot]).download()
+        got = c0.batch_normalize(1, state["last"][None, :])
+        rec["result_matches"] = bool(np.array_equal(got[0][0], want[0][0]) and got[1][0] == want[1][0])
+        c0.close()
+    bases.free(); g.close()
+    return rec
+
+
+def run_group(args):
+    import torch
+    import bls12_381_amd as bls
+    N = args.group
+    ndev = torch.cuda.device_count()
+    devices = list(range(N)) if (ndev >= N and not args.same_device) else [0] * N
+    steps = args.steps if args.steps is not None else (100 if N == 1 else 20)
+    warmup = args.warmup if args.warmup is not None else 5
+    strong = N > 1 and not args.weak
+    log_n = args.log_n if args.log_n is not None else 20
+    total = (1 << args.log_total) if strong else (1 << log_n) * N
+    rec = group_measure(bls, torch, devices, total, steps, warmup, weak_n=None if strong else (1 << log_n))
+    if not rec.get("result_matches", True):
+        raise SystemExit("bench --group: the folded MSM result is wrong")
+    ctx = bls.Context(devices[0])
+    peak = max(ctx.mad_throughput(2000) for _ in range(3))
+    windows = (256 + WINDOW_BITS - 1) // WINDOW_BITS
+    mac = float(rec["points_per_member"]) * windows * MAC32_G1_ADD
+    dur = rec["member0_accumulate_launch_ms"] * 1e-3
+    roof = {"bound": "int-valu", "kernel": "k_msm_accumulate<G1> (member 0)", "achieved": mac / dur / 1e12 if dur else None, "peak": peak / 1e12, "unit": "TMAC32/s",
+            "frac": mac / dur / peak if dur else None, "traffic": None, "launch_ms": rec["member0_accumulate_launch_ms"]}
+    workload = ("ONE 2^%d-point G1 MSM sharded over %d members of a blsgpu_group in ONE process (%d distinct GPUs; %d points per member), bases and scalars resident in HBM; "
+                "one folded result per step" % (args.log_total, N, rec["distinct_gpus"], rec["points_per_member"])) if strong else (
+                "2^%d-point G1 MSM per member of a blsgpu_group of %d in ONE process (%d distinct GPUs), bases and scalars resident in HBM; one folded result per step"
+                % (log_n, N, rec["distinct_gpus"]))
+    line = {"metric": "G1 MSM throughput (scalar-muls/sec) at 2^%d points" % (args.log_total if strong else log_n) + ("" if strong or N == 1 else " per member"),
+            "value": rec["value"], "unit": "scalar-muls/s", "n_gpus": rec["distinct_gpus"], "steps": steps, "warmup": warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u32 (14x28-bit limbs, 64-bit accumulators)", "data": "synthetic",
+            "config": {"workload": workload, "points_per_gpu": rec["points_per_member"], "total_points": rec["total_points"], "parallelism": "group%d" % N, "members": N,
+                       "devices": rec["devices"]},
+            "roofline": roof, "cpu_baseline": None, "group_path": rec}
+    emit(line)
+
+
 def main():
     args = parse()
+    if args.group:
+        return run_group(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     e = setup(args)

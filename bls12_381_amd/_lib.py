@@ -111,6 +111,14 @@ SIGNATURES = {
     "blsgpu_group_bases_free": (None, [c_vp]),
     "blsgpu_g1_msm_sharded": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g2_msm_sharded": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_g1_msm_sharded_device": (c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "blsgpu_g2_msm_sharded_device": (c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "blsgpu_g1_partials_fold": (c_int, [c_vp, c_vp, c_int, c_vp]),
+    "blsgpu_g2_partials_fold": (c_int, [c_vp, c_vp, c_int, c_vp]),
+    "blsgpu_g1_partials_fold_device": (c_int, [c_vp, c_vp, c_int, c_vp]),
+    "blsgpu_g2_partials_fold_device": (c_int, [c_vp, c_vp, c_int, c_vp]),
+    "blsgpu_group_set_pipelining": (c_int, [c_vp, c_int]),
+    "blsgpu_group_synchronize": (c_int, [c_vp]),
     "blsgpu_pairing_batch_sharded": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_miller_loop_batch_sharded": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_multi_miller_loop_sharded": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),

@@ -720,6 +720,47 @@ class Group:
         check(fn(self.h, bases.handle, _ptr(sb), sb.shape[0], _ptr(out)), "msm_sharded")
         return out
 
+    # device-pointer, asynchronous MSMs on every member (the pipelined headline path from one process)
+    def member_ctx(self, k):
+        """raw handle of member k's context (blsgpu_group_ctx) for per-context calls through the ctypes layer"""
+        return ctypes.c_void_p(self.lib.blsgpu_group_ctx(self.h, k))
+
+    def shard_sizes(self, n):
+        """points per member for n resident points (the rule of blsgpu_group_bases_*: contiguous slices, sizes differ by at most one)"""
+        w = len(self)
+        return [n // w + (1 if k < n % w else 0) for k in range(w)]
+
+    def set_pipelining(self, on):
+        check(self.lib.blsgpu_group_set_pipelining(self.h, 1 if on else 0), "group_set_pipelining")
+
+    def synchronize(self):
+        check(self.lib.blsgpu_group_synchronize(self.h), "group_synchronize")
+
+    def msm_sharded_device(self, bases, d_scalars, d_partials):
+        """member k: partial sum of its whole resident slice times the scalars at d_scalars[k] -> d_partials[k] (device pointers as ints,
+        each in member k's device memory); only enqueues"""
+        w = len(self)
+        sp = (ctypes.c_void_p * w)(*[ctypes.c_void_p(int(p)) for p in d_scalars])
+        op = (ctypes.c_void_p * w)(*[ctypes.c_void_p(int(p)) for p in d_partials])
+        fn = self.lib.blsgpu_g1_msm_sharded_device if bases.gid == 1 else self.lib.blsgpu_g2_msm_sharded_device
+        check(fn(self.h, bases.handle, sp, op), "msm_sharded_device")
+
+    def partials_fold(self, gid, d_partials, lag=0):
+        """the sum of the members' partial sums at d_partials (waiting, per member, for all but the `lag` most recent MSM calls)"""
+        w = len(self)
+        op = (ctypes.c_void_p * w)(*[ctypes.c_void_p(int(p)) for p in d_partials])
+        out = np.zeros(18 if gid == 1 else 36, dtype=np.uint64)
+        fn = self.lib.blsgpu_g1_partials_fold if gid == 1 else self.lib.blsgpu_g2_partials_fold
+        check(fn(self.h, op, lag, _ptr(out)), "partials_fold")
+        return out
+
+    def partials_fold_device(self, gid, d_partials, d_out, lag=0):
+        """the same fold queued on the members' streams: the sum lands at d_out (member 0's device memory), nothing is synchronised"""
+        w = len(self)
+        op = (ctypes.c_void_p * w)(*[ctypes.c_void_p(int(p)) for p in d_partials])
+        fn = self.lib.blsgpu_g1_partials_fold_device if gid == 1 else self.lib.blsgpu_g2_partials_fold_device
+        check(fn(self.h, op, lag, ctypes.c_void_p(int(d_out))), "partials_fold_device")
+
     _pair_args = Context._pair_args
 
     def pairing_batch(self, g1_xy, g1_inf, g2_xy, g2_inf):

@@ -10,6 +10,8 @@
 #include <vector>
 #include <atomic>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <functional>
 
 #include "../../include/bls12_381_hip.h"
@@ -1712,6 +1714,8 @@ extern "C" int blsgpu_pairing_layout(blsgpu_ctx* c, size_t n) { CTX_CLAIM(c);
 // "" when the wide programs are loaded, otherwise the reason they are not (also tried now if no pairing call has tried yet)
 extern "C" const char* blsgpu_wide_status(blsgpu_ctx* c) {
   if (!c) return "NULL context";
+  CtxClaim claim_(&c->owner_thread, &c->owner_depth);
+  if (claim_.clash) return "the context is in use by another host thread";
   if (hipSetDevice(c->device) != hipSuccess) { (void)hipGetLastError(); return "hipSetDevice failed"; }
   return wide_load(c) == 1 ? "" : c->wide_why.c_str();
 }
@@ -2446,7 +2450,58 @@ extern "C" int blsgpu_bls_verify_batch(blsgpu_ctx* c, int mode, const uint8_t* p
 // library: each member hands its few hundred bytes back through host memory and member 0 folds them on its device.  One context and
 // one host thread per member (a context is single-threaded by contract); a device may be listed more than once (logical members on
 // one GPU: how the single-GPU tests exercise the 8-member code path).
-struct blsgpu_group { std::vector<blsgpu_ctx*> ctx; };
+// One PERSISTENT worker thread per member beyond the first (created by blsgpu_group_create; member 0 runs on the caller's thread): a
+// sharded call posts one job per member and waits -- no thread is created or joined per call.  A context is driven by one host thread at
+// a time, and a member's context is only ever driven by its worker (or, for member 0, by the thread inside the group call).
+struct GroupWorker {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::function<int()> job;
+  bool has = false, done = true, quit = false;
+  int rc = BLSGPU_OK;
+  std::string msg;
+  void loop() {
+    for (;;) {
+      std::function<int()> j;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return has || quit; });
+        if (quit) return;
+        j = std::move(job); has = false;
+      }
+      int r; std::string e;
+      try { r = j(); if (r) e = g_err; } catch (...) { r = BLSGPU_ERR_HIP; e = "exception in a group worker"; }
+      {
+        std::lock_guard<std::mutex> lk(m);
+        rc = r; msg = e; done = true;
+      }
+      cv.notify_all();
+    }
+  }
+  void post(std::function<int()> j) {
+    { std::lock_guard<std::mutex> lk(m); job = std::move(j); has = true; done = false; }
+    cv.notify_all();
+  }
+  int wait(std::string& e) {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return done; });
+    e = msg;
+    return rc;
+  }
+};
+struct blsgpu_group {
+  std::vector<blsgpu_ctx*> ctx;
+  std::vector<GroupWorker*> worker;            // worker[i] drives member i, i >= 1 (worker[0] is null)
+  std::vector<void*> pinned;                   // per member: 576 B of pinned host memory for its partial result
+  // asynchronous fold (blsgpu_g{1,2}_partials_fold_device): four staging rows of w partial sums on member 0's device, one event per
+  // member (its copy has been queued) and one per staging row (the sum that read it has been queued)
+  void* fold_in = nullptr;
+  std::vector<hipEvent_t> ev_copy;
+  hipEvent_t ev_sum[4] = {};
+  bool ev_sum_used[4] = {false, false, false, false};
+  unsigned fold_seq = 0;
+};
 struct blsgpu_group_bases { int group = 1; size_t n = 0; std::vector<blsgpu_bases*> part; };
 
 // contiguous slice [lo, hi) of n items owned by member k of w (sizes differ by at most one; the same rule as distributed.shard_range)
@@ -2455,23 +2510,39 @@ static void group_range(size_t n, size_t k, size_t w, size_t& lo, size_t& hi) {
   lo = k * q + (k < r ? k : r);
   hi = lo + q + (k < r ? 1 : 0);
 }
-// fn(member, context) on one host thread per member (member 0 on the caller's); the first failing member's code and message win
+// fn(member, context) on the member's persistent worker (member 0 on the caller's thread); the first failing member's code and message win
 template <class Fn> static int group_run(blsgpu_group* g, Fn fn) {
   const size_t w = g->ctx.size();
-  std::vector<int> rc(w, BLSGPU_OK);
-  std::vector<std::string> msg(w);
-  auto body = [&](size_t i) { rc[i] = fn(i, g->ctx[i]); if (rc[i]) msg[i] = g_err; };
-  std::vector<std::thread> th;
-  th.reserve(w);
-  for (size_t i = 1; i < w; i++) th.emplace_back(body, i);
-  body(0);
-  for (auto& t : th) t.join();
-  for (size_t i = 0; i < w; i++)
-    if (rc[i]) { g_err = "group member " + std::to_string(i) + ": " + msg[i]; return rc[i]; }
+  for (size_t i = 1; i < w; i++) g->worker[i]->post([&fn, g, i]() { return fn(i, g->ctx[i]); });
+  int rc0 = fn(0, g->ctx[0]);
+  std::string msg0 = rc0 ? g_err : std::string();
+  int rc = BLSGPU_OK; std::string msg; size_t who = 0;
+  if (rc0) { rc = rc0; msg = msg0; }
+  for (size_t i = 1; i < w; i++) {             // every posted job is awaited, whatever failed (the jobs reference this frame)
+    std::string e;
+    int r = g->worker[i]->wait(e);
+    if (r && !rc) { rc = r; msg = e; who = i; }
+  }
+  if (rc) { g_err = "group member " + std::to_string(who) + ": " + msg; return rc; }
   return BLSGPU_OK;
 }
 extern "C" void blsgpu_group_destroy(blsgpu_group* g) {
   if (!g) return;
+  for (auto wk : g->worker) {
+    if (!wk) continue;
+    { std::lock_guard<std::mutex> lk(wk->m); wk->quit = true; }
+    wk->cv.notify_all();
+    if (wk->th.joinable()) wk->th.join();
+    delete wk;
+  }
+  for (size_t i = 0; i < g->ev_copy.size(); i++) if (g->ev_copy[i]) { hipSetDevice(g->ctx[i]->device); hipEventDestroy(g->ev_copy[i]); }
+  if (!g->ctx.empty() && g->ctx[0]) {
+    hipSetDevice(g->ctx[0]->device);
+    hipDeviceSynchronize();
+    for (auto e : g->ev_sum) if (e) hipEventDestroy(e);
+    if (g->fold_in) hipFree(g->fold_in);
+  }
+  for (size_t i = 0; i < g->pinned.size(); i++) if (g->pinned[i]) { if (i < g->ctx.size() && g->ctx[i]) hipSetDevice(g->ctx[i]->device); hipHostFree(g->pinned[i]); }
   for (auto c : g->ctx) blsgpu_destroy(c);
   delete g;
 }
@@ -2483,6 +2554,29 @@ extern "C" int blsgpu_group_create(const int* devices, int ndev, blsgpu_group** 
     int rc = blsgpu_create(devices[i], &c);
     if (rc) { const std::string keep = g_err; blsgpu_group_destroy(g); g_err = "group_create: member " + std::to_string(i) + ": " + keep; return rc; }
     g->ctx.push_back(c);
+    void* pin = nullptr;
+    if (hipHostMalloc(&pin, 576, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); blsgpu_group_destroy(g); g_err = "group_create: hipHostMalloc failed"; return BLSGPU_ERR_HIP; }
+    g->pinned.push_back(pin);
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); blsgpu_group_destroy(g); g_err = "group_create: hipEventCreate failed"; return BLSGPU_ERR_HIP; }
+    g->ev_copy.push_back(ev);
+  }
+  {
+    hipError_t e = hipSetDevice(g->ctx[0]->device);
+    if (e == hipSuccess) e = hipMalloc(&g->fold_in, (size_t)4 * ndev * 288);
+    for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&g->ev_sum[i], hipEventDisableTiming);
+    if (e != hipSuccess) { (void)hipGetLastError(); blsgpu_group_destroy(g); g_err = "group_create: staging for the asynchronous fold could not be allocated"; return BLSGPU_ERR_HIP; }
+  }
+  g->worker.assign((size_t)ndev, nullptr);
+  try {
+    for (int i = 1; i < ndev; i++) {
+      g->worker[(size_t)i] = new GroupWorker();
+      g->worker[(size_t)i]->th = std::thread([wk = g->worker[(size_t)i]] { wk->loop(); });
+    }
+  } catch (...) {                                // e.g. the process's thread limit: nothing escapes the C ABI
+    blsgpu_group_destroy(g);
+    g_err = "group_create: a worker thread could not be started";
+    return BLSGPU_ERR_HIP;
   }
   *out = g;
   return BLSGPU_OK;
@@ -2544,6 +2638,88 @@ static int msm_sharded(blsgpu_group* g, const blsgpu_group_bases* b, const uint8
 }
 extern "C" int blsgpu_g1_msm_sharded(blsgpu_group* g, const blsgpu_group_bases* b, const uint8_t* scalars, size_t n, uint64_t out[18]) { return msm_sharded<1>(g, b, scalars, n, out); }
 extern "C" int blsgpu_g2_msm_sharded(blsgpu_group* g, const blsgpu_group_bases* b, const uint8_t* scalars, size_t n, uint64_t out[36]) { return msm_sharded<2>(g, b, scalars, n, out); }
+// Device-pointer form: member k multiplies ITS WHOLE resident slice by the scalars at d_scalars[k] (on its device) and writes its partial
+// sum (projective wire form) to d_partials[k] (on its device); every member only ENQUEUES (with pipelining on -- blsgpu_group_set_pipelining --
+// up to four calls per member are in flight), nothing is synchronised.  blsgpu_g{1,2}_partials_fold collects and adds the partial sums.
+template <int G>
+static int msm_sharded_device(blsgpu_group* g, const blsgpu_group_bases* b, const void* const* d_scalars, void* const* d_partials) {
+  if (!g || !b || !d_scalars || !d_partials) return bad("msm_sharded_device: NULL argument");
+  if (b->group != G) return bad("msm_sharded_device: bases belong to the other group");
+  if (b->part.size() != g->ctx.size()) return bad("msm_sharded_device: the bases were sharded over another group");
+  return group_run(g, [&](size_t k, blsgpu_ctx* c) {
+    const size_t cnt = blsgpu_bases_len(b->part[k]);
+    return G == 1 ? blsgpu_g1_msm_device(c, b->part[k], 0, d_scalars[k], cnt, d_partials[k]) : blsgpu_g2_msm_device(c, b->part[k], 0, d_scalars[k], cnt, d_partials[k]);
+  });
+}
+extern "C" int blsgpu_g1_msm_sharded_device(blsgpu_group* g, const blsgpu_group_bases* b, const void* const* d_scalars, void* const* d_partials) { return msm_sharded_device<1>(g, b, d_scalars, d_partials); }
+extern "C" int blsgpu_g2_msm_sharded_device(blsgpu_group* g, const blsgpu_group_bases* b, const void* const* d_scalars, void* const* d_partials) { return msm_sharded_device<2>(g, b, d_scalars, d_partials); }
+// out = sum_k partial_k: every member waits (on ITS stream) for its MSMs except the `lag` most recent ones, copies its partial sum into
+// pinned host memory and synchronises that stream only -- the calls still in flight run on the member's internal streams and are not
+// held up -- then member 0 adds the w points (`Sum for G1Projective`, g1.rs:161-171).  lag = 0 collects the most recent call.
+template <int G>
+static int partials_fold(blsgpu_group* g, const void* const* d_partials, int lag, uint64_t* out) {
+  constexpr size_t PW = G == 1 ? 18 : 36;
+  if (!g || !d_partials || !out || lag < 0) return bad("partials_fold: bad argument");
+  const size_t w = g->ctx.size();
+  int rc = group_run(g, [&](size_t k, blsgpu_ctx* c) {
+    CTX_CLAIM(c);
+    int r = blsgpu_join_lag(c, lag);
+    if (r) return r;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(g->pinned[k], d_partials[k], PW * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return (int)BLSGPU_OK;
+  });
+  if (rc) return rc;
+  std::vector<uint64_t> parts(w * PW);
+  for (size_t k = 0; k < w; k++) memcpy(parts.data() + k * PW, g->pinned[k], PW * 8);
+  return G == 1 ? blsgpu_g1_sum(g->ctx[0], parts.data(), w, out) : blsgpu_g2_sum(g->ctx[0], parts.data(), w, out);
+}
+extern "C" int blsgpu_g1_partials_fold(blsgpu_group* g, const void* const* d_partials, int lag, uint64_t out[18]) { return partials_fold<1>(g, d_partials, lag, out); }
+extern "C" int blsgpu_g2_partials_fold(blsgpu_group* g, const void* const* d_partials, int lag, uint64_t out[36]) { return partials_fold<2>(g, d_partials, lag, out); }
+// The same fold without a host round trip: every member queues (behind its MSMs except the `lag` most recent ones) a copy of its partial
+// sum into a staging row on member 0's device; member 0's stream waits for the w copies and adds them into d_out (device memory of member
+// 0, projective wire form).  Nothing is synchronised: the fold of MSM i - 2 runs under the accumulation of MSMs i - 1 and i.
+template <int G>
+static int partials_fold_device(blsgpu_group* g, const void* const* d_partials, int lag, void* d_out) {
+  constexpr size_t PB = G == 1 ? 144 : 288;
+  if (!g || !d_partials || !d_out || lag < 0) return bad("partials_fold_device: bad argument");
+  const size_t w = g->ctx.size();
+  const unsigned row = g->fold_seq++ & 3u;
+  uint8_t* stage = (uint8_t*)g->fold_in + (size_t)row * w * 288;
+  blsgpu_ctx* c0 = g->ctx[0];
+  int rc = group_run(g, [&](size_t k, blsgpu_ctx* c) {
+    CTX_CLAIM(c);
+    int r = blsgpu_join_lag(c, lag);
+    if (r) return r;
+    HIPCHK(hipSetDevice(c->device));
+    if (g->ev_sum_used[row]) HIPCHK(hipStreamWaitEvent(c->stream, g->ev_sum[row], 0));       // the sum that last read this staging row
+    HIPCHK(hipMemcpyPeerAsync(stage + k * PB, c0->device, d_partials[k], c->device, PB, c->stream));
+    HIPCHK(hipEventRecord(g->ev_copy[k], c->stream));
+    return (int)BLSGPU_OK;
+  });
+  if (rc) return rc;
+  CTX_CLAIM(c0);
+  HIPCHK(hipSetDevice(c0->device));
+  for (size_t k = 1; k < w; k++) HIPCHK(hipStreamWaitEvent(c0->stream, g->ev_copy[k], 0));
+  rc = G == 1 ? blsgpu_g1_sum_device(c0, stage, w, d_out) : blsgpu_g2_sum_device(c0, stage, w, d_out);
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(g->ev_sum[row], c0->stream));
+  g->ev_sum_used[row] = true;
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_g1_partials_fold_device(blsgpu_group* g, const void* const* d_partials, int lag, void* d_out) { return partials_fold_device<1>(g, d_partials, lag, d_out); }
+extern "C" int blsgpu_g2_partials_fold_device(blsgpu_group* g, const void* const* d_partials, int lag, void* d_out) { return partials_fold_device<2>(g, d_partials, lag, d_out); }
+extern "C" int blsgpu_group_set_pipelining(blsgpu_group* g, int on) {
+  if (!g) return bad("group_set_pipelining: NULL group");
+  for (auto c : g->ctx) { int rc = blsgpu_set_pipelining(c, on); if (rc) return rc; }
+  return BLSGPU_OK;
+}
+// wait for everything queued on every member; the first failing member's verdict (e.g. a non-canonical scalar of an asynchronous call) wins
+extern "C" int blsgpu_group_synchronize(blsgpu_group* g) {
+  if (!g) return bad("group_synchronize: NULL group");
+  return group_run(g, [&](size_t, blsgpu_ctx* c) { return blsgpu_synchronize(c); });
+}
 // n independent pairings (mode 0) or raw Miller values (mode 1): index slices, every member writes its slice of `out`; no fold
 static int pairings_sharded(blsgpu_group* g, int mode, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, size_t n, uint64_t* out) {
   if (!g || (n && (!g1 || !g2 || !out))) return bad("pairing_batch_sharded: NULL argument");

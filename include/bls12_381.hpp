@@ -8,6 +8,7 @@
 // CPU fallback here).
 #pragma once
 #include <array>
+#include <memory>
 #include <optional>
 #include <cstdint>
 #include <cstring>
@@ -181,11 +182,55 @@ struct MillerLoopResult {
   }
 };
 
-// src/pairings.rs:498-546: opaque in the reference; keeps the affine point here (lines are recomputed on the GPU)
+// m `G2Prepared` values resident on the device (blsgpu_g2_prepared): shared by the G2Prepared objects built from it
+class PreparedTable {
+ public:
+  explicit PreparedTable(const std::vector<G2Affine>& pts) {
+    std::vector<uint64_t> xy(pts.size() * 24 + 1); std::vector<uint8_t> inf(pts.size() + 1);
+    for (size_t i = 0; i < pts.size(); i++) { std::memcpy(xy.data() + 24 * i, pts[i].xy.data(), 192); inf[i] = pts[i].infinity; }
+    check(blsgpu_g2_prepare(Context::instance().handle(), xy.data(), inf.data(), pts.size(), &h_), "g2_prepare");
+  }
+  ~PreparedTable() { blsgpu_g2_prepared_free(h_); }
+  PreparedTable(const PreparedTable&) = delete;
+  PreparedTable& operator=(const PreparedTable&) = delete;
+  const blsgpu_g2_prepared* handle() const { return h_; }
+  size_t size() const { return blsgpu_g2_prepared_len(h_); }
+ private:
+  blsgpu_g2_prepared* h_ = nullptr;
+};
+// src/pairings.rs:487-546: opaque in the reference.  G2Prepared(q) keeps the affine point (its lines are computed on the fly in every
+// Miller loop); G2Prepared::resident(q) / resident_many(points) do what `From<G2Affine>` does in the reference: the 68 coefficient triples
+// are computed ONCE, into a device-resident table, and every later multi_miller_loop only evaluates them.
 struct G2Prepared {
   G2Affine q;
+  std::shared_ptr<PreparedTable> table;                    // null: not resident
+  uint32_t index = BLSGPU_UNPREPARED;
   explicit G2Prepared(const G2Affine& p) : q(p) {}
+  static std::vector<G2Prepared> resident_many(const std::vector<G2Affine>& pts) {
+    auto t = std::make_shared<PreparedTable>(pts);
+    std::vector<G2Prepared> out;
+    for (size_t i = 0; i < pts.size(); i++) { G2Prepared g(pts[i]); g.table = t; g.index = (uint32_t)i; out.push_back(g); }
+    return out;
+  }
+  static G2Prepared resident(const G2Affine& p) { return resident_many({p})[0]; }
+  // `coeffs: Vec<(Fp2, Fp2, Fp2)>` of a resident value: 68 x 3 x 12 u64 in the reference's value format
+  std::vector<uint64_t> coeffs() const {
+    if (!table) throw std::invalid_argument("G2Prepared::coeffs: not resident");
+    std::vector<uint64_t> c(68 * 36); uint8_t inf = 0;
+    check(blsgpu_g2_prepared_coeffs(Context::instance().handle(), table->handle(), index, c.data(), &inf), "g2_prepared_coeffs");
+    return c;
+  }
 };
+namespace detail {
+// the table shared by the resident terms (the first one found) and the per-term indices; terms of another table stay unprepared
+template <class It> const PreparedTable* resident_indices(It begin, It end, std::vector<uint32_t>& qi) {
+  const PreparedTable* t = nullptr;
+  for (It i = begin; i != end; ++i) if (i->second.table) { t = i->second.table.get(); break; }
+  if (!t) return nullptr;
+  for (It i = begin; i != end; ++i) qi.push_back(i->second.table.get() == t ? i->second.index : BLSGPU_UNPREPARED);
+  return t;
+}
+}  // namespace detail
 
 inline Gt pairing(const G1Affine& p, const G2Affine& q) {    // src/pairings.rs:607-653
   Gt g; uint8_t i1 = p.infinity, i2 = q.infinity;
@@ -209,7 +254,11 @@ inline MillerLoopResult multi_miller_loop(const std::vector<std::pair<G1Affine, 
     fa[i] = terms[i].first.infinity; fb[i] = terms[i].second.q.infinity;
   }
   MillerLoopResult m;
-  check(blsgpu_multi_miller_loop(Context::instance().handle(), a.data(), fa.data(), b.data(), fb.data(), n, m.f.data()), "multi_miller_loop");
+  std::vector<uint32_t> qi;
+  if (const PreparedTable* t = detail::resident_indices(terms.begin(), terms.end(), qi))
+    check(blsgpu_multi_miller_loop_prepared(Context::instance().handle(), a.data(), fa.data(), b.data(), fb.data(), qi.data(), t->handle(), n, m.f.data()), "multi_miller_loop_prepared");
+  else
+    check(blsgpu_multi_miller_loop(Context::instance().handle(), a.data(), fa.data(), b.data(), fb.data(), n, m.f.data()), "multi_miller_loop");
   return m;
 }
 // N independent `multi_miller_loop(..).final_exponentiation()` in one device call: the bulk form of signature verification
@@ -225,12 +274,34 @@ inline std::vector<Gt> multi_miller_loop_many(const std::vector<std::vector<std:
       std::memcpy(a.data() + 12 * i, t.first.xy.data(), 96); std::memcpy(b.data() + 24 * i, t.second.q.xy.data(), 192);
       fa[i] = t.first.infinity; fb[i] = t.second.q.infinity; i++;
     }
-  check(blsgpu_multi_miller_loop_many(Context::instance().handle(), a.data(), fa.data(), b.data(), fb.data(), off.data(), equations.size(), 1, o.data()), "multi_miller_loop_many");
+  std::vector<std::pair<G1Affine, G2Prepared>> flat;
+  for (const auto& e : equations) flat.insert(flat.end(), e.begin(), e.end());
+  std::vector<uint32_t> qi;
+  if (const PreparedTable* t = detail::resident_indices(flat.begin(), flat.end(), qi))
+    check(blsgpu_multi_miller_loop_prepared_many(Context::instance().handle(), a.data(), fa.data(), b.data(), fb.data(), qi.data(), t->handle(), off.data(), equations.size(), 1,
+                                                 o.data()), "multi_miller_loop_prepared_many");
+  else
+    check(blsgpu_multi_miller_loop_many(Context::instance().handle(), a.data(), fa.data(), b.data(), fb.data(), off.data(), equations.size(), 1, o.data()), "multi_miller_loop_many");
   std::vector<Gt> out(equations.size());
   for (size_t s = 0; s < equations.size(); s++) std::memcpy(out[s].f.data(), o.data() + 72 * s, 576);
   return out;
 }
 inline Gt Gt::generator() { return pairing(G1Affine::generator(), G2Affine::generator()); }            // src/pairings.rs:359-475
+
+// Bulk signature verification from bytes (blsgpu_bls_verify_batch): compressed keys, signatures and messages in, one verdict byte each
+// out (1 valid, 0 invalid, 2 bad key encoding, 3 bad signature encoding); keys_in_g1 = true: 48-byte keys / 96-byte signatures
+inline std::vector<uint8_t> bls_verify_batch(bool keys_in_g1, const std::vector<uint8_t>& pk_bytes, const std::vector<uint8_t>& sig_bytes, const std::vector<std::string>& msgs,
+                                             const std::string& dst) {
+  const size_t n = msgs.size();
+  if (pk_bytes.size() != n * (keys_in_g1 ? 48 : 96) || sig_bytes.size() != n * (keys_in_g1 ? 96 : 48)) throw std::invalid_argument("bls_verify_batch: byte lengths");
+  std::vector<uint8_t> verdict(n);
+  if (!n) return verdict;
+  std::vector<uint64_t> offs(n + 1, 0); std::string blob;
+  for (size_t i = 0; i < n; i++) { blob += msgs[i]; offs[i + 1] = blob.size(); }
+  check(blsgpu_bls_verify_batch(Context::instance().handle(), keys_in_g1 ? 0 : 1, pk_bytes.data(), sig_bytes.data(), (const uint8_t*)blob.data(), offs.data(), n,
+                                (const uint8_t*)dst.data(), dst.size(), verdict.data()), "bls_verify_batch");
+  return verdict;
+}
 
 // src/hash_to_curve/mod.rs:86-108 with ExpandMsgXmd<Sha256>: `G::hash_to_curve(msg, dst)` / `G::encode_to_curve(msg, dst)` for a batch
 template <int G> std::vector<Projective<G>> hash_to_curve(const std::vector<std::string>& msgs, const std::string& dst, bool encode_only = false) {

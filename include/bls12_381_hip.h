@@ -206,7 +206,7 @@ int blsgpu_g2_to_bytes_batch(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t*
 int blsgpu_pairing_layout(blsgpu_ctx* ctx, size_t n);
 /* "" when the wide programs are loaded on this context, otherwise the reason they are not (file missing, stale format
  * version, generated for another kernel configuration, library path unknown in a static link: set $BLSGPU_WIDE_PROG). */
-const char* blsgpu_wide_status(blsgpu_ctx* ctx);
+const char* blsgpu_wide_status(blsgpu_ctx* ctx);      /* (the pointer is valid until the next call on this context) */
 /* out[i] = pairing(g1[i], g2[i]) for n independent pairs (`pairing`, src/pairings.rs:607-653; 72 u64 each).
  * An identity on either side yields Gt::identity() = Fp12::one(), as the reference does. */
 int blsgpu_pairing_batch(blsgpu_ctx* ctx, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy, const uint8_t* g2_inf, size_t n, uint64_t* out_gt);
@@ -300,10 +300,10 @@ int blsgpu_multi_miller_loop_prepared_many_device(blsgpu_ctx* ctx, const void* d
  * (:48-176).  Inside one process those few hundred bytes travel through host memory; no collective library is involved
  * (one process per GPU over RCCL is bls12_381_amd/distributed.py + bench.py --gpus N).  Results are the same group / field
  * elements as the single-context entry points'.  `devices` may name a device more than once (logical members on one GPU).
- * A group is driven by one host thread at a time; blsgpu_group_ctx gives access to a member's context for the per-context
- * settings (blsgpu_set_assume_subgroup, blsgpu_set_msm_window, ...) and for work the group calls do not cover: the sharded
- * calls are synchronous and take host buffers; a caller that wants pipelined / device-pointer MSMs on every GPU drives the
- * members' contexts itself (one host thread per context) and folds with blsgpu_g1_sum / blsgpu_fp12_product. */
+ * A group is driven by one host thread at a time; it owns one persistent worker thread per member beyond the first (created by
+ * blsgpu_group_create, joined by blsgpu_group_destroy: no thread is started per call).  blsgpu_group_ctx gives access to a member's
+ * context for the per-context settings (blsgpu_set_assume_subgroup, blsgpu_set_msm_window, ...).  The host-pointer `*_sharded`
+ * calls are synchronous; the `*_sharded_device` MSMs below are asynchronous and pipelined. */
 typedef struct blsgpu_group blsgpu_group;
 typedef struct blsgpu_group_bases blsgpu_group_bases;   /* resident bases, member k holds points [lo_k, hi_k) on its device */
 int blsgpu_group_create(const int* devices, int ndev, blsgpu_group** out);
@@ -319,6 +319,24 @@ void blsgpu_group_bases_free(blsgpu_group_bases* b);
  * member 0 adds the partial sums (blsgpu_g1_msm / blsgpu_g1_sum per member; same contracts, incl. canonical scalars). */
 int blsgpu_g1_msm_sharded(blsgpu_group* group, const blsgpu_group_bases* bases, const uint8_t* scalars, size_t n, uint64_t out_xyz[18]);
 int blsgpu_g2_msm_sharded(blsgpu_group* group, const blsgpu_group_bases* bases, const uint8_t* scalars, size_t n, uint64_t out_xyz[36]);
+/* Device-pointer, asynchronous form for pipelined use (the headline path on every GPU of the node): member k multiplies its WHOLE
+ * resident slice by the scalars at d_scalars[k] and writes its partial sum (18 / 36 u64) to d_partials[k], both in ITS device's memory;
+ * the call only enqueues on every member (one persistent host thread per member does the enqueueing).  With
+ * blsgpu_group_set_pipelining(group, 1) up to four calls per member overlap as described at blsgpu_set_pipelining.
+ * blsgpu_g{1,2}_partials_fold(group, d_partials, lag, out) then waits -- per member, without holding up the `lag` most recent calls --
+ * for the call whose partial sums `d_partials` name, and adds them on member 0 (`Sum`, src/g1.rs:161-171): the pattern is "enqueue MSM
+ * i, fold MSM i - 2".  blsgpu_group_synchronize waits for everything and reports the sticky verdict of asynchronous calls. */
+int blsgpu_g1_msm_sharded_device(blsgpu_group* group, const blsgpu_group_bases* bases, const void* const* d_scalars, void* const* d_partials);
+int blsgpu_g2_msm_sharded_device(blsgpu_group* group, const blsgpu_group_bases* bases, const void* const* d_scalars, void* const* d_partials);
+int blsgpu_g1_partials_fold(blsgpu_group* group, const void* const* d_partials, int lag, uint64_t out_xyz[18]);
+int blsgpu_g2_partials_fold(blsgpu_group* group, const void* const* d_partials, int lag, uint64_t out_xyz[36]);
+/* The fold without a host round trip: every member queues a copy of its partial sum to member 0's device behind the MSM it belongs to,
+ * member 0's stream adds the w points into d_out (device memory of member 0, 18 / 36 u64); nothing is synchronised -- the fold of MSM
+ * i - 2 runs under the accumulation of MSMs i - 1 and i.  At most four folds may be outstanding. */
+int blsgpu_g1_partials_fold_device(blsgpu_group* group, const void* const* d_partials, int lag, void* d_out_xyz);
+int blsgpu_g2_partials_fold_device(blsgpu_group* group, const void* const* d_partials, int lag, void* d_out_xyz);
+int blsgpu_group_set_pipelining(blsgpu_group* group, int enabled);
+int blsgpu_group_synchronize(blsgpu_group* group);
 /* n independent pairings / raw Miller values: index slices, each member writes its slice of `out` (n x 72 u64); nothing to fold. */
 int blsgpu_pairing_batch_sharded(blsgpu_group* group, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy, const uint8_t* g2_inf, size_t n, uint64_t* out_gt);
 int blsgpu_miller_loop_batch_sharded(blsgpu_group* group, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy, const uint8_t* g2_inf, size_t n, uint64_t* out_f);

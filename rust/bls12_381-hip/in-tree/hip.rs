@@ -27,9 +27,39 @@ use core::ffi::c_int;
 
 /// With the `hip` feature `G2Prepared` (opaque: private fields, src/pairings.rs:498-501) holds the affine point; the GPU
 /// recomputes the 68 line-coefficient triples on the fly instead of reading 19 584 B per point from memory.
-#[derive(Clone, Debug)]
-pub struct G2PreparedHip { pub(crate) q: G2Affine }
-impl From<G2Affine> for G2PreparedHip { fn from(q: G2Affine) -> Self { G2PreparedHip { q } } }
+/// `G2PreparedHip::from(q)` keeps the affine point (right for a point met once: its lines are computed inside the Miller kernel);
+/// `G2PreparedHip::resident_many(points)` does what the reference's `From<G2Affine> for G2Prepared` does (src/pairings.rs:504-546) --
+/// the 68 coefficient triples are computed ONCE, into a device-resident table (`blsgpu_g2_prepare`) -- and every later
+/// `multi_miller_loop` only evaluates them (verification keys, fixed generators).
+pub struct PreparedTable(*mut ffi::BlsgpuG2Prepared);
+unsafe impl Send for PreparedTable {}
+unsafe impl Sync for PreparedTable {}
+impl Drop for PreparedTable { fn drop(&mut self) { unsafe { ffi::blsgpu_g2_prepared_free(self.0) } } }
+#[derive(Clone)]
+pub struct G2PreparedHip { pub(crate) q: G2Affine, pub(crate) resident: Option<(alloc::sync::Arc<PreparedTable>, u32)> }
+impl core::fmt::Debug for G2PreparedHip {
+    fn fmt(&self, f: &mut core::fmt::Formatter<'_>) -> core::fmt::Result { write!(f, "G2PreparedHip({:?}, resident: {})", self.q, self.resident.is_some()) }
+}
+impl From<G2Affine> for G2PreparedHip { fn from(q: G2Affine) -> Self { G2PreparedHip { q, resident: None } } }
+impl G2PreparedHip {
+    /// one device table for all of `points`; falls back to the plain form when no device is available
+    pub fn resident_many(points: &[G2Affine]) -> Vec<G2PreparedHip> {
+        let table = with_ctx(|ctx| {
+            let (g2, f2) = g2_wire(points);
+            let mut h = core::ptr::null_mut();
+            ok(unsafe { ffi::blsgpu_g2_prepare(ctx, g2.as_ptr(), f2.as_ptr(), points.len(), &mut h) })?;
+            Some(alloc::sync::Arc::new(PreparedTable(h)))
+        });
+        points.iter().enumerate().map(|(i, q)| G2PreparedHip { q: *q, resident: table.as_ref().map(|t| (t.clone(), i as u32)) }).collect()
+    }
+}
+/// the table shared by the resident terms (the first one found) and the per-term indices (`UNPREPARED` for the others)
+const UNPREPARED: u32 = 0xffff_ffff;
+fn resident_indices(preps: &[&G2PreparedHip]) -> Option<(alloc::sync::Arc<PreparedTable>, Vec<u32>)> {
+    let table = preps.iter().find_map(|p| p.resident.as_ref().map(|r| r.0.clone()))?;
+    let qi = preps.iter().map(|p| match &p.resident { Some((t, i)) if alloc::sync::Arc::ptr_eq(t, &table) => *i, _ => UNPREPARED }).collect();
+    Some((table, qi))
+}
 
 /// Process-wide context (one device).  `None` = no GPU / creation failed: every caller below then falls back to the CPU path,
 /// which keeps the infallible signatures of the reference.
@@ -181,7 +211,12 @@ pub fn multi_miller_loop(terms: &[(&G1Affine, &G2PreparedHip)]) -> MillerLoopRes
         let q: Vec<G2Affine> = terms.iter().map(|t| t.1.q).collect();
         let ((g1, f1), (g2, f2)) = (g1_wire(&p), g2_wire(&q));
         let mut out = [0u64; 72];
-        ok(unsafe { ffi::blsgpu_multi_miller_loop(ctx, g1.as_ptr(), f1.as_ptr(), g2.as_ptr(), f2.as_ptr(), terms.len(), out.as_mut_ptr()) })?;
+        let preps: Vec<&G2PreparedHip> = terms.iter().map(|t| t.1).collect();
+        match resident_indices(&preps) {
+            Some((table, qi)) => ok(unsafe { ffi::blsgpu_multi_miller_loop_prepared(ctx, g1.as_ptr(), f1.as_ptr(), g2.as_ptr(), f2.as_ptr(), qi.as_ptr(), table.0, terms.len(),
+                                                                                    out.as_mut_ptr()) })?,
+            None => ok(unsafe { ffi::blsgpu_multi_miller_loop(ctx, g1.as_ptr(), f1.as_ptr(), g2.as_ptr(), f2.as_ptr(), terms.len(), out.as_mut_ptr()) })?,
+        }
         Some(MillerLoopResult(fp12(&out)))
     });
     gpu.unwrap_or_else(|| crate::pairings::multi_miller_loop_cpu(terms))
@@ -226,7 +261,12 @@ pub fn multi_miller_loop_many(equations: &[&[(&G1Affine, &G2PreparedHip)]]) -> V
         for e in equations { off.push(off[off.len() - 1] + e.len() as u64); }
         let ((g1, f1), (g2, f2)) = (g1_wire(&p), g2_wire(&q));
         let mut out = alloc::vec![0u64; equations.len() * 72];
-        ok(unsafe { ffi::blsgpu_multi_miller_loop_many(ctx, g1.as_ptr(), f1.as_ptr(), g2.as_ptr(), f2.as_ptr(), off.as_ptr(), equations.len(), 1, out.as_mut_ptr()) })?;
+        let preps: Vec<&G2PreparedHip> = equations.iter().flat_map(|e| e.iter().map(|t| t.1)).collect();
+        match resident_indices(&preps) {
+            Some((table, qi)) => ok(unsafe { ffi::blsgpu_multi_miller_loop_prepared_many(ctx, g1.as_ptr(), f1.as_ptr(), g2.as_ptr(), f2.as_ptr(), qi.as_ptr(), table.0, off.as_ptr(),
+                                                                                         equations.len(), 1, out.as_mut_ptr()) })?,
+            None => ok(unsafe { ffi::blsgpu_multi_miller_loop_many(ctx, g1.as_ptr(), f1.as_ptr(), g2.as_ptr(), f2.as_ptr(), off.as_ptr(), equations.len(), 1, out.as_mut_ptr()) })?,
+        }
         Some(out.chunks_exact(72).map(|c| Gt(fp12(c))).collect::<Vec<_>>())
     });
     gpu.unwrap_or_else(cpu)

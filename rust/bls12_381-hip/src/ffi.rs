@@ -99,6 +99,14 @@ extern "C" {
     pub fn blsgpu_group_bases_free(b: *mut BlsgpuGroupBases);
     pub fn blsgpu_g1_msm_sharded(group: *mut BlsgpuGroup, bases: *const BlsgpuGroupBases, scalars: *const u8, n: usize, out_xyz: *mut u64) -> c_int;
     pub fn blsgpu_g2_msm_sharded(group: *mut BlsgpuGroup, bases: *const BlsgpuGroupBases, scalars: *const u8, n: usize, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_g1_msm_sharded_device(group: *mut BlsgpuGroup, bases: *const BlsgpuGroupBases, d_scalars: *const *const c_void, d_partials: *const *mut c_void) -> c_int;
+    pub fn blsgpu_g2_msm_sharded_device(group: *mut BlsgpuGroup, bases: *const BlsgpuGroupBases, d_scalars: *const *const c_void, d_partials: *const *mut c_void) -> c_int;
+    pub fn blsgpu_g1_partials_fold(group: *mut BlsgpuGroup, d_partials: *const *const c_void, lag: c_int, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_g2_partials_fold(group: *mut BlsgpuGroup, d_partials: *const *const c_void, lag: c_int, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_g1_partials_fold_device(group: *mut BlsgpuGroup, d_partials: *const *const c_void, lag: c_int, d_out_xyz: *mut c_void) -> c_int;
+    pub fn blsgpu_g2_partials_fold_device(group: *mut BlsgpuGroup, d_partials: *const *const c_void, lag: c_int, d_out_xyz: *mut c_void) -> c_int;
+    pub fn blsgpu_group_set_pipelining(group: *mut BlsgpuGroup, enabled: c_int) -> c_int;
+    pub fn blsgpu_group_synchronize(group: *mut BlsgpuGroup) -> c_int;
     pub fn blsgpu_pairing_batch_sharded(group: *mut BlsgpuGroup, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, n: usize, out_gt: *mut u64) -> c_int;
     pub fn blsgpu_miller_loop_batch_sharded(group: *mut BlsgpuGroup, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, n: usize, out_f: *mut u64) -> c_int;
     pub fn blsgpu_multi_miller_loop_sharded(group: *mut BlsgpuGroup, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, n: usize, final_exp: c_int, out: *mut u64) -> c_int;

@@ -51,6 +51,17 @@ int main(int argc, char** argv) {
     auto pb = grp.pairing_batch({ga, G1Affine::generator(), G1Affine::identity()}, {hb, G2Affine::generator(), hb});
     REQUIRE(pb[0] == p && pb[1] == g && pb[2] == Gt::identity());
   }
+  // round 5: G2Prepared resident on the device (`From<G2Affine> for G2Prepared` once, evaluated by every later multi_miller_loop)
+  {
+    auto res = G2Prepared::resident_many({hb, G2Affine::generator()});
+    REQUIRE(res[0].coeffs().size() == 68 * 36);
+    auto ml2 = multi_miller_loop({{ga, res[0]}, {G1Affine::identity(), res[0]}, {G1Affine::generator(), res[1]}});
+    REQUIRE(ml2.f == ml.f);                                           // the raw Miller value, limb for limb
+    auto mixed = multi_miller_loop({{ga, G2Prepared(hb)}, {G1Affine::generator(), res[1]}});
+    REQUIRE(mixed.final_exponentiation() == p + g);
+    auto eq2 = multi_miller_loop_many({{{ga, res[0]}, {G1Affine::generator(), res[1]}}, {}, {{ga, G2Prepared(hb)}}});
+    REQUIRE(eq2.size() == 3 && eq2[0] == p + g && eq2[1] == Gt::identity() && eq2[2] == p);
+  }
   std::printf("host mirror ok\n");
   return 0;
 }

@@ -2258,3 +2258,63 @@ def test_bls_verify_batch_from_bytes_vs_oracle(ctx, mode):
     want_all = np.where(pok == 0, 2, np.where(sok == 0, 3, (lhs == rhs).all(axis=1).astype(np.uint8)))
     assert np.array_equal(got, want_all.astype(np.uint8)) and valid.sum() == n - 2
     assert ctx.bls_verify_batch(mode, pk_b[:0], sig_b[:0], [], dst).shape == (0,)
+
+
+@pytest.mark.parametrize("members", [1, 3, 8])
+def test_device_group_pipelined_device_pointer_msms(ctx, members):
+    """the asynchronous group path (blsgpu_g{1,2}_msm_sharded_device + blsgpu_g{1,2}_partials_fold, persistent worker threads, pipelining
+    on): six MSMs with different scalars in flight over logical members on device 0, every folded result against the single-context MSM
+    and the discrete-log identity; group_synchronize reports a non-canonical scalar of an asynchronous call"""
+    import torch
+    import bls12_381_amd as b
+    from bls12_381_amd import synthetic as sy
+    dev = torch.device("cuda", 0)
+    grp = b.Group([0] * members)
+    grp.set_pipelining(True)
+    for gid, n in ((1, 20011), (2, 3001)):
+        sizes = grp.shard_sizes(n)
+        kb = sy.scalars(n, 800 + gid)
+        gb = grp.bases_from_scalars(gid, kb)
+        single = ctx.bases_from_scalars(gid, kb)
+        sets = [sy.scalars(n, 810 + gid + 10 * j) for j in range(6)]
+        lo = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+        d_s = [[torch.from_numpy(sets[j][lo[k]:lo[k + 1]].copy()).to(dev) for k in range(members)] for j in range(6)]
+        w = 18 if gid == 1 else 36
+        d_o = [[torch.zeros(w, dtype=torch.int64, device=dev) for _ in range(members)] for _ in range(4)]
+        torch.cuda.synchronize()
+        got = []
+        for j in range(6):
+            grp.msm_sharded_device(gb, [t.data_ptr() for t in d_s[j]], [t.data_ptr() for t in d_o[j & 3]])
+            if j >= 2:
+                got.append(grp.partials_fold(gid, [t.data_ptr() for t in d_o[(j - 2) & 3]], lag=2))
+        got.append(grp.partials_fold(gid, [t.data_ptr() for t in d_o[4 & 3]], lag=1))
+        got.append(grp.partials_fold(gid, [t.data_ptr() for t in d_o[5 & 3]], lag=0))
+        grp.synchronize()
+        for j in range(6):
+            a = ctx.batch_normalize(gid, got[j][None, :]); want = ctx.batch_normalize(gid, ctx.msm(single, sets[j])[None, :])
+            assert np.array_equal(a[0], want[0]) and np.array_equal(a[1], want[1]), (gid, j)
+        tot = sy.dot_mod_r(kb, sets[3])
+        ref = ctx.bases_from_scalars(gid, [tot]).download()
+        a = ctx.batch_normalize(gid, got[3][None, :])
+        assert np.array_equal(a[0][0], ref[0][0]) and a[1][0] == ref[1][0]
+        # the same with the fold queued on the device (no host round trip): nine MSMs, every fold lagging two calls behind
+        d_f = [torch.zeros(w, dtype=torch.int64, device=dev) for _ in range(9)]
+        for j in range(9):
+            grp.msm_sharded_device(gb, [t.data_ptr() for t in d_s[j % 6]], [t.data_ptr() for t in d_o[j & 3]])
+            if j >= 2:
+                grp.partials_fold_device(gid, [t.data_ptr() for t in d_o[(j - 2) & 3]], d_f[j - 2].data_ptr(), lag=2)
+        grp.partials_fold_device(gid, [t.data_ptr() for t in d_o[7 & 3]], d_f[7].data_ptr(), lag=1)
+        grp.partials_fold_device(gid, [t.data_ptr() for t in d_o[8 & 3]], d_f[8].data_ptr(), lag=0)
+        grp.synchronize()
+        for j in range(9):
+            a = ctx.batch_normalize(gid, d_f[j].cpu().numpy().view(np.uint64)[None, :]); want = ctx.batch_normalize(gid, got[j % 6][None, :])
+            assert np.array_equal(a[0], want[0]) and np.array_equal(a[1], want[1]), (gid, j)
+        if gid == 1:
+            bad = sets[0].copy(); bad[lo[members - 1]] = 0xFF                    # >= r, in the last member's slice
+            d_bad = [torch.from_numpy(bad[lo[k]:lo[k + 1]].copy()).to(dev) for k in range(members)]
+            grp.msm_sharded_device(gb, [t.data_ptr() for t in d_bad], [t.data_ptr() for t in d_o[0]])
+            with pytest.raises(b.BlsGpuError, match="group member %d" % (members - 1)):
+                grp.synchronize()
+            grp.synchronize()
+        gb.free()
+    grp.close()

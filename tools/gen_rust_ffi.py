@@ -23,7 +23,7 @@ C_TO_RUST = {
     "const char*": "*const c_char", "const int*": "*const c_int",
     "blsgpu_group*": "*mut BlsgpuGroup", "const blsgpu_group*": "*const BlsgpuGroup", "blsgpu_group**": "*mut *mut BlsgpuGroup",
     "blsgpu_g2_prepared*": "*mut BlsgpuG2Prepared", "const blsgpu_g2_prepared*": "*const BlsgpuG2Prepared", "blsgpu_g2_prepared**": "*mut *mut BlsgpuG2Prepared",
-    "const uint32_t*": "*const u32", "uint32_t*": "*mut u32", "const void* const*": "*const *const c_void", "void* const*": "*const *mut c_void", "const size_t*": "*const usize",
+    "const uint32_t*": "*const u32", "uint32_t*": "*mut u32", "const void*const*": "*const *const c_void", "void*const*": "*const *mut c_void", "const size_t*": "*const usize",
     "blsgpu_group_bases*": "*mut BlsgpuGroupBases", "const blsgpu_group_bases*": "*const BlsgpuGroupBases", "blsgpu_group_bases**": "*mut *mut BlsgpuGroupBases",
 }
 
