@@ -43,6 +43,7 @@ SIGNATURES = {
     "blsgpu_g2_msm": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
     "blsgpu_g1_msm_device": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
     "blsgpu_g2_msm_device": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
+    "blsgpu_set_bases_cache": (c_int, [c_vp, c_int]),
     "blsgpu_g1_msm_host": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g2_msm_host": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_fr_op": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp, c_vp]),

@@ -297,6 +297,10 @@ class Context:
         check(fn(self.h, _ptr(buf), _ptr(s), n, _ptr(out)), "msm_bytes")
         return out.tobytes()
 
+    def set_bases_cache(self, entries):
+        """keep the base arrays of repeated one-shot MSMs (`msm_host`, the mirrored `msm_g1` / `msm_g2`) resident: see blsgpu_set_bases_cache"""
+        check(self.lib.blsgpu_set_bases_cache(self.h, int(entries)), "set_bases_cache")
+
     def msm_host(self, group, xy, infinity, scalars):
         w = 12 if group == 1 else 24
         xy = _u64(xy, (-1, w))

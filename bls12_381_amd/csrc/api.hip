@@ -133,11 +133,16 @@ struct blsgpu_ctx {
   int mmlp_k = 0;                       // A/B hook (env BLSGPU_MMLP_K): terms per accumulator of ONE long product (0 = automatic)
   int mml_impl = 0;                     // A/B hook (env BLSGPU_MML_IMPL): kernel behind blsgpu_multi_miller_loop_device with K > 1 -- 0 = automatic, 1 = k_multi_miller_shared
                                         // (rounds 2-4), 4 = k_mml_prep_quad with no prepared term
+  struct BasesCacheEntry { int group; size_t n; uint64_t fp; blsgpu_bases* b; unsigned long long last; };
+  std::vector<BasesCacheEntry> bcache;  // blsgpu_set_bases_cache: base arrays of repeated one-shot MSMs kept resident
+  int bcache_cap = 0; unsigned long long bcache_tick = 0;
   DevBuf mmlp_work, mmlp_out;           // prepared Miller loops (prep.hip.h): per-quad work area, partial products of one long product
+  void* pin_stage = nullptr; hipEvent_t pin_ev[8] = {};      // pinned bounce buffers of staged_upload
   DevBuf gt_one; bool gt_one_ready = false; hipEvent_t ev_gt_one = nullptr;      // the wire form of Fp12::one() (blsgpu_gt_is_identity_device, bulk verification)
   DevBuf ver;                           // bulk verification (blsgpu_bls_verify_batch): every intermediate of the chain
   blsgpu_g2_prepared* ver_table = nullptr;   // ... and the resident `G2Prepared` of -G2 for mode 1
   bool ver_consts_ready = false; hipEvent_t ev_ver = nullptr;
+  hipStream_t ver_stream[2] = {nullptr, nullptr}; hipEvent_t ev_ver_side[3] = {};     // the independent stages of the chain run side by side
   DevBuf fb_stage;                      // staging of the one-byte scalars the tables are built from
   DevBuf fb_table[2];                   // fixed-base comb tables of the generators (k_fixed_base): 32 x 256 affine records each, built at first use
   hipEvent_t ev_fb[2] = {};             // recorded where a table was built; awaited by every user (the caller may switch streams)
@@ -164,6 +169,54 @@ struct blsgpu_bases {
   // optional window-shifted tables: table[w * n + i] = [2^(table_c * w)] P_i   (blsgpu_bases_precompute)
   u32* table = nullptr; int table_c = 0, table_w = 0;
 };
+
+// Pageable host memory -> device.  hipMemcpyAsync from pageable memory is staged by the runtime on ONE host thread (measured here:
+// ~4 GB/s, 7.6 ms for the 32 MB of scalars of a 2^20-point MSM -- twice the MSM itself); large uploads of the host-pointer entry points
+// therefore go through pinned bounce buffers of the context, the host-side copy split over up to four threads, every chunk's DMA queued
+// on the context's stream as soon as it is staged.  On return everything is queued on the stream (the source may be reused at once).
+constexpr size_t STAGE_CHUNK = (size_t)2 << 20;
+constexpr int STAGE_THREADS = 4;
+static int staged_upload(blsgpu_ctx* c, void* dst, const void* src, size_t bytes) {
+  bool direct = bytes < ((size_t)4 << 20);
+  if (!direct) {
+    // a source the runtime already knows as pinned (hipHostMalloc / hipHostRegister) is DMA-able as it is
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, src) == hipSuccess) direct = at.type == hipMemoryTypeHost;
+    else (void)hipGetLastError();
+  }
+  if (direct) { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream)); return BLSGPU_OK; }
+  if (!c->pin_stage) {
+    if (hipHostMalloc(&c->pin_stage, STAGE_CHUNK * 2 * STAGE_THREADS, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError(); c->pin_stage = nullptr;
+      HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream)); return BLSGPU_OK;        // no pinned memory: the plain path
+    }
+    for (auto& e : c->pin_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const size_t nchunks = (bytes + STAGE_CHUNK - 1) / STAGE_CHUNK;
+  const int T = (int)(nchunks < (size_t)STAGE_THREADS ? nchunks : (size_t)STAGE_THREADS);
+  std::atomic<int> failed{0};
+  auto work = [&](int t) {
+    if (hipSetDevice(c->device) != hipSuccess) { failed = 1; return; }
+    const size_t lo = nchunks * (size_t)t / (size_t)T, hi = nchunks * (size_t)(t + 1) / (size_t)T;
+    for (size_t j = lo; j < hi && !failed; j++) {
+      const int b = (int)((j - lo) & 1);
+      uint8_t* pin = (uint8_t*)c->pin_stage + ((size_t)t * 2 + (size_t)b) * STAGE_CHUNK;
+      hipEvent_t ev = c->pin_ev[t * 2 + b];
+      if (j - lo >= 2 && hipEventSynchronize(ev) != hipSuccess) { failed = 1; return; }        // the DMA that last read this bounce buffer
+      const size_t off = j * STAGE_CHUNK, len = off + STAGE_CHUNK <= bytes ? STAGE_CHUNK : bytes - off;
+      memcpy(pin, (const uint8_t*)src + off, len);
+      if (hipMemcpyAsync((uint8_t*)dst + off, pin, len, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipEventRecord(ev, c->stream) != hipSuccess) { failed = 1; return; }
+    }
+  };
+  std::vector<std::thread> th;
+  try { for (int t = 1; t < T; t++) th.emplace_back(work, t); } catch (...) { failed = 1; }
+  if (!failed) work(0);
+  for (auto& x : th) x.join();
+  // the bounce buffers are reused by the next upload: their last DMAs must have been issued -- and read -- before then
+  for (int k = 0; k < 2 * T && !failed; k++) if (hipEventSynchronize(c->pin_ev[k]) != hipSuccess) failed = 1;
+  if (failed) { (void)hipGetLastError(); g_err = "staged upload failed"; return BLSGPU_ERR_HIP; }
+  return BLSGPU_OK;
+}
 
 template <class F> struct GroupTag;
 template <> struct GroupTag<FpPolicy> { static constexpr int id = 1; };
@@ -534,8 +587,13 @@ extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
   for (auto& e : c->ev_fr) if (e) hipEventDestroy(e);
   for (auto& e : c->ev_fb) if (e) hipEventDestroy(e);
   if (c->ev_gt_one) hipEventDestroy(c->ev_gt_one);
+  if (c->pin_stage) hipHostFree(c->pin_stage);
+  for (auto e : c->pin_ev) if (e) hipEventDestroy(e);
   if (c->ev_ver) hipEventDestroy(c->ev_ver);
+  for (auto q : c->ver_stream) if (q) hipStreamDestroy(q);
+  for (auto e : c->ev_ver_side) if (e) hipEventDestroy(e);
   if (c->ver_table) blsgpu_g2_prepared_free(c->ver_table);
+  for (auto& e : c->bcache) if (e.b) blsgpu_bases_free(e.b);
   if (c->acc_stream) hipStreamDestroy(c->acc_stream);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
@@ -690,7 +748,7 @@ static int bases_upload(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, s
   HIPCHK(hipSetDevice(c->device));
   size_t xb = n * 2 * Wire<F>::WORDS * 4;
   if (c->io_a.reserve(xb ? xb : 16) || c->flags_a.reserve(n ? n : 16)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
-  if (n) HIPCHK(hipMemcpyAsync(c->io_a.p, xy, xb, hipMemcpyHostToDevice, c->stream));
+  if (n) { int ru = staged_upload(c, c->io_a.p, xy, xb); if (ru) return ru; }
   if (n && inf) HIPCHK(hipMemcpyAsync(c->flags_a.p, inf, n, hipMemcpyHostToDevice, c->stream));
   int rc = bases_import<F>(c, c->io_a.p, inf ? c->flags_a.p : nullptr, n, out, oneshot);
   if (rc) return rc;
@@ -1173,7 +1231,7 @@ static int msm_host(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, cons
   SyncStatus ss(c);
   int rc = ss.begin();
   if (rc) return rc;
-  if (n) HIPCHK(hipMemcpyAsync(c->io_b.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+  if (n) { int ru = staged_upload(c, c->io_b.p, scalars, n * 32); if (ru) return ru; }
   rc = msm_device<F>(c, bases, first, c->io_b.p, n, c->io_out.p);
   if (rc) return rc;
   rc = blsgpu_join(c);
@@ -1215,7 +1273,7 @@ static int msm_many_host(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first,
   SyncStatus ss(c);
   int rc = ss.begin();
   if (rc) return rc;
-  if (n) HIPCHK(hipMemcpyAsync(c->io_b.p, scalars, n * k * 32, hipMemcpyHostToDevice, c->stream));
+  if (n) { int ru = staged_upload(c, c->io_b.p, scalars, n * k * 32); if (ru) return ru; }
   rc = msm_many_device<F>(c, bases, first, c->io_b.p, n, k, c->io_out.p);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, k * ob, hipMemcpyDeviceToHost, c->stream));
@@ -1226,14 +1284,57 @@ static int msm_many_host(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first,
 }
 extern "C" int blsgpu_g1_msm_many(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, size_t k, uint64_t* out) { CTX_CLAIM(c); return msm_many_host<FpPolicy>(c, b, first, s, n, k, out); }
 extern "C" int blsgpu_g2_msm_many(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, size_t k, uint64_t* out) { CTX_CLAIM(c); return msm_many_host<Fp2Policy>(c, b, first, s, n, k, out); }
+// Repeated one-shot MSMs over the SAME base array (a drop-in caller that passes its SRS slice on every call: the reference's surface
+// has no place for a resident handle).  Opt-in (blsgpu_set_bases_cache): a base array is recognised by its length and a fingerprint of
+// 64 evenly spaced points -- the caller promises not to change an array it passes again.  First sight: the one-shot path as always.
+// Second sight: the set is uploaded as RESIDENT bases (subgroup test, endomorphism images) and kept; from then on a call only moves its
+// scalars, i.e. it runs on the headline path (bases resident, 32 B per scalar over PCIe).
+static uint64_t bases_fingerprint(const uint64_t* xy, const uint8_t* inf, size_t n, size_t words) {
+  uint64_t h = 1469598103934665603ull ^ (uint64_t)n;
+  const size_t step = n > 64 ? n / 64 : 1;
+  for (size_t i = 0; i < n; i += step) {
+    for (size_t k = 0; k < words; k++) { h ^= xy[i * words + k]; h *= 1099511628211ull; }
+    h ^= inf ? inf[i] : 0; h *= 1099511628211ull;
+  }
+  for (size_t k = 0; k < words && n; k++) { h ^= xy[(n - 1) * words + k]; h *= 1099511628211ull; }
+  return h;
+}
 template <class F>
 static int msm_oneshot(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) {
+  if (c && c->bcache_cap > 0 && n >= 1024 && xy) {
+    constexpr size_t W = 2 * Wire<F>::WORDS / 2;            // u64 per affine point
+    const uint64_t fp = bases_fingerprint(xy, inf, n, W);
+    blsgpu_ctx::BasesCacheEntry* hit = nullptr;
+    for (auto& e : c->bcache) if (e.group == GroupTag<F>::id && e.n == n && e.fp == fp) hit = &e;
+    if (hit) {
+      hit->last = ++c->bcache_tick;
+      if (!hit->b) {                                          // second sight: make it resident
+        int rc = bases_upload<F>(c, xy, inf, n, &hit->b, false);
+        if (rc) { hit->b = nullptr; return rc; }
+      }
+      return msm_host<F>(c, hit->b, 0, s, n, out);
+    }
+    if ((int)c->bcache.size() >= c->bcache_cap) {             // evict the least recently used entry
+      size_t lru = 0;
+      for (size_t k = 1; k < c->bcache.size(); k++) if (c->bcache[k].last < c->bcache[lru].last) lru = k;
+      if (c->bcache[lru].b) blsgpu_bases_free(c->bcache[lru].b);
+      c->bcache.erase(c->bcache.begin() + (long)lru);
+    }
+    c->bcache.push_back({GroupTag<F>::id, n, fp, nullptr, ++c->bcache_tick});
+  }
   blsgpu_bases* b = nullptr;
   int rc = bases_upload<F>(c, xy, inf, n, &b, true);
   if (rc) return rc;
   rc = msm_host<F>(c, b, 0, s, n, out);
   blsgpu_bases_free(b);
   return rc;
+}
+extern "C" int blsgpu_set_bases_cache(blsgpu_ctx* c, int entries) { CTX_CLAIM(c);
+  if (!c || entries < 0 || entries > 8) return bad("set_bases_cache: entries must be in [0, 8]");
+  HIPCHK(hipSetDevice(c->device));
+  c->bcache_cap = entries;
+  while ((int)c->bcache.size() > entries) { if (c->bcache.back().b) blsgpu_bases_free(c->bcache.back().b); c->bcache.pop_back(); }
+  return BLSGPU_OK;
 }
 extern "C" int blsgpu_g1_msm_host(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) { CTX_CLAIM(c); return msm_oneshot<FpPolicy>(c, xy, inf, s, n, out); }
 extern "C" int blsgpu_g2_msm_host(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) { CTX_CLAIM(c); return msm_oneshot<Fp2Policy>(c, xy, inf, s, n, out); }
@@ -1276,8 +1377,7 @@ static int mul_batch_host(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf,
   SyncStatus ss(c);
   int rc = ss.begin();
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(c->io_a.p, xy, n * 2 * WB, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(c->io_b.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+  { int ru = staged_upload(c, c->io_a.p, xy, n * 2 * WB); if (!ru) ru = staged_upload(c, c->io_b.p, scalars, n * 32); if (ru) return ru; }
   if (inf) HIPCHK(hipMemcpyAsync(c->flags_a.p, inf, n, hipMemcpyHostToDevice, c->stream));
   rc = mul_batch_device<F>(c, c->io_a.p, inf ? c->flags_a.p : nullptr, c->io_b.p, n, c->io_out.p);
   if (rc) return rc;
@@ -2369,16 +2469,37 @@ extern "C" int blsgpu_bls_verify_batch_device(blsgpu_ctx* c, int mode, const voi
   }
   uint8_t* fl = base + o_fl;
   uint8_t *a_inf = fl, *a_ok = fl + n, *b_inf = fl + 2 * n, *b_ok = fl + 3 * n, *h_inf = fl + 4 * n, *is_one = fl + 5 * n;
-  // 1. checked decoding (`from_compressed`: on the curve, in the subgroup)
-  int rc = point_decode_device<FpPolicy>(c, mode == 0 ? d_pk : d_sig, n, 1, 1, base + o_a, a_inf, a_ok);
+  // 1.-3. three independent, latency-shaped stages (one lane or lane pair per point, a few thousand field multiplications each): they run
+  // side by side on the context's stream and two side streams and meet again before the terms are assembled
+  if (!c->ver_stream[0]) {
+    for (auto& q : c->ver_stream) HIPCHK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+    for (auto& e : c->ev_ver_side) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  hipStream_t main_stream = c->stream;
+  HIPCHK(hipEventRecord(c->ev_ver_side[0], main_stream));
+  int rc = BLSGPU_OK;
+  {
+    // checked decoding of the G2-side points (`from_compressed`: on the curve, in the subgroup) on side stream 0
+    c->stream = c->ver_stream[0];
+    hipError_t e = hipStreamWaitEvent(c->stream, c->ev_ver_side[0], 0);
+    if (e == hipSuccess) rc = point_decode_device<Fp2Policy>(c, mode == 0 ? d_sig : d_pk, n, 1, 1, base + o_b, b_inf, b_ok);
+    if (e == hipSuccess && !rc) e = hipEventRecord(c->ev_ver_side[1], c->stream);
+    // hash the messages to the signature's group and normalise, on side stream 1
+    c->stream = c->ver_stream[1];
+    if (e == hipSuccess && !rc) e = hipStreamWaitEvent(c->stream, c->ev_ver_side[0], 0);
+    if (e == hipSuccess && !rc) rc = blsgpu_hash_to_curve_device(c, mode == 0 ? 2 : 1, d_msgs, d_offsets, n, d_dst, dst_len, 0, base + o_hp);
+    if (e == hipSuccess && !rc)
+      rc = mode == 0 ? batch_normalize_device<Fp2Policy>(c, base + o_hp, n, base + o_h, h_inf) : batch_normalize_device<FpPolicy>(c, base + o_hp, n, base + o_h, h_inf);
+    if (e == hipSuccess && !rc) e = hipEventRecord(c->ev_ver_side[2], c->stream);
+    c->stream = main_stream;
+    if (e != hipSuccess) return fail("bls_verify_batch: side streams", e, __LINE__);
+    if (rc) return rc;
+  }
+  // checked decoding of the G1-side points on the context's stream, which then waits for the two side streams
+  rc = point_decode_device<FpPolicy>(c, mode == 0 ? d_pk : d_sig, n, 1, 1, base + o_a, a_inf, a_ok);
   if (rc) return rc;
-  rc = point_decode_device<Fp2Policy>(c, mode == 0 ? d_sig : d_pk, n, 1, 1, base + o_b, b_inf, b_ok);
-  if (rc) return rc;
-  // 2. hash the messages to the signature's group, 3. normalise
-  rc = blsgpu_hash_to_curve_device(c, mode == 0 ? 2 : 1, d_msgs, d_offsets, n, d_dst, dst_len, 0, base + o_hp);
-  if (rc) return rc;
-  rc = mode == 0 ? batch_normalize_device<Fp2Policy>(c, base + o_hp, n, base + o_h, h_inf) : batch_normalize_device<FpPolicy>(c, base + o_hp, n, base + o_h, h_inf);
-  if (rc) return rc;
+  HIPCHK(hipStreamWaitEvent(main_stream, c->ev_ver_side[1], 0));
+  HIPCHK(hipStreamWaitEvent(main_stream, c->ev_ver_side[2], 0));
   // 4. the two terms of every equation
   const uint8_t *pk_inf = mode == 0 ? a_inf : b_inf, *pk_ok = mode == 0 ? a_ok : b_ok, *sig_inf = mode == 0 ? b_inf : a_inf, *sig_ok = mode == 0 ? b_ok : a_ok;
   hipLaunchKernelGGL(k_bls_assemble, dim3(nblk(n + 1, 256)), dim3(256), 0, c->stream, mode, (const u32*)(base + (mode == 0 ? o_a : o_b)), pk_inf, pk_ok,
@@ -2694,11 +2815,14 @@ static int partials_fold_device(blsgpu_group* g, const void* const* d_partials, 
     if (r) return r;
     HIPCHK(hipSetDevice(c->device));
     if (g->ev_sum_used[row]) HIPCHK(hipStreamWaitEvent(c->stream, g->ev_sum[row], 0));       // the sum that last read this staging row
-    HIPCHK(hipMemcpyPeerAsync(stage + k * PB, c0->device, d_partials[k], c->device, PB, c->stream));
+    // (a plain device-to-device copy for members on member 0's device: the peer form need not be asynchronous there)
+    if (c->device == c0->device) HIPCHK(hipMemcpyAsync(w == 1 ? d_out : (void*)(stage + k * PB), d_partials[k], PB, hipMemcpyDeviceToDevice, c->stream));
+    else HIPCHK(hipMemcpyPeerAsync(stage + k * PB, c0->device, d_partials[k], c->device, PB, c->stream));
     HIPCHK(hipEventRecord(g->ev_copy[k], c->stream));
     return (int)BLSGPU_OK;
   });
   if (rc) return rc;
+  if (w == 1) return BLSGPU_OK;                 // one member: its partial sum IS the result (copied straight to d_out above)
   CTX_CLAIM(c0);
   HIPCHK(hipSetDevice(c0->device));
   for (size_t k = 1; k < w; k++) HIPCHK(hipStreamWaitEvent(c0->stream, g->ev_copy[k], 0));

@@ -199,6 +199,9 @@ k_mul_batch_gls(const u32* __restrict__ xy, const uint8_t* __restrict__ inf, con
       sgn[j] |= over << w;
     }
   }
+  u64 magp[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) magp[j] = (u64)mag[j][0] | ((u64)mag[j][1] << 32);
   Proj<F> tab[8];
   {
     Proj<F> p;
@@ -217,15 +220,14 @@ k_mul_batch_gls(const u32* __restrict__ xy, const uint8_t* __restrict__ inf, con
 #pragma nounroll
   for (int w = 15; w >= 0; w--) {
     if (w != 15) { acc = pt_double<F>(acc); acc = pt_double<F>(acc); acc = pt_double<F>(acc); acc = pt_double<F>(acc); }
-#pragma unroll
+#pragma nounroll
     for (int j = 0; j < 4; j++) {
-      const u32 d = (mag[j][w >> 3] >> ((w & 7) * 4)) & 15u;
+      const u32 d = (u32)(magp[j] >> (4 * w)) & 15u;
       const bool neg_d = (((sgn[j] >> w) & 1u) ^ flip[j]) != 0;
       Proj<F> t = tab[d ? d - 1 : 0];
       if (!d) t = pt_identity<F>();
-      if (j == 1) t = pt_psi<F>(t);
-      if (j == 2) t = pt_psi2<F>(t);
-      if (j == 3) t = pt_psi<F>(pt_psi2<F>(t));
+      if (j & 1) t = pt_psi<F>(t);
+      if (j & 2) t = pt_psi2<F>(t);
       t.y = select(neg_d, F::st(neg(t.y)), t.y);
       acc = pt_add<F>(acc, t);
     }

@@ -134,6 +134,12 @@ int blsgpu_g1_msm_many(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first,
 int blsgpu_g2_msm_many(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const uint8_t* scalars, size_t n, size_t k, uint64_t* out_xyz);
 int blsgpu_g1_msm_many_device(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const void* d_scalars, size_t n, size_t k, void* d_out_xyz);
 int blsgpu_g2_msm_many_device(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const void* d_scalars, size_t n, size_t k, void* d_out_xyz);
+/* Opt-in cache for callers that pass the SAME base array to the one-shot entry points again and again (a drop-in `msm(&bases, &scalars)`
+ * over an SRS: the reference's surface has no resident handle).  entries = 0 (default) switches it off and drops what is cached.  An
+ * array is recognised by its length and a fingerprint of 64 evenly spaced points, so the caller promises NOT to modify an array it
+ * passes again.  First sight: the one-shot path as always.  Second sight: the set is uploaded as resident bases (subgroup test,
+ * endomorphism images) and kept; later calls only move their scalars and run on the path of blsgpu_g1_msm. */
+int blsgpu_set_bases_cache(blsgpu_ctx* ctx, int entries);
 /* One-shot convenience: upload, multiply, free.  No subgroup test and no endomorphism split (plain windows: exact for every
  * curve point) unless blsgpu_set_assume_subgroup(ctx, 1) -- see the subgroup contract above.  For a set used more than once
  * upload it (blsgpu_g1_bases_upload) and call blsgpu_g1_msm. */

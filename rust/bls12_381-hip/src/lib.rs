@@ -168,6 +168,31 @@ pub fn multi_miller_loop(gpu: &Gpu, terms: &[(&G1Affine, &G2Affine)]) -> Result<
     Ok(GtLimbs(out))
 }
 
+/// `G2Prepared` values resident on the device (src/pairings.rs:487-546: the 68 line-coefficient triples of FIXED G2 arguments, computed
+/// once by `blsgpu_g2_prepare`); the prepared Miller loops name them by index.
+pub struct PreparedG2<'a> { gpu: &'a Gpu, handle: *mut ffi::BlsgpuG2Prepared, len: usize }
+impl<'a> PreparedG2<'a> {
+    pub fn new(gpu: &'a Gpu, points: &[G2Affine]) -> Result<Self, Error> {
+        let (g2, f2) = g2_wire(gpu, points)?;
+        let mut handle = core::ptr::null_mut();
+        check(unsafe { ffi::blsgpu_g2_prepare(gpu.ctx, g2.as_ptr(), f2.as_ptr(), points.len(), &mut handle) })?;
+        Ok(PreparedG2 { gpu, handle, len: points.len() })
+    }
+    pub fn len(&self) -> usize { self.len }
+    pub fn is_empty(&self) -> bool { self.len == 0 }
+    /// `multi_miller_loop` over terms (P_i, Q_i) with Q_i = table[i_q] (`Ok(index)`) or a fresh point (`Err(&G2Affine)`, lines on the fly)
+    pub fn multi_miller_loop(&self, terms: &[(&G1Affine, Result<u32, &G2Affine>)]) -> Result<GtLimbs, Error> {
+        let p: Vec<G1Affine> = terms.iter().map(|t| *t.0).collect();
+        let q: Vec<G2Affine> = terms.iter().map(|t| match t.1 { Ok(_) => G2Affine::identity(), Err(q) => *q }).collect();
+        let qi: Vec<u32> = terms.iter().map(|t| match t.1 { Ok(i) => i, Err(_) => u32::MAX }).collect();
+        let ((g1, f1), (g2, f2)) = (g1_wire(self.gpu, &p)?, g2_wire(self.gpu, &q)?);
+        let mut out = [0u64; 72];
+        check(unsafe { ffi::blsgpu_multi_miller_loop_prepared(self.gpu.ctx, g1.as_ptr(), f1.as_ptr(), g2.as_ptr(), f2.as_ptr(), qi.as_ptr(), self.handle, terms.len(), out.as_mut_ptr()) })?;
+        Ok(GtLimbs(out))
+    }
+}
+impl Drop for PreparedG2<'_> { fn drop(&mut self) { unsafe { ffi::blsgpu_g2_prepared_free(self.handle) } } }
+
 /// N independent `multi_miller_loop(terms).final_exponentiation()` in ONE device call (bulk signature verification: one product of
 /// k pairings per equation, src/pairings.rs:554-603, 817-824, 48-176): the `Gt` limbs of every equation; `final_exp = false` returns
 /// the raw `MillerLoopResult` limbs.  An equation without terms gives `Gt::identity()` / `MillerLoopResult::default()`.

@@ -2318,3 +2318,45 @@ def test_device_group_pipelined_device_pointer_msms(ctx, members):
             grp.synchronize()
         gb.free()
     grp.close()
+
+
+def test_bases_cache_for_repeated_one_shot_msms(kats):
+    """blsgpu_set_bases_cache: the same base array passed to the one-shot entry point again -- first sight one-shot (untested, plain
+    windows), second sight resident (tested, endomorphism images), later calls reuse it -- always the reference's group element, also for
+    a set with a point outside the subgroup (resident state 0: plain windows), another array of the same length, eviction, switching off"""
+    import bls12_381_amd as b
+    c = b.Context(0)
+    c.set_bases_cache(2)
+    n = 3000
+    kb, ks = _rand_scalars_np(n, 1201)
+    xy, inf = c.bases_from_scalars(1, kb).download()
+    want_for = lambda ss: g1aff_w(o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, sum(k * s for k, s in zip(ks, ss)) % o.R_ORDER)))
+    for call in range(4):
+        sb, ss = _rand_scalars_np(n, 1210 + call)
+        got = c.batch_normalize(1, c.msm_host(1, xy, inf, sb)[None, :])
+        ex, ei = want_for(ss)
+        assert np.array_equal(got[0][0], ex) and got[1][0] == ei, call
+    # another array of the same length (different fingerprint), then the first again; a third array evicts the least recently used
+    kb2, ks2 = _rand_scalars_np(n, 1202)
+    xy2, inf2 = c.bases_from_scalars(1, kb2).download()
+    sb, ss = _rand_scalars_np(n, 1220)
+    for arr, keys in ((xy2, ks2), (xy2, ks2), (xy, ks), (xy2, ks2)):
+        got = c.batch_normalize(1, c.msm_host(1, arr, None, sb)[None, :])
+        tot = sum(k * s for k, s in zip(keys, ss)) % o.R_ORDER
+        ex, ei = g1aff_w(o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, tot)))
+        assert np.array_equal(got[0][0], ex) and got[1][0] == ei
+    # a set with an off-subgroup point: the resident form falls back to plain windows and stays exact (reference `multiply` + Sum)
+    off = _off_subgroup_points(kats, 1)
+    xy3 = xy.copy(); xy3[7] = g1aff_w(off)[0]
+    small = 1100
+    sb3, ss3 = _rand_scalars_np(small, 1230)
+    want = o.g1_to_affine(o.g1_msm([off if i == 7 else o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, ks[i])) for i in range(16)], ss3[:16]))
+    for _ in range(3):
+        got = c.batch_normalize(1, c.msm_host(1, np.concatenate([xy3[:16], np.tile(xy3[:1], (small - 16, 1))]), None,
+                                              np.concatenate([sb3[:16], np.zeros((small - 16, 32), dtype=np.uint8)]))[None, :])
+        assert np.array_equal(got[0][0], g1aff_w(want)[0])
+    c.set_bases_cache(0)
+    got = c.batch_normalize(1, c.msm_host(1, xy, inf, sb)[None, :])
+    tot = sum(k * s for k, s in zip(ks, ss)) % o.R_ORDER
+    assert np.array_equal(got[0][0], g1aff_w(o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, tot)))[0])
+    c.close()

@@ -15,5 +15,9 @@ tools/pmc.sh prof_pair python tools/run_pairing.py pairing 16 3
 BLSGPU_PAIRING_LAYOUT=pair tools/pmc.sh prof_pair_lp python tools/run_pairing.py pairing 16 3
 tools/pmc.sh prof_mml python tools/run_pairing.py mml 18 3
 tools/pmc.sh prof_wide python tools/run_pairing.py pairing 8 20
-find gpurun_out/prof_msm gpurun_out/prof_pair gpurun_out/prof_pair_lp gpurun_out/prof_mml gpurun_out/prof_wide -name "*agent_info.csv" -delete
+# round 5: the prepared Miller loops (prep.hip.h)
+tools/pmc.sh prof_mmlp python tools/run_pairing.py mmlp 18 3
+tools/pmc.sh prof_eqp python tools/run_pairing.py eqp 16 3
+BLSGPU_MML_IMPL=4 tools/pmc.sh prof_mmlq python tools/run_pairing.py mml 18 3
+find gpurun_out/prof_msm gpurun_out/prof_pair gpurun_out/prof_pair_lp gpurun_out/prof_mml gpurun_out/prof_wide gpurun_out/prof_mmlp gpurun_out/prof_eqp gpurun_out/prof_mmlq -name "*agent_info.csv" -delete
 du -sh gpurun_out/prof_*

@@ -155,4 +155,13 @@ if one("prof_mml/stats/**/*kernel_trace.csv"):
 if one("prof_wide/stats/**/*kernel_trace.csv"):
     pairing("prof_wide", "k_pairing_wide", 256, "pairings", 4.8e6, "pairing_wide", "pairing 8 20",
             "wide layout: one pairing per 1024-lane workgroup, one workgroup per CU (the small-batch latency path)", 864, notes=WIDE_NOTES)
+if one("prof_mmlp/stats/**/*kernel_trace.csv"):
+    pairing("prof_mmlp", "k_mml_prep_quad", 262144, "terms", 2900 * 300, "mml_prepared", "mmlp 18 3",
+            "quad layout, eight PREPARED terms per shared accumulator (lines loaded from a resident G2Prepared table of four points)", 96, meta_key="k_mml_prep_quad")
+if one("prof_eqp/stats/**/*kernel_trace.csv"):
+    pairing("prof_eqp", "k_mml_prep_quad", 65536, "equations", (6900 + 2 * 2900) * 300, "equations_prepared", "eqp 16 3",
+            "quad layout, one accumulator per three-term equation: one unprepared term (running point in the coalesced work area) + two prepared terms", 3 * 96 + 192 + 576, meta_key="k_mml_prep_quad")
+if one("prof_mmlq/stats/**/*kernel_trace.csv"):
+    pairing("prof_mmlq", "k_mml_prep_quad", 262144, "terms", 2.07e6, "mml_quad_explicit", "mml 18 3 (BLSGPU_MML_IMPL=4)",
+            "quad layout, four UNPREPARED terms per shared accumulator, per-term state placed by hand (coalesced work area + LDS parking)", 288, meta_key="k_mml_prep_quad")
 print("profiles written for", RND)
