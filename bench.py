@@ -222,7 +222,13 @@ def setup(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if e.world == 1:
             s = socket.socket(); s.bind(("127.0.0.1", 0)); os.environ.setdefault("MASTER_PORT", str(s.getsockname()[1])); s.close()
-        if args.backend == "nccl":
+        if args.backend == "nccl" and not os.environ.get("BENCH_EAGER_PG"):
+            # NO device_id: binding the process group to the device creates the RCCL communicator eagerly, and with it every launch of this
+            # process got slower -- a one-rank run at 2^21 points took 6.9 ms per step against 5.7 ms, with NO collective inside the timed steps
+            # and unchanged kernel durations (1.2 ms of launch gaps per step; round 5, profiles/r05_group_compare.log).  The communicator is
+            # created by the first collective instead (torch.cuda.set_device above names the device).
+            dist.init_process_group("nccl", rank=e.rank, world_size=e.world)
+        elif args.backend == "nccl":                                              # diagnostic: the eager form of rounds 2-4
             dist.init_process_group("nccl", rank=e.rank, world_size=e.world, device_id=e.dev)
         else:
             dist.init_process_group(args.backend, rank=e.rank, world_size=e.world)
@@ -235,7 +241,7 @@ def setup(args):
 def fence(e):
     e.torch.cuda.synchronize()
     if e.multi:
-        e.dist.barrier()
+        e.dist.barrier(device_ids=[e.local_rank]) if e.dist.get_backend() == "nccl" else e.dist.barrier()
     e.torch.cuda.synchronize()
 
 
@@ -291,35 +297,66 @@ def run_msm(args, e):
     sb = synthetic.scalars(n, synthetic.SEED + 2 * rank)
     bases = ctx.bases_from_scalars(1, kb)                       # resident bases, built on the device
     d_scalars = torch.from_numpy(sb).to(dev)
-    d_out = [torch.zeros(18, dtype=torch.int64, device=dev) for _ in range(4)]      # up to four calls may be in flight
+    d_out = [torch.zeros(18, dtype=torch.int64, device=dev) for _ in range(8)]      # up to four calls in flight + the results the exchanges still read
     gathered = torch.zeros((world, 18), dtype=torch.int64, device=e.xdev) if multi else None
     d_fold = torch.zeros(18, dtype=torch.int64, device=dev)
     ctx.set_pipelining(True)         # the latency-bound tail of MSM i overlaps the chip-filling phases of MSM i+1
     state = {"i": 0}
-    LAG = 3                          # result i - 3 is consumed while MSMs i - 2 .. i are in flight (four pipeline slots, four output buffers)
+    LAG = 3                          # result i - 3 is consumed while MSMs i - 2 .. i are in flight (four pipeline slots)
+    # The exchange runs on a stream of its OWN: the front of an MSM waits for whatever is queued on the context's stream when it is launched
+    # (that is how it is ordered behind the producer of its scalars); with the exchange elsewhere a rank whose peers are late never holds its
+    # own next front back.  The context's stream is switched to the exchange stream for the join and the fold.  (Measured with one rank the
+    # two placements are equal -- 2.78 / 11.1 / 41.3 ms per step at 2^20 / 2^22 / 2^24 points against 2.77 / 11.0 / 41.0 on the context's
+    # stream, BENCH_EXCHANGE_MAIN=1 -- the ~1 ms per step the RCCL branch used to cost came from the eagerly created communicator: setup().)
+    main_stream = torch.cuda.current_stream()
+    xs = torch.cuda.Stream(device=dev) if (multi and e.xdev == dev) else None
+    ex_ev = [torch.cuda.Event() for _ in range(8)] if xs is not None else None
+    ex_used = [False] * 8
+    probe = os.environ.get("BENCH_EXCHANGE_PROBE", "")        # diagnostic: "join" / "gather" / "fold" run only that part of the exchange
+    if os.environ.get("BENCH_EXCHANGE_MAIN"):                 # diagnostic: the exchange on the context's stream (rounds 2-4)
+        xs_keep, xs = xs, None
 
-    def exchange(buf):
-        """the path's single exchange step: all-gather the per-rank partial sums, fold on every rank"""
-        all_gather_rows(gathered, buf.to(e.xdev), dist)
-        g = gathered if gathered.device == dev else gathered.to(dev)
-        ctx.point_sum_device(1, g.data_ptr(), world, d_fold.data_ptr())     # asynchronous fold on this rank's GPU
-        state["g"] = g
+    def exchange(j, lag):
+        """the path's single exchange step for MSM j: all-gather the per-rank partial sums, fold on every rank"""
+        buf = d_out[j & 7]
+        if xs is None:                           # CPU collectives (gloo test path): on the context's stream as before
+            ctx.join(lag)
+            all_gather_rows(gathered, buf.to(e.xdev), dist)
+            g = gathered if gathered.device == dev else gathered.to(dev)
+            ctx.point_sum_device(1, g.data_ptr(), world, d_fold.data_ptr())
+            state["g"] = g
+            return
+        ctx.set_stream(xs.cuda_stream)
+        try:
+            ctx.join(lag)                        # the exchange stream waits for the tail of MSM j
+            with torch.cuda.stream(xs):
+                if probe in ("", "gather"):
+                    all_gather_rows(gathered, buf, dist)
+                if probe in ("", "fold"):
+                    ctx.point_sum_device(1, gathered.data_ptr(), world, d_fold.data_ptr())     # asynchronous fold on this rank's GPU
+                ex_ev[j & 7].record(xs)
+            ex_used[j & 7] = True
+        finally:
+            ctx.set_stream(main_stream.cuda_stream)
 
     def step():
         i = state["i"]; state["i"] = i + 1
-        ctx.msm_device(bases, d_scalars.data_ptr(), n, d_out[i & 3].data_ptr())
-        if multi and i >= LAG:
-            # consume result i - LAG: the front of MSM i+1 records its dependency on this stream at its launch, so whatever is queued here
-            # holds it back.  MSM i+1 reuses the pipeline slot of MSM i-3 and must wait for that tail in any case; waiting for the tail of
-            # MSM i-2 instead (round 4) cut the pipeline to three calls in flight (3.50 against 3.75*10^8 scalar-muls/s at 2^20 points).
-            ctx.join(LAG)
-            exchange(d_out[(i - LAG) & 3])
+        if xs is not None and ex_used[i & 7]:
+            main_stream.wait_event(ex_ev[i & 7])     # the exchange of MSM i - 8 read this output buffer (long complete: no stall, formal ordering)
+        ctx.msm_device(bases, d_scalars.data_ptr(), n, d_out[i & 7].data_ptr())
+        if multi and i >= LAG and probe != "none":
+            # consume result i - LAG: MSM i+1 reuses the pipeline slot of MSM i-3 and must wait for that tail in any case; consuming i - 2
+            # (rounds 2-4) made the pipeline three calls deep
+            exchange(i - LAG, LAG)
 
     def drain():
-        ctx.join(0)
+        i = state["i"]
         if multi:
-            for k in range(max(0, state["i"] - LAG), state["i"]):
-                exchange(d_out[k & 3])
+            for j in range(max(0, i - LAG), i):
+                exchange(j, i - 1 - j)
+        ctx.join(0)
+        if xs is not None:
+            main_stream.wait_stream(xs)
         state["i"] = 0
 
     for _ in range(warmup):
@@ -426,8 +463,10 @@ def run_msm(args, e):
     # ---- the same sharded MSM from ONE process (the C library's device group: what a Rust host uses), timed by rank 0 while the other
     # ranks wait at a CPU-side barrier (gloo: an RCCL barrier would spin on their GPUs) ------------------------------------------------
     group_path = None
-    if multi and world > 1 and args.backend == "nccl" and not args.no_extras and not args.same_device:
+    # (BENCH_FORCE_GROUP_PATH: run this block with ONE rank too -- how the one-GPU box exercises it)
+    if multi and args.backend == "nccl" and not args.same_device and ((world > 1 and not args.no_extras) or os.environ.get("BENCH_FORCE_GROUP_PATH")):
         try:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")        # the container's hostname may not resolve
             cpu_pg = dist.new_group(backend="gloo")
             torch.cuda.synchronize()
             dist.barrier(group=cpu_pg)
@@ -1070,26 +1109,38 @@ def group_measure(bls, torch, devices, total, steps, warmup, weak_n=None, check=
     sbs = [synthetic.scalars(sizes[k], synthetic.SEED + 2 * k) for k in range(N)]
     bases = g.bases_from_scalars(1, np.concatenate(kbs))
     d_s = [torch.from_numpy(sbs[k]).to(torch.device("cuda", devices[k])) for k in range(N)]
-    d_o = [[torch.zeros(18, dtype=torch.int64, device=torch.device("cuda", devices[k])) for _ in range(4)] for k in range(N)]
+    d_o = [[torch.zeros(18, dtype=torch.int64, device=torch.device("cuda", devices[k])) for _ in range(8)] for k in range(N)]      # eight: see blsgpu_g1_partials_fold_device
     for d in set(devices):
         torch.cuda.synchronize(d)
     sp = [t.data_ptr() for t in d_s]
-    d_fold = [torch.zeros(18, dtype=torch.int64, device=torch.device("cuda", devices[0])) for _ in range(4)]
+    d_fold = [torch.zeros(18, dtype=torch.int64, device=torch.device("cuda", devices[0])) for _ in range(8)]
     state = {"i": 0, "last": None}
 
     def step():
         i = state["i"]; state["i"] = i + 1
-        g.msm_sharded_device(bases, sp, [d_o[k][i & 3].data_ptr() for k in range(N)])
-        if i >= 3:           # the fold of MSM i - 3 (whose pipeline slot MSM i + 1 reuses) is queued behind it on the members' streams: no host
-            g.partials_fold_device(1, [d_o[k][(i - 3) & 3].data_ptr() for k in range(N)], d_fold[(i - 3) & 3].data_ptr(), lag=3)      # synchronisation in the step
+        g.msm_sharded_device(bases, sp, [d_o[k][i & 7].data_ptr() for k in range(N)])
+        if i >= 3:           # the fold of MSM i - 3 (whose pipeline slot MSM i + 1 reuses)
+            fold(i - 3, 3)
+
+    # members on ONE device: the fold is queued behind the MSM on the members' streams (no host synchronisation in the step).  Members on
+    # DIFFERENT devices: the synchronous fold through pinned host memory -- it waits only for MSM i - 3, which has long finished -- because the
+    # cross-device form (peer copies + events between devices) has never run on real multi-GPU hardware (the build box has one GPU)
+    device_fold = len(set(devices)) == 1
+
+    def fold(j, lag):
+        ptrs = [d_o[k][j & 7].data_ptr() for k in range(N)]
+        if device_fold:
+            g.partials_fold_device(1, ptrs, d_fold[j & 7].data_ptr(), lag=lag)
+        else:
+            state["last"] = g.partials_fold(1, ptrs, lag=lag)
 
     def drain():
         i = state["i"]
         for j in range(max(0, i - 3), i):
-            g.partials_fold_device(1, [d_o[k][j & 3].data_ptr() for k in range(N)], d_fold[j & 3].data_ptr(), lag=i - 1 - j)
+            fold(j, i - 1 - j)
         g.synchronize()
-        if i:
-            state["last"] = d_fold[(i - 1) & 3].cpu().numpy().view(np.uint64).copy()
+        if i and device_fold:
+            state["last"] = d_fold[(i - 1) & 7].cpu().numpy().view(np.uint64).copy()
         state["i"] = 0
 
     for _ in range(warmup):
@@ -1104,7 +1155,7 @@ def group_measure(bls, torch, devices, total, steps, warmup, weak_n=None, check=
     drain()
     dt = time.perf_counter() - t0
     bls._lib.check(lib.blsgpu_msm_accumulate_stats(g.member_ctx(0), 0, ctypes.byref(avg), ctypes.byref(cnt)), "msm_accumulate_stats")
-    rec = {"members": N, "devices": list(devices), "distinct_gpus": len(set(devices)), "total_points": n_all, "points_per_member": sizes[0], "steps": steps, "warmup": warmup,
+    rec = {"members": N, "devices": list(devices), "fold": "device (queued on the members' streams)" if device_fold else "host (pinned staging, lag 3)", "distinct_gpus": len(set(devices)), "total_points": n_all, "points_per_member": sizes[0], "steps": steps, "warmup": warmup,
            "ms_per_step": 1e3 * dt / steps, "value": float(n_all) * steps / dt, "member0_accumulate_launch_ms": avg.value, "member0_launches_timed": int(cnt.value)}
     if check:
         # discrete-log identity: sum_i s_i [k_i]G = [sum_i s_i k_i] G

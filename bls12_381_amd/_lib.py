@@ -120,6 +120,11 @@ SIGNATURES = {
     "blsgpu_g2_partials_fold_device": (c_int, [c_vp, c_vp, c_int, c_vp]),
     "blsgpu_group_set_pipelining": (c_int, [c_vp, c_int]),
     "blsgpu_group_synchronize": (c_int, [c_vp]),
+    "blsgpu_group_g2_prepare": (c_int, [c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
+    "blsgpu_group_g2_prepared_len": (c_sz, [c_vp]),
+    "blsgpu_group_g2_prepared_free": (None, [c_vp]),
+    "blsgpu_multi_miller_loop_prepared_sharded": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
+    "blsgpu_multi_miller_loop_prepared_many_sharded": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
     "blsgpu_pairing_batch_sharded": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_miller_loop_batch_sharded": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_multi_miller_loop_sharded": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),

@@ -672,6 +672,27 @@ class GroupBases:
             pass
 
 
+class GroupPreparedG2:
+    """the same `G2Prepared` table on every member of a Group (`blsgpu_group_g2_prepared`)"""
+
+    def __init__(self, group, handle):
+        self.group, self.handle = group, handle
+
+    def __len__(self):
+        return int(_lib.load().blsgpu_group_g2_prepared_len(self.handle)) if self.handle else 0
+
+    def free(self):
+        if self.handle:
+            _lib.load().blsgpu_group_g2_prepared_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Group:
     """The hot path sharded over several GPUs of one node from ONE process (`blsgpu_group`, include/bls12_381_hip.h): one
     context and one host thread per listed device; partial results (one group element per member) are folded with `Sum`
@@ -756,6 +777,34 @@ class Group:
         out = np.zeros(18 if gid == 1 else 36, dtype=np.uint64)
         fn = self.lib.blsgpu_g1_partials_fold if gid == 1 else self.lib.blsgpu_g2_partials_fold
         check(fn(self.h, op, lag, _ptr(out)), "partials_fold")
+        return out
+
+    # G2Prepared tables on every member; the prepared Miller loops sharded like the unprepared ones
+    def g2_prepare(self, g2_xy, g2_inf=None):
+        g2 = _u64(g2_xy, (-1, 24))
+        m = g2.shape[0]
+        h = ctypes.c_void_p()
+        check(self.lib.blsgpu_group_g2_prepare(self.h, _ptr(g2), _ptr(_flags(g2_inf, m)) if g2_inf is not None else None, m, ctypes.byref(h)), "group_g2_prepare")
+        return GroupPreparedG2(self, h)
+
+    def multi_miller_loop_prepared(self, g1_xy, g1_inf, table, q_index, g2_xy=None, g2_inf=None, final_exp=False):
+        g1, f1, g2, f2, qi, n = Context._prepared_args(self, g1_xy, g1_inf, q_index, g2_xy, g2_inf)
+        out = np.zeros(72, dtype=np.uint64)
+        check(self.lib.blsgpu_multi_miller_loop_prepared_sharded(self.h, _ptr(g1), _ptr(f1), _ptr(g2) if g2 is not None else None, _ptr(f2) if f2 is not None else None,
+                                                                 _ptr(qi) if qi is not None else None, table.handle if table is not None else None, n, 1 if final_exp else 0,
+                                                                 _ptr(out)), "multi_miller_loop_prepared_sharded")
+        return out
+
+    def multi_miller_loop_prepared_many(self, g1_xy, g1_inf, table, q_index, offsets, g2_xy=None, g2_inf=None, final_exp=True):
+        g1, f1, g2, f2, qi, n = Context._prepared_args(self, g1_xy, g1_inf, q_index, g2_xy, g2_inf)
+        off = np.ascontiguousarray(np.asarray(offsets, dtype=np.uint64))
+        if off.ndim != 1 or off.shape[0] < 1 or int(off[-1]) != n:
+            raise ValueError("multi_miller_loop_prepared_many: offsets must be nseg + 1 values ending at the number of terms")
+        nseg = off.shape[0] - 1
+        out = np.zeros((nseg, 72), dtype=np.uint64)
+        check(self.lib.blsgpu_multi_miller_loop_prepared_many_sharded(self.h, _ptr(g1), _ptr(f1), _ptr(g2) if g2 is not None else None, _ptr(f2) if f2 is not None else None,
+                                                                      _ptr(qi) if qi is not None else None, table.handle if table is not None else None, _ptr(off), nseg,
+                                                                      1 if final_exp else 0, _ptr(out)), "multi_miller_loop_prepared_many_sharded")
         return out
 
     def partials_fold_device(self, gid, d_partials, d_out, lag=0):

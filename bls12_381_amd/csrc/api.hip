@@ -10,6 +10,7 @@
 #include <vector>
 #include <atomic>
 #include <thread>
+#include <array>
 #include <mutex>
 #include <condition_variable>
 #include <functional>
@@ -137,6 +138,7 @@ struct blsgpu_ctx {
   std::vector<BasesCacheEntry> bcache;  // blsgpu_set_bases_cache: base arrays of repeated one-shot MSMs kept resident
   int bcache_cap = 0; unsigned long long bcache_tick = 0;
   DevBuf mmlp_work, mmlp_out;           // prepared Miller loops (prep.hip.h): per-quad work area, partial products of one long product
+  hipStream_t fold_stream = nullptr;    // the asynchronous group fold's copies and sums run here, NOT on `stream`: an MSM's front waits for whatever is queued on `stream`
   void* pin_stage = nullptr; hipEvent_t pin_ev[8] = {};      // pinned bounce buffers of staged_upload
   DevBuf gt_one; bool gt_one_ready = false; hipEvent_t ev_gt_one = nullptr;      // the wire form of Fp12::one() (blsgpu_gt_is_identity_device, bulk verification)
   DevBuf ver;                           // bulk verification (blsgpu_bls_verify_batch): every intermediate of the chain
@@ -587,6 +589,7 @@ extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
   for (auto& e : c->ev_fr) if (e) hipEventDestroy(e);
   for (auto& e : c->ev_fb) if (e) hipEventDestroy(e);
   if (c->ev_gt_one) hipEventDestroy(c->ev_gt_one);
+  if (c->fold_stream) hipStreamDestroy(c->fold_stream);
   if (c->pin_stage) hipHostFree(c->pin_stage);
   for (auto e : c->pin_ev) if (e) hipEventDestroy(e);
   if (c->ev_ver) hipEventDestroy(c->ev_ver);
@@ -633,6 +636,7 @@ extern "C" int blsgpu_synchronize(blsgpu_ctx* c) { CTX_CLAIM(c);
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipStreamSynchronize(c->acc_stream));
   for (auto& sl : c->slot) { HIPCHK(hipStreamSynchronize(sl.front)); HIPCHK(hipStreamSynchronize(sl.tail)); HIPCHK(hipStreamSynchronize(sl.tail2)); sl.tail_pending = false; }
+  if (c->fold_stream) HIPCHK(hipStreamSynchronize(c->fold_stream));
   return take_status(c);
 }
 // fold the finished accumulation timings into the running statistics (never blocks)
@@ -2469,8 +2473,10 @@ extern "C" int blsgpu_bls_verify_batch_device(blsgpu_ctx* c, int mode, const voi
   }
   uint8_t* fl = base + o_fl;
   uint8_t *a_inf = fl, *a_ok = fl + n, *b_inf = fl + 2 * n, *b_ok = fl + 3 * n, *h_inf = fl + 4 * n, *is_one = fl + 5 * n;
-  // 1.-3. three independent, latency-shaped stages (one lane or lane pair per point, a few thousand field multiplications each): they run
-  // side by side on the context's stream and two side streams and meet again before the terms are assembled
+  // 1.-3. independent, latency-shaped stages (one lane or lane pair per point, a few thousand field multiplications each): the two
+  // checked decodings run on the context's stream, hash-to-curve + normalisation beside them on a side stream (ONE side stream: the
+  // runtime multiplexes streams onto a few hardware queues, and two side streams created back to back shared one -- kernel trace of
+  // round 5 -- which serialised exactly the two longest stages), and they meet again before the terms are assembled
   if (!c->ver_stream[0]) {
     for (auto& q : c->ver_stream) HIPCHK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
     for (auto& e : c->ev_ver_side) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -2479,27 +2485,23 @@ extern "C" int blsgpu_bls_verify_batch_device(blsgpu_ctx* c, int mode, const voi
   HIPCHK(hipEventRecord(c->ev_ver_side[0], main_stream));
   int rc = BLSGPU_OK;
   {
-    // checked decoding of the G2-side points (`from_compressed`: on the curve, in the subgroup) on side stream 0
+    // hash the messages to the signature's group and normalise, on the side stream
     c->stream = c->ver_stream[0];
     hipError_t e = hipStreamWaitEvent(c->stream, c->ev_ver_side[0], 0);
-    if (e == hipSuccess) rc = point_decode_device<Fp2Policy>(c, mode == 0 ? d_sig : d_pk, n, 1, 1, base + o_b, b_inf, b_ok);
-    if (e == hipSuccess && !rc) e = hipEventRecord(c->ev_ver_side[1], c->stream);
-    // hash the messages to the signature's group and normalise, on side stream 1
-    c->stream = c->ver_stream[1];
-    if (e == hipSuccess && !rc) e = hipStreamWaitEvent(c->stream, c->ev_ver_side[0], 0);
-    if (e == hipSuccess && !rc) rc = blsgpu_hash_to_curve_device(c, mode == 0 ? 2 : 1, d_msgs, d_offsets, n, d_dst, dst_len, 0, base + o_hp);
+    if (e == hipSuccess) rc = blsgpu_hash_to_curve_device(c, mode == 0 ? 2 : 1, d_msgs, d_offsets, n, d_dst, dst_len, 0, base + o_hp);
     if (e == hipSuccess && !rc)
       rc = mode == 0 ? batch_normalize_device<Fp2Policy>(c, base + o_hp, n, base + o_h, h_inf) : batch_normalize_device<FpPolicy>(c, base + o_hp, n, base + o_h, h_inf);
-    if (e == hipSuccess && !rc) e = hipEventRecord(c->ev_ver_side[2], c->stream);
+    if (e == hipSuccess && !rc) e = hipEventRecord(c->ev_ver_side[1], c->stream);
     c->stream = main_stream;
-    if (e != hipSuccess) return fail("bls_verify_batch: side streams", e, __LINE__);
+    if (e != hipSuccess) return fail("bls_verify_batch: side stream", e, __LINE__);
     if (rc) return rc;
   }
-  // checked decoding of the G1-side points on the context's stream, which then waits for the two side streams
+  // checked decoding (`from_compressed`: on the curve, in the subgroup) of both point arrays on the context's stream, which then waits for the side stream
+  rc = point_decode_device<Fp2Policy>(c, mode == 0 ? d_sig : d_pk, n, 1, 1, base + o_b, b_inf, b_ok);
+  if (rc) return rc;
   rc = point_decode_device<FpPolicy>(c, mode == 0 ? d_pk : d_sig, n, 1, 1, base + o_a, a_inf, a_ok);
   if (rc) return rc;
   HIPCHK(hipStreamWaitEvent(main_stream, c->ev_ver_side[1], 0));
-  HIPCHK(hipStreamWaitEvent(main_stream, c->ev_ver_side[2], 0));
   // 4. the two terms of every equation
   const uint8_t *pk_inf = mode == 0 ? a_inf : b_inf, *pk_ok = mode == 0 ? a_ok : b_ok, *sig_inf = mode == 0 ? b_inf : a_inf, *sig_ok = mode == 0 ? b_ok : a_ok;
   hipLaunchKernelGGL(k_bls_assemble, dim3(nblk(n + 1, 256)), dim3(256), 0, c->stream, mode, (const u32*)(base + (mode == 0 ? o_a : o_b)), pk_inf, pk_ok,
@@ -2618,6 +2620,10 @@ struct blsgpu_group {
   // asynchronous fold (blsgpu_g{1,2}_partials_fold_device): four staging rows of w partial sums on member 0's device, one event per
   // member (its copy has been queued) and one per staging row (the sum that read it has been queued)
   void* fold_in = nullptr;
+  // per member: the last eight folds' (partial-sum buffer, "its copy has run" event): an MSM that is about to overwrite a buffer a fold
+  // still has to read waits for that fold's copy (a pipelined caller rotates >= 8 buffers, so the event it meets is long complete)
+  struct FoldRead { const void* ptr = nullptr; hipEvent_t ev = nullptr; bool used = false; };
+  std::vector<std::array<FoldRead, 8>> fold_reads;
   std::vector<hipEvent_t> ev_copy;
   hipEvent_t ev_sum[4] = {};
   bool ev_sum_used[4] = {false, false, false, false};
@@ -2657,6 +2663,7 @@ extern "C" void blsgpu_group_destroy(blsgpu_group* g) {
     delete wk;
   }
   for (size_t i = 0; i < g->ev_copy.size(); i++) if (g->ev_copy[i]) { hipSetDevice(g->ctx[i]->device); hipEventDestroy(g->ev_copy[i]); }
+  for (size_t i = 0; i < g->fold_reads.size(); i++) for (auto& fr : g->fold_reads[i]) if (fr.ev) { hipSetDevice(g->ctx[i]->device); hipEventDestroy(fr.ev); }
   if (!g->ctx.empty() && g->ctx[0]) {
     hipSetDevice(g->ctx[0]->device);
     hipDeviceSynchronize();
@@ -2681,6 +2688,9 @@ extern "C" int blsgpu_group_create(const int* devices, int ndev, blsgpu_group** 
     hipEvent_t ev = nullptr;
     if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); blsgpu_group_destroy(g); g_err = "group_create: hipEventCreate failed"; return BLSGPU_ERR_HIP; }
     g->ev_copy.push_back(ev);
+    g->fold_reads.emplace_back();
+    for (auto& fr : g->fold_reads.back())
+      if (hipEventCreateWithFlags(&fr.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); blsgpu_group_destroy(g); g_err = "group_create: hipEventCreate failed"; return BLSGPU_ERR_HIP; }
   }
   {
     hipError_t e = hipSetDevice(g->ctx[0]->device);
@@ -2768,6 +2778,9 @@ static int msm_sharded_device(blsgpu_group* g, const blsgpu_group_bases* b, cons
   if (b->group != G) return bad("msm_sharded_device: bases belong to the other group");
   if (b->part.size() != g->ctx.size()) return bad("msm_sharded_device: the bases were sharded over another group");
   return group_run(g, [&](size_t k, blsgpu_ctx* c) {
+    CTX_CLAIM(c);
+    HIPCHK(hipSetDevice(c->device));
+    for (auto& fr : g->fold_reads[k]) if (fr.used && fr.ptr == d_partials[k]) HIPCHK(hipStreamWaitEvent(c->stream, fr.ev, 0));     // a fold still owns this buffer
     const size_t cnt = blsgpu_bases_len(b->part[k]);
     return G == 1 ? blsgpu_g1_msm_device(c, b->part[k], 0, d_scalars[k], cnt, d_partials[k]) : blsgpu_g2_msm_device(c, b->part[k], 0, d_scalars[k], cnt, d_partials[k]);
   });
@@ -2806,29 +2819,43 @@ static int partials_fold_device(blsgpu_group* g, const void* const* d_partials, 
   constexpr size_t PB = G == 1 ? 144 : 288;
   if (!g || !d_partials || !d_out || lag < 0) return bad("partials_fold_device: bad argument");
   const size_t w = g->ctx.size();
-  const unsigned row = g->fold_seq++ & 3u;
+  const unsigned seq = g->fold_seq++;
+  const unsigned row = seq & 3u;
   uint8_t* stage = (uint8_t*)g->fold_in + (size_t)row * w * 288;
   blsgpu_ctx* c0 = g->ctx[0];
+  // everything below runs on the members' FOLD streams: the context's own stream stays empty, so the front of the next MSM (which waits
+  // for whatever is queued on that stream when it is launched) never waits for a fold -- with the fold on the main stream an MSM's front
+  // queued behind the copy / sum kernels, which in turn wait for a free CU slot under the running accumulation
   int rc = group_run(g, [&](size_t k, blsgpu_ctx* c) {
     CTX_CLAIM(c);
-    int r = blsgpu_join_lag(c, lag);
-    if (r) return r;
     HIPCHK(hipSetDevice(c->device));
-    if (g->ev_sum_used[row]) HIPCHK(hipStreamWaitEvent(c->stream, g->ev_sum[row], 0));       // the sum that last read this staging row
+    if (!c->fold_stream) HIPCHK(hipStreamCreateWithFlags(&c->fold_stream, hipStreamNonBlocking));
+    hipStream_t keep = c->stream;
+    c->stream = c->fold_stream;
+    int r = blsgpu_join_lag(c, lag);
+    c->stream = keep;
+    if (r) return r;
+    if (g->ev_sum_used[row]) HIPCHK(hipStreamWaitEvent(c->fold_stream, g->ev_sum[row], 0));       // the sum that last read this staging row
     // (a plain device-to-device copy for members on member 0's device: the peer form need not be asynchronous there)
-    if (c->device == c0->device) HIPCHK(hipMemcpyAsync(w == 1 ? d_out : (void*)(stage + k * PB), d_partials[k], PB, hipMemcpyDeviceToDevice, c->stream));
-    else HIPCHK(hipMemcpyPeerAsync(stage + k * PB, c0->device, d_partials[k], c->device, PB, c->stream));
-    HIPCHK(hipEventRecord(g->ev_copy[k], c->stream));
+    if (c->device == c0->device) HIPCHK(hipMemcpyAsync(w == 1 ? d_out : (void*)(stage + k * PB), d_partials[k], PB, hipMemcpyDeviceToDevice, c->fold_stream));
+    else HIPCHK(hipMemcpyPeerAsync(stage + k * PB, c0->device, d_partials[k], c->device, PB, c->fold_stream));
+    HIPCHK(hipEventRecord(g->ev_copy[k], c->fold_stream));
+    blsgpu_group::FoldRead& fr = g->fold_reads[k][seq & 7u];
+    HIPCHK(hipEventRecord(fr.ev, c->fold_stream));
+    fr.ptr = d_partials[k]; fr.used = true;
     return (int)BLSGPU_OK;
   });
   if (rc) return rc;
   if (w == 1) return BLSGPU_OK;                 // one member: its partial sum IS the result (copied straight to d_out above)
   CTX_CLAIM(c0);
   HIPCHK(hipSetDevice(c0->device));
-  for (size_t k = 1; k < w; k++) HIPCHK(hipStreamWaitEvent(c0->stream, g->ev_copy[k], 0));
+  for (size_t k = 1; k < w; k++) HIPCHK(hipStreamWaitEvent(c0->fold_stream, g->ev_copy[k], 0));
+  hipStream_t keep = c0->stream;
+  c0->stream = c0->fold_stream;
   rc = G == 1 ? blsgpu_g1_sum_device(c0, stage, w, d_out) : blsgpu_g2_sum_device(c0, stage, w, d_out);
+  c0->stream = keep;
   if (rc) return rc;
-  HIPCHK(hipEventRecord(g->ev_sum[row], c0->stream));
+  HIPCHK(hipEventRecord(g->ev_sum[row], c0->fold_stream));
   g->ev_sum_used[row] = true;
   return BLSGPU_OK;
 }
@@ -2877,6 +2904,63 @@ extern "C" int blsgpu_multi_miller_loop_sharded(blsgpu_group* g, const uint64_t*
   rc = blsgpu_fp12_product(g->ctx[0], parts.data(), w, f);
   if (rc) return rc;
   return blsgpu_final_exponentiation_batch(g->ctx[0], f, 1, out);
+}
+// `G2Prepared` tables for a group: the same m points prepared on EVERY member (a verification key is small: 26 KB per point), so that
+// the prepared Miller loops shard exactly like the unprepared ones
+struct blsgpu_group_g2_prepared { std::vector<blsgpu_g2_prepared*> part; size_t n = 0; };
+extern "C" void blsgpu_group_g2_prepared_free(blsgpu_group_g2_prepared* p) {
+  if (!p) return;
+  for (auto t : p->part) blsgpu_g2_prepared_free(t);
+  delete p;
+}
+extern "C" size_t blsgpu_group_g2_prepared_len(const blsgpu_group_g2_prepared* p) { return p ? p->n : 0; }
+extern "C" int blsgpu_group_g2_prepare(blsgpu_group* g, const uint64_t* g2, const uint8_t* inf, size_t m, blsgpu_group_g2_prepared** out) {
+  if (!g || !out || (m && !g2)) return bad("group_g2_prepare: NULL argument");
+  blsgpu_group_g2_prepared* p = new blsgpu_group_g2_prepared();
+  p->n = m; p->part.assign(g->ctx.size(), nullptr);
+  int rc = group_run(g, [&](size_t k, blsgpu_ctx* c) { return blsgpu_g2_prepare(c, g2, inf, m, &p->part[k]); });
+  if (rc) { const std::string keep = g_err; blsgpu_group_g2_prepared_free(p); g_err = keep; return rc; }
+  *out = p;
+  return BLSGPU_OK;
+}
+// `multi_miller_loop` over n terms, prepared or not: member-local products of index slices, folded by member 0, ONE final exponentiation
+extern "C" int blsgpu_multi_miller_loop_prepared_sharded(blsgpu_group* g, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, const uint32_t* qidx,
+                                                         const blsgpu_group_g2_prepared* p, size_t n, int final_exp, uint64_t out[72]) {
+  if (!g || !out || (n && !g1)) return bad("multi_miller_loop_prepared_sharded: NULL argument");
+  if (p && p->part.size() != g->ctx.size()) return bad("multi_miller_loop_prepared_sharded: the table was prepared for another group");
+  const size_t w = g->ctx.size();
+  std::vector<uint64_t> parts(w * 72);
+  int rc = group_run(g, [&](size_t k, blsgpu_ctx* c) {
+    size_t lo, hi; group_range(n, k, w, lo, hi);
+    return blsgpu_multi_miller_loop_prepared(c, n ? g1 + lo * 12 : g1, g1inf ? g1inf + lo : nullptr, g2 ? g2 + lo * 24 : g2, (g2 && g2inf) ? g2inf + lo : nullptr,
+                                             qidx ? qidx + lo : nullptr, p ? p->part[k] : nullptr, hi - lo, parts.data() + k * 72);
+  });
+  if (rc) return rc;
+  if (!final_exp) return blsgpu_fp12_product(g->ctx[0], parts.data(), w, out);
+  uint64_t f[72];
+  rc = blsgpu_fp12_product(g->ctx[0], parts.data(), w, f);
+  if (rc) return rc;
+  return blsgpu_final_exponentiation_batch(g->ctx[0], f, 1, out);
+}
+// blsgpu_multi_miller_loop_prepared_many with the SEGMENTS dealt to the members in contiguous slices
+extern "C" int blsgpu_multi_miller_loop_prepared_many_sharded(blsgpu_group* g, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, const uint32_t* qidx,
+                                                              const blsgpu_group_g2_prepared* p, const uint64_t* offsets, size_t nseg, int final_exp, uint64_t* out) {
+  if (!g || (nseg && (!offsets || !out))) return bad("multi_miller_loop_prepared_many_sharded: NULL argument");
+  if (!nseg) return BLSGPU_OK;
+  if (p && p->part.size() != g->ctx.size()) return bad("multi_miller_loop_prepared_many_sharded: the table was prepared for another group");
+  if (offsets[0] != 0) return bad("multi_miller_loop_prepared_many: offsets[0] must be 0");
+  for (size_t i = 0; i < nseg; i++) if (offsets[i] > offsets[i + 1]) return bad("multi_miller_loop_prepared_many: offsets must be non-decreasing");
+  if (offsets[nseg] && !g1) return bad("multi_miller_loop_prepared_many_sharded: NULL argument");
+  const size_t w = g->ctx.size();
+  return group_run(g, [&](size_t k, blsgpu_ctx* c) {
+    size_t lo, hi; group_range(nseg, k, w, lo, hi);
+    if (lo == hi) return (int)BLSGPU_OK;
+    const size_t t0 = (size_t)offsets[lo];
+    std::vector<uint64_t> off(hi - lo + 1);
+    for (size_t i = lo; i <= hi; i++) off[i - lo] = offsets[i] - t0;
+    return blsgpu_multi_miller_loop_prepared_many(c, g1 ? g1 + t0 * 12 : g1, g1inf ? g1inf + t0 : nullptr, g2 ? g2 + t0 * 24 : g2, (g2 && g2inf) ? g2inf + t0 : nullptr,
+                                                  qidx ? qidx + t0 : nullptr, p ? p->part[k] : nullptr, off.data(), hi - lo, final_exp, out + lo * 72);
+  });
 }
 // N independent multi_miller_loops (blsgpu_multi_miller_loop_many): the SEGMENTS are dealt in contiguous slices, nothing to fold
 extern "C" int blsgpu_multi_miller_loop_many_sharded(blsgpu_group* g, const uint64_t* g1, const uint8_t* g1inf, const uint64_t* g2, const uint8_t* g2inf, const uint64_t* offsets,

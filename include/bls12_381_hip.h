@@ -338,7 +338,10 @@ int blsgpu_g1_partials_fold(blsgpu_group* group, const void* const* d_partials, 
 int blsgpu_g2_partials_fold(blsgpu_group* group, const void* const* d_partials, int lag, uint64_t out_xyz[36]);
 /* The fold without a host round trip: every member queues a copy of its partial sum to member 0's device behind the MSM it belongs to,
  * member 0's stream adds the w points into d_out (device memory of member 0, 18 / 36 u64); nothing is synchronised -- the fold of MSM
- * i - 2 runs under the accumulation of MSMs i - 1 and i.  At most four folds may be outstanding. */
+ * i - 3 runs under the accumulation of the later MSMs, on the members' own fold streams (an MSM's front waits for what is queued on its
+ * context's stream, so the fold is kept off it).  At most four folds may be outstanding; an MSM whose output buffer one of the last eight
+ * folds still has to read waits for that fold's copy, so a pipelined caller rotates at least eight partial-sum buffers per member (with
+ * four, every MSM waits for the fold three calls back).  d_out is valid after blsgpu_group_synchronize. */
 int blsgpu_g1_partials_fold_device(blsgpu_group* group, const void* const* d_partials, int lag, void* d_out_xyz);
 int blsgpu_g2_partials_fold_device(blsgpu_group* group, const void* const* d_partials, int lag, void* d_out_xyz);
 int blsgpu_group_set_pipelining(blsgpu_group* group, int enabled);
@@ -350,6 +353,18 @@ int blsgpu_miller_loop_batch_sharded(blsgpu_group* group, const uint64_t* g1_xy,
  * final exponentiation (out = a `Gt`), final_exp = 0 returns the `MillerLoopResult`. */
 int blsgpu_multi_miller_loop_sharded(blsgpu_group* group, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy, const uint8_t* g2_inf, size_t n, int final_exp,
                                      uint64_t out[72]);
+/* Prepared G2 arguments for a group: the same m points prepared on EVERY member (blsgpu_g2_prepare per member), and the prepared Miller
+ * loops sharded like the unprepared ones (terms / segments in contiguous slices, partial products folded on member 0, ONE final
+ * exponentiation where asked). */
+typedef struct blsgpu_group_g2_prepared blsgpu_group_g2_prepared;
+int blsgpu_group_g2_prepare(blsgpu_group* group, const uint64_t* g2_xy, const uint8_t* g2_inf, size_t m, blsgpu_group_g2_prepared** out);
+size_t blsgpu_group_g2_prepared_len(const blsgpu_group_g2_prepared* p);
+void blsgpu_group_g2_prepared_free(blsgpu_group_g2_prepared* p);
+int blsgpu_multi_miller_loop_prepared_sharded(blsgpu_group* group, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy, const uint8_t* g2_inf, const uint32_t* q_index,
+                                              const blsgpu_group_g2_prepared* prepared, size_t n, int final_exp, uint64_t out[72]);
+int blsgpu_multi_miller_loop_prepared_many_sharded(blsgpu_group* group, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy, const uint8_t* g2_inf,
+                                                   const uint32_t* q_index, const blsgpu_group_g2_prepared* prepared, const uint64_t* offsets, size_t nseg, int final_exp,
+                                                   uint64_t* out);
 /* blsgpu_multi_miller_loop_many with the SEGMENTS dealt to the members in contiguous slices. */
 int blsgpu_multi_miller_loop_many_sharded(blsgpu_group* group, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy, const uint8_t* g2_inf,
                                           const uint64_t* offsets, size_t nseg, int final_exp, uint64_t* out);

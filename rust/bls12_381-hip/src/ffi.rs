@@ -13,6 +13,8 @@ use core::ffi::{c_char, c_int, c_uint, c_void};
 #[repr(C)] pub struct BlsgpuGroupBases { _private: [u8; 0] }
 /// opaque: `G2Prepared` values resident in HBM (blsgpu_g2_prepare / blsgpu_g2_prepared_free)
 #[repr(C)] pub struct BlsgpuG2Prepared { _private: [u8; 0] }
+/// opaque: the same `G2Prepared` table on every member of a group (blsgpu_group_g2_prepare / blsgpu_group_g2_prepared_free)
+#[repr(C)] pub struct BlsgpuGroupG2Prepared { _private: [u8; 0] }
 
 pub const BLSGPU_OK: c_int = 0;
 
@@ -111,6 +113,11 @@ extern "C" {
     pub fn blsgpu_pairing_batch_sharded(group: *mut BlsgpuGroup, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, n: usize, out_gt: *mut u64) -> c_int;
     pub fn blsgpu_miller_loop_batch_sharded(group: *mut BlsgpuGroup, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, n: usize, out_f: *mut u64) -> c_int;
     pub fn blsgpu_multi_miller_loop_sharded(group: *mut BlsgpuGroup, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, n: usize, final_exp: c_int, out: *mut u64) -> c_int;
+    pub fn blsgpu_group_g2_prepare(group: *mut BlsgpuGroup, g2_xy: *const u64, g2_inf: *const u8, m: usize, out: *mut *mut BlsgpuGroupG2Prepared) -> c_int;
+    pub fn blsgpu_group_g2_prepared_len(p: *const BlsgpuGroupG2Prepared) -> usize;
+    pub fn blsgpu_group_g2_prepared_free(p: *mut BlsgpuGroupG2Prepared);
+    pub fn blsgpu_multi_miller_loop_prepared_sharded(group: *mut BlsgpuGroup, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, q_index: *const u32, prepared: *const BlsgpuGroupG2Prepared, n: usize, final_exp: c_int, out: *mut u64) -> c_int;
+    pub fn blsgpu_multi_miller_loop_prepared_many_sharded(group: *mut BlsgpuGroup, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, q_index: *const u32, prepared: *const BlsgpuGroupG2Prepared, offsets: *const u64, nseg: usize, final_exp: c_int, out: *mut u64) -> c_int;
     pub fn blsgpu_multi_miller_loop_many_sharded(group: *mut BlsgpuGroup, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, offsets: *const u64, nseg: usize, final_exp: c_int, out: *mut u64) -> c_int;
     pub fn blsgpu_fp_op(ctx: *mut BlsgpuCtx, op: c_int, a: *const u64, b: *const u64, n: usize, out: *mut u64) -> c_int;
     pub fn blsgpu_fp2_op(ctx: *mut BlsgpuCtx, op: c_int, a: *const u64, b: *const u64, n: usize, out: *mut u64) -> c_int;

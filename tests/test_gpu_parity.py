@@ -1185,7 +1185,7 @@ def test_bench_distributed_branch_over_rccl_with_one_rank(workload):
         cmd += ["--log-total", "18"]
     else:
         cmd += ["--workload", "mixed", "--mixed-log", "14", "12", "10"]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", BENCH_FORCE_GROUP_PATH="1")
     env.pop("MASTER_PORT", None)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -1194,6 +1194,9 @@ def test_bench_distributed_branch_over_rccl_with_one_rank(workload):
     if workload == "msm":
         assert line["scaling"] == "strong" and line["config"]["total_points"] == 1 << 18
         assert "RCCL all-gather" in line["config"]["workload"]
+        # the one-process device-group measurement a multi-rank run appends (rank 0 drives every GPU while the others wait at a CPU-side barrier)
+        gp = line["group_path"]
+        assert "error" not in gp and gp["result_matches"] is True and gp["total_points"] == 1 << 18 and gp["value"] > 0
     else:
         assert line["ranks_agree"] is True
 
@@ -2049,6 +2052,16 @@ def test_multi_miller_loop_prepared_matches_unprepared_and_oracle(ctx):
     off11 = np.array([0, 11, 15], dtype=np.uint64)                           # 11 terms: two passes of the shared loop, multiplied in the kernel
     raw11 = ctx.multi_miller_loop_prepared_many(G1, F1, table, qi, off11, G2, F2, final_exp=False)
     assert np.array_equal(raw11, ctx.multi_miller_loop_many(G1, F1, EG2, EF2, off11, final_exp=False))
+    # the same over a device group (the table on every member, terms / segments in contiguous slices, ONE final exponentiation)
+    for members in (2, 3):
+        grp = b.Group([0] * members)
+        gtab = grp.g2_prepare(TG, TF)
+        assert len(gtab) == 4
+        assert np.array_equal(grp.multi_miller_loop_prepared(G1, F1, gtab, qi, G2, F2), got)
+        assert np.array_equal(grp.multi_miller_loop_prepared(G1, F1, gtab, qi, G2, F2, final_exp=True), fp12w(o.final_exponentiation(want)))
+        assert np.array_equal(grp.multi_miller_loop_prepared_many(G1, F1, gtab, qi, off, G2, F2, final_exp=True), gt)
+        assert np.array_equal(grp.multi_miller_loop_prepared_many(G1, F1, gtab, qi, off, G2, F2, final_exp=False), raw)
+        gtab.free(); grp.close()
     # argument errors: index outside the table, an unprepared term without g2, indices without a table
     bad = qi.copy(); bad[3] = 4
     for args in ((G1, F1, table, bad, G2, F2), (G1, F1, table, qi, None, None), (G1, F1, None, qi, G2, F2)):

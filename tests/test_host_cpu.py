@@ -277,6 +277,8 @@ _RUST_TYPES = {"c_int": "int", "usize": "size_t", "c_uint": "unsigned", "*mut Bl
                "*mut BlsgpuGroup": "blsgpu_group*", "*const BlsgpuGroup": "const blsgpu_group*", "*mut *mut BlsgpuGroup": "blsgpu_group**",
                "*mut BlsgpuG2Prepared": "blsgpu_g2_prepared*", "*const BlsgpuG2Prepared": "const blsgpu_g2_prepared*", "*mut *mut BlsgpuG2Prepared": "blsgpu_g2_prepared**",
                "*const u32": "const uint32_t*", "*mut u32": "uint32_t*", "*const *const c_void": "const void*const*", "*const *mut c_void": "void*const*", "*const usize": "const size_t*",
+               "*mut BlsgpuGroupG2Prepared": "blsgpu_group_g2_prepared*", "*const BlsgpuGroupG2Prepared": "const blsgpu_group_g2_prepared*",
+               "*mut *mut BlsgpuGroupG2Prepared": "blsgpu_group_g2_prepared**",
                "*mut BlsgpuGroupBases": "blsgpu_group_bases*", "*const BlsgpuGroupBases": "const blsgpu_group_bases*", "*mut *mut BlsgpuGroupBases": "blsgpu_group_bases**"}
 
 

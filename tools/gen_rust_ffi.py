@@ -24,6 +24,7 @@ C_TO_RUST = {
     "blsgpu_group*": "*mut BlsgpuGroup", "const blsgpu_group*": "*const BlsgpuGroup", "blsgpu_group**": "*mut *mut BlsgpuGroup",
     "blsgpu_g2_prepared*": "*mut BlsgpuG2Prepared", "const blsgpu_g2_prepared*": "*const BlsgpuG2Prepared", "blsgpu_g2_prepared**": "*mut *mut BlsgpuG2Prepared",
     "const uint32_t*": "*const u32", "uint32_t*": "*mut u32", "const void*const*": "*const *const c_void", "void*const*": "*const *mut c_void", "const size_t*": "*const usize",
+    "blsgpu_group_g2_prepared*": "*mut BlsgpuGroupG2Prepared", "const blsgpu_group_g2_prepared*": "*const BlsgpuGroupG2Prepared", "blsgpu_group_g2_prepared**": "*mut *mut BlsgpuGroupG2Prepared",
     "blsgpu_group_bases*": "*mut BlsgpuGroupBases", "const blsgpu_group_bases*": "*const BlsgpuGroupBases", "blsgpu_group_bases**": "*mut *mut BlsgpuGroupBases",
 }
 
@@ -74,6 +75,8 @@ def rust_source():
              "#[repr(C)] pub struct BlsgpuGroupBases { _private: [u8; 0] }",
              "/// opaque: `G2Prepared` values resident in HBM (blsgpu_g2_prepare / blsgpu_g2_prepared_free)",
              "#[repr(C)] pub struct BlsgpuG2Prepared { _private: [u8; 0] }",
+             "/// opaque: the same `G2Prepared` table on every member of a group (blsgpu_group_g2_prepare / blsgpu_group_g2_prepared_free)",
+             "#[repr(C)] pub struct BlsgpuGroupG2Prepared { _private: [u8; 0] }",
              "",
              "pub const BLSGPU_OK: c_int = 0;",
              "",
