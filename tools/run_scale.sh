@@ -9,6 +9,8 @@ NG=$(python -c "import torch; print(torch.cuda.device_count())")
 for N in 1 2 4 8; do
   if [ "$N" -le "$NG" ]; then
     python bench.py --gpus $N --no-cpu-baseline --no-extras "$@" | tail -1
+    # the same sharded MSM from ONE process (the C library's device group; round 5)
+    python bench.py --group $N --no-cpu-baseline --no-extras "$@" | tail -1
   else
     echo "{\"n_gpus\": $N, \"skipped\": \"only $NG GPU(s) visible\"}"
   fi
