@@ -379,11 +379,13 @@ def run_msm(args, e):
     dt = time.perf_counter() - t0
     live_acc_ms, live_acc_n = ctx.msm_accumulate_stats(False)
     dt = max_over_ranks(e, dt)
+    aff_rccl = None
     if multi:
         last = d_fold.cpu().numpy().view(np.uint64)
         aff = ctx.batch_normalize(1, last[None, :])[0][0]
         if not ranks_agree(e, aff):
             raise SystemExit("bench: ranks disagree on the folded MSM result")
+        aff_rccl = aff.copy()
     ctx.set_pipelining(False)
     d_out0 = d_out[0]
     log_n = int(round(np.log2(n))) if n & (n - 1) == 0 else None
@@ -472,7 +474,7 @@ def run_msm(args, e):
             dist.barrier(group=cpu_pg)
             if rank == 0:
                 try:
-                    group_path = group_measure(bls, torch, list(range(world)), total if strong else None, 10, 3, weak_n=None if strong else n)
+                    group_path = group_measure(bls, torch, list(range(world)), total if strong else None, 10, 3, weak_n=None if strong else n, expect_affine=aff_rccl)
                 except Exception as ex:           # never lose the headline over the secondary measurement
                     group_path = {"error": str(ex)[:200]}
             dist.barrier(group=cpu_pg)
@@ -1095,7 +1097,7 @@ def run_mixed(args, e):
 # =====================================================================================================================
 # the same workload from ONE process: a device group of the C library (what a Rust host without torch.distributed uses)
 # =====================================================================================================================
-def group_measure(bls, torch, devices, total, steps, warmup, weak_n=None, check=True):
+def group_measure(bls, torch, devices, total, steps, warmup, weak_n=None, check=True, expect_affine=None):
     """K pipelined sharded MSMs through blsgpu_g1_msm_sharded_device + blsgpu_g1_partials_fold ("enqueue MSM i, fold MSM i - 3"); returns the
     record of the run.  total = points of the ONE MSM split over the members (strong), or weak_n points per member."""
     import ctypes
@@ -1157,13 +1159,21 @@ def group_measure(bls, torch, devices, total, steps, warmup, weak_n=None, check=
     bls._lib.check(lib.blsgpu_msm_accumulate_stats(g.member_ctx(0), 0, ctypes.byref(avg), ctypes.byref(cnt)), "msm_accumulate_stats")
     rec = {"members": N, "devices": list(devices), "fold": "device (queued on the members' streams)" if device_fold else "host (pinned staging, lag 3)", "distinct_gpus": len(set(devices)), "total_points": n_all, "points_per_member": sizes[0], "steps": steps, "warmup": warmup,
            "ms_per_step": 1e3 * dt / steps, "value": float(n_all) * steps / dt, "member0_accumulate_launch_ms": avg.value, "member0_launches_timed": int(cnt.value)}
-    if check:
-        # discrete-log identity: sum_i s_i [k_i]G = [sum_i s_i k_i] G
+    if expect_affine is not None:
+        # the same shards, seeds and sizes as the one-process-per-GPU run that precedes this measurement: the two folded sums must agree
+        c0 = bls.Context(devices[0])
+        got = c0.batch_normalize(1, state["last"][None, :])
+        rec["result_matches"] = bool(np.array_equal(got[0][0], expect_affine))
+        rec["checked_against"] = "the folded result of the RCCL path"
+        c0.close()
+    elif check:
+        # discrete-log identity: sum_i s_i [k_i]G = [sum_i s_i k_i] G  (Python big integers: about a minute for 2^24 terms)
         tot = sum(synthetic.dot_mod_r(kbs[k], sbs[k]) for k in range(N)) % synthetic.R_ORDER
         c0 = bls.Context(devices[0])
         want = c0.bases_from_scalars(1, [tot]).download()
         got = c0.batch_normalize(1, state["last"][None, :])
         rec["result_matches"] = bool(np.array_equal(got[0][0], want[0][0]) and got[1][0] == want[1][0])
+        rec["checked_against"] = "[sum s_i k_i] G"
         c0.close()
     bases.free(); g.close()
     return rec
