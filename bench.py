@@ -710,6 +710,9 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
                "paths_agree": bool(torch.equal(got_p, d_e[:512])),
                "roofline": {"bound": "int-valu", "kernel": "k_mml_prep_quad + k_final_exp_quad", "mac32_per_unit": mac_eq_prep, "achieved": nn * mac_eq_prep / (tp * 1e-3) / 1e12,
                             "peak": peak / 1e12, "unit": "TMAC32/s", "frac": nn * mac_eq_prep / (tp * 1e-3) / peak, "algorithmic_bytes": nn * (ke * 96 + 192 + 576), "traffic": None}}
+        if nn == ne2:
+            # counter traffic of the Miller kernel of this very call shape (2^16 equations), from the committed rocprofv3 --pmc passes
+            rec["roofline"]["traffic"], rec["roofline"]["traffic_source"] = static_traffic("equations_prepared")
         if nn == ne:
             prep.update(rec); prep["n"] = nn
             if not args.no_cpu_baseline:

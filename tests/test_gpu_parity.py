@@ -2373,3 +2373,85 @@ def test_bases_cache_for_repeated_one_shot_msms(kats):
     tot = sum(k * s for k, s in zip(ks, ss)) % o.R_ORDER
     assert np.array_equal(got[0][0], g1aff_w(o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, tot)))[0])
     c.close()
+
+
+def test_prepared_equations_full_size_2_16_bilinearity(ctx):
+    """2^16 verification-shaped equations at the bench's size through the prepared path, checked by a size-independent property:
+    e(a_i G1, [k1] G2) e(b_i G1, [k2] G2) e(-(a_i k1 + b_i k2) G1, G2) = 1 for every i (bilinearity), with [k1] G2 and [k2] G2 prepared and
+    the generator unprepared; one tampered equation must fail.  Everything stays on the device (blsgpu_gt_is_identity_device)."""
+    import torch
+    import bls12_381_amd as b
+    from bls12_381_amd import synthetic as sy
+    dev = torch.device("cuda", 0)
+    ne = 1 << 16
+    k1, k2 = 0x1234567890ABCDEF1234567, 0x0FEDCBA987654321FEDCBA9
+    ab = sy.scalars(ne, 5501); bb = sy.scalars(ne, 5502)
+    ai = np.array(sy.to_ints(ab), dtype=object); bi = np.array(sy.to_ints(bb), dtype=object)
+    ci = (-(ai * k1 + bi * k2)) % o.R_ORDER
+    cb = np.frombuffer(b"".join(int(c).to_bytes(32, "little") for c in ci), dtype=np.uint8).reshape(ne, 32)
+    pa, _ = ctx.bases_from_scalars(1, ab).download(); pb, _ = ctx.bases_from_scalars(1, bb).download(); pc, _ = ctx.bases_from_scalars(1, cb).download()
+    g1 = np.empty((3 * ne, 12), dtype=np.uint64); g1[0::3] = pa; g1[1::3] = pb; g1[2::3] = pc
+    key, _ = ctx.bases_from_scalars(2, [k1, k2]).download()
+    gen2 = g2aff_w(o.G2_GEN)[0]
+    g2 = np.zeros((3 * ne, 24), dtype=np.uint64); g2[2::3] = gen2
+    qi = np.zeros(3 * ne, dtype=np.uint32); qi[1::3] = 1; qi[2::3] = b.UNPREPARED
+    g1[3 * 777] = pa[778]                                            # one tampered equation
+    table = ctx.g2_prepare(key, None)
+    t = lambda a: torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).to(dev)
+    d_g1, d_g2, d_qi = t(g1), t(g2), t(qi.view(np.int32))
+    d_off = torch.arange(0, 3 * (ne + 1), 3, dtype=torch.int64, device=dev)
+    d_gt = torch.zeros((ne, 72), dtype=torch.int64, device=dev); d_fl = torch.zeros(ne, dtype=torch.uint8, device=dev)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.multi_miller_loop_prepared_many_device(d_g1.data_ptr(), table, d_qi.data_ptr(), d_off.data_ptr(), ne, 3 * ne, d_gt.data_ptr(), max_seg_terms=3, final_exp=True,
+                                                   d_g2=d_g2.data_ptr())
+        ctx.gt_is_identity_device(d_gt.data_ptr(), ne, d_fl.data_ptr())
+        ctx.synchronize()
+    finally:
+        ctx.set_stream(None)
+    fl = d_fl.cpu().numpy()
+    assert fl[777] == 0 and fl.sum() == ne - 1
+    table.free()
+
+
+def test_device_group_on_distinct_physical_devices(ctx):
+    """the group paths with members on DIFFERENT GPUs (peer copies and events across devices in the asynchronous fold): skipped on a
+    one-GPU box -- the build box and the driver's GPU test box have one GPU, so this runs only where a multi-GPU node executes the suite"""
+    import torch
+    import bls12_381_amd as b
+    from bls12_381_amd import synthetic as sy
+    nd = torch.cuda.device_count()
+    if nd < 2:
+        pytest.skip("needs at least two GPUs")
+    devs = list(range(min(nd, 8)))
+    grp = b.Group(devs)
+    grp.set_pipelining(True)
+    n = 40001
+    kb = sy.scalars(n, 8801)
+    gb = grp.bases_from_scalars(1, kb)
+    single = ctx.bases_from_scalars(1, kb)
+    sizes = grp.shard_sizes(n)
+    lo = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+    sets = [sy.scalars(n, 8810 + j) for j in range(5)]
+    d_s = [[torch.from_numpy(sets[j][lo[k]:lo[k + 1]].copy()).to(torch.device("cuda", devs[k])) for k in range(len(devs))] for j in range(5)]
+    d_o = [[torch.zeros(18, dtype=torch.int64, device=torch.device("cuda", devs[k])) for k in range(len(devs))] for _ in range(8)]
+    d_f = [torch.zeros(18, dtype=torch.int64, device=torch.device("cuda", devs[0])) for _ in range(5)]
+    for d in devs:
+        torch.cuda.synchronize(d)
+    host = []
+    for j in range(5):
+        grp.msm_sharded_device(gb, [t.data_ptr() for t in d_s[j]], [t.data_ptr() for t in d_o[j]])
+        grp.partials_fold_device(1, [t.data_ptr() for t in d_o[j]], d_f[j].data_ptr(), lag=0)
+        host.append(grp.partials_fold(1, [t.data_ptr() for t in d_o[j]], lag=0))
+    grp.synchronize()
+    for j in range(5):
+        want = ctx.batch_normalize(1, ctx.msm(single, sets[j])[None, :])
+        for got in (d_f[j].cpu().numpy().view(np.uint64), host[j]):
+            a = ctx.batch_normalize(1, got[None, :])
+            assert np.array_equal(a[0], want[0]) and np.array_equal(a[1], want[1]), j
+    # and the synchronous sharded entry points over real devices
+    ps, qs = _pair_inputs(9, 8820)
+    G1, F1, G2, F2 = _terms_w(ps, qs)
+    assert np.array_equal(grp.multi_miller_loop(G1, F1, G2, F2), ctx.multi_miller_loop(G1, F1, G2, F2))
+    assert np.array_equal(grp.pairing_batch(G1, F1, G2, F2), ctx.pairing_batch(G1, F1, G2, F2))
+    gb.free(); grp.close()
