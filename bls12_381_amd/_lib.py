@@ -118,6 +118,8 @@ SIGNATURES = {
     "blsgpu_g2_partials_fold": (c_int, [c_vp, c_vp, c_int, c_vp]),
     "blsgpu_g1_partials_fold_device": (c_int, [c_vp, c_vp, c_int, c_vp]),
     "blsgpu_g2_partials_fold_device": (c_int, [c_vp, c_vp, c_int, c_vp]),
+    "blsgpu_pairings_sharded_device": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "blsgpu_fp12_partials_fold_device": (c_int, [c_vp, c_vp, c_int, c_vp]),
     "blsgpu_group_set_pipelining": (c_int, [c_vp, c_int]),
     "blsgpu_group_synchronize": (c_int, [c_vp]),
     "blsgpu_group_g2_prepare": (c_int, [c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),

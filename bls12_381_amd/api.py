@@ -779,6 +779,18 @@ class Group:
         check(fn(self.h, op, lag, _ptr(out)), "partials_fold")
         return out
 
+    def pairings_sharded_device(self, mode, d_g1, d_g2, counts, d_out, d_g1_inf=None, d_g2_inf=None):
+        """member k: mode 0 pairings / 1 raw Miller values / 2 its local multi_miller_loop product of counts[k] pairs at d_g1[k], d_g2[k] -> d_out[k]; enqueues only"""
+        w = len(self)
+        arr = lambda ps: (ctypes.c_void_p * w)(*[ctypes.c_void_p(int(p)) for p in ps]) if ps is not None else None
+        cnt = (ctypes.c_size_t * w)(*[int(c) for c in counts])
+        check(self.lib.blsgpu_pairings_sharded_device(self.h, mode, arr(d_g1), arr(d_g1_inf), arr(d_g2), arr(d_g2_inf), cnt, arr(d_out)), "pairings_sharded_device")
+
+    def fp12_partials_fold_device(self, d_partials, d_out, final_exp=False):
+        w = len(self)
+        op = (ctypes.c_void_p * w)(*[ctypes.c_void_p(int(p)) for p in d_partials])
+        check(self.lib.blsgpu_fp12_partials_fold_device(self.h, op, 1 if final_exp else 0, ctypes.c_void_p(int(d_out))), "fp12_partials_fold_device")
+
     # G2Prepared tables on every member; the prepared Miller loops sharded like the unprepared ones
     def g2_prepare(self, g2_xy, g2_inf=None):
         g2 = _u64(g2_xy, (-1, 24))

@@ -2624,7 +2624,7 @@ struct blsgpu_group {
   // still has to read waits for that fold's copy (a pipelined caller rotates >= 8 buffers, so the event it meets is long complete)
   struct FoldRead { const void* ptr = nullptr; hipEvent_t ev = nullptr; bool used = false; };
   std::vector<std::array<FoldRead, 8>> fold_reads;
-  std::vector<hipEvent_t> ev_copy;
+  std::vector<hipEvent_t> ev_copy, ev_main;
   hipEvent_t ev_sum[4] = {};
   bool ev_sum_used[4] = {false, false, false, false};
   unsigned fold_seq = 0;
@@ -2663,6 +2663,7 @@ extern "C" void blsgpu_group_destroy(blsgpu_group* g) {
     delete wk;
   }
   for (size_t i = 0; i < g->ev_copy.size(); i++) if (g->ev_copy[i]) { hipSetDevice(g->ctx[i]->device); hipEventDestroy(g->ev_copy[i]); }
+  for (size_t i = 0; i < g->ev_main.size(); i++) if (g->ev_main[i]) { hipSetDevice(g->ctx[i]->device); hipEventDestroy(g->ev_main[i]); }
   for (size_t i = 0; i < g->fold_reads.size(); i++) for (auto& fr : g->fold_reads[i]) if (fr.ev) { hipSetDevice(g->ctx[i]->device); hipEventDestroy(fr.ev); }
   if (!g->ctx.empty() && g->ctx[0]) {
     hipSetDevice(g->ctx[0]->device);
@@ -2688,13 +2689,16 @@ extern "C" int blsgpu_group_create(const int* devices, int ndev, blsgpu_group** 
     hipEvent_t ev = nullptr;
     if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); blsgpu_group_destroy(g); g_err = "group_create: hipEventCreate failed"; return BLSGPU_ERR_HIP; }
     g->ev_copy.push_back(ev);
+    hipEvent_t evm = nullptr;
+    if (hipEventCreateWithFlags(&evm, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); blsgpu_group_destroy(g); g_err = "group_create: hipEventCreate failed"; return BLSGPU_ERR_HIP; }
+    g->ev_main.push_back(evm);
     g->fold_reads.emplace_back();
     for (auto& fr : g->fold_reads.back())
       if (hipEventCreateWithFlags(&fr.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); blsgpu_group_destroy(g); g_err = "group_create: hipEventCreate failed"; return BLSGPU_ERR_HIP; }
   }
   {
     hipError_t e = hipSetDevice(g->ctx[0]->device);
-    if (e == hipSuccess) e = hipMalloc(&g->fold_in, (size_t)4 * ndev * 288);
+    if (e == hipSuccess) e = hipMalloc(&g->fold_in, (size_t)4 * ndev * 576);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&g->ev_sum[i], hipEventDisableTiming);
     if (e != hipSuccess) { (void)hipGetLastError(); blsgpu_group_destroy(g); g_err = "group_create: staging for the asynchronous fold could not be allocated"; return BLSGPU_ERR_HIP; }
   }
@@ -2815,13 +2819,13 @@ extern "C" int blsgpu_g2_partials_fold(blsgpu_group* g, const void* const* d_par
 // sum into a staging row on member 0's device; member 0's stream waits for the w copies and adds them into d_out (device memory of member
 // 0, projective wire form).  Nothing is synchronised: the fold of MSM i - 2 runs under the accumulation of MSMs i - 1 and i.
 template <int G>
-static int partials_fold_device(blsgpu_group* g, const void* const* d_partials, int lag, void* d_out) {
-  constexpr size_t PB = G == 1 ? 144 : 288;
+static int partials_fold_device(blsgpu_group* g, const void* const* d_partials, int lag, void* d_out, int final_exp = 0) {
+  constexpr size_t PB = G == 1 ? 144 : G == 2 ? 288 : 576;
   if (!g || !d_partials || !d_out || lag < 0) return bad("partials_fold_device: bad argument");
   const size_t w = g->ctx.size();
   const unsigned seq = g->fold_seq++;
   const unsigned row = seq & 3u;
-  uint8_t* stage = (uint8_t*)g->fold_in + (size_t)row * w * 288;
+  uint8_t* stage = (uint8_t*)g->fold_in + (size_t)row * w * 576;
   blsgpu_ctx* c0 = g->ctx[0];
   // everything below runs on the members' FOLD streams: the context's own stream stays empty, so the front of the next MSM (which waits
   // for whatever is queued on that stream when it is launched) never waits for a fold -- with the fold on the main stream an MSM's front
@@ -2835,6 +2839,10 @@ static int partials_fold_device(blsgpu_group* g, const void* const* d_partials, 
     int r = blsgpu_join_lag(c, lag);
     c->stream = keep;
     if (r) return r;
+    // ... and for whatever the caller queued on the context's own stream (the producers of Fp12 partials run there; for pipelined MSMs that
+    // stream is empty and the event is complete at once)
+    HIPCHK(hipEventRecord(g->ev_main[k], keep));
+    HIPCHK(hipStreamWaitEvent(c->fold_stream, g->ev_main[k], 0));
     if (g->ev_sum_used[row]) HIPCHK(hipStreamWaitEvent(c->fold_stream, g->ev_sum[row], 0));       // the sum that last read this staging row
     // (a plain device-to-device copy for members on member 0's device: the peer form need not be asynchronous there)
     if (c->device == c0->device) HIPCHK(hipMemcpyAsync(w == 1 ? d_out : (void*)(stage + k * PB), d_partials[k], PB, hipMemcpyDeviceToDevice, c->fold_stream));
@@ -2846,13 +2854,19 @@ static int partials_fold_device(blsgpu_group* g, const void* const* d_partials, 
     return (int)BLSGPU_OK;
   });
   if (rc) return rc;
-  if (w == 1) return BLSGPU_OK;                 // one member: its partial sum IS the result (copied straight to d_out above)
+  if (w == 1 && !(G == 12 && final_exp)) return BLSGPU_OK;      // one member: its partial result IS the result (copied straight to d_out above)
   CTX_CLAIM(c0);
   HIPCHK(hipSetDevice(c0->device));
   for (size_t k = 1; k < w; k++) HIPCHK(hipStreamWaitEvent(c0->fold_stream, g->ev_copy[k], 0));
   hipStream_t keep = c0->stream;
   c0->stream = c0->fold_stream;
-  rc = G == 1 ? blsgpu_g1_sum_device(c0, stage, w, d_out) : blsgpu_g2_sum_device(c0, stage, w, d_out);
+  if (G == 12) {
+    // `MillerLoopResult + MillerLoopResult` over the members' partial products (pairings.rs:179-186), then -- if asked -- the ONE final exponentiation
+    rc = w == 1 ? BLSGPU_OK : blsgpu_fp12_product_device(c0, stage, w, d_out);
+    if (!rc && final_exp) rc = blsgpu_final_exponentiation_device(c0, d_out, 1, d_out);
+  } else {
+    rc = G == 1 ? blsgpu_g1_sum_device(c0, stage, w, d_out) : blsgpu_g2_sum_device(c0, stage, w, d_out);
+  }
   c0->stream = keep;
   if (rc) return rc;
   HIPCHK(hipEventRecord(g->ev_sum[row], c0->fold_stream));
@@ -2861,6 +2875,20 @@ static int partials_fold_device(blsgpu_group* g, const void* const* d_partials, 
 }
 extern "C" int blsgpu_g1_partials_fold_device(blsgpu_group* g, const void* const* d_partials, int lag, void* d_out) { return partials_fold_device<1>(g, d_partials, lag, d_out); }
 extern "C" int blsgpu_g2_partials_fold_device(blsgpu_group* g, const void* const* d_partials, int lag, void* d_out) { return partials_fold_device<2>(g, d_partials, lag, d_out); }
+extern "C" int blsgpu_fp12_partials_fold_device(blsgpu_group* g, const void* const* d_partials, int final_exp, void* d_out) { return partials_fold_device<12>(g, d_partials, 0, d_out, final_exp); }
+// Device-pointer, asynchronous forms of the pairing entry points: member k works on ITS arrays (device pointers in its memory, counts[k] items) and
+// only enqueues.  mode 0: out[k][i] = pairing, 1: raw Miller values (nothing to fold: the outputs stay sharded); mode 2: d_out[k] = the member-local
+// product of its Miller values (one Fp12 value, 576 B), to be folded by blsgpu_fp12_partials_fold_device
+extern "C" int blsgpu_pairings_sharded_device(blsgpu_group* g, int mode, const void* const* d_g1, const void* const* d_g1inf, const void* const* d_g2, const void* const* d_g2inf,
+                                              const size_t* counts, void* const* d_out) {
+  if (!g || !d_g1 || !d_g2 || !counts || !d_out || mode < 0 || mode > 2) return bad("pairings_sharded_device: bad argument");
+  return group_run(g, [&](size_t k, blsgpu_ctx* c) {
+    const void* f1 = d_g1inf ? d_g1inf[k] : nullptr; const void* f2 = d_g2inf ? d_g2inf[k] : nullptr;
+    if (mode == 0) return blsgpu_pairing_batch_device(c, d_g1[k], f1, d_g2[k], f2, counts[k], d_out[k]);
+    if (mode == 1) return blsgpu_miller_loop_batch_device(c, d_g1[k], f1, d_g2[k], f2, counts[k], d_out[k]);
+    return blsgpu_multi_miller_loop_device(c, d_g1[k], f1, d_g2[k], f2, counts[k], d_out[k]);
+  });
+}
 extern "C" int blsgpu_group_set_pipelining(blsgpu_group* g, int on) {
   if (!g) return bad("group_set_pipelining: NULL group");
   for (auto c : g->ctx) { int rc = blsgpu_set_pipelining(c, on); if (rc) return rc; }

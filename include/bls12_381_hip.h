@@ -344,6 +344,15 @@ int blsgpu_g2_partials_fold(blsgpu_group* group, const void* const* d_partials, 
  * four, every MSM waits for the fold three calls back).  d_out is valid after blsgpu_group_synchronize. */
 int blsgpu_g1_partials_fold_device(blsgpu_group* group, const void* const* d_partials, int lag, void* d_out_xyz);
 int blsgpu_g2_partials_fold_device(blsgpu_group* group, const void* const* d_partials, int lag, void* d_out_xyz);
+/* The pairing entry points in the same form: member k works on ITS arrays (device pointers in its memory, counts[k] items; the infinity
+ * arrays may be NULL) and only enqueues.  mode 0: d_out[k] = counts[k] pairings (`Gt`), mode 1: raw Miller values -- the outputs stay sharded,
+ * nothing to fold; mode 2: d_out[k] = the member-local `multi_miller_loop` of its terms (ONE Fp12 value), and
+ * blsgpu_fp12_partials_fold_device(group, d_partials, final_exp, d_out) multiplies the members' values on member 0
+ * (`MillerLoopResult + MillerLoopResult`, src/pairings.rs:179-186) and applies the ONE final exponentiation if asked; d_out (72 u64 in
+ * member 0's memory) is valid after blsgpu_group_synchronize. */
+int blsgpu_pairings_sharded_device(blsgpu_group* group, int mode, const void* const* d_g1_xy, const void* const* d_g1_inf, const void* const* d_g2_xy,
+                                   const void* const* d_g2_inf, const size_t* counts, void* const* d_out);
+int blsgpu_fp12_partials_fold_device(blsgpu_group* group, const void* const* d_partials, int final_exp, void* d_out_f);
 int blsgpu_group_set_pipelining(blsgpu_group* group, int enabled);
 int blsgpu_group_synchronize(blsgpu_group* group);
 /* n independent pairings / raw Miller values: index slices, each member writes its slice of `out` (n x 72 u64); nothing to fold. */
@@ -445,7 +454,7 @@ int blsgpu_g1_to_bytes_batch_device(blsgpu_ctx* ctx, const void* d_xy, const voi
 int blsgpu_g2_to_bytes_batch_device(blsgpu_ctx* ctx, const void* d_xy, const void* d_infinity, size_t n, int compressed, void* d_out);
 int blsgpu_gt_mul_scalar_batch_device(blsgpu_ctx* ctx, const void* d_gt, const void* d_scalars, size_t n, void* d_out);
 /* d_flags[i] = 1 if gt[i] == Gt::identity() (= Fp12::one(), src/pairings.rs:211-218), else 0: the verdict of an equation
- * prod e(P_j, Q_j) == 1 without bringing 576 B per equation to the host. */
+ * prod e(P_j, Q_j) == 1 without bringing 576 B per equation to the host.  (d_gt must be 16-byte aligned, as device allocations are.) */
 int blsgpu_gt_is_identity_device(blsgpu_ctx* ctx, const void* d_gt, size_t n, void* d_flags);
 /* Bulk BLS signature verification, bytes in -> verdict bytes out, every stage on the device (one upload, one download in the
  * host-pointer form): checked decoding of the compressed public keys and signatures, hash_to_curve of the messages (message i =

@@ -108,6 +108,8 @@ extern "C" {
     pub fn blsgpu_g2_partials_fold(group: *mut BlsgpuGroup, d_partials: *const *const c_void, lag: c_int, out_xyz: *mut u64) -> c_int;
     pub fn blsgpu_g1_partials_fold_device(group: *mut BlsgpuGroup, d_partials: *const *const c_void, lag: c_int, d_out_xyz: *mut c_void) -> c_int;
     pub fn blsgpu_g2_partials_fold_device(group: *mut BlsgpuGroup, d_partials: *const *const c_void, lag: c_int, d_out_xyz: *mut c_void) -> c_int;
+    pub fn blsgpu_pairings_sharded_device(group: *mut BlsgpuGroup, mode: c_int, d_g1_xy: *const *const c_void, d_g1_inf: *const *const c_void, d_g2_xy: *const *const c_void, d_g2_inf: *const *const c_void, counts: *const usize, d_out: *const *mut c_void) -> c_int;
+    pub fn blsgpu_fp12_partials_fold_device(group: *mut BlsgpuGroup, d_partials: *const *const c_void, final_exp: c_int, d_out_f: *mut c_void) -> c_int;
     pub fn blsgpu_group_set_pipelining(group: *mut BlsgpuGroup, enabled: c_int) -> c_int;
     pub fn blsgpu_group_synchronize(group: *mut BlsgpuGroup) -> c_int;
     pub fn blsgpu_pairing_batch_sharded(group: *mut BlsgpuGroup, g1_xy: *const u64, g1_inf: *const u8, g2_xy: *const u64, g2_inf: *const u8, n: usize, out_gt: *mut u64) -> c_int;

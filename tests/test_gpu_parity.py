@@ -2455,3 +2455,38 @@ def test_device_group_on_distinct_physical_devices(ctx):
     assert np.array_equal(grp.multi_miller_loop(G1, F1, G2, F2), ctx.multi_miller_loop(G1, F1, G2, F2))
     assert np.array_equal(grp.pairing_batch(G1, F1, G2, F2), ctx.pairing_batch(G1, F1, G2, F2))
     gb.free(); grp.close()
+
+
+@pytest.mark.parametrize("members", [1, 3])
+def test_device_group_asynchronous_pairings_and_fp12_fold(ctx, members):
+    """blsgpu_pairings_sharded_device (pairings / raw Miller values stay sharded; member-local multi_miller_loop products) and
+    blsgpu_fp12_partials_fold_device (product on member 0, optional ONE final exponentiation) against the single-context entry points"""
+    import torch
+    import bls12_381_amd as b
+    dev = torch.device("cuda", 0)
+    grp = b.Group([0] * members)
+    n = 23
+    ps, qs = _pair_inputs(n, 9100 + members)
+    ps[5] = o.G1_IDENTITY_AFF
+    G1, F1, G2, F2 = _terms_w(ps, qs)
+    sizes = grp.shard_sizes(n)
+    lo = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+    t = lambda a: torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).to(dev)
+    d1 = [t(G1[lo[k]:lo[k + 1]].copy()) for k in range(members)]; d2 = [t(G2[lo[k]:lo[k + 1]].copy()) for k in range(members)]
+    f1 = [t(F1[lo[k]:lo[k + 1]].copy()) for k in range(members)]; f2 = [t(F2[lo[k]:lo[k + 1]].copy()) for k in range(members)]
+    ptr = lambda ts: [x.data_ptr() for x in ts]
+    for mode, want in ((0, ctx.pairing_batch(G1, F1, G2, F2)), (1, ctx.miller_loop_batch(G1, F1, G2, F2))):
+        outs = [torch.zeros((max(1, sizes[k]), 72), dtype=torch.int64, device=dev) for k in range(members)]
+        grp.pairings_sharded_device(mode, ptr(d1), ptr(d2), sizes, ptr(outs), d_g1_inf=ptr(f1), d_g2_inf=ptr(f2))
+        grp.synchronize()
+        got = np.concatenate([outs[k][:sizes[k]].cpu().numpy().view(np.uint64) for k in range(members)])
+        assert np.array_equal(got, want), mode
+    parts = [torch.zeros(72, dtype=torch.int64, device=dev) for _ in range(members)]
+    res = torch.zeros(72, dtype=torch.int64, device=dev)
+    ml = ctx.multi_miller_loop(G1, F1, G2, F2)
+    for fe, want in ((False, ml), (True, ctx.final_exponentiation_batch(ml[None, :])[0])):
+        grp.pairings_sharded_device(2, ptr(d1), ptr(d2), sizes, ptr(parts), d_g1_inf=ptr(f1), d_g2_inf=ptr(f2))
+        grp.fp12_partials_fold_device(ptr(parts), res.data_ptr(), final_exp=fe)
+        grp.synchronize()
+        assert np.array_equal(res.cpu().numpy().view(np.uint64), want), fe
+    grp.close()
