@@ -74,7 +74,7 @@ def static_traffic(tag):
 _DROP = {"note", "traffic_source", "launch_sampling", "sample_detail", "per_op_ns", "host", "mac32_per_launch", "reference_algorithm_mac32_per_unit",
          "executed_mac_per_unit", "executed_frac_of_peak", "mac32_per_unit_is", "launch_ms_isolated", "hbm_frac_of_8TBs", "table_build_s", "resident_bytes",
          "single_thread_value", "parallel_speedup", "algorithmic_bytes", "scalars", "single_call_scalar_muls_per_s", "end_to_end_scalar_muls_per_s",
-         "with_final_exponentiation_ms", "window_bits", "per_term_path_ms", "launches_timed", "peak", "unit", "bound", "kernel", "mac32_per_unit"}
+         "with_final_exponentiation_ms", "window_bits", "per_term_path_ms", "launches_timed", "peak", "unit", "bound", "kernel", "mac32_per_unit", "achieved"}
 _KEEP_SMALL = ("pairing_n1_ms", "pairing_n1024_ms", "final_exponentiation_n1_ms", "multi_miller_loop_n3_plus_final_exponentiation_ms")
 
 
@@ -647,7 +647,7 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
                   "Fp12 product, batched final exponentiation), inputs and outputs in HBM",
           "roofline": {"bound": "int-valu", "kernel": "k_pairing_quad (Miller) + k_fp12_prod_seg_quad + k_final_exp_quad", "mac32_per_unit": mac_eq,
                        "achieved": ne * mac_eq / (eqms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s", "frac": ne * mac_eq / (eqms * 1e-3) / peak,
-                       "algorithmic_bytes": ne * (ke * 288 + 576), "traffic": None}}
+                       "algorithmic_bytes": ne * (ke * 288 + 576), "traffic": static_traffic("equations")[0], "traffic_source": static_traffic("equations")[1]}}
     if not args.no_cpu_baseline:
         from oracle import c_oracle
         from oracle import bls12_381_ref as o_ref
@@ -826,7 +826,37 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
                             "roofline": {"bound": "int-valu", "kernel": "k_hash_to_curve<G2, lane pair>", "mac32_per_unit": mac_h2c, "mac32_per_unit_is": "estimate (see bench.py)",
                                          "achieved": np_ * mac_h2c / (hms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s", "frac": np_ * mac_h2c / (hms * 1e-3) / peak,
                                          "algorithmic_bytes": np_ * (32 + 288), "traffic": None}}
-    del hm, ho, hout
+    # ... and to G1 (the min-sig placement), same messages
+    hout1 = torch.zeros((np_, 18), dtype=torch.int64, device=dev)
+    hdst1 = b"BLS_SIG_BLS12381G1_XMD:SHA-256_SSWU_RO_NUL_"
+    hd1 = torch.from_numpy(np.frombuffer(hdst1, dtype=np.uint8).copy()).to(dev)
+    h1ms = median_ms(lambda: bls._lib.check(ctx.lib.blsgpu_hash_to_curve_device(ctx.h, 1, hm.data_ptr(), ho.data_ptr(), np_, hd1.data_ptr(), len(hdst1), 0, hout1.data_ptr()), "hash_to_curve_device"),
+                     sync, warm=1, reps=3)
+    mac_h2c1 = 2400 * 300        # two SSWU maps with one square-root-ratio power each (~2 x 560), the 11-isogeny, the addition, the cofactor power by 1 - x (~64 doublings + adds): ~2 400 mul (estimate)
+    extras["hash_to_g1"] = {"n": np_, "ms": h1ms, "hashes_per_s": np_ / (h1ms * 1e-3),
+                            "roofline": {"bound": "int-valu", "kernel": "k_hash_to_curve<G1>", "mac32_per_unit": mac_h2c1, "mac32_per_unit_is": "estimate (see bench.py)",
+                                         "achieved": np_ * mac_h2c1 / (h1ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s", "frac": np_ * mac_h2c1 / (h1ms * 1e-3) / peak,
+                                         "algorithmic_bytes": np_ * (32 + 144), "traffic": None}}
+    del hm, ho, hout, hout1
+    # point codecs with device pointers: checked decoding of 2^16 compressed points (square root + subgroup test) and encoding
+    cod = {}
+    for grp, xy_, cb in ((1, g1xy, 48), (2, g2xy, 96)):
+        enc = ctx.points_to_bytes(grp, xy_, None, compressed=True)
+        d_enc = torch.from_numpy(enc).to(dev)
+        d_cx = torch.zeros((np_, 12 * grp), dtype=torch.int64, device=dev); d_ci = torch.zeros(np_, dtype=torch.uint8, device=dev); d_ck = torch.zeros(np_, dtype=torch.uint8, device=dev)
+        dms = median_ms(lambda: ctx.points_from_bytes_device(grp, d_enc.data_ptr(), np_, d_cx.data_ptr(), d_ci.data_ptr(), d_ck.data_ptr(), compressed=True, checked=True), sync, warm=1, reps=3)
+        ok_all = bool(d_ck.all().item()) and bool(torch.equal(d_cx, (d_g1 if grp == 1 else d_g2)))
+        d_eo = torch.zeros((np_, cb), dtype=torch.uint8, device=dev)
+        ems = median_ms(lambda: ctx.points_to_bytes_device(grp, d_cx.data_ptr(), d_ci.data_ptr(), np_, d_eo.data_ptr(), compressed=True), sync, warm=1, reps=3)
+        mac_dec = (2500 if grp == 1 else 9000) * 300      # square root + subgroup test: estimates of the algorithms' multiplication counts
+        cod["g%d" % grp] = {"n": np_, "decode_checked_ms": dms, "decoded_per_s": np_ / (dms * 1e-3), "encode_ms": ems, "roundtrip_ok": ok_all and bool(torch.equal(d_eo, d_enc)),
+                            "roofline": {"bound": "int-valu", "kernel": "k_point_decode<G%d>" % grp, "mac32_per_unit": mac_dec, "mac32_per_unit_is": "estimate (see bench.py)",
+                                         "achieved": np_ * mac_dec / (dms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s", "frac": np_ * mac_dec / (dms * 1e-3) / peak,
+                                         "algorithmic_bytes": np_ * (cb + 2 * cb + 2), "traffic": None}}
+        if not cod["g%d" % grp]["roundtrip_ok"]:
+            raise SystemExit("bench: codec round trip failed")
+        del d_enc, d_cx, d_eo
+    extras["codec"] = cod
     # 2^20-point G2 MSM (BASELINE configs[2]), pipelined like the headline
     n2 = min(1 << 20, n)
     k2 = synthetic.scalars(n2, 101)

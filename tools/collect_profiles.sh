@@ -19,5 +19,6 @@ tools/pmc.sh prof_wide python tools/run_pairing.py pairing 8 20
 tools/pmc.sh prof_mmlp python tools/run_pairing.py mmlp 18 3
 tools/pmc.sh prof_eqp python tools/run_pairing.py eqp 16 3
 BLSGPU_MML_IMPL=4 tools/pmc.sh prof_mmlq python tools/run_pairing.py mml 18 3
-find gpurun_out/prof_msm gpurun_out/prof_pair gpurun_out/prof_pair_lp gpurun_out/prof_mml gpurun_out/prof_wide gpurun_out/prof_mmlp gpurun_out/prof_eqp gpurun_out/prof_mmlq -name "*agent_info.csv" -delete
+tools/pmc.sh prof_eq python tools/run_pairing.py equations 14 3
+find gpurun_out/prof_msm gpurun_out/prof_pair gpurun_out/prof_pair_lp gpurun_out/prof_mml gpurun_out/prof_wide gpurun_out/prof_mmlp gpurun_out/prof_eqp gpurun_out/prof_mmlq gpurun_out/prof_eq -name "*agent_info.csv" -delete
 du -sh gpurun_out/prof_*

@@ -164,4 +164,26 @@ if one("prof_eqp/stats/**/*kernel_trace.csv"):
 if one("prof_mmlq/stats/**/*kernel_trace.csv"):
     pairing("prof_mmlq", "k_mml_prep_quad", 262144, "terms", 2.07e6, "mml_quad_explicit", "mml 18 3 (BLSGPU_MML_IMPL=4)",
             "quad layout, four UNPREPARED terms per shared accumulator, per-term state placed by hand (coalesced work area + LDS parking)", 288, meta_key="k_mml_prep_quad")
+if one("prof_eq/stats/**/*kernel_trace.csv"):
+    # the whole call: Miller quads + segmented product + final exponentiations; the counters below are those of the Miller kernel, the call's
+    # traffic (all kernels) is in the json as hbm_bytes_per_call
+    pairing("prof_eq", "k_pairing_quad", 49152, "Miller loops (2^14 three-term equations)", 2.07e6, "equations", "equations 14 3",
+            "quad layout, one Miller loop per term (per-term path of blsgpu_multi_miller_loop_many)", 288)
+    try:
+        import csv as _csv
+        tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+        names = ("k_pairing_quad", "k_multi_miller_seg", "k_fp12_prod_seg_quad", "k_final_exp_quad", "k_mml_prep_quad")
+        for f in glob.glob(os.path.join(G, "prof_eq", "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+            for r in _csv.DictReader(open(f)):
+                if r["Counter_Name"] in tot and any(k in r["Kernel_Name"] for k in names):
+                    tot[r["Counter_Name"]] += float(r["Counter_Value"])
+        calls = 3                                                        # tools/run_pairing.py equations 14 3
+        jp = os.path.join(OUT, f"{RND}_equations_pmc.json")
+        j = json.load(open(jp)); j["hbm_bytes_per_launch_miller_kernel"] = j["hbm_bytes_per_launch_corrected"]
+        j["hbm_bytes_per_launch_corrected"] = (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / calls
+        j["algorithmic_bytes_per_call"] = 16384 * (3 * 288 + 576)
+        j["note"] = "hbm_bytes_per_launch_corrected = every kernel of ONE blsgpu_multi_miller_loop_many call (2^14 three-term equations) together"
+        json.dump(j, open(jp, "w"), indent=1)
+    except Exception as ex:
+        print("equations: call-level traffic not written:", ex)
 print("profiles written for", RND)
