@@ -152,6 +152,8 @@ struct blsgpu_ctx {
   DevBuf fr_tw[2], fr_tmp, fr_ninv;     // Fr transform: twiddle tables (forward / inverse), permutation target, n^-1
   int fr_tw_log[2] = {-1, -1};
   int fr_ninv_log = -1;
+  int fr_cols_want = 1;                 // 0 never / 1 from 2^20 elements / 2 always: BLSGPU_NTT_IMPL=stage|cols, read when the context is created
+  int fr_cols_ok = -1;                  // k_fr_cols usable on this device (144 KB of dynamic LDS granted); decided at the first transform
   hipEvent_t ev_fr[3] = {};             // twiddles forward / inverse, n^-1: recorded where the table was built, awaited by every user
                                         // (the caller may have switched streams with blsgpu_set_stream in between)
 };
@@ -561,6 +563,7 @@ extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
   }
   if (const char* v = getenv("BLSGPU_MMLP_K")) { long k = atol(v); if (k >= 1 && k <= MMLP_MAX_K) c->mmlp_k = (int)k; }
   if (const char* v = getenv("BLSGPU_MML_IMPL")) { long k = atol(v); if (k == 1 || k == 4) c->mml_impl = (int)k; }
+  if (const char* v = getenv("BLSGPU_NTT_IMPL")) c->fr_cols_want = !strcmp(v, "cols") ? 2 : !strcmp(v, "stage") ? 0 : 1;      // cols: at every size (tests)
   if (const char* v = getenv("BLSGPU_ITEM_CAP")) { long k = atol(v); if (k >= 8 && k <= ITEM_CAP_MAX) c->item_cap = (u32)k; }
   int rc = ctx_init(c);
   if (rc != BLSGPU_OK) { blsgpu_destroy(c); return rc; }       // destroy tolerates the half-built context (null handles are skipped)
@@ -1714,6 +1717,36 @@ extern "C" int blsgpu_fr_ntt_device(blsgpu_ctx* c, void* d_data, int log_n, int 
   // one tile goes through the scratch buffer and is copied back.
   const u32* src = data;
   u32* cur = lh >= tl ? tmp : data;
+  // round 5: the top log_n - tl stages on column tiles in LDS (k_fr_cols), at most ten stages per pass over the data; needs 144 KB of
+  // dynamic LDS per workgroup (gfx950 has 160 KB per CU) -- the stage-pair passes below remain for a device that refuses it and as the
+  // A/B twin (BLSGPU_NTT_IMPL=stage)
+  if (c->fr_cols_ok < 0) {
+    int lds_max = 0;
+    const size_t want = ((size_t)9 << FR_COLS_LOG) * 4;
+    c->fr_cols_ok = 0;
+    if (c->fr_cols_want && hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) == hipSuccess && (size_t)lds_max >= want &&
+        hipFuncSetAttribute((const void*)k_fr_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) == hipSuccess)
+      c->fr_cols_ok = 1;
+    (void)hipGetLastError();
+  }
+  // Measured on MI355X (tools/ntt_time.py): tiles of 2^11 elements, at most seven stages per pass, 512 lanes per workgroup (two workgroups
+  // per CU overlap their load / barrier / store phases): 2.52-2.55 ms at 2^24 and 11.2 ms at 2^26 against 2.85-2.91 / 12.2-12.4 ms for the
+  // stage-pair passes (-11 % / -10 %); at 2^20 and 2^22 the two are equal within the run-to-run spread (0.155-0.17 / 0.60-0.66 ms): the
+  // vector sits in the 256 MB Infinity Cache, a stage-pair pass is 19 us, and every variant costs 7-9 us per stage -- the butterflies'
+  // ~375 instructions per multiplication, not the passes over the data, are what the transform pays for.  Below 2^20 the stage-pair
+  // passes stay.  BLSGPU_NTT_COLS="tile log2,stages per pass,lanes" overrides the shape for experiments.
+  if (c->fr_cols_ok && lh >= tl && (log_n >= 20 || c->fr_cols_want == 2)) {
+    int tlog = 11, dmax = 7, block = 512;
+    if (const char* v = getenv("BLSGPU_NTT_COLS")) { int a = 0, b = 0, cc = 0; if (sscanf(v, "%d,%d,%d", &a, &b, &cc) == 3 && a >= 6 && a <= FR_COLS_LOG && b >= 1 && b <= a && cc >= 64 && cc <= 1024) { tlog = a; dmax = b; block = cc; } }
+    const int m = lh + 1 - tl, passes = (m + dmax - 1) / dmax;
+    for (int ps = 0; ps < passes; ps++) {
+      const int d = (lh + 1 - tl + (passes - ps) - 1) / (passes - ps);      // the remaining stages split evenly over the remaining passes
+      const int ls = lh - d + 1;
+      const int lk = tlog - d < ls ? tlog - d : ls;
+      hipLaunchKernelGGL(k_fr_cols, dim3((unsigned)(n >> (d + lk))), dim3(block), ((size_t)9 << (d + lk)) * 4, st, src, cur, tw, lh, d, lk);
+      src = cur; lh -= d;
+    }
+  }
   while (lh - 1 >= tl) {                                // two stages per pass over the data
     hipLaunchKernelGGL(k_fr_stage2, dim3(nblk(n / 4, 256)), dim3(256), 0, st, src, cur, tw, log_n, lh);
     src = cur; lh -= 2;

@@ -313,12 +313,15 @@ __global__ void __launch_bounds__(256) k_fr_stage2(const u32* src, u32* x, const
 }
 
 // ---- the last stages on a tile in LDS + bit-reversed store ---------------------------------------------------
+#ifndef FR_TILE_WAVES
+#define FR_TILE_WAVES 4
+#endif
 constexpr int FR_TILE_LOG = 10;                  // 1024 elements x 9 limbs = 36 KB of LDS per workgroup
 // Runs the stages with half-spans 2^(tl-1) ... 1 on each aligned tile of 2^tl elements (tl = min(FR_TILE_LOG,
 // log_n)), then writes element p of the (bit-reversed) result to its natural position bitrev(p), optionally
 // scaled (the inverse transform's n^-1), in canonical form.  `x` is read, `y` written (they differ: the permutation
 // is not in place).  Stages alternate R (sums kept unreduced) and F (sums reduced), see the bound table above.
-__global__ void __launch_bounds__(256) k_fr_tile(const u32* __restrict__ x, u32* __restrict__ y, const u32* __restrict__ tw, int log_n,
+__global__ void __launch_bounds__(256, FR_TILE_WAVES) k_fr_tile(const u32* __restrict__ x, u32* __restrict__ y, const u32* __restrict__ tw, int log_n,
                                                  int tl, const u32* __restrict__ scale) {
   extern __shared__ u32 lds[];                   // 2^tl elements, limb-interleaved: limb k of element e at lds[k * 2^tl + e]
   const int T = 1 << tl;
@@ -377,6 +380,70 @@ __global__ void __launch_bounds__(256) k_fr_tile(const u32* __restrict__ x, u32*
     const size_t p = base + e;
     const size_t r = (size_t)(__brevll((unsigned long long)p) >> (64 - log_n));
     fr_store(y + r * 8, frl_canon(v));
+  }
+}
+// ---- the TOP stages on column tiles in LDS (round 5) -------------------------------------------------------------------------------
+// The stages with half-spans 2^lh_top ... 2^(lh_top-d+1) only couple elements whose indices differ in bits [lh_top-d+1, lh_top]: a
+// "column" of 2^d elements S = 2^ls apart (ls = lh_top - d + 1).  A workgroup takes K = 2^lk ADJACENT columns -- K * 32 contiguous
+// bytes per row, 2 KB for the 2^20 transform -- into LDS (element (row, col) at tile index row * K + col, limb-interleaved like
+// k_fr_tile), runs all d stages there with the radix-4 schedule of k_fr_tile (R stage + F stage per round trip, twiddles read from the
+// per-level tables at the element's GLOBAL offset), and writes the tile back where it came from with values in [0, 2r).  One pass over
+// the data instead of d / 2: the 2^20 transform is two such passes of five stages + k_fr_tile (ten stages) = three passes instead of
+// six, the 2^24 transform 2 x 7 stages + k_fr_tile instead of eight passes (the shape is the host's: api.hip::blsgpu_fr_ntt_device).
+// Block b = (hi, chunk): hi = b >> (ls - lk) selects the aligned block of 2^(lh_top+1) elements, chunk the K columns inside a stride.
+constexpr int FR_COLS_LOG = 12;                    // largest tile the host may ask for: 4096 elements x 9 limbs = 144 KB of the CU's 160 KB
+constexpr int FR_COLS_BLOCK = 1024;
+__global__ void __launch_bounds__(FR_COLS_BLOCK) k_fr_cols(const u32* src, u32* dst, const u32* __restrict__ tw, int lh_top, int d, int lk) {
+  extern __shared__ u32 lds[];
+  const int T = 1 << (d + lk), K = 1 << lk;
+  const int ls = lh_top - d + 1;
+  const size_t lo = ((size_t)blockIdx.x & (((size_t)1 << (ls - lk)) - 1)) << lk;
+  const size_t base = (((size_t)blockIdx.x >> (ls - lk)) << (lh_top + 1)) + lo;
+  for (int e = threadIdx.x; e < T; e += blockDim.x) {
+    FrL v = frl_load(src + (base + ((size_t)(e >> lk) << ls) + (e & (K - 1))) * 8);
+#pragma unroll
+    for (int k = 0; k < 9; k++) lds[k * T + e] = v.l[k];
+  }
+  __syncthreads();
+  int s = d;                                       // stages left; the next one has local half-span 2^(s-1) * K, global 2^(s-1) * S
+  for (; s >= 2; s -= 2) {
+    const int lq = s - 2 + lk, q = 1 << lq;        // local half-span of the SECOND stage of this round trip
+    const int gh = s - 1 + ls;                     // log2 of the global half-span of the first
+    for (int t = threadIdx.x; t < T / 4; t += blockDim.x) {
+      const int i = t & (q - 1), p = ((t >> lq) << (lq + 2)) + i;
+      const size_t gi = ((size_t)(i >> lk) << ls) + lo + (size_t)(i & (K - 1));      // offset of p inside the second stage's global half-span
+      FrL a0, a1, a2, a3;
+#pragma unroll
+      for (int k = 0; k < 9; k++) { a0.l[k] = lds[k * T + p]; a1.l[k] = lds[k * T + p + q]; a2.l[k] = lds[k * T + p + 2 * q]; a3.l[k] = lds[k * T + p + 3 * q]; }
+      FrL w0 = frl_load(tw + (fr_tw_off(gh) + gi) * 8), w1 = frl_load(tw + (fr_tw_off(gh) + gi + ((size_t)1 << (gh - 1))) * 8);
+      FrL w2 = frl_load(tw + (fr_tw_off(gh - 1) + gi) * 8);
+      FrL b0 = frl_add(a0, a2), b2 = frl_mul(frl_sub<1>(a0, a2), w0);
+      FrL b1 = frl_add(a1, a3), b3 = frl_mul(frl_sub<1>(a1, a3), w1);
+      FrL c0 = frl_reduce(frl_add(b0, b1)), c1 = frl_mul(frl_sub<2>(b0, b1), w2);
+      FrL c2 = frl_reduce(frl_add(b2, b3)), c3 = frl_mul(frl_sub<2>(b2, b3), w2);
+#pragma unroll
+      for (int k = 0; k < 9; k++) { lds[k * T + p] = c0.l[k]; lds[k * T + p + q] = c1.l[k]; lds[k * T + p + 2 * q] = c2.l[k]; lds[k * T + p + 3 * q] = c3.l[k]; }
+    }
+    __syncthreads();
+  }
+  if (s == 1) {                                    // odd depth: one more stage (R), local half-span K, global half-span S
+    for (int t = threadIdx.x; t < T / 2; t += blockDim.x) {
+      const int i = t & (K - 1), p = ((t >> lk) << (lk + 1)) + i;
+      FrL a, b;
+#pragma unroll
+      for (int k = 0; k < 9; k++) { a.l[k] = lds[k * T + p]; b.l[k] = lds[k * T + p + K]; }
+      FrL w = frl_load(tw + (fr_tw_off(ls) + lo + (size_t)i) * 8);
+      FrL s2 = frl_add(a, b), df = frl_mul(frl_sub<1>(a, b), w);
+#pragma unroll
+      for (int k = 0; k < 9; k++) { lds[k * T + p] = s2.l[k]; lds[k * T + p + K] = df.l[k]; }
+    }
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < T; e += blockDim.x) {
+    FrL v;
+#pragma unroll
+    for (int k = 0; k < 9; k++) v.l[k] = lds[k * T + e];
+    fr_store(dst + (base + ((size_t)(e >> lk) << ls) + (e & (K - 1))) * 8, frl_pack(frl_reduce(v)));
   }
 }
 // n^-1 in Montgomery form (n = 2^log_n): (2^-1)^log_n

@@ -649,6 +649,54 @@ def test_fr_ntt_vs_oracle(ctx, log_n):
     assert frs(ctx.fr_ntt(X, inverse=True)) == o.fr_ntt(x, inverse=True)
 
 
+@pytest.mark.parametrize("log_n", [11, 13, 14, 17, 20, 21, 22, 23])
+def test_fr_ntt_column_tiles_equal_stage_passes(log_n):
+    """round 5: from 2^20 elements the top stages run on column tiles in LDS (k_fr_cols: up to seven stages per pass).  A context that
+    uses them at EVERY size (BLSGPU_NTT_IMPL=cols) against one that never does (=stage: the passes of rounds 2-4, which the oracle pins
+    at 2^0 .. 2^13): canonical outputs limb-identical in both directions, odd and even depths, one to four column passes; the
+    2^11 / 2^13 results also against the oracle, sampled outputs of 2^14 against the defining sum; two other tile shapes at 2^20"""
+    import bls12_381_amd as bls
+    n = 1 << log_n
+    rs = np.random.RandomState(50 + log_n)
+    raw = rs.randint(0, 256, size=(n, 32), dtype=np.uint8); raw[:, 31] &= 0x3F
+    X = raw.view(np.uint64).reshape(n, 4).copy()
+    X[0] = 0; X[1] = frw(o.R_ORDER - 1)
+    made = []
+    for impl in ("cols", "stage"):
+        os.environ["BLSGPU_NTT_IMPL"] = impl
+        try:
+            made.append(bls.Context(0))
+        finally:
+            os.environ.pop("BLSGPU_NTT_IMPL")
+    new, old = made
+    try:
+        Y, Yo = new.fr_ntt(X), old.fr_ntt(X)
+        assert np.array_equal(Y, Yo)
+        assert np.array_equal(new.fr_ntt(Y, inverse=True), X)
+        assert np.array_equal(new.fr_ntt(X, inverse=True), old.fr_ntt(X, inverse=True))
+        if log_n == 20:
+            for shape in ("12,10,1024", "10,3,256"):
+                os.environ["BLSGPU_NTT_COLS"] = shape
+                try:
+                    assert np.array_equal(new.fr_ntt(X), Yo), shape
+                finally:
+                    os.environ.pop("BLSGPU_NTT_COLS")
+    finally:
+        new.close(); old.close()
+    if log_n <= 13:
+        assert frs(Y) == o.fr_ntt([o.fr_from_mont_limbs(v) for v in X])
+    if log_n == 14:
+        w = o.fr_omega(log_n)
+        xs = [o.fr_from_mont_limbs(X[j]) for j in range(n)]
+        for k in (1, 4097, n - 1):
+            wk = pow(w, k, o.R_ORDER)
+            acc, t = 0, 1
+            for j in range(n):
+                acc += xs[j] * t
+                t = t * wk % o.R_ORDER
+            assert o.fr_from_mont_limbs(Y[k]) == acc % o.R_ORDER
+
+
 def test_fr_ntt_large_properties(ctx):
     """2^20 scalars (the MSM's scalar vector at the headline size): round trip, linearity, sampled outputs against the
     defining sum, and the convolution theorem on a sparse product."""

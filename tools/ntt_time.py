@@ -1,22 +1,61 @@
 #!/usr/bin/env python3
-"""Fr NTT timing: python tools/ntt_time.py [log_n ...]  (default 2^10, 2^16, 2^20, 2^24 elements in HBM, in place; median of 20)"""
-import hashlib, os, sys, time
-import numpy as np
+"""A/B timing of the Fr transform (round 5): the column-tile path (k_fr_cols + k_fr_tile) against the stage-pair passes of rounds 2-4
+(BLSGPU_NTT_IMPL=stage), 2^16 .. 2^24 elements resident in HBM; outputs compared limb for limb.
+   usage: python tools/ntt_time.py [log2 sizes ...]"""
+import json
+import os
+import sys
+import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import numpy as np
 import torch
 import bls12_381_amd as bls
-ctx = bls.Context(0)
-ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-for log_n in ([int(a) for a in sys.argv[1:]] or (10, 16, 20, 24)):
+
+sizes = [int(a) for a in sys.argv[1:]] or [16, 18, 20, 22, 24]
+dev = torch.device("cuda", 0)
+sync = torch.cuda.synchronize
+
+
+def make(impl):
+    if impl:
+        os.environ["BLSGPU_NTT_IMPL"] = impl
+    try:
+        c = bls.Context(0)
+    finally:
+        os.environ.pop("BLSGPU_NTT_IMPL", None)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    return c
+
+
+def med(fn, reps=20):
+    fn(); sync()
+    ts = []
+    for _ in range(reps):
+        t = time.perf_counter(); fn(); sync(); ts.append(time.perf_counter() - t)
+    return 1e3 * float(np.median(ts))
+
+
+new, old = make(None), make("stage")
+rows = []
+for log_n in sizes:
     n = 1 << log_n
     rs = np.random.RandomState(log_n)
-    a = rs.randint(0, 2**62, size=(n, 4), dtype=np.int64).astype(np.uint64)
-    a[:, 3] &= np.uint64(0x0fffffffffffffff)
-    d = torch.from_numpy(a.view(np.int64)).cuda()
-    ctx.fr_ntt_device(d.data_ptr(), log_n, False); torch.cuda.synchronize()
-    h = hashlib.sha256(d.cpu().numpy().tobytes()).hexdigest()[:12]
-    ts = []
-    for _ in range(20):
-        t = time.perf_counter(); ctx.fr_ntt_device(d.data_ptr(), log_n, False); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
-    print("2^%d  %.4f ms  sha(first transform) %s" % (log_n, 1e3 * float(np.median(ts)), h))
+    raw = rs.randint(0, 256, size=(n, 32), dtype=np.uint8); raw[:, 31] &= 0x3F
+    x = torch.from_numpy(raw.view(np.int64).reshape(n, 4).copy()).to(dev)
+    a, b = x.clone(), x.clone()
+    new.fr_ntt_device(a.data_ptr(), log_n); old.fr_ntt_device(b.data_ptr(), log_n); sync()
+    same = bool(torch.equal(a, b))
+    b0 = b.clone()
+    tn = med(lambda: new.fr_ntt_device(a.data_ptr(), log_n))
+    to = med(lambda: old.fr_ntt_device(b.data_ptr(), log_n))
+    row = {"log_n": log_n, "column_tiles_ms": round(tn, 4), "stage_passes_ms": round(to, 4), "identical": same}
+    for shape in os.environ.get("NTT_TIME_SHAPES", "").split():          # "tile log2,max depth per pass,block" variants of the column pass
+        os.environ["BLSGPU_NTT_COLS"] = shape
+        a.copy_(x); sync(); new.fr_ntt_device(a.data_ptr(), log_n); sync()
+        ok = bool(torch.equal(a, b0))
+        row["cols " + shape] = (round(med(lambda: new.fr_ntt_device(a.data_ptr(), log_n)), 4), ok)
+        os.environ.pop("BLSGPU_NTT_COLS")
+    rows.append(row)
+    print(rows[-1], flush=True)
+print(json.dumps({"fr_ntt": rows}))
