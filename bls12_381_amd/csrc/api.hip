@@ -152,6 +152,7 @@ struct blsgpu_ctx {
   DevBuf fr_tw[2], fr_tmp, fr_ninv;     // Fr transform: twiddle tables (forward / inverse), permutation target, n^-1
   int fr_tw_log[2] = {-1, -1};
   int fr_ninv_log = -1;
+  int h2c_split = -1;                   // -1 by batch size / 0 never / 1 always: BLSGPU_H2C_SPLIT, read when the context is created
   int fr_cols_want = 1;                 // 0 never / 1 from 2^20 elements / 2 always: BLSGPU_NTT_IMPL=stage|cols, read when the context is created
   int fr_cols_ok = -1;                  // k_fr_cols usable on this device (144 KB of dynamic LDS granted); decided at the first transform
   hipEvent_t ev_fr[3] = {};             // twiddles forward / inverse, n^-1: recorded where the table was built, awaited by every user
@@ -563,6 +564,7 @@ extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
   }
   if (const char* v = getenv("BLSGPU_MMLP_K")) { long k = atol(v); if (k >= 1 && k <= MMLP_MAX_K) c->mmlp_k = (int)k; }
   if (const char* v = getenv("BLSGPU_MML_IMPL")) { long k = atol(v); if (k == 1 || k == 4) c->mml_impl = (int)k; }
+  if (const char* v = getenv("BLSGPU_H2C_SPLIT")) c->h2c_split = atoi(v) ? 1 : 0;
   if (const char* v = getenv("BLSGPU_NTT_IMPL")) c->fr_cols_want = !strcmp(v, "cols") ? 2 : !strcmp(v, "stage") ? 0 : 1;      // cols: at every size (tests)
   if (const char* v = getenv("BLSGPU_ITEM_CAP")) { long k = atol(v); if (k >= 8 && k <= ITEM_CAP_MAX) c->item_cap = (u32)k; }
   int rc = ctx_init(c);
@@ -1593,6 +1595,20 @@ extern "C" int blsgpu_g2_msm_bytes(blsgpu_ctx* c, const uint8_t* bases, const ui
 // ---------------------------------------------------------------------------------------------------
 // hash-to-curve (h2c.hip.h)
 // ---------------------------------------------------------------------------------------------------
+// one launch of the batched hash: group 1 = one lane per message, group 2 = one lane pair; batches that leave the chip under-filled take
+// the split form (two lane groups per message, h2c.hip.h) -- up to 2^15 messages to G1 (<= 1 024 wavefronts of 64 lanes at one per SIMD),
+// up to 2^14 to G2 (4 lanes each: 1 024 wavefronts).  Measured on MI355X, 2^14 32-byte messages: see DESIGN.md 4.8.
+static void h2c_launch(blsgpu_ctx* c, int group, const uint8_t* msgs, const unsigned long long* offs, size_t n, const uint8_t* dst, u32 dlen, int encode_only, u32* out) {
+  const int forced = c->h2c_split;
+  const bool split = !encode_only && (forced >= 0 ? forced == 1 : n <= (group == 1 ? (size_t)1 << 15 : (size_t)1 << 14));
+  if (group == 1) {
+    if (split) hipLaunchKernelGGL(k_hash_to_curve_split<FpPolicy>, dim3(nblk(n * 2, 64)), dim3(64), 0, c->stream, msgs, offs, n, dst, dlen, out);
+    else hipLaunchKernelGGL(k_hash_to_curve<FpPolicy>, dim3(nblk(n, 64)), dim3(64), 0, c->stream, msgs, offs, n, dst, dlen, encode_only ? 1 : 0, out);
+  } else {
+    if (split) hipLaunchKernelGGL(k_hash_to_curve_split<Fp2PairPolicy>, dim3(nblk(n * 4, 256)), dim3(256), 0, c->stream, msgs, offs, n, dst, dlen, out);
+    else hipLaunchKernelGGL(k_hash_to_curve<Fp2PairPolicy>, dim3(nblk(n * 2, 256)), dim3(256), 0, c->stream, msgs, offs, n, dst, dlen, encode_only ? 1 : 0, out);
+  }
+}
 template <class F>
 static int h2c_host(blsgpu_ctx* c, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst, size_t dst_len, int encode_only,
                     uint64_t* out) {
@@ -1622,12 +1638,7 @@ static int h2c_host(blsgpu_ctx* c, const uint8_t* msgs, const uint64_t* offsets,
   HIPCHK(hipMemcpyAsync(c->io_b.p, offsets, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
   if (dlen) HIPCHK(hipMemcpyAsync(c->io_c.p, d, dlen, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));                 // `d` lives on this stack frame
-  if constexpr (GroupTag<F>::id == 1)
-    hipLaunchKernelGGL(k_hash_to_curve<FpPolicy>, dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->io_a.as<uint8_t>(), (const unsigned long long*)c->io_b.p, n,
-                       c->io_c.as<uint8_t>(), dlen, encode_only ? 1 : 0, c->io_out.as<u32>());
-  else                                               // G2: one message per lane pair (pairlane.hip.h)
-    hipLaunchKernelGGL(k_hash_to_curve<Fp2PairPolicy>, dim3(nblk(n * 2, 256)), dim3(256), 0, c->stream, c->io_a.as<uint8_t>(), (const unsigned long long*)c->io_b.p, n,
-                       c->io_c.as<uint8_t>(), dlen, encode_only ? 1 : 0, c->io_out.as<u32>());
+  h2c_launch(c, GroupTag<F>::id, c->io_a.as<uint8_t>(), (const unsigned long long*)c->io_b.p, n, c->io_c.as<uint8_t>(), dlen, encode_only, c->io_out.as<u32>());
   LAUNCHCHK();
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, n * 3 * WW * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1649,12 +1660,7 @@ extern "C" int blsgpu_hash_to_curve_device(blsgpu_ctx* c, int group, const void*
   if (group != 1 && group != 2) return bad("hash_to_curve: group must be 1 or 2");
   if (!n) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
-  if (group == 1)
-    hipLaunchKernelGGL(k_hash_to_curve<FpPolicy>, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (const uint8_t*)d_msgs, (const unsigned long long*)d_offsets, n,
-                       (const uint8_t*)d_dst, (u32)dst_len, encode_only ? 1 : 0, (u32*)d_out_xyz);
-  else
-    hipLaunchKernelGGL(k_hash_to_curve<Fp2PairPolicy>, dim3(nblk(n * 2, 256)), dim3(256), 0, c->stream, (const uint8_t*)d_msgs, (const unsigned long long*)d_offsets, n,
-                       (const uint8_t*)d_dst, (u32)dst_len, encode_only ? 1 : 0, (u32*)d_out_xyz);
+  h2c_launch(c, group, (const uint8_t*)d_msgs, (const unsigned long long*)d_offsets, n, (const uint8_t*)d_dst, (u32)dst_len, encode_only, (u32*)d_out_xyz);
   LAUNCHCHK();
   return BLSGPU_OK;
 }

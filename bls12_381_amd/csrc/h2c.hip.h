@@ -391,4 +391,46 @@ k_hash_to_curve(const uint8_t* __restrict__ msgs, const unsigned long long* __re
   H2cField<F>::save(r.z, out + i * 3 * WW + 2 * WW);
 }
 
+// ---- small batches (round 5): the two maps of one message on two lane groups ---------------------------------------------------------
+// hash_to_curve maps TWO field elements u0, u1 to the isogenous curve independently (mod.rs:93-99) before it adds the images and clears
+// the cofactor; each map carries a square-root-ratio power (~560 / ~2 100 multiplications of the ~2 400 / ~8 700 per hash).  With few
+// messages the chip is not full (2^14 hashes to G2 = 512 wavefronts on 1 024 SIMDs) and a hash costs its LATENCY: here message i takes
+// 2 x LANES lanes, group 0 maps u0 and group 1 maps u1 side by side, group 1 hands its image over with one DPP move per word
+// (LANES = 1: quad_perm:[1,0,3,2], LANES = 2: quad_perm:[2,3,0,1]) and retires; group 0 adds, clears the cofactor and stores.  Same
+// field elements in the same order as k_hash_to_curve, so the projective limbs are identical.  The host picks it for batches that leave
+// the chip under-filled (api.hip::h2c_launch); `BLSGPU_H2C_SPLIT=0|1` forces either form.
+template <int CTRL> DEV u32 h2c_dpp(u32 x) { return (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xF, 0xF, true); }
+template <int CTRL, int A, int V> DEV Fe<A, V> h2c_partner(const Fe<A, V>& a) {
+  Fe<A, V> r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.l[i] = h2c_dpp<CTRL>(a.l[i]);
+  return r;
+}
+template <int CTRL, int A, int V> DEV FeP<A, V> h2c_partner(const FeP<A, V>& a) { FeP<A, V> r; r.v = h2c_partner<CTRL>(a.v); return r; }
+template <class F>
+__global__ void __launch_bounds__(H2cField<F>::LANES == 2 ? 256 : 64, H2cField<F>::LANES == 2 ? 2 : 1)
+k_hash_to_curve_split(const uint8_t* __restrict__ msgs, const unsigned long long* __restrict__ offs, size_t n, const uint8_t* __restrict__ dst, u32 dlen,
+                      u32* __restrict__ out) {
+  constexpr int L = H2cField<F>::LANES, CTRL = L == 2 ? 0x4E : 0xB1;
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / (2 * L);
+  if (i >= n) return;
+  const bool second = (threadIdx.x & L) != 0;
+  constexpr int M = H2cField<F>::M, WW = M * 12;
+  const int ell = 2 * M * 2;
+  u32 ub[64];
+  h2c_expand_xmd(msgs + offs[i], (size_t)(offs[i + 1] - offs[i]), dst, dlen, (u32)(ell * 32), ell, ub);
+  Proj<F> q, t;
+  H2cField<F>::sswu(t, H2cField<F>::from_okm(ub + (second ? 16 * M : 0)));
+  h2c_iso_map<F>(q, t);
+  Proj<F> q1;
+  q1.x = h2c_partner<CTRL>(q.x); q1.y = h2c_partner<CTRL>(q.y); q1.z = h2c_partner<CTRL>(q.z);
+  if (second) return;
+  q = pt_add<F>(q, q1);
+  Proj<F> r;
+  H2cField<F>::clear(r, q);
+  H2cField<F>::save(r.x, out + i * 3 * WW);
+  H2cField<F>::save(r.y, out + i * 3 * WW + WW);
+  H2cField<F>::save(r.z, out + i * 3 * WW + 2 * WW);
+}
+
 }  // namespace bls

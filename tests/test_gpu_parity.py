@@ -782,6 +782,34 @@ def test_hash_to_curve_vs_oracle(ctx, group):
     assert ctx.hash_to_curve(group, [], b"x").shape[0] == 0
 
 
+@pytest.mark.parametrize("group", [1, 2])
+def test_hash_to_curve_split_and_plain_forms_agree(group):
+    """round 5: small batches map u0 and u1 of a message on two lane groups (k_hash_to_curve_split); 1 001 messages of ragged lengths
+    through a context that always splits and one that never does give identical PROJECTIVE limbs, and both match the oracle on a
+    sample (the default context of the tests above takes the split form for these sizes)"""
+    import bls12_381_amd as bls
+    from oracle import h2c_ref as h
+    r = o.SplitMix64(77 + group)
+    msgs = [b""] + [bytes((r.next() >> 8) & 0xFF for _ in range(int(r.next() % 150))) for _ in range(1000)]
+    dst = b"BLS_SIG_BLS12381G%d_XMD:SHA-256_SSWU_RO_NUL_" % group
+    outs = []
+    for split in ("1", "0"):
+        os.environ["BLSGPU_H2C_SPLIT"] = split
+        try:
+            c = bls.Context(0)
+        finally:
+            os.environ.pop("BLSGPU_H2C_SPLIT")
+        try:
+            outs.append(c.hash_to_curve(group, msgs, dst))
+        finally:
+            c.close()
+    assert np.array_equal(outs[0], outs[1])
+    for k in (0, 1, 500, 1000):
+        p = (h.g1_hash_to_curve if group == 1 else h.g2_hash_to_curve)(msgs[k], dst)
+        want = np.concatenate([(fpw(c) if group == 1 else fp2w(c)) for c in p])
+        assert np.array_equal(outs[0][k], want) and np.array_equal(outs[1][k], want), (group, k)
+
+
 # ---- BASELINE.json full sizes (configs[2] and the per-GPU share of configs[4]) through size-independent identities --------
 def _rand_scalars_np(n, seed):
     rs = np.random.RandomState(seed)

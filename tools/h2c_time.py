@@ -1,23 +1,55 @@
 #!/usr/bin/env python3
-"""hash-to-curve timing: python tools/h2c_time.py [log_n]  (32-byte messages, both groups; host-batch entry point, so the
-figure includes the 2 MB upload and the download of the points)"""
-import hashlib, os, sys, time
-import numpy as np
+"""A/B timing of the batched hash-to-curve (round 5): the split form (two lane groups per message) against one lane / lane pair per
+message, 32-byte messages resident in HBM.   usage: python tools/h2c_time.py"""
+import json
+import os
+import sys
+import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import numpy as np
+import torch
 import bls12_381_amd as bls
-from bls12_381_amd.api import _ptr, check
-ctx = bls.default_context()
-n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 16)
-rs = np.random.RandomState(1)
-blob = np.frombuffer(rs.bytes(32 * n) + b"\0", dtype=np.uint8).copy()
-offs = (np.arange(n + 1, dtype=np.uint64) * 32)
-dst = b"QUUX-V01-CS02-with-BLS12381G1_XMD:SHA-256_SSWU_RO_"
-d = np.frombuffer(dst + b"\0", dtype=np.uint8).copy()
-for g in (1, 2):
-    out = np.zeros((n, 18 * g), dtype=np.uint64)
-    fn = ctx.lib.blsgpu_g1_hash_to_curve_batch if g == 1 else ctx.lib.blsgpu_g2_hash_to_curve_batch
+
+dev = torch.device("cuda", 0)
+sync = torch.cuda.synchronize
+
+
+def make(split):
+    os.environ["BLSGPU_H2C_SPLIT"] = split
+    try:
+        c = bls.Context(0)
+    finally:
+        os.environ.pop("BLSGPU_H2C_SPLIT")
+    return c
+
+
+def med(fn, reps=7):
+    fn(); sync()
     ts = []
-    for _ in range(6):
-        a = time.perf_counter(); check(fn(ctx.h, _ptr(blob), _ptr(offs), n, _ptr(d), len(dst), 0, _ptr(out)), "h2c"); ts.append(time.perf_counter() - a)
-    print("G%d n=%d  %.3f ms  sha %s" % (g, n, 1e3 * min(ts[1:]), hashlib.sha256(out.tobytes()).hexdigest()[:12]))
+    for _ in range(reps):
+        t = time.perf_counter(); fn(); sync(); ts.append(time.perf_counter() - t)
+    return 1e3 * float(np.median(ts))
+
+
+ctxs = {"split": make("1"), "plain": make("0")}
+rows = []
+for group in (1, 2):
+    dst = b"BLS_SIG_BLS12381G%d_XMD:SHA-256_SSWU_RO_NUL_" % group
+    d_dst = torch.from_numpy(np.frombuffer(dst, dtype=np.uint8).copy()).to(dev)
+    for logn in (10, 12, 13, 14, 15, 16, 17):
+        n = 1 << logn
+        m = torch.from_numpy(np.random.RandomState(logn).randint(0, 256, size=n * 32, dtype=np.uint8)).to(dev)
+        off = torch.arange(0, (n + 1) * 32, 32, dtype=torch.int64, device=dev)
+        row = {"group": group, "log_n": logn}
+        res = {}
+        for name, c in ctxs.items():
+            out = torch.zeros((n, 18 * group), dtype=torch.int64, device=dev)
+            sync()
+            f = lambda: bls._lib.check(c.lib.blsgpu_hash_to_curve_device(c.h, group, m.data_ptr(), off.data_ptr(), n, d_dst.data_ptr(), len(dst), 0, out.data_ptr()), "h2c")
+            row[name + "_ms"] = round(med(f), 4)
+            res[name] = out
+        row["identical"] = bool(torch.equal(res["split"], res["plain"]))
+        rows.append(row)
+        print(row, flush=True)
+print(json.dumps({"hash_to_curve": rows}))
