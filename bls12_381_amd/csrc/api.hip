@@ -2527,7 +2527,12 @@ extern "C" int blsgpu_bls_verify_batch_device(blsgpu_ctx* c, int mode, const voi
     // hash the messages to the signature's group and normalise, on the side stream
     c->stream = c->ver_stream[0];
     hipError_t e = hipStreamWaitEvent(c->stream, c->ev_ver_side[0], 0);
+    // (the plain form of the hash even for a small batch: the split form buys latency with 45 % more lane-time, which only pays while the chip
+    // has nothing else to do -- here the decoders run beside it; measured 2^14 signatures: 16.6 ms plain, 21.7 ms split)
+    const int keep_split = c->h2c_split;
+    c->h2c_split = 0;
     if (e == hipSuccess) rc = blsgpu_hash_to_curve_device(c, mode == 0 ? 2 : 1, d_msgs, d_offsets, n, d_dst, dst_len, 0, base + o_hp);
+    c->h2c_split = keep_split;
     if (e == hipSuccess && !rc)
       rc = mode == 0 ? batch_normalize_device<Fp2Policy>(c, base + o_hp, n, base + o_h, h_inf) : batch_normalize_device<FpPolicy>(c, base + o_hp, n, base + o_h, h_inf);
     if (e == hipSuccess && !rc) e = hipEventRecord(c->ev_ver_side[1], c->stream);
