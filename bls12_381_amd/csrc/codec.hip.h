@@ -7,7 +7,7 @@
 // to_uncompressed), :264-322 (from_uncompressed[_unchecked]), :326-390 (from_compressed[_unchecked]),
 // :401-410 (is_torsion_free: endomorphism(P) == -[x^2]P), :412-416 (is_on_curve), :777-795 (mul_by_x);
 // G2 src/g2.rs:254-299, :303-380, :390-464, :475-489, :847-890 (psi), :914-931 (mul_by_x);
-// Fp::sqrt src/fp.rs:324-340, Fp2::sqrt src/fp2.rs:245-295, lexicographically_largest src/fp.rs:273-298,
+// Fp::sqrt src/fp.rs:324-340, Fp2::sqrt src/fp2.rs:245-295 (any root: see fe2_sqrt), lexicographically_largest src/fp.rs:273-298,
 // src/fp2.rs:171-180, Fp::from_bytes / to_bytes src/fp.rs:179-227.
 // Outputs are the reference's values: a decoded point is returned in wire limbs with its infinity flag and
 // an `ok` byte that is 1 exactly where the reference returns `CtOption::some`.
@@ -49,34 +49,30 @@ DEV fe2p fe_sqrt(const Fe<A, V>& a, bool& ok) {
   return s;
 }
 
-// Fp2 exponentiation by a fixed exponent (plain square-and-multiply, MSB first)
-DEVNI void fe2_pow_raw(fe2& r, const fe2& a, int which) {
-  constexpr u64 e0[6] = BLS_EXP_P_MINUS_3_DIV_4_U64, e1[6] = BLS_EXP_P_MINUS_1_DIV_2_U64;
-  fe2 acc = fe2_one();
-  for (int w = 5; w >= 0; w--) {
-    u64 word = which == 0 ? e0[w] : e1[w];
-    for (int i = 63; i >= 0; i--) {
-      acc = store2(sqr(acc));
-      if ((word >> i) & 1) acc = store2(mul(acc, a));
-    }
-  }
-  r = acc;
-}
-// fp2.rs:245-295 (Algorithm 9 of eprint 2012/685)
+// A square root in Fp2 = Fp[u]/(u^2 + 1).  The reference computes one by two Fp2 exponentiations (fp2.rs:245-295, Algorithm 9 of eprint
+// 2012/685: a^((p-3)/4), then (alpha + 1)^((p-1)/2); ~2 700 base-field multiplications); the decoders below only ever use a root up to
+// SIGN -- `from_compressed` picks y or -y by the sign flag (g2.rs:436-452) -- so any root gives the reference's point, and this one
+// costs two BASE-FIELD exponentiations and an inversion (~1 100 multiplications; round 5).  With a = a0 + a1 u, n = sqrt(a0^2 + a1^2)
+// (the norm is a square in Fp exactly when a is one in Fp2) and D = 2 (a0 + n): e = D^((p+1)/4) squares to D or to -D (p = 3 mod 4), and
+//     e^2 =  D:  sqrt(a) = e/2 + (a1/e) u            e^2 = -D:  sqrt(a) = a1/e + (e/2) u
+// (write delta = (a0 + n)/2, delta' = (a0 - n)/2: delta + delta' = a0, delta delta' = -(a1/2)^2, so exactly one of them is a square and
+// the root is sqrt(delta) + a1 / (2 sqrt(delta)) u or sqrt(delta') + ... with sqrt(delta') = (a1/2) / sqrt(-delta)).  a1 = 0: the same
+// exponentiation on a0 itself gives (e, 0) or (0, e).  `ok` = the result squares back to a, as in the reference.
 DEV fe2 fe2_sqrt(const fe2& a, bool& ok) {
   if (is_zero(a)) { ok = true; return fe2_zero(); }
-  fe2 a1; fe2_pow_raw(a1, a, 0);                       // a^((p-3)/4)
-  fe2 alpha = store2(mul(sqr(a1), a));
-  fe2 x0 = store2(mul(a1, a));
-  fe2 minus_one = store2(neg(fe2_one()));
+  constexpr PLimbs half = {BLS_TWO_INV_MONT};
+  const fe a0 = store(a.c0), a1 = store(a.c1);
+  const bool real = is_zero(a1);
+  bool okn, qr;
+  const fe n = (fe)fe_sqrt(store(add(sqr(a0), sqr(a1))), okn);
+  const fe X = select(real, a0, store(dbl(add(a0, n))));
+  const fe e = (fe)fe_sqrt(X, qr);
+  const fe h = store(mul(e, fe1_const(half)));
+  const fe w = store(mul(a1, inv(e)));
+  const fe lo = select(real, e, h), hi = select(real, fe_zero(), w);
   fe2 s;
-  if (fe_eq(alpha.c0, minus_one.c0) && fe_eq(alpha.c1, minus_one.c1)) {
-    s = store2(Fe2<2, VS2 + 1>{neg(x0.c1), (Fe<2, VS2 + 1>)x0.c0});      // x0 * u = (-x0.c1) + x0.c0 u
-  } else {
-    fe2 t; fe2 ap1 = store2(add(alpha, fe2_one()));
-    fe2_pow_raw(t, ap1, 1);                            // (alpha + 1)^((p-1)/2)
-    s = store2(mul(t, x0));
-  }
+  s.c0 = (Fe<1, VS2>)select(qr, lo, hi);
+  s.c1 = (Fe<1, VS2>)select(qr, hi, lo);
   fe2 sq = store2(sqr(s));
   ok = fe_eq(sq.c0, a.c0) && fe_eq(sq.c1, a.c1);
   return s;
