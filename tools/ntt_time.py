@@ -36,7 +36,9 @@ def med(fn, reps=20):
     return 1e3 * float(np.median(ts))
 
 
-new, old = make(None), make("stage")
+only_new = bool(os.environ.get("NTT_TIME_ONLY_DEFAULT"))            # profiling target (tools/ntt_traffic.py): the default path alone
+new = make(None)
+old = new if only_new else make("stage")
 rows = []
 for log_n in sizes:
     n = 1 << log_n

@@ -4,7 +4,7 @@
     python tools/ntt_traffic.py collect      # two --pmc passes (FETCH_SIZE, WRITE_SIZE) + a kernel trace of tools/ntt_time.py 20 -> gpurun_out/prof_ntt
     python tools/ntt_traffic.py summarise r04   # -> profiles/r04_ntt_pmc.json / .md
 
-A transform is several launches (radix-4 passes over global memory + the LDS tile kernel); the counters are summed over the launches
+A transform is several launches (column-tile passes since round 5, radix-4 passes over global memory before, + the LDS tile kernel); the counters are summed over the launches
 of one transform: total over the run / number of transforms in it (twiddle-table kernels excluded).  FETCH_SIZE / WRITE_SIZE are in
 KiB... on gfx950 FETCH_SIZE counts 64-byte units as 32-byte ones (MI355X_MICROARCH.md): the summary applies the same correction
 as tools/summarise_profiles.py (fetch bytes doubled)."""
@@ -18,11 +18,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 D = os.path.join(ROOT, "gpurun_out", "prof_ntt")
-KERNELS = ("k_fr_stage2", "k_fr_stage1", "k_fr_tile")
+KERNELS = ("k_fr_stage2", "k_fr_stage1", "k_fr_cols", "k_fr_tile")
 
 
 def collect():
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", NTT_TIME_ONLY_DEFAULT="1")
     subprocess.run(["rm", "-rf", D]); os.makedirs(D)
     cmd = [sys.executable, os.path.join(ROOT, "tools", "ntt_time.py"), "20"]
     subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", os.path.join(D, "stats"), "--"] + cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
