@@ -2528,9 +2528,10 @@ extern "C" int blsgpu_bls_verify_batch_device(blsgpu_ctx* c, int mode, const voi
     c->stream = c->ver_stream[0];
     hipError_t e = hipStreamWaitEvent(c->stream, c->ev_ver_side[0], 0);
     // (the plain form of the hash even for a small batch: the split form buys latency with 45 % more lane-time, which only pays while the chip
-    // has nothing else to do -- here the decoders run beside it; measured 2^14 signatures: 16.6 ms plain, 21.7 ms split)
+    // has nothing else to do -- here the decoders run beside it; measured 2^14 signatures: 15.5 ms plain, 18.7-18.9 ms split (16.6 / 21.7 ms with the
+    // slower G2 decoder of before); BLSGPU_VERIFY_H2C_SPLIT=1 lets the batch-size rule apply here too, for re-measuring)
     const int keep_split = c->h2c_split;
-    c->h2c_split = 0;
+    c->h2c_split = getenv("BLSGPU_VERIFY_H2C_SPLIT") ? keep_split : 0;
     if (e == hipSuccess) rc = blsgpu_hash_to_curve_device(c, mode == 0 ? 2 : 1, d_msgs, d_offsets, n, d_dst, dst_len, 0, base + o_hp);
     c->h2c_split = keep_split;
     if (e == hipSuccess && !rc)
