@@ -467,14 +467,17 @@ def run_msm(args, e):
     group_path = None
     # (BENCH_FORCE_GROUP_PATH: run this block with ONE rank too -- how the one-GPU box exercises it)
     if multi and args.backend == "nccl" and not args.same_device and ((world > 1 and not args.no_extras) or os.environ.get("BENCH_FORCE_GROUP_PATH")):
+        # The group run is a CHILD process of rank 0 with a time limit (`bench.py --group N`, the mode tools/run_scale.sh also uses): its cross-device
+        # paths have never run on real multi-GPU hardware (the build box has one GPU), and a fault or a hang there must not cost the line above.
         try:
+            import datetime
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")        # the container's hostname may not resolve
-            cpu_pg = dist.new_group(backend="gloo")
+            cpu_pg = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=900))
             torch.cuda.synchronize()
             dist.barrier(group=cpu_pg)
             if rank == 0:
                 try:
-                    group_path = group_measure(bls, torch, list(range(world)), total if strong else None, 10, 3, weak_n=None if strong else n, expect_affine=aff_rccl)
+                    group_path = group_child(args, world, strong, aff_rccl)
                 except Exception as ex:           # never lose the headline over the secondary measurement
                     group_path = {"error": str(ex)[:200]}
             dist.barrier(group=cpu_pg)
@@ -1215,6 +1218,33 @@ def group_measure(bls, torch, devices, total, steps, warmup, weak_n=None, check=
     return rec
 
 
+def group_child(args, world, strong, expect_affine, limit_s=420):
+    """`bench.py --group <world>` as a child process with a time limit; returns its group_path record (or an error record)"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--group", str(world), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-extras", "--log-total", str(args.log_total)]
+    if not strong:
+        cmd += ["--weak"] + (["--log-n", str(args.log_n)] if args.log_n is not None else [])
+    elif world == 1:                                        # --dist-single: the ONE "shard" is the whole MSM (a group of one is never "strong")
+        cmd += ["--weak", "--log-n", str(args.log_total)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
+           and not k.startswith("TORCHELASTIC_")}
+    if expect_affine is not None:
+        env["BENCH_EXPECT_AFFINE"] = np.ascontiguousarray(expect_affine, dtype=np.uint64).tobytes().hex()
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "bench.py --group %d did not finish within %d s" % (world, limit_s)}
+    out = r.stdout.decode(errors="replace").strip().splitlines()
+    if r.returncode != 0 or not out:
+        return {"error": ("bench.py --group %d exited with %d: " % (world, r.returncode)) + r.stderr.decode(errors="replace")[-160:]}
+    try:
+        rec = json.loads(out[-1]).get("group_path") or {"error": "no group_path in the child's line"}
+    except ValueError:
+        rec = {"error": "unparsable child line: " + out[-1][:120]}
+    rec["run_as"] = "child process of rank 0 (bench.py --group %d), the other ranks idle at a CPU-side barrier" % world
+    return rec
+
+
 def run_group(args):
     import torch
     import bls12_381_amd as bls
@@ -1226,7 +1256,9 @@ def run_group(args):
     strong = N > 1 and not args.weak
     log_n = args.log_n if args.log_n is not None else 20
     total = (1 << args.log_total) if strong else (1 << log_n) * N
-    rec = group_measure(bls, torch, devices, total, steps, warmup, weak_n=None if strong else (1 << log_n))
+    expect = os.environ.get("BENCH_EXPECT_AFFINE")          # set by group_child(): the folded result of the RCCL run on the same shards
+    expect = np.frombuffer(bytes.fromhex(expect), dtype=np.uint64).copy() if expect else None
+    rec = group_measure(bls, torch, devices, total, steps, warmup, weak_n=None if strong else (1 << log_n), expect_affine=expect)
     if not rec.get("result_matches", True):
         raise SystemExit("bench --group: the folded MSM result is wrong")
     ctx = bls.Context(devices[0])
