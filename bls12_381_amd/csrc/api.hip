@@ -313,15 +313,18 @@ __global__ void __launch_bounds__(256) k_proj_to_affine(const u32* __restrict__ 
 // points t, t+T, t+2T, ... (K per lane), multiplies their non-zero z's into a running product while saving the
 // prefixes, inverts ONCE, and walks back.  5 multiplications per point + one inversion per K points instead of one
 // inversion (~410 multiplications) per point.
+// K is the host's: 32 for large arrays, fewer for arrays that would otherwise leave the chip to a few wavefronts walking long chains
+// (2^14 points: 4 per lane = 64 wavefronts, 0.15 ms, instead of 8 wavefronts and 1.1 ms); the affine values do not depend on it.
 constexpr int NORMALIZE_K = 32;
+static inline int normalize_k(size_t n) { size_t k = n >> 16; return k < 4 ? 4 : k > NORMALIZE_K ? NORMALIZE_K : (int)k; }
 template <class F>
 __global__ void __launch_bounds__(256) k_batch_normalize(const u32* __restrict__ rec, u32* __restrict__ pref, u32* __restrict__ xy,
-                                                         uint8_t* __restrict__ inf, size_t n, size_t T) {
+                                                         uint8_t* __restrict__ inf, size_t n, size_t T, int K) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= T) return;
   constexpr int WW = Wire<F>::WORDS, EL = Store<F>::EL, PW = Store<F>::PROJ_WORDS;
   typename F::elem acc = F::one();
-  for (int k = 0; k < NORMALIZE_K; k++) {
+  for (int k = 0; k < K; k++) {
     size_t i = t + (size_t)k * T;
     if (i >= n) break;
     typename F::elem z; Store<F>::ldw(rec + i * PW + 2 * EL, z);
@@ -329,7 +332,7 @@ __global__ void __launch_bounds__(256) k_batch_normalize(const u32* __restrict__
     if (!is_zero(z)) acc = F::st(mul(acc, z));
   }
   typename F::elem ai = F::st(inv(acc));
-  for (int k = NORMALIZE_K - 1; k >= 0; k--) {
+  for (int k = K - 1; k >= 0; k--) {
     size_t i = t + (size_t)k * T;
     if (i >= n) continue;
     Proj<F> p; load_proj<F>(rec + i * PW, p);
@@ -1451,8 +1454,9 @@ static int batch_normalize_device(blsgpu_ctx* c, const void* d_xyz, size_t n, vo
   if (c->io_c.reserve(n * PW * 4) || c->io_d.reserve(n * Store<F>::EL * 4)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
   hipLaunchKernelGGL(k_proj_import<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (const u32*)d_xyz, c->io_c.as<u32>(), n);
   if (n >= 4096) {
-    size_t T = (n + NORMALIZE_K - 1) / NORMALIZE_K;
-    hipLaunchKernelGGL(k_batch_normalize<F>, dim3(nblk(T, 256)), dim3(256), 0, c->stream, c->io_c.as<u32>(), c->io_d.as<u32>(), (u32*)d_xy, (uint8_t*)d_inf, n, T);
+    const int K = normalize_k(n);
+    size_t T = (n + K - 1) / K;
+    hipLaunchKernelGGL(k_batch_normalize<F>, dim3(nblk(T, 256)), dim3(256), 0, c->stream, c->io_c.as<u32>(), c->io_d.as<u32>(), (u32*)d_xy, (uint8_t*)d_inf, n, T, K);
   } else {
     hipLaunchKernelGGL(k_proj_to_affine<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_c.as<u32>(), (u32*)d_xy, (uint8_t*)d_inf, n);
   }

@@ -20,5 +20,10 @@ tools/pmc.sh prof_mmlp python tools/run_pairing.py mmlp 18 3
 tools/pmc.sh prof_eqp python tools/run_pairing.py eqp 16 3
 BLSGPU_MML_IMPL=4 tools/pmc.sh prof_mmlq python tools/run_pairing.py mml 18 3
 tools/pmc.sh prof_eq python tools/run_pairing.py equations 14 3
-find gpurun_out/prof_msm gpurun_out/prof_pair gpurun_out/prof_pair_lp gpurun_out/prof_mml gpurun_out/prof_wide gpurun_out/prof_mmlp gpurun_out/prof_eqp gpurun_out/prof_mmlq gpurun_out/prof_eq -name "*agent_info.csv" -delete
+# the bulk-verification chain (kernel trace only): 2^14 signatures, keys in G1 and keys in G2
+cd /tmp && export TMPDIR=/tmp && cd "$R"
+rm -rf gpurun_out/prof_verify; mkdir -p gpurun_out/prof_verify
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_verify/mode0 -- python tools/run_verify.py 14 0 3 > gpurun_out/prof_verify/mode0.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_verify/mode1 -- python tools/run_verify.py 14 1 3 > gpurun_out/prof_verify/mode1.log 2>&1
+find gpurun_out/prof_msm gpurun_out/prof_pair gpurun_out/prof_pair_lp gpurun_out/prof_mml gpurun_out/prof_wide gpurun_out/prof_mmlp gpurun_out/prof_eqp gpurun_out/prof_mmlq gpurun_out/prof_eq gpurun_out/prof_verify -name "*agent_info.csv" -delete
 du -sh gpurun_out/prof_*

@@ -186,4 +186,9 @@ if one("prof_eq/stats/**/*kernel_trace.csv"):
         json.dump(j, open(jp, "w"), indent=1)
     except Exception as ex:
         print("equations: call-level traffic not written:", ex)
+for mode, what in ((0, "keys in G1, signatures in G2"), (1, "keys in G2, signatures in G1")):
+    f = one("prof_verify/mode%d/**/*kernel_stats.csv" % mode)
+    if f:
+        stats_table(f, f"{RND}: rocprofv3 --kernel-trace --stats -- python tools/run_verify.py 14 {mode} 3  (bulk verification of 2^14 signatures from bytes, {what}; "
+                       "three calls + the construction of the synthetic signatures)", os.path.join(OUT, f"{RND}_verify_chain_mode{mode}_kernel_stats.md"))
 print("profiles written for", RND)
