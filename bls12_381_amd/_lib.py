@@ -44,6 +44,21 @@ SIGNATURES = {
     "blsgpu_g1_msm_device": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
     "blsgpu_g2_msm_device": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
     "blsgpu_set_bases_cache": (c_int, [c_vp, c_int]),
+    "blsgpu_set_scalar_form": (c_int, [c_vp, c_int]),
+    "blsgpu_g1_msm_mont": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
+    "blsgpu_g2_msm_mont": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
+    "blsgpu_g1_msm_mont_device": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
+    "blsgpu_g2_msm_mont_device": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
+    "blsgpu_g1_mul_batch_mont": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_g2_mul_batch_mont": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_g1_mul_batch_mont_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_g2_mul_batch_mont_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_fr_to_bytes": (c_int, [c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "blsgpu_fr_from_bytes": (c_int, [c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "blsgpu_fr_from_bytes_wide": (c_int, [c_vp, c_vp, c_sz, c_vp]),
+    "blsgpu_fr_to_bytes_device": (c_int, [c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "blsgpu_fr_from_bytes_device": (c_int, [c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "blsgpu_fr_from_bytes_wide_device": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g1_msm_host": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g2_msm_host": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_fr_op": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp, c_vp]),
@@ -146,6 +161,8 @@ SIGNATURES = {
     "blsgpu_mad_throughput": (c_int, [c_vp, c_int, ctypes.POINTER(ctypes.c_double)]),
     "blsgpu_last_msm_phase_ms": (c_int, [c_vp, c_int, ctypes.POINTER(ctypes.c_float)]),
     "blsgpu_set_profiling": (c_int, [c_vp, c_int]),
+    "blsgpu_kernel_timing": (c_int, [c_vp, c_int]),
+    "blsgpu_kernel_timing_report": (c_int, [c_vp, ctypes.c_char_p, c_sz, ctypes.POINTER(c_sz)]),
 }
 
 _lib = None

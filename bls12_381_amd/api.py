@@ -62,6 +62,7 @@ def _flags(f, n):
 
 
 _R_WORDS = np.frombuffer(R_ORDER.to_bytes(32, "little"), dtype="<u8")
+SCALAR_BYTES, SCALAR_MONT = 0, 1          # include/bls12_381_hip.h: BLSGPU_SCALAR_BYTES / BLSGPU_SCALAR_MONT
 
 
 def scalars_are_canonical(sb):
@@ -222,6 +223,21 @@ class Context:
         check(self.lib.blsgpu_msm_accumulate_stats(self.h, int(enable), ctypes.byref(avg), ctypes.byref(cnt)), "msm_accumulate_stats")
         return avg.value, cnt.value
 
+    def kernel_timing(self, on):
+        """record the HIP-event duration of every kernel this context launches (blsgpu_kernel_timing); read with kernel_timing_report()"""
+        check(self.lib.blsgpu_kernel_timing(self.h, 1 if on else 0), "kernel_timing")
+
+    def kernel_timing_report(self):
+        """{kernel name: {"launches", "total_ms", "min_ms", "max_ms"}} in first-launch order; clears the records"""
+        buf = ctypes.create_string_buffer(1 << 16)
+        need = ctypes.c_size_t(0)
+        check(self.lib.blsgpu_kernel_timing_report(self.h, buf, len(buf), ctypes.byref(need)), "kernel_timing_report")
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, n, tot, mn, mx = line.split("\t")
+            out[name] = {"launches": int(n), "total_ms": float(tot), "min_ms": float(mn), "max_ms": float(mx)}
+        return out
+
     def set_profiling(self, on):
         check(self.lib.blsgpu_set_profiling(self.h, 1 if on else 0), "set_profiling")
 
@@ -270,6 +286,38 @@ class Context:
     def msm_device(self, bases, d_scalars, n, d_out, first=0):
         fn = self.lib.blsgpu_g1_msm_device if bases.group == 1 else self.lib.blsgpu_g2_msm_device
         check(fn(self.h, bases.handle, first, ctypes.c_void_p(d_scalars), n, ctypes.c_void_p(d_out)), "msm_device")
+
+    # scalars as the reference stores them: (n, 4) u64 Montgomery limbs of `Scalar([u64; 4])` (scalar.rs:23-27); `to_bytes` runs on the device
+    def set_scalar_form(self, form):
+        """SCALAR_BYTES (0, default) or SCALAR_MONT (1) for every later scalar argument of this context (blsgpu_set_scalar_form)"""
+        check(self.lib.blsgpu_set_scalar_form(self.h, int(form)), "set_scalar_form")
+
+    def msm_mont(self, bases, scalar_limbs, first=0):
+        """sum_i scalars[i] * bases[first+i] with scalars as (n, 4) u64 Montgomery limbs (`&[Scalar]` memory)."""
+        s = _u64(scalar_limbs, (-1, 4))
+        out = np.zeros(18 if bases.group == 1 else 36, dtype=np.uint64)
+        fn = self.lib.blsgpu_g1_msm_mont if bases.group == 1 else self.lib.blsgpu_g2_msm_mont
+        check(fn(self.h, bases.handle, first, _ptr(s), s.shape[0], _ptr(out)), "msm_mont")
+        return out
+
+    def msm_mont_device(self, bases, d_scalar_limbs, n, d_out, first=0):
+        fn = self.lib.blsgpu_g1_msm_mont_device if bases.group == 1 else self.lib.blsgpu_g2_msm_mont_device
+        check(fn(self.h, bases.handle, first, ctypes.c_void_p(d_scalar_limbs), n, ctypes.c_void_p(d_out)), "msm_mont_device")
+
+    def mul_batch_mont(self, group, xy, infinity, scalar_limbs):
+        """mul_batch with the scalars as (n, 4) u64 Montgomery limbs"""
+        w = 12 if group == 1 else 24
+        xy = _u64(xy, (-1, w))
+        s = _u64(scalar_limbs, (xy.shape[0], 4))
+        inf = _flags(infinity, xy.shape[0])
+        out = np.zeros((xy.shape[0], 18 if group == 1 else 36), dtype=np.uint64)
+        fn = self.lib.blsgpu_g1_mul_batch_mont if group == 1 else self.lib.blsgpu_g2_mul_batch_mont
+        check(fn(self.h, _ptr(xy), _ptr(inf), _ptr(s), xy.shape[0], _ptr(out)), "mul_batch_mont")
+        return out
+
+    def mul_batch_mont_device(self, group, d_xy, d_inf, d_scalar_limbs, n, d_out):
+        fn = self.lib.blsgpu_g1_mul_batch_mont_device if group == 1 else self.lib.blsgpu_g2_mul_batch_mont_device
+        check(fn(self.h, ctypes.c_void_p(d_xy), ctypes.c_void_p(d_inf) if d_inf else None, ctypes.c_void_p(d_scalar_limbs), n, ctypes.c_void_p(d_out)), "mul_batch_mont_device")
 
     def msm_many(self, bases, scalar_sets):
         """k MSMs over the same resident bases; scalar_sets: (k, n, 32) uint8 (or a list of k scalar lists).  Returns (k, 18|36)."""
@@ -447,6 +495,38 @@ class Context:
 
     def fr_ntt_device(self, d_ptr, log_n, inverse=False):
         check(self.lib.blsgpu_fr_ntt_device(self.h, d_ptr, log_n, 1 if inverse else 0), "fr_ntt_device")
+
+    def fr_to_bytes(self, limbs, return_flags=False):
+        """`Scalar::to_bytes` (scalar.rs:284-296) over (n, 4) u64 Montgomery limbs -> (n, 32) uint8; flags: limbs below r"""
+        a = _u64(limbs, (-1, 4))
+        out = np.zeros((a.shape[0], 32), dtype=np.uint8)
+        ok = np.ones(a.shape[0], dtype=np.uint8)
+        check(self.lib.blsgpu_fr_to_bytes(self.h, _ptr(a), a.shape[0], _ptr(out), _ptr(ok)), "fr_to_bytes")
+        return (out, ok) if return_flags else out
+
+    def fr_from_bytes(self, data):
+        """`Scalar::from_bytes` (scalar.rs:256-280) over (n, 32) uint8 -> ((n, 4) u64 Montgomery limbs, is_some bytes)"""
+        b = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8).reshape(-1, 32)
+        out = np.zeros((b.shape[0], 4), dtype=np.uint64)
+        ok = np.ones(b.shape[0], dtype=np.uint8)
+        check(self.lib.blsgpu_fr_from_bytes(self.h, _ptr(b), b.shape[0], _ptr(out), _ptr(ok)), "fr_from_bytes")
+        return out, ok
+
+    def fr_from_bytes_wide(self, data):
+        """`Scalar::from_bytes_wide` (scalar.rs:300-331) over (n, 64) uint8 -> (n, 4) u64 Montgomery limbs"""
+        b = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8).reshape(-1, 64)
+        out = np.zeros((b.shape[0], 4), dtype=np.uint64)
+        check(self.lib.blsgpu_fr_from_bytes_wide(self.h, _ptr(b), b.shape[0], _ptr(out)), "fr_from_bytes_wide")
+        return out
+
+    def fr_to_bytes_device(self, d_limbs, n, d_bytes, d_ok=None):
+        check(self.lib.blsgpu_fr_to_bytes_device(self.h, ctypes.c_void_p(d_limbs), n, ctypes.c_void_p(d_bytes), ctypes.c_void_p(d_ok) if d_ok else None), "fr_to_bytes_device")
+
+    def fr_from_bytes_device(self, d_bytes, n, d_limbs, d_ok=None):
+        check(self.lib.blsgpu_fr_from_bytes_device(self.h, ctypes.c_void_p(d_bytes), n, ctypes.c_void_p(d_limbs), ctypes.c_void_p(d_ok) if d_ok else None), "fr_from_bytes_device")
+
+    def fr_from_bytes_wide_device(self, d_bytes, n, d_limbs):
+        check(self.lib.blsgpu_fr_from_bytes_wide_device(self.h, ctypes.c_void_p(d_bytes), n, ctypes.c_void_p(d_limbs)), "fr_from_bytes_wide_device")
 
     def fp_mul_throughput(self, iters=2000):
         v = ctypes.c_double()

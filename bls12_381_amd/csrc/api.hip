@@ -53,11 +53,52 @@ struct CtxClaim {
   ~CtxClaim() { if (!clash && --*depth == 0) owner->store(0, std::memory_order_release); }
 };
 #define CTX_CLAIM(c) CtxClaim claim_((c) ? &(c)->owner_thread : &g_no_ctx_owner, (c) ? &(c)->owner_depth : &g_no_ctx_depth); \
-  if (claim_.clash) return bad("the context is in use by another host thread (one context per host thread: include/bls12_381_hip.h)")
+  if (claim_.clash) return bad("the context is in use by another host thread (one context per host thread: include/bls12_381_hip.h)"); \
+  KtBind ktbind_((c) ? ktimer_of(c) : nullptr)
 static thread_local std::atomic<size_t> g_no_ctx_owner{0};
 static thread_local int g_no_ctx_depth = 0;
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(#x, e_, __LINE__); } while (0)
 #define LAUNCHCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail("kernel launch", e_, __LINE__); } while (0)
+
+// ---- per-kernel timing (diagnostics: blsgpu_kernel_timing / blsgpu_kernel_timing_report) ------------------------------------------
+// Every kernel of this file is launched through KLAUNCH.  While a context has timing switched on, the entry points it is passed to
+// bracket each of their launches with two HIP events ON THE STREAM THE KERNEL IS LAUNCHED ON (a torch / caller-side event sees only the
+// caller's stream, and a call's kernels run on up to four library streams); the report aggregates the durations by kernel name.  Off
+// (the default) the cost is one thread-local pointer test per launch.  The timer of the context an entry point was called with is
+// bound to the calling thread for the duration of the call (CTX_CLAIM), so group workers time their own members.
+struct KTimer {
+  struct Rec { const char* name; hipEvent_t a, b; };
+  bool on = false;
+  std::vector<Rec> recs;
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return e;
+  }
+  void clear() { for (auto& r : recs) { pool.push_back(r.a); pool.push_back(r.b); } recs.clear(); }
+  void destroy() { clear(); for (auto e : pool) hipEventDestroy(e); pool.clear(); }
+};
+static thread_local KTimer* g_kt = nullptr;
+static inline KTimer* ktimer_of(blsgpu_ctx* c);
+struct KtBind {
+  KTimer* saved;
+  explicit KtBind(KTimer* t) : saved(g_kt) { if (t && t->on) g_kt = t; }
+  ~KtBind() { g_kt = saved; }
+};
+struct KtScope {
+  KTimer* t; hipStream_t st; const char* name; hipEvent_t a = nullptr, b = nullptr;
+  KtScope(const char* n, hipStream_t s) : t(g_kt), st(s), name(n) {
+    if (!t) return;
+    a = t->get(); b = t->get();
+    if (!a || !b) { if (a) t->pool.push_back(a); if (b) t->pool.push_back(b); t = nullptr; return; }
+    hipEventRecord(a, st);
+  }
+  ~KtScope() { if (t) { hipEventRecord(b, st); t->recs.push_back({name, a, b}); } }
+};
+#define KLAUNCH(kern, grid, block, lds, stream, ...) \
+  do { KtScope kt_(#kern, (stream)); hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__); } while (0)
 
 struct DevBuf {
   void* p = nullptr; size_t cap = 0;
@@ -98,6 +139,8 @@ struct blsgpu_ctx {
   size_t wide_off[4] = {0, 0, 0, 0};   // word offsets of the Miller-loop / final-exponentiation programs: [0..1] 1024 lanes x 4 limbs, [2..3] 512 lanes x 8 limbs
   int wide_state = 0;                  // 0 = not tried, 1 = loaded, -1 = unavailable (the quad kernels take every size then)
   std::string wide_why;                // ... and why (blsgpu_wide_status)
+  int scalar_form = SCALAR_BYTES;      // blsgpu_set_scalar_form: what the scalar arguments of MSM / mul_batch / Gt * Scalar calls hold -- 32 canonical LE bytes (default) or
+                                       // the four u64 Montgomery limbs of a `Scalar` (scalar.hip.h); the *_mont entry points switch it for one call
   bool assume_subgroup = false;        // blsgpu_set_assume_subgroup: skip the subgroup check of uploaded bases (the caller vouches for them)
   bool no_glv = false;                 // A/B hook (env BLSGPU_NO_GLV at create): plain 256-bit windows (no GLV for G1, no psi decomposition for G2)
   bool force_slow_sort = false;        // test hook (env BLSGPU_FORCE_SLOW_SORT at create): the global-atomic sort used beyond 2^24 points
@@ -152,12 +195,15 @@ struct blsgpu_ctx {
   DevBuf fr_tw[2], fr_tmp, fr_ninv;     // Fr transform: twiddle tables (forward / inverse), permutation target, n^-1
   int fr_tw_log[2] = {-1, -1};
   int fr_ninv_log = -1;
+  KTimer ktimer;                        // blsgpu_kernel_timing
   int h2c_split = -1;                   // -1 by batch size / 0 never / 1 always: BLSGPU_H2C_SPLIT, read when the context is created
   int fr_cols_want = 1;                 // 0 never / 1 from 2^20 elements / 2 always: BLSGPU_NTT_IMPL=stage|cols, read when the context is created
   int fr_cols_ok = -1;                  // k_fr_cols usable on this device (144 KB of dynamic LDS granted); decided at the first transform
   hipEvent_t ev_fr[3] = {};             // twiddles forward / inverse, n^-1: recorded where the table was built, awaited by every user
                                         // (the caller may have switched streams with blsgpu_set_stream in between)
 };
+
+static inline KTimer* ktimer_of(blsgpu_ctx* c) { return &c->ktimer; }
 
 struct blsgpu_bases {
   int group = 1; size_t n = 0; int device = 0; u32* rec = nullptr;   // AFF_WORDS per point
@@ -605,6 +651,7 @@ extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
   for (auto e : c->ev_ver_side) if (e) hipEventDestroy(e);
   if (c->ver_table) blsgpu_g2_prepared_free(c->ver_table);
   for (auto& e : c->bcache) if (e.b) blsgpu_bases_free(e.b);
+  c->ktimer.destroy();
   if (c->acc_stream) hipStreamDestroy(c->acc_stream);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
@@ -638,6 +685,17 @@ struct SyncStatus {
   int fetch() { HIPCHK(hipMemcpyAsync(&host, c->d_status + 2, 4, hipMemcpyDeviceToHost, c->stream)); return BLSGPU_OK; }      // then synchronise the stream
   int verdict() const { return host ? bad("msm: a scalar is not canonical (>= r); Scalar::to_bytes never produces such bytes (scalar.rs:284-296)") : BLSGPU_OK; }
 };
+// one call with another scalar form than the context's setting (the *_mont entry points; the byte-format compositions pin SCALAR_BYTES)
+struct ScalarFormScope {
+  blsgpu_ctx* c; int saved;
+  ScalarFormScope(blsgpu_ctx* c_, int form) : c(c_), saved(c_ ? c_->scalar_form : 0) { if (c) c->scalar_form = form; }
+  ~ScalarFormScope() { if (c) c->scalar_form = saved; }
+};
+extern "C" int blsgpu_set_scalar_form(blsgpu_ctx* c, int form) { CTX_CLAIM(c);
+  if (!c) return bad("ctx is NULL");
+  if (form != SCALAR_BYTES && form != SCALAR_MONT) return bad("scalar form must be BLSGPU_SCALAR_BYTES (0) or BLSGPU_SCALAR_MONT (1)");
+  c->scalar_form = form; return BLSGPU_OK;
+}
 extern "C" int blsgpu_synchronize(blsgpu_ctx* c) { CTX_CLAIM(c);
   if (!c) return bad("ctx is NULL");
   HIPCHK(hipSetDevice(c->device));
@@ -666,6 +724,42 @@ extern "C" int blsgpu_msm_accumulate_stats(blsgpu_ctx* c, int enable, double* av
   if (launches) *launches = c->acc_count;
   c->acc_ms_sum = 0.0; c->acc_count = 0;
   c->acc_timing = enable < 0 ? 0 : enable; c->acc_tick = 0;
+  return BLSGPU_OK;
+}
+// diagnostics: HIP-event duration of every kernel the context's entry points launch (see KLAUNCH)
+extern "C" int blsgpu_kernel_timing(blsgpu_ctx* c, int enable) {
+  if (!c) return bad("ctx is NULL");
+  CtxClaim claim_(&c->owner_thread, &c->owner_depth);
+  if (claim_.clash) return bad("the context is in use by another host thread");
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->ktimer.recs.empty()) HIPCHK(hipDeviceSynchronize());     // events still in flight go back to the pool
+  c->ktimer.clear();
+  c->ktimer.on = enable != 0;
+  return BLSGPU_OK;
+}
+// One line per kernel name in first-launch order: "name<TAB>launches<TAB>total_ms<TAB>min_ms<TAB>max_ms\n".  Waits for the timed launches,
+// writes at most cap - 1 characters + NUL, stores the full length in *needed (may be NULL), and clears the records.
+extern "C" int blsgpu_kernel_timing_report(blsgpu_ctx* c, char* buf, size_t cap, size_t* needed) {
+  if (!c || (cap && !buf)) return bad("kernel_timing_report: NULL argument");
+  CtxClaim claim_(&c->owner_thread, &c->owner_depth);
+  if (claim_.clash) return bad("the context is in use by another host thread");
+  HIPCHK(hipSetDevice(c->device));
+  struct Agg { const char* name; unsigned n; double tot, mn, mx; };
+  std::vector<Agg> agg;
+  for (auto& r : c->ktimer.recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) { (void)hipGetLastError(); continue; }
+    Agg* a = nullptr;
+    for (auto& x : agg) if (!strcmp(x.name, r.name)) { a = &x; break; }
+    if (!a) { agg.push_back({r.name, 0, 0.0, 1e300, 0.0}); a = &agg.back(); }
+    a->n++; a->tot += ms; if (ms < a->mn) a->mn = ms; if (ms > a->mx) a->mx = ms;
+  }
+  c->ktimer.clear();
+  std::string out;
+  char line[512];
+  for (auto& a : agg) { snprintf(line, sizeof line, "%s\t%u\t%.6f\t%.6f\t%.6f\n", a.name, a.n, a.tot, a.mn, a.mx); out += line; }
+  if (needed) *needed = out.size();
+  if (cap) { size_t k = out.size() < cap - 1 ? out.size() : cap - 1; memcpy(buf, out.data(), k); buf[k] = 0; }
   return BLSGPU_OK;
 }
 extern "C" int blsgpu_set_pipelining(blsgpu_ctx* c, int on) { CTX_CLAIM(c); if (!c) return bad("ctx is NULL"); c->pipelining = on != 0; return BLSGPU_OK; }
@@ -714,8 +808,8 @@ static int bases_make_endo(blsgpu_ctx* c, blsgpu_bases* b, bool trusted) {
     // upload): the result decides on the host whether images are built, so this synchronises the context's stream
     u32 nbad = 0;
     HIPCHK(hipMemsetAsync(c->d_status + 1, 0, 4, c->stream));
-    if (b->group == 1) hipLaunchKernelGGL(k_bases_subgroup_check<FpPolicy>, dim3(nblk(b->n, 128)), dim3(128), 0, c->stream, b->rec, b->n, c->d_status + 1);
-    else hipLaunchKernelGGL(k_bases_subgroup_check<Fp2Policy>, dim3(nblk(b->n, 128)), dim3(128), 0, c->stream, b->rec, b->n, c->d_status + 1);
+    if (b->group == 1) KLAUNCH(k_bases_subgroup_check<FpPolicy>, dim3(nblk(b->n, 128)), dim3(128), 0, c->stream, b->rec, b->n, c->d_status + 1);
+    else KLAUNCH(k_bases_subgroup_check<Fp2Policy>, dim3(nblk(b->n, 128)), dim3(128), 0, c->stream, b->rec, b->n, c->d_status + 1);
     LAUNCHCHK();
     HIPCHK(hipMemcpyAsync(&nbad, c->d_status + 1, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -725,8 +819,8 @@ static int bases_make_endo(blsgpu_ctx* c, blsgpu_bases* b, bool trusted) {
   // the images are an accelerator, not a requirement: without memory for them the MSM runs on plain 256-bit windows
   const size_t bytes = (b->group == 1 ? b->n * Store<FpPolicy>::AFF_WORDS : 4 * b->n * Store<Fp2Policy>::AFF_WORDS) * 4;
   if (hipMalloc((void**)&b->endo, bytes) != hipSuccess) { (void)hipGetLastError(); b->endo = nullptr; return BLSGPU_OK; }
-  if (b->group == 1) hipLaunchKernelGGL(k_bases_endo, dim3(nblk(b->n, 256)), dim3(256), 0, c->stream, b->rec, b->endo, b->n);
-  else hipLaunchKernelGGL(k_bases_endo_g2, dim3(nblk(b->n, 256)), dim3(256), 0, c->stream, b->rec, b->endo, b->n);
+  if (b->group == 1) KLAUNCH(k_bases_endo, dim3(nblk(b->n, 256)), dim3(256), 0, c->stream, b->rec, b->endo, b->n);
+  else KLAUNCH(k_bases_endo_g2, dim3(nblk(b->n, 256)), dim3(256), 0, c->stream, b->rec, b->endo, b->n);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipEventRecord(b->ev_ready, c->stream);     // MSMs on another stream (blsgpu_set_stream) wait for the records and images
   if (e != hipSuccess) { hipFree(b->endo); b->endo = nullptr; return fail("k_bases_endo", e, __LINE__); }
@@ -744,7 +838,7 @@ static int bases_import(blsgpu_ctx* c, const void* d_xy, const void* d_inf, size
   if (hipEventCreateWithFlags(&b->ev_ready, hipEventDisableTiming) != hipSuccess) { delete b; g_err = "hipEventCreate(bases) failed"; return BLSGPU_ERR_HIP; }
   if (hipMalloc((void**)&b->rec, bytes) != hipSuccess) { bases_drop(b); g_err = "hipMalloc(bases) failed"; return BLSGPU_ERR_HIP; }
   if (n) {
-    hipLaunchKernelGGL(k_bases_import<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (const u32*)d_xy, (const uint8_t*)d_inf, b->rec, n);
+    KLAUNCH(k_bases_import<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (const u32*)d_xy, (const uint8_t*)d_inf, b->rec, n);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipEventRecord(b->ev_ready, c->stream);
     if (e != hipSuccess) { bases_drop(b); return fail("k_bases_import", e, __LINE__); }
@@ -804,8 +898,8 @@ extern "C" int blsgpu_bases_from_scalars(blsgpu_ctx* c, int group, const uint8_t
       hipError_t e = hipMemcpyAsync(c->fb_stage.p, one_byte.data(), one_byte.size(), hipMemcpyHostToDevice, c->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(c->stream);                 // `one_byte` lives on this frame
       if (e != hipSuccess) { bases_drop(b); return fail("fixed-base table upload", e, __LINE__); }
-      if (group == 1) hipLaunchKernelGGL(k_bases_from_scalars<FpPolicy>, dim3(nblk(8192, 256)), dim3(256), 0, c->stream, c->fb_stage.as<u32>(), tb.as<u32>(), (size_t)8192);
-      else hipLaunchKernelGGL(k_bases_from_scalars<Fp2Policy>, dim3(nblk(8192, 256)), dim3(256), 0, c->stream, c->fb_stage.as<u32>(), tb.as<u32>(), (size_t)8192);
+      if (group == 1) KLAUNCH(k_bases_from_scalars<FpPolicy>, dim3(nblk(8192, 256)), dim3(256), 0, c->stream, c->fb_stage.as<u32>(), tb.as<u32>(), (size_t)8192);
+      else KLAUNCH(k_bases_from_scalars<Fp2Policy>, dim3(nblk(8192, 256)), dim3(256), 0, c->stream, c->fb_stage.as<u32>(), tb.as<u32>(), (size_t)8192);
       e = hipGetLastError();
       if (e == hipSuccess) e = hipEventRecord(c->ev_fb[group - 1], c->stream);
       if (e != hipSuccess) { bases_drop(b); return fail("fixed-base table build", e, __LINE__); }
@@ -814,10 +908,10 @@ extern "C" int blsgpu_bases_from_scalars(blsgpu_ctx* c, int group, const uint8_t
     if (comb) {
       hipError_t e = hipStreamWaitEvent(c->stream, c->ev_fb[group - 1], 0);
       if (e != hipSuccess) { bases_drop(b); return fail("fixed-base table wait", e, __LINE__); }
-      if (group == 1) hipLaunchKernelGGL(k_fixed_base<FpPolicy>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), c->fb_table[0].as<u32>(), b->rec, n);
-      else hipLaunchKernelGGL(k_fixed_base<Fp2Policy>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), c->fb_table[1].as<u32>(), b->rec, n);
-    } else if (group == 1) hipLaunchKernelGGL(k_bases_from_scalars<FpPolicy>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), b->rec, n);
-    else hipLaunchKernelGGL(k_bases_from_scalars<Fp2Policy>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), b->rec, n);
+      if (group == 1) KLAUNCH(k_fixed_base<FpPolicy>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), c->fb_table[0].as<u32>(), b->rec, n);
+      else KLAUNCH(k_fixed_base<Fp2Policy>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), c->fb_table[1].as<u32>(), b->rec, n);
+    } else if (group == 1) KLAUNCH(k_bases_from_scalars<FpPolicy>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), b->rec, n);
+    else KLAUNCH(k_bases_from_scalars<Fp2Policy>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), b->rec, n);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipEventRecord(b->ev_ready, c->stream);
     if (e != hipSuccess) { bases_drop(b); return fail("k_bases_from_scalars", e, __LINE__); }
@@ -848,7 +942,7 @@ static int bases_precompute(blsgpu_ctx* c, blsgpu_bases* b, int cw) {
   size_t bytes = (size_t)nwin * (b->n ? b->n : 1) * Store<F>::AFF_WORDS * 4;
   HIPCHK(hipMalloc((void**)&b->table, bytes));
   if (b->n) {
-    hipLaunchKernelGGL(k_bases_precompute<F>, dim3(nblk(b->n, 256)), dim3(256), 0, c->stream, b->rec, b->table, b->n, cw, nwin);
+    KLAUNCH(k_bases_precompute<F>, dim3(nblk(b->n, 256)), dim3(256), 0, c->stream, b->rec, b->table, b->n, cw, nwin);
     LAUNCHCHK();
   }
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -868,7 +962,7 @@ static int bases_download(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, si
   size_t xb = count * 2 * Wire<F>::WORDS * 4;
   if (c->io_out.reserve(xb ? xb : 16) || c->flags_b.reserve(count ? count : 16)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
   if (!count) return BLSGPU_OK;
-  hipLaunchKernelGGL(k_bases_export<F>, dim3(nblk(count, 256)), dim3(256), 0, c->stream, b->rec + first * Store<F>::AFF_WORDS, c->io_out.as<u32>(),
+  KLAUNCH(k_bases_export<F>, dim3(nblk(count, 256)), dim3(256), 0, c->stream, b->rec + first * Store<F>::AFF_WORDS, c->io_out.as<u32>(),
                      c->flags_b.as<uint8_t>(), count);
   LAUNCHCHK();
   HIPCHK(hipMemcpyAsync(xy, c->io_out.p, xb, hipMemcpyDeviceToHost, c->stream));
@@ -918,9 +1012,9 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   if (c->result.reserve(PW * 4)) { g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP; }
   if (n == 0) {
     if (blsgpu_join(c) != BLSGPU_OK) return BLSGPU_ERR_HIP;
-    hipLaunchKernelGGL(k_store_identity<F>, dim3(1), dim3(64), 0, st, c->result.as<u32>());
+    KLAUNCH(k_store_identity<F>, dim3(1), dim3(64), 0, st, c->result.as<u32>());
     LAUNCHCHK();
-    hipLaunchKernelGGL(k_proj_export<F>, dim3(1), dim3(256), 0, st, c->result.as<u32>(), (u32*)d_out_wire, (size_t)1);
+    KLAUNCH(k_proj_export<F>, dim3(1), dim3(256), 0, st, c->result.as<u32>(), (u32*)d_out_wire, (size_t)1);
     LAUNCHCHK();
     return BLSGPU_OK;
   }
@@ -967,8 +1061,11 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     if (fresh && !bad_alloc) HIPCHK(hipMemsetAsync(sl.hist.p, 0, sl.hist.cap, ft));      // the sort keeps its counters zeroed between calls
   }
   if (!fast_sort) bad_alloc |= sl.cursor.reserve(total * 4);      // per-entry rank inside its bucket (fallback sort only)
+  const int sform = c->scalar_form;
+  const bool plain_mont = sform == SCALAR_MONT && !glv && !gls;      // no decomposition kernel touches the scalars: reduce them first
   if (glv) bad_alloc |= sl.glv.reserve(ns * 16);
   if (gls) bad_alloc |= sl.glv.reserve(ns * 8);
+  if (plain_mont) bad_alloc |= sl.glv.reserve(n * 32);
   bad_alloc |= sl.offs.reserve((nb + 1) * 4);
   bad_alloc |= sl.bsum.reserve(4096 * 4);
   // item cap: ~4x the mean bucket load, so that with uniform scalars (almost) no bucket is cut
@@ -1000,6 +1097,11 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   if (ft != st) { HIPCHK(hipEventRecord(sl.ev_in, st)); HIPCHK(hipStreamWaitEvent(ft, sl.ev_in, 0)); }
 
   mark(0);
+  if (plain_mont) {
+    KLAUNCH(k_scalars_from_mont, dim3(nblk(n, 256)), dim3(256), 0, ft, (const u32*)d_scalars, sl.glv.as<u32>(), (int)n, c->status_word);
+    LAUNCHCHK();
+    d_scalars = sl.glv.p;
+  }
   if (fast_sort) {
     // 1'-3'. two-level counting sort (LDS atomics; see msm.hip.h)
     // fixed layout: [MAX] counts (kept zero between calls) | [MAX+1] bases | [MAX] cursors
@@ -1010,29 +1112,29 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     const unsigned tiles = nblk(ns, SORT_TILE);
     const u32* sort_in = (const u32*)d_scalars;
     if (glv) {
-      hipLaunchKernelGGL(k_glv_decompose, dim3(nblk(n, 256)), dim3(256), 0, ft, (const u32*)d_scalars, sl.glv.as<u32>(), (int)n, c->status_word);
+      KLAUNCH(k_glv_decompose, dim3(nblk(n, 256)), dim3(256), 0, ft, (const u32*)d_scalars, sl.glv.as<u32>(), (int)n, c->status_word, sform);
       sort_in = sl.glv.as<u32>();
-      hipLaunchKernelGGL(k_sort_hist<4>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, 0, c->status_word);
+      KLAUNCH(k_sort_hist<4>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, 0, c->status_word);
     } else if (gls) {
-      hipLaunchKernelGGL(k_gls_decompose, dim3(nblk(n, 256)), dim3(256), 0, ft, (const u32*)d_scalars, sl.glv.as<u32>(), (int)n, c->status_word);
+      KLAUNCH(k_gls_decompose, dim3(nblk(n, 256)), dim3(256), 0, ft, (const u32*)d_scalars, sl.glv.as<u32>(), (int)n, c->status_word, sform);
       sort_in = sl.glv.as<u32>();
-      hipLaunchKernelGGL(k_sort_hist<2>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, 0, c->status_word);
+      KLAUNCH(k_sort_hist<2>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, 0, c->status_word);
     } else {
-      hipLaunchKernelGGL(k_sort_hist<8>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, merged ? 1 : 0, c->status_word);
+      KLAUNCH(k_sort_hist<8>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 4, ft, sort_in, ghist, (int)ns, cw, nwin, fine_bits, ncoarse, merged ? 1 : 0, c->status_word);
     }
     LAUNCHCHK();
     mark(1);
-    hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, ft, ghist, gbase, gcur, nc, sl.ctrl.as<u32>(), 4 + 2 * ITEM_BINS);
+    KLAUNCH(k_sort_scan, dim3(1), dim3(1024), 0, ft, ghist, gbase, gcur, nc, sl.ctrl.as<u32>(), 4 + 2 * ITEM_BINS);
     LAUNCHCHK();
     mark(2);
     if (glv)
-      hipLaunchKernelGGL(k_sort_scatter<4>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 8, ft, sort_in, gbase, gcur, sl.ent.as<u32>(), (int)ns, cw, nwin, fine_bits, ncoarse, 0, (u32)0);
+      KLAUNCH(k_sort_scatter<4>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 8, ft, sort_in, gbase, gcur, sl.ent.as<u32>(), (int)ns, cw, nwin, fine_bits, ncoarse, 0, (u32)0);
     else if (gls)
-      hipLaunchKernelGGL(k_sort_scatter<2>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 8, ft, sort_in, gbase, gcur, sl.ent.as<u32>(), (int)ns, cw, nwin, fine_bits, ncoarse, 0, (u32)0);
+      KLAUNCH(k_sort_scatter<2>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 8, ft, sort_in, gbase, gcur, sl.ent.as<u32>(), (int)ns, cw, nwin, fine_bits, ncoarse, 0, (u32)0);
     else
-      hipLaunchKernelGGL(k_sort_scatter<8>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 8, ft, sort_in, gbase, gcur, sl.ent.as<u32>(), (int)ns, cw, nwin,
+      KLAUNCH(k_sort_scatter<8>, dim3(tiles), dim3(SORT_THREADS), (size_t)nc * 8, ft, sort_in, gbase, gcur, sl.ent.as<u32>(), (int)ns, cw, nwin,
                          fine_bits, ncoarse, merged ? 1 : 0, (u32)bases->n);
-    hipLaunchKernelGGL(k_sort_fine, dim3(nc), dim3(256), 0, ft, sl.ent.as<u32>(), gbase, sl.sorted.as<u32>(), sl.offs.as<u32>(), fine_bits, nc);
+    KLAUNCH(k_sort_fine, dim3(nc), dim3(256), 0, ft, sl.ent.as<u32>(), gbase, sl.sorted.as<u32>(), sl.offs.as<u32>(), fine_bits, nc);
     LAUNCHCHK();
     mark(3);
   } else {
@@ -1040,18 +1142,18 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
     sl.hist_dirty = true;
     HIPCHK(hipMemsetAsync(sl.hist.p, 0, nb * 4, ft));
     HIPCHK(hipMemsetAsync(sl.ctrl.p, 0, (4 + 2 * ITEM_BINS) * 4, ft));
-    hipLaunchKernelGGL(k_msm_digits, dim3(nblk(n, 256)), dim3(256), 0, ft, (const u32*)d_scalars, sl.ent.as<u32>(), sl.cursor.as<u32>(), sl.hist.as<u32>(), (int)n, cw, nwin, c->status_word);
+    KLAUNCH(k_msm_digits, dim3(nblk(n, 256)), dim3(256), 0, ft, (const u32*)d_scalars, sl.ent.as<u32>(), sl.cursor.as<u32>(), sl.hist.as<u32>(), (int)n, cw, nwin, c->status_word);
     LAUNCHCHK();
     mark(1);
     // 2. scan
     unsigned sb = nblk(nb, 1024);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(sb), dim3(256), 0, ft, sl.hist.as<u32>(), sl.bsum.as<u32>(), (int)nb);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, ft, sl.bsum.as<u32>(), (int)sb);
-    hipLaunchKernelGGL(k_scan_apply, dim3(sb), dim3(256), 0, ft, sl.hist.as<u32>(), sl.bsum.as<u32>(), sl.offs.as<u32>(), (int)nb);
+    KLAUNCH(k_scan_block_sums, dim3(sb), dim3(256), 0, ft, sl.hist.as<u32>(), sl.bsum.as<u32>(), (int)nb);
+    KLAUNCH(k_scan_top, dim3(1), dim3(1024), 0, ft, sl.bsum.as<u32>(), (int)sb);
+    KLAUNCH(k_scan_apply, dim3(sb), dim3(256), 0, ft, sl.hist.as<u32>(), sl.bsum.as<u32>(), sl.offs.as<u32>(), (int)nb);
     LAUNCHCHK();
     mark(2);
     // 3. scatter
-    hipLaunchKernelGGL(k_msm_scatter, dim3(nblk(total, 256)), dim3(256), 0, ft, sl.ent.as<u32>(), sl.cursor.as<u32>(), sl.offs.as<u32>(), sl.sorted.as<u32>(),
+    KLAUNCH(k_msm_scatter, dim3(nblk(total, 256)), dim3(256), 0, ft, sl.ent.as<u32>(), sl.cursor.as<u32>(), sl.offs.as<u32>(), sl.sorted.as<u32>(),
                        (int)n, total);
     LAUNCHCHK();
     mark(3);
@@ -1071,9 +1173,9 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   u32* bins = ctrl + 4;
   u32* bcur = ctrl + 4 + ITEM_BINS;
   {
-    hipLaunchKernelGGL(k_item_count, dim3(nblk(gnb, ITEM_BLOCK_BUCKETS)), dim3(256), 0, gft, goffs, bins, ctrl, (int)gnb, cap);
-    hipLaunchKernelGGL(k_item_scan, dim3(1), dim3(256), 0, gft, bins, ctrl, cap);
-    hipLaunchKernelGGL(k_item_fill, dim3(nblk(gnb, ITEM_BLOCK_BUCKETS)), dim3(256), 0, gft, goffs, bins, bcur, ctrl, gs.items.as<ItemDesc>(),
+    KLAUNCH(k_item_count, dim3(nblk(gnb, ITEM_BLOCK_BUCKETS)), dim3(256), 0, gft, goffs, bins, ctrl, (int)gnb, cap);
+    KLAUNCH(k_item_scan, dim3(1), dim3(256), 0, gft, bins, ctrl, cap);
+    KLAUNCH(k_item_fill, dim3(nblk(gnb, ITEM_BLOCK_BUCKETS)), dim3(256), 0, gft, goffs, bins, bcur, ctrl, gs.items.as<ItemDesc>(),
                        gs.heavy.as<uint4>(), (int)gnb, cap);
     LAUNCHCHK();
     if (last) mark(4);
@@ -1091,16 +1193,16 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   u32* records = gs.buckets.as<u32>();
   const u32* base_rec = (merged ? bases->table : bases->rec) + first * Store<F>::AFF_WORDS;
   if constexpr (GroupTag<F>::id == 2)
-    hipLaunchKernelGGL(k_msm_accumulate_g2pair, dim3(nblk(2 * gmax_items, BLS_G2ACC_BLOCK)), dim3(BLS_G2ACC_BLOCK), 0, gas, gls ? bases->endo + 4 * first * Store<F>::AFF_WORDS : base_rec,
+    KLAUNCH(k_msm_accumulate_g2pair, dim3(nblk(2 * gmax_items, BLS_G2ACC_BLOCK)), dim3(BLS_G2ACC_BLOCK), 0, gas, gls ? bases->endo + 4 * first * Store<F>::AFF_WORDS : base_rec,
                        sl.sorted.as<u32>(), gs.items.as<ItemDesc>(), ctrl, records);
   else
-    hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(nblk(gmax_items, BLS_ACC_BLOCK)), dim3(BLS_ACC_BLOCK), 0, gas, base_rec, glv ? bases->endo + first * Store<F>::AFF_WORDS : (const u32*)nullptr,
+    KLAUNCH(k_msm_accumulate<F>, dim3(nblk(gmax_items, BLS_ACC_BLOCK)), dim3(BLS_ACC_BLOCK), 0, gas, base_rec, glv ? bases->endo + first * Store<F>::AFF_WORDS : (const u32*)nullptr,
                        glv ? (u32)n : 0xffffffffu, sl.sorted.as<u32>(), gs.items.as<ItemDesc>(), ctrl, records);
   if (time_this) { hipEventRecord(gs.ev_k1, gas); gs.k_pending = true; }
   // the fold of cut buckets (almost always a no-op) stays on the accumulation stream: as the first kernel of the tail it made
   // the next accumulation start ~90 us earlier, inside the previous call's bottom reduction level, and the pipelined rate FELL
   // by 2.6 % (A/B on one box, twice: 3.57 vs 3.66*10^8 scalar-muls/s)
-  hipLaunchKernelGGL(k_msm_heavy<F>, dim3(HEAVY_SMALL_BLOCKS + 512), dim3(256), 0, gas, gs.heavy.as<uint4>(), ctrl, records);
+  KLAUNCH(k_msm_heavy<F>, dim3(HEAVY_SMALL_BLOCKS + 512), dim3(256), 0, gas, gs.heavy.as<uint4>(), ctrl, records);
   LAUNCHCHK();
   if (prof) hipEventRecord(c->ev[5], gas);
   // ---- tail ------------------------------------------------------------------------------------------------------
@@ -1131,11 +1233,11 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
           J.in[j] = tr.in; J.out[j] = o; J.n[j] = tr.n; J.M[j] = TM; J.G[j] = TG; J.first_team[j + 1] = J.first_team[j] + nseg * TG;
           if (TM > J.maxM) J.maxM = TM;
         } else {
-          hipLaunchKernelGGL(k_tree_sum<F>, dim3(nblk((size_t)nseg * TG, 256)), dim3(256), 0, t2, tr.in, o, nseg, tr.n, TM);
+          KLAUNCH(k_tree_sum<F>, dim3(nblk((size_t)nseg * TG, 256)), dim3(256), 0, t2, tr.in, o, nseg, tr.n, TM);
         }
         tr.in = o; tr.n = TG; tr.pp ^= 1;
       }
-      if (J.njobs) hipLaunchKernelGGL(k_tree_sum_team_multi<F>, dim3(nblk((size_t)J.first_team[J.njobs] * TEAM, 256)), dim3(256), TEAM_LDS(256), t2, J);
+      if (J.njobs) KLAUNCH(k_tree_sum_team_multi<F>, dim3(nblk((size_t)J.first_team[J.njobs] * TEAM, 256)), dim3(256), TEAM_LDS(256), t2, J);
       LAUNCHCHK();
       return BLSGPU_OK;
     };
@@ -1149,14 +1251,14 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
       // the two running sums of a chain (R and T) advance on two teams / two lanes, T one step behind R: M + 1 dependent
       // additions per level instead of 2 M
       if ((size_t)nseg * G * 2 * TEAM <= TEAM_LANES_MAX)
-        hipLaunchKernelGGL(k_wsum_level_team2<F>, dim3(nblk((size_t)nseg * G * 2 * TEAM, 256)), dim3(256),
+        KLAUNCH(k_wsum_level_team2<F>, dim3(nblk((size_t)nseg * G * 2 * TEAM, 256)), dim3(256),
                            TEAM_LDS(256) + (size_t)(256 / TEAM / 2) * 3 * TeamTraits<F>::WORDS * 4, tt, E, Rout, Tout, nseg, nn, M, off);
       else if ((size_t)nseg * G * TEAM <= TEAM_LANES_MAX)
-        hipLaunchKernelGGL(k_wsum_level_team<F>, dim3(nblk((size_t)nseg * G * TEAM, 256)), dim3(256), TEAM_LDS(256), tt, E, Rout, Tout, nseg, nn, M, off);
+        KLAUNCH(k_wsum_level_team<F>, dim3(nblk((size_t)nseg * G * TEAM, 256)), dim3(256), TEAM_LDS(256), tt, E, Rout, Tout, nseg, nn, M, off);
       else if constexpr (GroupTag<F>::id == 2)
-        hipLaunchKernelGGL(k_wsum_level_g2pair, dim3(nblk((size_t)nseg * G * 2, 256)), dim3(256), 0, tt, E, Rout, Tout, nseg, nn, M, off);
+        KLAUNCH(k_wsum_level_g2pair, dim3(nblk((size_t)nseg * G * 2, 256)), dim3(256), 0, tt, E, Rout, Tout, nseg, nn, M, off);
       else
-        hipLaunchKernelGGL(k_wsum_level_pair, dim3(nblk((size_t)nseg * G * 2, BLS_WSUM_BLOCK)), dim3(BLS_WSUM_BLOCK), 0, tt, E, Rout, Tout, nseg, nn, M, off);
+        KLAUNCH(k_wsum_level_pair, dim3(nblk((size_t)nseg * G * 2, BLS_WSUM_BLOCK)), dim3(BLS_WSUM_BLOCK), 0, tt, E, Rout, Tout, nseg, nn, M, off);
       LAUNCHCHK();
       // sum the G T-records of each window down to one -- on the second tail stream: the next level needs only Rout.  Level l
       // needs log8(G_l) passes; after every level ONE launch carries the next pass of every tree that still has one (the T
@@ -1171,7 +1273,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
           while (tn > 1) {
             int TM = tn >= 8 ? 8 : tn; int TG = (tn + TM - 1) / TM;
             u32* o = TG == 1 ? tstore + (size_t)level * nseg * PW : sl.tsum[tc].template as<u32>() + toff * PW;
-            hipLaunchKernelGGL(k_tree_sum<F>, dim3(nblk((size_t)nseg * TG, 256)), dim3(256), 0, tt, Tin, o, nseg, tn, TM);
+            KLAUNCH(k_tree_sum<F>, dim3(nblk((size_t)nseg * TG, 256)), dim3(256), 0, tt, Tin, o, nseg, tn, TM);
             LAUNCHCHK();
             Tin = o; tn = TG; tc ^= 1;
           }
@@ -1198,7 +1300,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
       HIPCHK(hipMemcpyAsync(accbuf, tstore + (size_t)(level - 1) * nseg * PW, (size_t)nseg * PW * 4, hipMemcpyDeviceToDevice, tt));
       for (int l = level - 2; l >= 0; l--) {
         int k = 0; while ((1 << k) < Ms[l]) k++;
-        hipLaunchKernelGGL(k_shift_add_team<F>, dim3(nblk((size_t)nseg * TEAM, 256)), dim3(256), TEAM_LDS(256), tt, accbuf, tstore + (size_t)l * nseg * PW, accbuf, nseg, k);
+        KLAUNCH(k_shift_add_team<F>, dim3(nblk((size_t)nseg * TEAM, 256)), dim3(256), TEAM_LDS(256), tt, accbuf, tstore + (size_t)l * nseg * PW, accbuf, nseg, k);
         LAUNCHCHK();
       }
       HIPCHK(hipMemcpyAsync(sl.wsums.p, accbuf, (size_t)nseg * PW * 4, hipMemcpyDeviceToDevice, tt));
@@ -1206,10 +1308,10 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   }
   if (prof) hipEventRecord(c->ev[6], gtt);
   // 7. combine windows
-  hipLaunchKernelGGL(k_msm_combine_team<F>, dim3(1), dim3(TEAM), TEAM_LDS(TEAM), gtt, gs.wsums.as<u32>(), gs.result.as<u32>(), ng, cw);
+  KLAUNCH(k_msm_combine_team<F>, dim3(1), dim3(TEAM), TEAM_LDS(TEAM), gtt, gs.wsums.as<u32>(), gs.result.as<u32>(), ng, cw);
   LAUNCHCHK();
   if (last) {
-    hipLaunchKernelGGL(k_proj_export<F>, dim3(1), dim3(256), 0, gtt, gs.result.as<u32>(), (u32*)d_out_wire, (size_t)1);
+    KLAUNCH(k_proj_export<F>, dim3(1), dim3(256), 0, gtt, gs.result.as<u32>(), (u32*)d_out_wire, (size_t)1);
     LAUNCHCHK();
   }
   if (prof) hipEventRecord(c->ev[7], gtt);
@@ -1258,6 +1360,16 @@ extern "C" int blsgpu_g1_msm(blsgpu_ctx* c, const blsgpu_bases* b, size_t first,
 extern "C" int blsgpu_g2_msm(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint8_t* s, size_t n, uint64_t* out) { CTX_CLAIM(c); return msm_host<Fp2Policy>(c, b, first, s, n, out); }
 extern "C" int blsgpu_g1_msm_device(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const void* s, size_t n, void* out) { CTX_CLAIM(c); return msm_device<FpPolicy>(c, b, first, s, n, out); }
 extern "C" int blsgpu_g2_msm_device(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const void* s, size_t n, void* out) { CTX_CLAIM(c); return msm_device<Fp2Policy>(c, b, first, s, n, out); }
+// the same four with the scalars as `&[Scalar]` memory holds them: four u64 Montgomery limbs each (scalar.rs:23-27); `Scalar::to_bytes`
+// (:284-296) runs on the device, fused into the decomposition kernels
+extern "C" int blsgpu_g1_msm_mont(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint64_t* s, size_t n, uint64_t* out) { CTX_CLAIM(c);
+  ScalarFormScope f(c, SCALAR_MONT); return msm_host<FpPolicy>(c, b, first, (const uint8_t*)s, n, out); }
+extern "C" int blsgpu_g2_msm_mont(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const uint64_t* s, size_t n, uint64_t* out) { CTX_CLAIM(c);
+  ScalarFormScope f(c, SCALAR_MONT); return msm_host<Fp2Policy>(c, b, first, (const uint8_t*)s, n, out); }
+extern "C" int blsgpu_g1_msm_mont_device(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const void* s, size_t n, void* out) { CTX_CLAIM(c);
+  ScalarFormScope f(c, SCALAR_MONT); return msm_device<FpPolicy>(c, b, first, s, n, out); }
+extern "C" int blsgpu_g2_msm_mont_device(blsgpu_ctx* c, const blsgpu_bases* b, size_t first, const void* s, size_t n, void* out) { CTX_CLAIM(c);
+  ScalarFormScope f(c, SCALAR_MONT); return msm_device<Fp2Policy>(c, b, first, s, n, out); }
 // k MSMs over the SAME resident bases (e.g. commitments to k polynomials under one SRS): scalars of call j at
 // d_scalars + j * n * 32, result j at d_out + j * 3 * WORDS * 4.  The calls go through the pipeline slots, so the sort,
 // accumulation and tail of consecutive MSMs overlap; results are ordered on the context's stream on return.
@@ -1362,20 +1474,20 @@ static int mul_batch_device(blsgpu_ctx* c, const void* d_xy, const void* d_inf, 
   if constexpr (MbIO<F>::LANES == 1) {
     // G1 points the caller vouches for (blsgpu_set_assume_subgroup): the endomorphism split halves the doublings, as in the MSM
     if (c->assume_subgroup && !c->no_glv) {
-      hipLaunchKernelGGL(k_mul_batch_glv, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (const u32*)d_xy, (const uint8_t*)d_inf, (const u32*)d_scalars, (u32*)d_out, n, c->status_word);
+      KLAUNCH(k_mul_batch_glv, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (const u32*)d_xy, (const uint8_t*)d_inf, (const u32*)d_scalars, (u32*)d_out, n, c->status_word, c->scalar_form);
       LAUNCHCHK();
       return BLSGPU_OK;
     }
   }
   if constexpr (MbIO<F>::LANES == 2) {
     if (c->assume_subgroup && !c->no_glv) {         // G2 points the caller vouches for: the four-dimensional psi split
-      hipLaunchKernelGGL(k_mul_batch_gls, dim3(nblk(n * 2, 256)), dim3(256), 0, c->stream, (const u32*)d_xy, (const uint8_t*)d_inf, (const u32*)d_scalars, (u32*)d_out, n, c->status_word);
+      KLAUNCH(k_mul_batch_gls, dim3(nblk(n * 2, 256)), dim3(256), 0, c->stream, (const u32*)d_xy, (const uint8_t*)d_inf, (const u32*)d_scalars, (u32*)d_out, n, c->status_word, c->scalar_form);
       LAUNCHCHK();
       return BLSGPU_OK;
     }
   }
-  hipLaunchKernelGGL(k_mul_batch<F>, dim3(nblk(n * MbIO<F>::LANES, 256)), dim3(256), 0, c->stream, (const u32*)d_xy, (const uint8_t*)d_inf, (const u32*)d_scalars,
-                     (u32*)d_out, n, c->status_word);
+  KLAUNCH(k_mul_batch<F>, dim3(nblk(n * MbIO<F>::LANES, 256)), dim3(256), 0, c->stream, (const u32*)d_xy, (const uint8_t*)d_inf, (const u32*)d_scalars,
+                     (u32*)d_out, n, c->status_word, c->scalar_form);
   LAUNCHCHK();
   return BLSGPU_OK;
 }
@@ -1403,6 +1515,15 @@ extern "C" int blsgpu_g1_mul_batch(blsgpu_ctx* c, const uint64_t* xy, const uint
 extern "C" int blsgpu_g2_mul_batch(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) { CTX_CLAIM(c); return mul_batch_host<Fp2PairPolicy>(c, xy, inf, s, n, out); }
 extern "C" int blsgpu_g1_mul_batch_device(blsgpu_ctx* c, const void* xy, const void* inf, const void* s, size_t n, void* out) { CTX_CLAIM(c); return mul_batch_device<FpPolicy>(c, xy, inf, s, n, out); }
 extern "C" int blsgpu_g2_mul_batch_device(blsgpu_ctx* c, const void* xy, const void* inf, const void* s, size_t n, void* out) { CTX_CLAIM(c); return mul_batch_device<Fp2PairPolicy>(c, xy, inf, s, n, out); }
+// `&G1Affine * &Scalar` over slices with the scalars as Montgomery limbs (g1.rs:556-594 calls `Scalar::to_bytes` per product)
+extern "C" int blsgpu_g1_mul_batch_mont(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { CTX_CLAIM(c);
+  ScalarFormScope f(c, SCALAR_MONT); return mul_batch_host<FpPolicy>(c, xy, inf, (const uint8_t*)s, n, out); }
+extern "C" int blsgpu_g2_mul_batch_mont(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { CTX_CLAIM(c);
+  ScalarFormScope f(c, SCALAR_MONT); return mul_batch_host<Fp2PairPolicy>(c, xy, inf, (const uint8_t*)s, n, out); }
+extern "C" int blsgpu_g1_mul_batch_mont_device(blsgpu_ctx* c, const void* xy, const void* inf, const void* s, size_t n, void* out) { CTX_CLAIM(c);
+  ScalarFormScope f(c, SCALAR_MONT); return mul_batch_device<FpPolicy>(c, xy, inf, s, n, out); }
+extern "C" int blsgpu_g2_mul_batch_mont_device(blsgpu_ctx* c, const void* xy, const void* inf, const void* s, size_t n, void* out) { CTX_CLAIM(c);
+  ScalarFormScope f(c, SCALAR_MONT); return mul_batch_device<Fp2PairPolicy>(c, xy, inf, s, n, out); }
 
 // ---------------------------------------------------------------------------------------------------
 // group helpers
@@ -1417,10 +1538,10 @@ static int proj_sum(blsgpu_ctx* c, const uint64_t* xyz, size_t n, uint64_t* out)
   }
   if (n) {
     HIPCHK(hipMemcpyAsync(c->io_a.p, xyz, n * 3 * WW * 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_proj_import<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), c->io_c.as<u32>(), n);
+    KLAUNCH(k_proj_import<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_a.as<u32>(), c->io_c.as<u32>(), n);
   }
-  hipLaunchKernelGGL(k_proj_sum_team<F>, dim3(1), dim3(TEAM), TEAM_LDS(TEAM), c->stream, c->io_c.as<u32>(), c->result.as<u32>(), n);
-  hipLaunchKernelGGL(k_proj_export<F>, dim3(1), dim3(256), 0, c->stream, c->result.as<u32>(), c->io_out.as<u32>(), (size_t)1);
+  KLAUNCH(k_proj_sum_team<F>, dim3(1), dim3(TEAM), TEAM_LDS(TEAM), c->stream, c->io_c.as<u32>(), c->result.as<u32>(), n);
+  KLAUNCH(k_proj_export<F>, dim3(1), dim3(256), 0, c->stream, c->result.as<u32>(), c->io_out.as<u32>(), (size_t)1);
   LAUNCHCHK();
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, 3 * WW * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1433,9 +1554,9 @@ static int proj_sum_device(blsgpu_ctx* c, const void* d_xyz, size_t n, void* d_o
   HIPCHK(hipSetDevice(c->device));
   constexpr int PW = Store<F>::PROJ_WORDS;
   if (c->io_c.reserve((n ? n : 1) * PW * 4) || c->result.reserve(PW * 4)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
-  if (n) hipLaunchKernelGGL(k_proj_import<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (const u32*)d_xyz, c->io_c.as<u32>(), n);
-  hipLaunchKernelGGL(k_proj_sum_team<F>, dim3(1), dim3(TEAM), TEAM_LDS(TEAM), c->stream, c->io_c.as<u32>(), c->result.as<u32>(), n);
-  hipLaunchKernelGGL(k_proj_export<F>, dim3(1), dim3(256), 0, c->stream, c->result.as<u32>(), (u32*)d_out, (size_t)1);
+  if (n) KLAUNCH(k_proj_import<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (const u32*)d_xyz, c->io_c.as<u32>(), n);
+  KLAUNCH(k_proj_sum_team<F>, dim3(1), dim3(TEAM), TEAM_LDS(TEAM), c->stream, c->io_c.as<u32>(), c->result.as<u32>(), n);
+  KLAUNCH(k_proj_export<F>, dim3(1), dim3(256), 0, c->stream, c->result.as<u32>(), (u32*)d_out, (size_t)1);
   LAUNCHCHK();
   return BLSGPU_OK;
 }
@@ -1452,13 +1573,13 @@ static int batch_normalize_device(blsgpu_ctx* c, const void* d_xyz, size_t n, vo
   HIPCHK(hipSetDevice(c->device));
   constexpr int PW = Store<F>::PROJ_WORDS;
   if (c->io_c.reserve(n * PW * 4) || c->io_d.reserve(n * Store<F>::EL * 4)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
-  hipLaunchKernelGGL(k_proj_import<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (const u32*)d_xyz, c->io_c.as<u32>(), n);
+  KLAUNCH(k_proj_import<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (const u32*)d_xyz, c->io_c.as<u32>(), n);
   if (n >= 4096) {
     const int K = normalize_k(n);
     size_t T = (n + K - 1) / K;
-    hipLaunchKernelGGL(k_batch_normalize<F>, dim3(nblk(T, 256)), dim3(256), 0, c->stream, c->io_c.as<u32>(), c->io_d.as<u32>(), (u32*)d_xy, (uint8_t*)d_inf, n, T, K);
+    KLAUNCH(k_batch_normalize<F>, dim3(nblk(T, 256)), dim3(256), 0, c->stream, c->io_c.as<u32>(), c->io_d.as<u32>(), (u32*)d_xy, (uint8_t*)d_inf, n, T, K);
   } else {
-    hipLaunchKernelGGL(k_proj_to_affine<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_c.as<u32>(), (u32*)d_xy, (uint8_t*)d_inf, n);
+    KLAUNCH(k_proj_to_affine<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->io_c.as<u32>(), (u32*)d_xy, (uint8_t*)d_inf, n);
   }
   LAUNCHCHK();
   return BLSGPU_OK;
@@ -1494,11 +1615,11 @@ static int elem_op(blsgpu_ctx* c, int words, int kind, int op, const uint64_t* a
   HIPCHK(hipMemcpyAsync(c->io_a.p, a, bytes, hipMemcpyHostToDevice, c->stream));
   if (b) HIPCHK(hipMemcpyAsync(c->io_b.p, b, bytes, hipMemcpyHostToDevice, c->stream));
   const u32* bp = b ? c->io_b.as<u32>() : nullptr;
-  if (kind == 1) hipLaunchKernelGGL(k_fp_op, dim3(nblk(n, 256)), dim3(256), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
-  else if (kind == 2) hipLaunchKernelGGL(k_fp2_op, dim3(nblk(n, 256)), dim3(256), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
-  else if (kind == 6) hipLaunchKernelGGL(k_fp6_op, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
-  else if (c->pairing_layout != 2 && op != 3) hipLaunchKernelGGL(k_fp12_op_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
-  else hipLaunchKernelGGL(k_fp12_op, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
+  if (kind == 1) KLAUNCH(k_fp_op, dim3(nblk(n, 256)), dim3(256), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
+  else if (kind == 2) KLAUNCH(k_fp2_op, dim3(nblk(n, 256)), dim3(256), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
+  else if (kind == 6) KLAUNCH(k_fp6_op, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
+  else if (c->pairing_layout != 2 && op != 3) KLAUNCH(k_fp12_op_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
+  else KLAUNCH(k_fp12_op, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, op, c->io_a.as<u32>(), bp, c->io_out.as<u32>(), n);
   LAUNCHCHK();
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1530,7 +1651,7 @@ static int point_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint64_t* b,
   HIPCHK(hipMemcpyAsync(c->io_a.p, a, ab, hipMemcpyHostToDevice, c->stream));
   if (op != 1) HIPCHK(hipMemcpyAsync(c->io_b.p, b, bb, hipMemcpyHostToDevice, c->stream));
   if (op == 2 && binf) HIPCHK(hipMemcpyAsync(c->flags_a.p, binf, n, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_point_op<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, op, c->io_a.as<u32>(), c->io_b.as<u32>(),
+  KLAUNCH(k_point_op<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, op, c->io_a.as<u32>(), c->io_b.as<u32>(),
                      (op == 2 && binf) ? c->flags_a.as<uint8_t>() : nullptr, c->io_out.as<u32>(), n);
   LAUNCHCHK();
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, ab, hipMemcpyDeviceToHost, c->stream));
@@ -1552,8 +1673,8 @@ static int chain_probe(blsgpu_ctx* c, int iters, double* rate, bool fp) {
   if (c->io_a.reserve(256 * 28 * 4 + 4096) || c->io_out.reserve((size_t)blocks * 256 * NL * 4)) { g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP; }
   HIPCHK(hipMemsetAsync(c->io_a.p, 0x11, 256 * 28 * 4 + 4096, c->stream));
   auto launch = [&](int it) {
-    if (fp) hipLaunchKernelGGL(k_fp_mul_chain, dim3(blocks), dim3(256), 0, c->stream, c->io_out.as<u32>(), c->io_a.as<u32>(), it);
-    else hipLaunchKernelGGL(k_mad_chain, dim3(blocks), dim3(256), 0, c->stream, c->io_out.as<u32>(), c->io_a.as<u32>(), it);
+    if (fp) KLAUNCH(k_fp_mul_chain, dim3(blocks), dim3(256), 0, c->stream, c->io_out.as<u32>(), c->io_a.as<u32>(), it);
+    else KLAUNCH(k_mad_chain, dim3(blocks), dim3(256), 0, c->stream, c->io_out.as<u32>(), c->io_a.as<u32>(), it);
   };
   launch(4);
   HIPCHK(hipEventRecord(c->ev[0], c->stream));
@@ -1577,6 +1698,7 @@ template <int G>
 static int msm_bytes(blsgpu_ctx* c, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t* out) {
   constexpr int W = G == 1 ? 12 : 24, BYTES = G == 1 ? 96 : 192;
   if (!c || !out || (n && (!bases || !scalars))) return bad("msm_bytes: NULL argument");
+  ScalarFormScope bytes_form(c, SCALAR_BYTES);        // this entry point's scalars ARE `Scalar::to_bytes()` output, whatever the context's setting
   std::vector<uint64_t> xy(n * W + 1), xyz(3 * W), axy(2 * W);
   std::vector<uint8_t> inf(n + 1), ok(n + 1);
   uint8_t ainf = 0;
@@ -1606,11 +1728,11 @@ static void h2c_launch(blsgpu_ctx* c, int group, const uint8_t* msgs, const unsi
   const int forced = c->h2c_split;
   const bool split = !encode_only && (forced >= 0 ? forced == 1 : n <= (group == 1 ? (size_t)1 << 15 : (size_t)1 << 14));
   if (group == 1) {
-    if (split) hipLaunchKernelGGL(k_hash_to_curve_split<FpPolicy>, dim3(nblk(n * 2, 64)), dim3(64), 0, c->stream, msgs, offs, n, dst, dlen, out);
-    else hipLaunchKernelGGL(k_hash_to_curve<FpPolicy>, dim3(nblk(n, 64)), dim3(64), 0, c->stream, msgs, offs, n, dst, dlen, encode_only ? 1 : 0, out);
+    if (split) KLAUNCH(k_hash_to_curve_split<FpPolicy>, dim3(nblk(n * 2, 64)), dim3(64), 0, c->stream, msgs, offs, n, dst, dlen, out);
+    else KLAUNCH(k_hash_to_curve<FpPolicy>, dim3(nblk(n, 64)), dim3(64), 0, c->stream, msgs, offs, n, dst, dlen, encode_only ? 1 : 0, out);
   } else {
-    if (split) hipLaunchKernelGGL(k_hash_to_curve_split<Fp2PairPolicy>, dim3(nblk(n * 4, 256)), dim3(256), 0, c->stream, msgs, offs, n, dst, dlen, out);
-    else hipLaunchKernelGGL(k_hash_to_curve<Fp2PairPolicy>, dim3(nblk(n * 2, 256)), dim3(256), 0, c->stream, msgs, offs, n, dst, dlen, encode_only ? 1 : 0, out);
+    if (split) KLAUNCH(k_hash_to_curve_split<Fp2PairPolicy>, dim3(nblk(n * 4, 256)), dim3(256), 0, c->stream, msgs, offs, n, dst, dlen, out);
+    else KLAUNCH(k_hash_to_curve<Fp2PairPolicy>, dim3(nblk(n * 2, 256)), dim3(256), 0, c->stream, msgs, offs, n, dst, dlen, encode_only ? 1 : 0, out);
   }
 }
 template <class F>
@@ -1678,7 +1800,7 @@ extern "C" int blsgpu_fr_op_device(blsgpu_ctx* c, int op, const void* a, const v
   if (op <= 2 && n && !b) return bad("fr_op: binary op needs b");
   if (!n) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
-  hipLaunchKernelGGL(k_fr_op, dim3(nblk(n, 256)), dim3(256), 0, c->stream, op, (const u32*)a, op <= 2 ? (const u32*)b : (const u32*)nullptr, (u32*)out,
+  KLAUNCH(k_fr_op, dim3(nblk(n, 256)), dim3(256), 0, c->stream, op, (const u32*)a, op <= 2 ? (const u32*)b : (const u32*)nullptr, (u32*)out,
                      (uint8_t*)nonzero_flags, n);
   LAUNCHCHK();
   return BLSGPU_OK;
@@ -1699,6 +1821,35 @@ extern "C" int blsgpu_fr_op(blsgpu_ctx* c, int op, const uint64_t* a, const uint
   HIPCHK(hipStreamSynchronize(c->stream));
   return BLSGPU_OK;
 }
+// `Scalar::to_bytes` / `from_bytes` / `from_bytes_wide` over vectors (scalar.rs:284-296, :256-280, :300-331; k_fr_convert)
+static int fr_convert_device(blsgpu_ctx* c, int op, const void* in, size_t n, void* out, void* ok) {
+  if (!c || (n && (!in || !out))) return bad("fr conversion: NULL argument");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  KLAUNCH(k_fr_convert, dim3(nblk(n, 256)), dim3(256), 0, c->stream, op, (const u32*)in, (u32*)out, (uint8_t*)ok, n);
+  LAUNCHCHK();
+  return BLSGPU_OK;
+}
+static int fr_convert_host(blsgpu_ctx* c, int op, const void* in, size_t n, void* out, uint8_t* ok) {
+  if (!c || (n && (!in || !out))) return bad("fr conversion: NULL argument");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  const size_t ib = n * (op == 2 ? 64 : 32);
+  if (c->io_a.reserve(ib) || c->io_out.reserve(n * 32) || c->flags_a.reserve(n)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  { int ru = staged_upload(c, c->io_a.p, in, ib); if (ru) return ru; }
+  int rc = fr_convert_device(c, op, c->io_a.p, n, c->io_out.p, ok ? c->flags_a.p : nullptr);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(out, c->io_out.p, n * 32, hipMemcpyDeviceToHost, c->stream));
+  if (ok) HIPCHK(hipMemcpyAsync(ok, c->flags_a.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_fr_to_bytes_device(blsgpu_ctx* c, const void* scalars, size_t n, void* bytes, void* ok) { CTX_CLAIM(c); return fr_convert_device(c, 0, scalars, n, bytes, ok); }
+extern "C" int blsgpu_fr_from_bytes_device(blsgpu_ctx* c, const void* bytes, size_t n, void* scalars, void* ok) { CTX_CLAIM(c); return fr_convert_device(c, 1, bytes, n, scalars, ok); }
+extern "C" int blsgpu_fr_from_bytes_wide_device(blsgpu_ctx* c, const void* bytes, size_t n, void* scalars) { CTX_CLAIM(c); return fr_convert_device(c, 2, bytes, n, scalars, nullptr); }
+extern "C" int blsgpu_fr_to_bytes(blsgpu_ctx* c, const uint64_t* scalars, size_t n, uint8_t* bytes, uint8_t* ok) { CTX_CLAIM(c); return fr_convert_host(c, 0, scalars, n, bytes, ok); }
+extern "C" int blsgpu_fr_from_bytes(blsgpu_ctx* c, const uint8_t* bytes, size_t n, uint64_t* scalars, uint8_t* ok) { CTX_CLAIM(c); return fr_convert_host(c, 1, bytes, n, scalars, ok); }
+extern "C" int blsgpu_fr_from_bytes_wide(blsgpu_ctx* c, const uint8_t* bytes, size_t n, uint64_t* scalars) { CTX_CLAIM(c); return fr_convert_host(c, 2, bytes, n, scalars, nullptr); }
 // in-place transform of 2^log_n scalars in device memory (natural order in and out)
 extern "C" int blsgpu_fr_ntt_device(blsgpu_ctx* c, void* d_data, int log_n, int inverse) { CTX_CLAIM(c);
   if (!c || !d_data) return bad("fr_ntt: NULL argument");
@@ -1710,8 +1861,8 @@ extern "C" int blsgpu_fr_ntt_device(blsgpu_ctx* c, void* d_data, int log_n, int 
   const size_t n = (size_t)1 << log_n, half = n >> 1;
   if (c->fr_tw[dir].reserve(n * 32) || c->fr_tmp.reserve(n * 32) || c->fr_ninv.reserve(64)) { g_err = "hipMalloc(fr scratch) failed"; return BLSGPU_ERR_HIP; }
   if (c->fr_tw_log[dir] != log_n) {
-    hipLaunchKernelGGL(k_fr_twiddles, dim3(nblk((half + FR_TW_RUN - 1) / FR_TW_RUN, 256)), dim3(256), 0, st, c->fr_tw[dir].as<u32>(), log_n, dir);
-    if (log_n > 1) hipLaunchKernelGGL(k_fr_tw_levels, dim3(nblk(half, 256)), dim3(256), 0, st, c->fr_tw[dir].as<u32>(), log_n);
+    KLAUNCH(k_fr_twiddles, dim3(nblk((half + FR_TW_RUN - 1) / FR_TW_RUN, 256)), dim3(256), 0, st, c->fr_tw[dir].as<u32>(), log_n, dir);
+    if (log_n > 1) KLAUNCH(k_fr_tw_levels, dim3(nblk(half, 256)), dim3(256), 0, st, c->fr_tw[dir].as<u32>(), log_n);
     LAUNCHCHK();
     c->fr_tw_log[dir] = log_n;
     HIPCHK(hipEventRecord(c->ev_fr[dir], st));
@@ -1753,27 +1904,27 @@ extern "C" int blsgpu_fr_ntt_device(blsgpu_ctx* c, void* d_data, int log_n, int 
       const int d = (lh + 1 - tl + (passes - ps) - 1) / (passes - ps);      // the remaining stages split evenly over the remaining passes
       const int ls = lh - d + 1;
       const int lk = tlog - d < ls ? tlog - d : ls;
-      hipLaunchKernelGGL(k_fr_cols, dim3((unsigned)(n >> (d + lk))), dim3(block), ((size_t)9 << (d + lk)) * 4, st, src, cur, tw, lh, d, lk);
+      KLAUNCH(k_fr_cols, dim3((unsigned)(n >> (d + lk))), dim3(block), ((size_t)9 << (d + lk)) * 4, st, src, cur, tw, lh, d, lk);
       src = cur; lh -= d;
     }
   }
   while (lh - 1 >= tl) {                                // two stages per pass over the data
-    hipLaunchKernelGGL(k_fr_stage2, dim3(nblk(n / 4, 256)), dim3(256), 0, st, src, cur, tw, log_n, lh);
+    KLAUNCH(k_fr_stage2, dim3(nblk(n / 4, 256)), dim3(256), 0, st, src, cur, tw, log_n, lh);
     src = cur; lh -= 2;
   }
-  if (lh >= tl) { hipLaunchKernelGGL(k_fr_stage1, dim3(nblk(n / 2, 256)), dim3(256), 0, st, src, cur, tw, log_n, lh); src = cur; lh--; }
+  if (lh >= tl) { KLAUNCH(k_fr_stage1, dim3(nblk(n / 2, 256)), dim3(256), 0, st, src, cur, tw, log_n, lh); src = cur; lh--; }
   LAUNCHCHK();
   const u32* scale = nullptr;
   if (inverse) {
     if (c->fr_ninv_log != log_n) {
-      hipLaunchKernelGGL(k_fr_ninv, dim3(1), dim3(64), 0, st, c->fr_ninv.as<u32>(), log_n); c->fr_ninv_log = log_n;
+      KLAUNCH(k_fr_ninv, dim3(1), dim3(64), 0, st, c->fr_ninv.as<u32>(), log_n); c->fr_ninv_log = log_n;
       HIPCHK(hipEventRecord(c->ev_fr[2], st));
     }
     HIPCHK(hipStreamWaitEvent(st, c->ev_fr[2], 0));
     scale = c->fr_ninv.as<u32>();
   }
   u32* dst = src == data ? tmp : data;
-  hipLaunchKernelGGL(k_fr_tile, dim3((unsigned)(n >> tl)), dim3(256), ((size_t)9 << tl) * 4, st, src, dst, tw, log_n, tl, scale);
+  KLAUNCH(k_fr_tile, dim3((unsigned)(n >> tl)), dim3(256), ((size_t)9 << tl) * 4, st, src, dst, tw, log_n, tl, scale);
   LAUNCHCHK();
   if (dst != data) HIPCHK(hipMemcpyAsync(data, tmp, n * 32, hipMemcpyDeviceToDevice, st));
   return BLSGPU_OK;
@@ -1868,10 +2019,10 @@ extern "C" const char* blsgpu_wide_status(blsgpu_ctx* c) {
 }
 static void wide_launch(blsgpu_ctx* c, int mode, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) {
   if (n <= WIDE_ONE_PER_CU)
-    hipLaunchKernelGGL((k_pairing_wide_t<1024, 4>), dim3((unsigned)n), dim3(1024), 0, c->stream, mode, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2, (const uint8_t*)g2inf,
+    KLAUNCH((k_pairing_wide_t<1024, 4>), dim3((unsigned)n), dim3(1024), 0, c->stream, mode, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2, (const uint8_t*)g2inf,
                        (u32*)out, n, c->d_wide + c->wide_off[0], c->d_wide + c->wide_off[1]);
   else
-    hipLaunchKernelGGL((k_pairing_wide_t<512, 8>), dim3((unsigned)n), dim3(512), 0, c->stream, mode, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2, (const uint8_t*)g2inf,
+    KLAUNCH((k_pairing_wide_t<512, 8>), dim3((unsigned)n), dim3(512), 0, c->stream, mode, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2, (const uint8_t*)g2inf,
                        (u32*)out, n, c->d_wide + c->wide_off[2], c->d_wide + c->wide_off[3]);
 }
 static int pairing_launch(blsgpu_ctx* c, int mode, const void* g1, const void* g1inf, const void* g2, const void* g2inf, size_t n, void* out) {
@@ -1880,12 +2031,12 @@ static int pairing_launch(blsgpu_ctx* c, int mode, const void* g1, const void* g
   if (layout < 0) return wide_missing(c);
   if (layout == 256) { wide_launch(c, mode, g1, g1inf, g2, g2inf, n, out); LAUNCHCHK(); return BLSGPU_OK; }
   if (layout == 4) {
-    hipLaunchKernelGGL(k_pairing_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, mode, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2,
+    KLAUNCH(k_pairing_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, mode, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2,
                        (const uint8_t*)g2inf, (u32*)out, n);
     LAUNCHCHK();
     return BLSGPU_OK;
   }
-  hipLaunchKernelGGL(k_pairing, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, mode, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2,
+  KLAUNCH(k_pairing, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, mode, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2,
                      (const uint8_t*)g2inf, (u32*)out, n);
   LAUNCHCHK();
   return BLSGPU_OK;
@@ -1933,8 +2084,8 @@ extern "C" int blsgpu_final_exponentiation_device(blsgpu_ctx* c, const void* in,
   const int layout = pairing_layout_for(c, n);
   if (layout < 0) return wide_missing(c);
   if (layout == 256) wide_launch(c, 2, in, nullptr, nullptr, nullptr, n, out);
-  else if (layout == 4) hipLaunchKernelGGL(k_final_exp_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, (const u32*)in, (u32*)out, n);
-  else hipLaunchKernelGGL(k_final_exp, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)in, (u32*)out, n);
+  else if (layout == 4) KLAUNCH(k_final_exp_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, (const u32*)in, (u32*)out, n);
+  else KLAUNCH(k_final_exp, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)in, (u32*)out, n);
   LAUNCHCHK();
   return BLSGPU_OK;
 }
@@ -1943,7 +2094,7 @@ extern "C" int blsgpu_final_exponentiation_device(blsgpu_ctx* c, const void* in,
 static int fp12_product_device(blsgpu_ctx* c, const u32* d_in, size_t n, u32* d_out) {
   if (c->io_c.reserve((n / 2 + 1) * 576) || c->io_d.reserve((n / 4 + 1) * 576)) { g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP; }
   if (n == 0) {
-    hipLaunchKernelGGL(k_fp12_one, dim3(1), dim3(64), 0, c->stream, d_out);
+    KLAUNCH(k_fp12_one, dim3(1), dim3(64), 0, c->stream, d_out);
     LAUNCHCHK();
     return BLSGPU_OK;
   }
@@ -1957,9 +2108,9 @@ static int fp12_product_device(blsgpu_ctx* c, const u32* d_in, size_t n, u32* d_
     size_t m = (n + fan - 1) / fan;
     u32* o = (m == 1) ? d_out : (flip ? c->io_d.as<u32>() : c->io_c.as<u32>());
     if (m <= 32768 && c->pairing_layout != 2)            // latency-bound level: a quad per product
-      hipLaunchKernelGGL(k_fp12_prod_quad, dim3(nblk(m * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, in, o, n, m, fan);
+      KLAUNCH(k_fp12_prod_quad, dim3(nblk(m * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, in, o, n, m, fan);
     else
-      hipLaunchKernelGGL(k_fp12_prod, dim3(nblk(m * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, in, o, n, m, fan);
+      KLAUNCH(k_fp12_prod, dim3(nblk(m * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, in, o, n, m, fan);
     LAUNCHCHK();
     in = o; n = m; flip ^= 1;
   }
@@ -1990,7 +2141,7 @@ extern "C" int blsgpu_multi_miller_loop_device(blsgpu_ctx* c, const void* g1, co
   const size_t groups = (n + K - 1) / K;
   const int impl = c->mml_impl ? c->mml_impl : MML_IMPL_DEFAULT;
   if (impl == 1) {
-    hipLaunchKernelGGL(k_multi_miller_shared, dim3(nblk(groups * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)g1, (const uint8_t*)g1inf,
+    KLAUNCH(k_multi_miller_shared, dim3(nblk(groups * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)g1, (const uint8_t*)g1inf,
                        (const u32*)g2, (const uint8_t*)g2inf, c->io_out.as<u32>(), n, K);
     LAUNCHCHK();
   } else {
@@ -2026,8 +2177,8 @@ static int final_exp_launch(blsgpu_ctx* c, const void* in, size_t n, void* out) 
   const int layout = pairing_layout_for(c, n);
   if (layout < 0) return wide_missing(c);
   if (layout == 256) wide_launch(c, 2, in, nullptr, nullptr, nullptr, n, out);
-  else if (layout == 4) hipLaunchKernelGGL(k_final_exp_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, (const u32*)in, (u32*)out, n);
-  else hipLaunchKernelGGL(k_final_exp, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)in, (u32*)out, n);
+  else if (layout == 4) KLAUNCH(k_final_exp_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, (const u32*)in, (u32*)out, n);
+  else KLAUNCH(k_final_exp, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)in, (u32*)out, n);
   LAUNCHCHK();
   return BLSGPU_OK;
 }
@@ -2057,17 +2208,17 @@ extern "C" int blsgpu_multi_miller_loop_many_device(blsgpu_ctx* c, const void* g
   // squarings per term disappear); it needs >= 2^16 lanes' worth of segments to beat the per-term quads (a quarter-filled chip runs
   // at the latency of one shared loop: ~13 ms for k = 3)
   if (seg_shared) {
-    hipLaunchKernelGGL(k_multi_miller_seg, dim3(nblk(nseg * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2,
+    KLAUNCH(k_multi_miller_seg, dim3(nblk(nseg * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2,
                        (const uint8_t*)g2inf, (const unsigned long long*)d_offsets, nseg, total, prod, c->d_status);
     LAUNCHCHK();
     return final_exp ? final_exp_launch(c, prod, nseg, out) : BLSGPU_OK;
   }
   if (total) { int rc = pairing_launch(c, 1, g1, g1inf, g2, g2inf, total, c->io_out.p); if (rc) return rc; }
-  hipLaunchKernelGGL(k_fp12_prod_seg_quad, dim3(nblk(nseg * parts * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, c->io_out.as<u32>(), (const unsigned long long*)d_offsets,
+  KLAUNCH(k_fp12_prod_seg_quad, dim3(nblk(nseg * parts * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, c->io_out.as<u32>(), (const unsigned long long*)d_offsets,
                      nseg, total, parts, parts > 1 ? c->io_c.as<u32>() : prod);
   LAUNCHCHK();
   if (parts > 1) {
-    hipLaunchKernelGGL(k_fp12_prod_quad, dim3(nblk(nseg * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, c->io_c.as<u32>(), prod, nseg * parts, nseg, parts);
+    KLAUNCH(k_fp12_prod_quad, dim3(nblk(nseg * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, c->io_c.as<u32>(), prod, nseg * parts, nseg, parts);
     LAUNCHCHK();
   }
   return final_exp ? final_exp_launch(c, prod, nseg, out) : BLSGPU_OK;
@@ -2123,7 +2274,7 @@ extern "C" int blsgpu_g2_prepare_device(blsgpu_ctx* c, const void* d_g2, const v
   if (hipMalloc((void**)&p->tab, (m ? m : 1) * PREP_POINT_WORDS * 4) != hipSuccess || hipMalloc((void**)&p->inf, m ? m : 1) != hipSuccess) {
     (void)hipGetLastError(); prepared_drop(p); g_err = "hipMalloc(g2_prepared) failed"; return BLSGPU_ERR_HIP;
   }
-  if (m) hipLaunchKernelGGL(k_g2_prepare_quad, dim3(nblk(m * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, (const u32*)d_g2, (const uint8_t*)d_inf, m, p->tab, p->inf);
+  if (m) KLAUNCH(k_g2_prepare_quad, dim3(nblk(m * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, (const u32*)d_g2, (const uint8_t*)d_inf, m, p->tab, p->inf);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipEventRecord(p->ev_ready, c->stream);          // consumers on another stream (blsgpu_set_stream) wait for the table
   if (e != hipSuccess) { prepared_drop(p); return fail("k_g2_prepare_quad", e, __LINE__); }
@@ -2158,7 +2309,7 @@ extern "C" int blsgpu_g2_prepared_coeffs(blsgpu_ctx* c, const blsgpu_g2_prepared
   const size_t bytes = (size_t)PREP_STEPS * 3 * 24 * 4;
   if (c->io_out.reserve(bytes)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
   HIPCHK(hipStreamWaitEvent(c->stream, p->ev_ready, 0));
-  hipLaunchKernelGGL(k_g2_prepared_export, dim3(1), dim3(256), 0, c->stream, p->tab, index, c->io_out.as<u32>());
+  KLAUNCH(k_g2_prepared_export, dim3(1), dim3(256), 0, c->stream, p->tab, index, c->io_out.as<u32>());
   LAUNCHCHK();
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, bytes, hipMemcpyDeviceToHost, c->stream));
   if (out_inf) HIPCHK(hipMemcpyAsync(out_inf, p->inf + index, 1, hipMemcpyDeviceToHost, c->stream));
@@ -2178,7 +2329,7 @@ static int mmlp_launch(blsgpu_ctx* c, const void* g1, const void* g1inf, const v
   if (c->mmlp_work.reserve(meta_b + pp_b + rr_b)) { g_err = "hipMalloc(prepared Miller work area) failed"; return BLSGPU_ERR_HIP; }
   uint8_t* w = c->mmlp_work.as<uint8_t>();
   if (p) HIPCHK(hipStreamWaitEvent(c->stream, p->ev_ready, 0));
-  hipLaunchKernelGGL(k_mml_prep_quad, dim3(blocks), dim3(QUAD_BLOCK), 0, c->stream, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2, (const uint8_t*)g2inf,
+  KLAUNCH(k_mml_prep_quad, dim3(blocks), dim3(QUAD_BLOCK), 0, c->stream, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2, (const uint8_t*)g2inf,
                      (const u32*)(p ? qidx : nullptr), p ? p->tab : (const u32*)nullptr, p ? p->inf : (const uint8_t*)nullptr, (u32)(p ? p->n : 0),
                      (const unsigned long long*)d_off, nseg, total, kuni, kmax, (u32*)w, (uint4*)(w + meta_b), (uint4*)(w + meta_b + pp_b), (u32*)out, c->d_status);
   LAUNCHCHK();
@@ -2282,8 +2433,8 @@ extern "C" int blsgpu_final_exponentiation_batch(blsgpu_ctx* c, const uint64_t* 
   const int layout = pairing_layout_for(c, n);
   if (layout < 0) return wide_missing(c);
   if (layout == 256) wide_launch(c, 2, c->io_a.p, nullptr, nullptr, nullptr, n, c->io_out.p);
-  else if (layout == 4) hipLaunchKernelGGL(k_final_exp_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, c->io_a.as<u32>(), c->io_out.as<u32>(), n);
-  else hipLaunchKernelGGL(k_final_exp, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, c->io_a.as<u32>(), c->io_out.as<u32>(), n);
+  else if (layout == 4) KLAUNCH(k_final_exp_quad, dim3(nblk(n * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, c->io_a.as<u32>(), c->io_out.as<u32>(), n);
+  else KLAUNCH(k_final_exp, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, c->io_a.as<u32>(), c->io_out.as<u32>(), n);
   LAUNCHCHK();
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, n * 576, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -2293,7 +2444,7 @@ extern "C" int blsgpu_gt_mul_scalar_batch_device(blsgpu_ctx* c, const void* gt, 
   if (!c || (n && (!gt || !scalars || !out))) return bad("gt_mul_scalar: NULL argument");
   if (!n) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
-  hipLaunchKernelGGL(k_gt_mul_scalar, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)gt, (const u32*)scalars, (u32*)out, n);
+  KLAUNCH(k_gt_mul_scalar, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, (const u32*)gt, (const u32*)scalars, (u32*)out, n, c->scalar_form);
   LAUNCHCHK();
   return BLSGPU_OK;
 }
@@ -2310,7 +2461,7 @@ __global__ void __launch_bounds__(256) k_fp12_equals(const u32* __restrict__ gt,
 static int gt_one_ready(blsgpu_ctx* c) {
   if (c->gt_one_ready) return BLSGPU_OK;
   if (c->gt_one.reserve(576)) { g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP; }
-  hipLaunchKernelGGL(k_fp12_one, dim3(1), dim3(64), 0, c->stream, c->gt_one.as<u32>());
+  KLAUNCH(k_fp12_one, dim3(1), dim3(64), 0, c->stream, c->gt_one.as<u32>());
   LAUNCHCHK();
   HIPCHK(hipEventRecord(c->ev_gt_one, c->stream));
   c->gt_one_ready = true;
@@ -2322,7 +2473,7 @@ extern "C" int blsgpu_gt_is_identity_device(blsgpu_ctx* c, const void* gt, size_
   HIPCHK(hipSetDevice(c->device));
   if (int rc = gt_one_ready(c)) return rc;
   HIPCHK(hipStreamWaitEvent(c->stream, c->ev_gt_one, 0));
-  hipLaunchKernelGGL(k_fp12_equals, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (const u32*)gt, c->gt_one.as<u32>(), n, (uint8_t*)flags);
+  KLAUNCH(k_fp12_equals, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (const u32*)gt, c->gt_one.as<u32>(), n, (uint8_t*)flags);
   LAUNCHCHK();
   return BLSGPU_OK;
 }
@@ -2333,7 +2484,7 @@ extern "C" int blsgpu_gt_mul_scalar_batch(blsgpu_ctx* c, const uint64_t* gt, con
   if (c->io_a.reserve(n * 576) || c->io_b.reserve(n * 32) || c->io_out.reserve(n * 576)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
   HIPCHK(hipMemcpyAsync(c->io_a.p, gt, n * 576, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->io_b.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_gt_mul_scalar, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, c->io_a.as<u32>(), c->io_b.as<u32>(), c->io_out.as<u32>(), n);
+  KLAUNCH(k_gt_mul_scalar, dim3(nblk(n * PL, PAIRING_BLOCK)), dim3(PAIRING_BLOCK), 0, c->stream, c->io_a.as<u32>(), c->io_b.as<u32>(), c->io_out.as<u32>(), n, c->scalar_form);
   LAUNCHCHK();
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, n * 576, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -2359,7 +2510,7 @@ static int point_decode_device(blsgpu_ctx* c, const void* d_bytes, size_t n, int
   if (!c || (n && (!d_bytes || !d_xy || !d_inf || !d_ok))) return bad("decode: NULL argument");
   if (!n) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
-  hipLaunchKernelGGL(k_point_decode<F>, dim3(nblk(n, 128)), dim3(128), 0, c->stream, (const uint8_t*)d_bytes, n, (compressed ? 1 : 0) | (checked ? 2 : 0), (u32*)d_xy, (uint8_t*)d_inf,
+  KLAUNCH(k_point_decode<F>, dim3(nblk(n, 128)), dim3(128), 0, c->stream, (const uint8_t*)d_bytes, n, (compressed ? 1 : 0) | (checked ? 2 : 0), (u32*)d_xy, (uint8_t*)d_inf,
                      (uint8_t*)d_ok);
   LAUNCHCHK();
   return BLSGPU_OK;
@@ -2369,7 +2520,7 @@ static int point_encode_device(blsgpu_ctx* c, const void* d_xy, const void* d_in
   if (!c || (n && (!d_xy || !d_out))) return bad("encode: NULL argument");
   if (!n) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
-  hipLaunchKernelGGL(k_point_encode<F>, dim3(nblk(n, 128)), dim3(128), 0, c->stream, (const u32*)d_xy, (const uint8_t*)d_inf, n, compressed, (uint8_t*)d_out);
+  KLAUNCH(k_point_encode<F>, dim3(nblk(n, 128)), dim3(128), 0, c->stream, (const u32*)d_xy, (const uint8_t*)d_inf, n, compressed, (uint8_t*)d_out);
   LAUNCHCHK();
   return BLSGPU_OK;
 }
@@ -2503,7 +2654,7 @@ extern "C" int blsgpu_bls_verify_batch_device(blsgpu_ctx* c, int mode, const voi
   if (c->ver.reserve(o)) { g_err = "hipMalloc(bulk verification) failed"; return BLSGPU_ERR_HIP; }
   uint8_t* base = c->ver.as<uint8_t>();
   if (fresh || !c->ver_consts_ready) {
-    hipLaunchKernelGGL(k_bls_consts, dim3(1), dim3(64), 0, c->stream, (u32*)(base + o_consts));
+    KLAUNCH(k_bls_consts, dim3(1), dim3(64), 0, c->stream, (u32*)(base + o_consts));
     LAUNCHCHK();
     HIPCHK(hipEventRecord(c->ev_ver, c->stream));
     c->ver_consts_ready = true;
@@ -2553,7 +2704,7 @@ extern "C" int blsgpu_bls_verify_batch_device(blsgpu_ctx* c, int mode, const voi
   HIPCHK(hipStreamWaitEvent(main_stream, c->ev_ver_side[1], 0));
   // 4. the two terms of every equation
   const uint8_t *pk_inf = mode == 0 ? a_inf : b_inf, *pk_ok = mode == 0 ? a_ok : b_ok, *sig_inf = mode == 0 ? b_inf : a_inf, *sig_ok = mode == 0 ? b_ok : a_ok;
-  hipLaunchKernelGGL(k_bls_assemble, dim3(nblk(n + 1, 256)), dim3(256), 0, c->stream, mode, (const u32*)(base + (mode == 0 ? o_a : o_b)), pk_inf, pk_ok,
+  KLAUNCH(k_bls_assemble, dim3(nblk(n + 1, 256)), dim3(256), 0, c->stream, mode, (const u32*)(base + (mode == 0 ? o_a : o_b)), pk_inf, pk_ok,
                      (const u32*)(base + (mode == 0 ? o_b : o_a)), sig_inf, sig_ok, (const u32*)(base + o_h), h_inf, (const u32*)(base + o_consts), n, (u32*)(base + o_g1t),
                      base + o_tf, (u32*)(base + o_g2t), base + o_tf + 2 * n, (u32*)(base + o_qi), (unsigned long long*)(base + o_off));
   LAUNCHCHK();
@@ -2567,7 +2718,7 @@ extern "C" int blsgpu_bls_verify_batch_device(blsgpu_ctx* c, int mode, const voi
   // 6. == Gt::identity()?
   rc = blsgpu_gt_is_identity_device(c, base + o_gt, n, is_one);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_bls_verdict, dim3(nblk(n, 256)), dim3(256), 0, c->stream, is_one, pk_ok, sig_ok, n, (uint8_t*)d_verdict);
+  KLAUNCH(k_bls_verdict, dim3(nblk(n, 256)), dim3(256), 0, c->stream, is_one, pk_ok, sig_ok, n, (uint8_t*)d_verdict);
   LAUNCHCHK();
   return BLSGPU_OK;
 }

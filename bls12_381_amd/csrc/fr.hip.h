@@ -17,88 +17,10 @@
 // the inverse uses w^-1 and scales by n^-1.  The reference crate has no transform; oracle/bls12_381_ref.py
 // fr_ntt states the definition the kernels are tested against.
 #pragma once
-#include "fe.hip.h"
+#include "scalar.hip.h"
 
 namespace bls {
 
-struct Fr { u32 l[8]; };
-
-struct FrWords { u32 w[8]; };
-constexpr FrWords FR_MOD_C = {BLS_FR_MOD_W};   // scalar.rs:76-81
-#define FR_MOD (FR_MOD_C.w)
-constexpr u32 FR_INV32 = BLS_FR_INV32;         // -r^-1 mod 2^32 (low word of scalar.rs:156 INV)
-
-DEV Fr fr_zero() { Fr r; for (int i = 0; i < 8; i++) r.l[i] = 0; return r; }
-DEV Fr fr_load(const u32* p) {
-  const uint4* v = reinterpret_cast<const uint4*>(p);
-  uint4 a = v[0], b = v[1];
-  Fr r; r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-  return r;
-}
-DEV void fr_store(u32* p, const Fr& a) {
-  uint4* v = reinterpret_cast<uint4*>(p);
-  v[0] = make_uint4(a.l[0], a.l[1], a.l[2], a.l[3]);
-  v[1] = make_uint4(a.l[4], a.l[5], a.l[6], a.l[7]);
-}
-DEV bool fr_is_zero(const Fr& a) { u32 t = 0; for (int i = 0; i < 8; i++) t |= a.l[i]; return t == 0; }
-// a - r if a >= r (a < 2r, possibly with a carry bit out of the top word)
-DEV Fr fr_cond_sub(const Fr& a, u32 carry) {
-  Fr s; int64_t br = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) { int64_t d = (int64_t)a.l[i] - FR_MOD[i] + br; s.l[i] = (u32)d; br = d >> 32; }
-  const bool take = (int64_t)carry + br >= 0;        // no borrow overall
-  Fr r;
-#pragma unroll
-  for (int i = 0; i < 8; i++) r.l[i] = take ? s.l[i] : a.l[i];
-  return r;
-}
-DEV Fr fr_add(const Fr& a, const Fr& b) {
-  Fr t; u64 c = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) { u64 x = (u64)a.l[i] + b.l[i] + c; t.l[i] = (u32)x; c = x >> 32; }
-  return fr_cond_sub(t, (u32)c);
-}
-DEV Fr fr_sub(const Fr& a, const Fr& b) {
-  Fr t; int64_t br = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) { int64_t d = (int64_t)a.l[i] - b.l[i] + br; t.l[i] = (u32)d; br = d >> 32; }
-  const u32 m = (u32)br;                              // all ones if a < b: add r back
-  u64 c = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) { u64 x = (u64)t.l[i] + (FR_MOD[i] & m) + c; t.l[i] = (u32)x; c = x >> 32; }
-  return t;
-}
-DEV Fr fr_neg(const Fr& a) { return fr_sub(fr_zero(), a); }
-// CIOS Montgomery product, canonical result
-DEV Fr fr_mul(const Fr& a, const Fr& b) {
-  u32 t[10];
-#pragma unroll
-  for (int i = 0; i < 10; i++) t[i] = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    u64 c = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) { u64 x = (u64)a.l[j] * b.l[i] + t[j] + c; t[j] = (u32)x; c = x >> 32; }
-    u64 x = (u64)t[8] + c; t[8] = (u32)x; t[9] = (u32)(x >> 32);
-    const u32 m = t[0] * FR_INV32;
-    c = ((u64)m * FR_MOD[0] + t[0]) >> 32;
-#pragma unroll
-    for (int j = 1; j < 8; j++) { u64 y = (u64)m * FR_MOD[j] + t[j] + c; t[j - 1] = (u32)y; c = y >> 32; }
-    x = (u64)t[8] + c; t[7] = (u32)x; t[8] = t[9] + (u32)(x >> 32);
-  }
-  Fr r;
-#pragma unroll
-  for (int i = 0; i < 8; i++) r.l[i] = t[i];
-  return fr_cond_sub(r, t[8]);
-}
-DEV Fr fr_sqr(const Fr& a) { return fr_mul(a, a); }
-DEV Fr fr_one() {
-  // R mod r (scalar.rs:159-164)
-  constexpr FrWords k = {BLS_FR_ONE_W};
-  Fr r;
-  for (int i = 0; i < 8; i++) r.l[i] = k.w[i];
-  return r;
-}
 // a^e, e = 8 little-endian u32 words (scalar.rs:371-404), square-and-multiply from the top bit
 DEVNI Fr fr_pow(const Fr& a, const u32* e) {
   Fr r = fr_one();
@@ -152,6 +74,25 @@ __global__ void __launch_bounds__(256) k_fr_op(int op, const u32* __restrict__ a
     default: r = fr_add(x, x); break;
   }
   fr_store(out + i * 8, r);
+}
+
+// ---- `Scalar` <-> bytes for whole vectors (scalar.rs:256-331) --------------------------------------------------------------
+// op 0 to_bytes: Montgomery limbs -> 32 canonical LE bytes (ok[i] = the limbs were below r, i.e. a value `Scalar` can hold);
+// op 1 from_bytes: 32 LE bytes -> Montgomery limbs, ok[i] = 0 where the reference returns CtOption::none (integer >= r);
+// op 2 from_bytes_wide: 64 LE bytes -> Montgomery limbs of the 512-bit integer mod r (always defined).  `ok` may be NULL.
+__global__ void __launch_bounds__(256) k_fr_convert(int op, const u32* __restrict__ in, u32* __restrict__ out, uint8_t* __restrict__ ok, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr r; bool good = true;
+  if (op == 2) {
+    r = fr_from_wide(fr_load(in + i * 16), fr_load(in + i * 16 + 8));
+  } else {
+    const Fr a = fr_load(in + i * 8);
+    good = fr_words_below_r(a.l);
+    r = op == 0 ? fr_from_mont(a) : fr_to_mont(a);
+  }
+  fr_store(out + i * 8, r);
+  if (ok) ok[i] = good ? 1 : 0;
 }
 
 // ---- twiddle table: tw[j] = 2^5 w^j, j < n/2 ---------------------------------------------------------------

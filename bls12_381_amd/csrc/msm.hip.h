@@ -27,6 +27,7 @@
 #pragma once
 #include <type_traits>
 #include "convert.hip.h"
+#include "scalar.hip.h"
 #include "team.hip.h"
 #include "pairlane.hip.h"
 
@@ -129,12 +130,16 @@ DEV Proj<F> pt_add_mixed_y(const Proj<F>& p, const typename F::aff_elem& qx, con
 // recoding relies on it: scalars < r < 2^255 leave the top window a spare bit, so no carry leaves it.  A raw 32-byte input
 // that is NOT canonical is reported through a sticky device flag (blsgpu_synchronize / the synchronous MSM entry points
 // return BLSGPU_ERR_ARG) instead of silently producing s*P for some window widths and (s - 2^256)*P for others.
-DEV bool scalar_is_canonical(const u32* s) {
-  constexpr u32 r[8] = BLS_FR_MOD_W;
-  bool lt = false, eq = true;
-#pragma unroll
-  for (int i = 7; i >= 0; i--) { lt = lt || (eq && s[i] < r[i]); eq = eq && s[i] == r[i]; }
-  return lt;
+DEV bool scalar_is_canonical(const u32* s) { return fr_words_below_r(s); }
+// `&[Scalar]` memory (Montgomery limbs, scalar.hip.h) -> the canonical words the digit kernels read: used where no decomposition
+// kernel touches the scalars first (plain 256-bit windows); with the endomorphism splits the reduction is fused into k_glv_decompose /
+// k_gls_decompose.  scalar.rs:284-296.
+__global__ void __launch_bounds__(256) k_scalars_from_mont(const u32* __restrict__ scalars, u32* __restrict__ out, int n, u32* __restrict__ status) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr k;
+  if (!scalar_load(scalars, (size_t)i, SCALAR_MONT, k.l)) atomicOr(status, 1u);
+  fr_store(out + (size_t)i * 8, k);
 }
 
 // ---- 1. digits + histogram -------------------------------------------------------------------------
@@ -317,14 +322,11 @@ DEV void glv_split(const u32* k, u32* k1o, u32* k2o) {
   k1o[0] = k1[0]; k1o[1] = k1[1]; k1o[2] = k1[2]; k1o[3] = k1[3] | (neg1 << 31);
   k2o[0] = k2[0]; k2o[1] = k2[1]; k2o[2] = k2[2]; k2o[3] = k2[3] | (sub2 << 31);
 }
-__global__ void __launch_bounds__(256) k_glv_decompose(const u32* __restrict__ scalars, u32* __restrict__ out, int n, u32* __restrict__ status) {
+__global__ void __launch_bounds__(256) k_glv_decompose(const u32* __restrict__ scalars, u32* __restrict__ out, int n, u32* __restrict__ status, int form) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u32 k[8];
-  const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
-  uint4 a = sp[0], b = sp[1];
-  k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
-  if (!scalar_is_canonical(k)) atomicOr(status, 1u);
+  if (!scalar_load(scalars, (size_t)i, form, k)) atomicOr(status, 1u);
   u32 k1[4], k2[4];
   glv_split(k, k1, k2);
   uint4* o = reinterpret_cast<uint4*>(out);
@@ -407,14 +409,12 @@ DEV void gls_split(u32* k, u64* d_out, u32* sub) {
   sub[0] = neg[0]; sub[1] = neg[1] ^ 1u; sub[2] = neg[2]; sub[3] = neg[3] ^ 1u;
   d_out[0] = d[0]; d_out[1] = d[1]; d_out[2] = d[2]; d_out[3] = d[3];
 }
-__global__ void __launch_bounds__(256) k_gls_decompose(const u32* __restrict__ scalars, u32* __restrict__ out, int n, u32* __restrict__ status) {
+__global__ void __launch_bounds__(256) k_gls_decompose(const u32* __restrict__ scalars, u32* __restrict__ out, int n, u32* __restrict__ status, int form) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u32 k[10];
-  const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
-  uint4 a = sp[0], b = sp[1];
-  k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w; k[8] = 0; k[9] = 0;
-  if (!scalar_is_canonical(k)) atomicOr(status, 1u);
+  if (!scalar_load(scalars, (size_t)i, form, k)) atomicOr(status, 1u);
+  k[8] = 0; k[9] = 0;
   u64 d[4]; u32 sb[4];
   gls_split(k, d, sb);
   uint4* o = reinterpret_cast<uint4*>(out + (size_t)i * 8);

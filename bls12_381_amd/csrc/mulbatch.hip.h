@@ -35,17 +35,12 @@ template <> struct MbIO<Fp2PairPolicy> {
 template <class F>
 __global__ void __launch_bounds__(256, 2)
 k_mul_batch(const u32* __restrict__ xy, const uint8_t* __restrict__ inf, const u32* __restrict__ scalars, u32* __restrict__ out, size_t n,
-            u32* __restrict__ status) {
+            u32* __restrict__ status, int form) {
   constexpr int LANES = MbIO<F>::LANES, WW = MbIO<F>::WW;
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES;
   if (i >= n) return;
   u32 s[8];
-  {
-    const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
-    uint4 a = sp[0], b = sp[1];
-    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
-  }
-  if (!scalar_is_canonical(s)) atomicOr(status, 1u);          // no `Scalar` has such bytes (scalar.rs:256-280): reported, result unspecified
+  if (!scalar_load(scalars, i, form, s)) atomicOr(status, 1u);          // no `Scalar` has such bytes (scalar.rs:256-280): reported, result unspecified
   // signed digits d_w in [-8, 8], k = sum d_w 16^w; k < 2^255 leaves the top window at most 7 + carry: no 65th window
   u32 mag[8], sgn[2] = {0, 0};
   {
@@ -97,18 +92,13 @@ k_mul_batch(const u32* __restrict__ xy, const uint8_t* __restrict__ inf, const u
 // -[z^2] P, so unverified inputs keep the kernel above.
 __global__ void __launch_bounds__(256, 2)
 k_mul_batch_glv(const u32* __restrict__ xy, const uint8_t* __restrict__ inf, const u32* __restrict__ scalars, u32* __restrict__ out, size_t n,
-                u32* __restrict__ status) {
+                u32* __restrict__ status, int form) {
   typedef FpPolicy F;
   constexpr int WW = 12;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u32 s[8];
-  {
-    const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
-    uint4 a = sp[0], b = sp[1];
-    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
-  }
-  if (!scalar_is_canonical(s)) atomicOr(status, 1u);
+  if (!scalar_load(scalars, i, form, s)) atomicOr(status, 1u);
   u32 h[2][4];
   glv_split(s, h[0], h[1]);
   const u32 flip[2] = {h[0][3] >> 31, h[1][3] >> 31};        // the whole term is subtracted
@@ -169,18 +159,14 @@ k_mul_batch_glv(const u32* __restrict__ xy, const uint8_t* __restrict__ inf, con
 // 64 doublings + 71 additions instead of 256 + 67.  One multiplication per lane pair (pairlane.hip.h), like k_mul_batch<Fp2PairPolicy>.
 __global__ void __launch_bounds__(256, 2)
 k_mul_batch_gls(const u32* __restrict__ xy, const uint8_t* __restrict__ inf, const u32* __restrict__ scalars, u32* __restrict__ out, size_t n,
-                u32* __restrict__ status) {
+                u32* __restrict__ status, int form) {
   typedef Fp2PairPolicy F;
   constexpr int WW = 24;
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / 2;
   if (i >= n) return;
   u32 k[10];
-  {
-    const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
-    uint4 a = sp[0], b = sp[1];
-    k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w; k[8] = 0; k[9] = 0;
-  }
-  if (!scalar_is_canonical(k)) atomicOr(status, 1u);
+  if (!scalar_load(scalars, i, form, k)) atomicOr(status, 1u);
+  k[8] = 0; k[9] = 0;
   u64 dg[4]; u32 flip[4];
   gls_split(k, dg, flip);
   // signed digits in [-8, 8] of the four 63-bit digits; |d_j| <= X/2 + 1 leaves the top window at most 6 + carry: no 17th window

@@ -23,6 +23,7 @@
 // reference, i.e. operands are staged in per-lane scratch and streamed through the VGPRs.
 #pragma once
 #include "convert.hip.h"
+#include "scalar.hip.h"
 #include "pairlane.hip.h"
 
 namespace bls {
@@ -648,13 +649,13 @@ PAIR_KERNEL k_fp12_prod(const u32* __restrict__ in, u32* __restrict__ out, size_
 }
 // `&Gt * &Scalar` (pairings.rs:297-322): double-and-add over the 255 low bits of the scalar's little-endian bytes,
 // most significant first; out[i] = gt[i]^(scalar[i]) (the target group is written additively in the reference)
-PAIR_KERNEL k_gt_mul_scalar(const u32* __restrict__ gt, const u32* __restrict__ scalars, u32* __restrict__ out, size_t n) {
+PAIR_KERNEL k_gt_mul_scalar(const u32* __restrict__ gt, const u32* __restrict__ scalars, u32* __restrict__ out, size_t n, int form) {
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / PL;
   if (i >= n) return;
   Fp12T<PE> base, acc = fp12_one<PE>(), t;
   fp12_load(base, gt + i * 144);
   u32 s[8];
-  for (int k = 0; k < 8; k++) s[k] = scalars[i * 8 + k];
+  scalar_load(scalars, i, form, s);             // bytes or `Scalar` limbs (scalar.hip.h)
   for (int bit = 254; bit >= 0; bit--) {
     fp12_sqr(acc, acc);
     if ((s[bit >> 5] >> (bit & 31)) & 1u) { fp12_mul(t, acc, base); acc = t; }

@@ -127,6 +127,25 @@ int blsgpu_g2_msm(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, cons
  * context's stream and the call returns without synchronising. */
 int blsgpu_g1_msm_device(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const void* d_scalars, size_t n, void* d_out_xyz);
 int blsgpu_g2_msm_device(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const void* d_scalars, size_t n, void* d_out_xyz);
+/* Scalars as the reference STORES them.  Every entry point above (and blsgpu_*_mul_batch*, blsgpu_gt_mul_scalar_batch*, the `*_many`,
+ * `*_host` and `*_sharded` MSMs) reads n x 32 bytes per scalar vector; what the 32 bytes are is the context's scalar form:
+ *   BLSGPU_SCALAR_BYTES (default)  the canonical little-endian integer, `Scalar::to_bytes()` (src/scalar.rs:284-296), the bit source
+ *                                  of `multiply` (src/g1.rs:559-561);
+ *   BLSGPU_SCALAR_MONT             the four u64 Montgomery limbs of `Scalar([u64; 4])` (src/scalar.rs:23-27), i.e. the memory of a
+ *                                  `&[Scalar]`: `to_bytes` = one `montgomery_reduce` (src/scalar.rs:506-550) then runs on the device,
+ *                                  fused into the kernels that decompose the scalars, and an in-tree `msm(&[G1Affine], &[Scalar])`
+ *                                  passes its slice as it is (2^20 host-side `to_bytes` calls cost several times the MSM).
+ * Limbs / bytes that no `Scalar` can hold (>= r) are reported like non-canonical bytes (BLSGPU_ERR_ARG from the synchronous entry
+ * points / blsgpu_synchronize).  blsgpu_set_scalar_form changes the form for all later calls on the context (members of a device
+ * group: through blsgpu_group_ctx); the `*_mont` entry points are the four MSMs above with BLSGPU_SCALAR_MONT for that one call.
+ * blsgpu_g{1,2}_msm_bytes always take `to_bytes()` output. */
+#define BLSGPU_SCALAR_BYTES 0
+#define BLSGPU_SCALAR_MONT 1
+int blsgpu_set_scalar_form(blsgpu_ctx* ctx, int form);
+int blsgpu_g1_msm_mont(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const uint64_t* scalars, size_t n, uint64_t out_xyz[18]);
+int blsgpu_g2_msm_mont(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const uint64_t* scalars, size_t n, uint64_t out_xyz[36]);
+int blsgpu_g1_msm_mont_device(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const void* d_scalars, size_t n, void* d_out_xyz);
+int blsgpu_g2_msm_mont_device(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t first, const void* d_scalars, size_t n, void* d_out_xyz);
 /* k MSMs over the same resident bases (k scalar vectors of n x 32 bytes back to back -> k projective results back to back),
  * e.g. commitments to k polynomials under one SRS.  Synchronous like blsgpu_g1_msm, but the k calls run through the
  * library's pipeline (sort / accumulation / tail of consecutive MSMs overlap): the sustained rate of the asynchronous API
@@ -173,6 +192,12 @@ int blsgpu_g2_mul_batch(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infi
 /* Same with device pointers, asynchronous on the context's stream. */
 int blsgpu_g1_mul_batch_device(blsgpu_ctx* ctx, const void* d_xy, const void* d_infinity, const void* d_scalars, size_t n, void* d_out_xyz);
 int blsgpu_g2_mul_batch_device(blsgpu_ctx* ctx, const void* d_xy, const void* d_infinity, const void* d_scalars, size_t n, void* d_out_xyz);
+/* The same four with the scalars as Montgomery limbs (BLSGPU_SCALAR_MONT for that one call; `Mul<&Scalar>` calls `to_bytes` per
+ * product, src/g1.rs:556-562). */
+int blsgpu_g1_mul_batch_mont(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, const uint64_t* scalars, size_t n, uint64_t* out_xyz);
+int blsgpu_g2_mul_batch_mont(blsgpu_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, const uint64_t* scalars, size_t n, uint64_t* out_xyz);
+int blsgpu_g1_mul_batch_mont_device(blsgpu_ctx* ctx, const void* d_xy, const void* d_infinity, const void* d_scalars, size_t n, void* d_out_xyz);
+int blsgpu_g2_mul_batch_mont_device(blsgpu_ctx* ctx, const void* d_xy, const void* d_infinity, const void* d_scalars, size_t n, void* d_out_xyz);
 
 /* ---- group helpers ----------------------------------------------------------------------------------- */
 /* out = sum of n projective points (`Sum for G1Projective`, src/g1.rs:161-171) -- the fold used after the
@@ -407,6 +432,14 @@ int blsgpu_set_profiling(blsgpu_ctx* ctx, int enabled);
  * their number, then resets the statistics and switches the measurement off (enable = 0) or on: enable = N > 0 times every
  * N-th launch (two event records per timed launch cost ~0.05-0.1 ms of queue time in a pipelined run, so benchmarks sample). */
 int blsgpu_msm_accumulate_stats(blsgpu_ctx* ctx, int enable, double* avg_ms, unsigned* launches);
+/* Diagnostics: the duration of EVERY kernel the context's entry points launch, measured with HIP events on the stream each kernel is
+ * launched on (a call's kernels run on up to four library streams, which a caller-side event never sees).  blsgpu_kernel_timing(ctx, 1)
+ * starts recording (and clears earlier records), (ctx, 0) stops; blsgpu_kernel_timing_report waits for the recorded launches and writes one
+ * line per kernel name in first-launch order -- "name<TAB>launches<TAB>total_ms<TAB>min_ms<TAB>max_ms\n" -- into buf (at most cap - 1
+ * characters + NUL; the full length goes to *needed, which may be NULL), then clears the records.  Two event records per launch: meant
+ * for one call at a time (bench.py's `kernel_ms` rows), not for pipelined production runs. */
+int blsgpu_kernel_timing(blsgpu_ctx* ctx, int enable);
+int blsgpu_kernel_timing_report(blsgpu_ctx* ctx, char* buf, size_t cap, size_t* needed);
 
 /* ---- scalar field Fr (the producer side of the MSM's scalars) ----------------------- */
 /* A scalar is the reference's `Scalar([u64; 4])`: four little-endian u64 Montgomery limbs (R = 2^256), canonical
@@ -416,6 +449,21 @@ int blsgpu_msm_accumulate_stats(blsgpu_ctx* ctx, int enable, double* avg_ms, uns
  * `nonzero_flags` (n bytes) may be NULL. */
 int blsgpu_fr_op(blsgpu_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, uint8_t* nonzero_flags);
 int blsgpu_fr_op_device(blsgpu_ctx* ctx, int op, const void* d_a, const void* d_b, size_t n, void* d_out, void* d_nonzero_flags);
+/* `Scalar` <-> bytes over vectors of n scalars:
+ *   to_bytes         Montgomery limbs -> 32 canonical little-endian bytes, `Scalar::to_bytes` (src/scalar.rs:284-296: one
+ *                    `montgomery_reduce`, :506-550); ok[i] = 0 where the limbs are not below r (no `Scalar` holds them);
+ *   from_bytes       32 bytes -> Montgomery limbs (multiplication by R2), ok[i] = 0 where `Scalar::from_bytes` returns
+ *                    CtOption::none: the integer is not below r (src/scalar.rs:256-280);
+ *   from_bytes_wide  64 bytes -> the 512-bit little-endian integer mod r as d0 R2 + d1 R3 (src/scalar.rs:300-331); always defined.
+ * `ok` (n bytes) may be NULL.  The device-pointer forms are asynchronous on the context's stream, e.g.
+ * blsgpu_fr_ntt_device -> blsgpu_g1_msm_mont_device needs no conversion at all, and blsgpu_fr_to_bytes_device feeds the byte-form
+ * entry points. */
+int blsgpu_fr_to_bytes(blsgpu_ctx* ctx, const uint64_t* scalars, size_t n, uint8_t* bytes, uint8_t* ok);
+int blsgpu_fr_from_bytes(blsgpu_ctx* ctx, const uint8_t* bytes, size_t n, uint64_t* scalars, uint8_t* ok);
+int blsgpu_fr_from_bytes_wide(blsgpu_ctx* ctx, const uint8_t* bytes, size_t n, uint64_t* scalars);
+int blsgpu_fr_to_bytes_device(blsgpu_ctx* ctx, const void* d_scalars, size_t n, void* d_bytes, void* d_ok);
+int blsgpu_fr_from_bytes_device(blsgpu_ctx* ctx, const void* d_bytes, size_t n, void* d_scalars, void* d_ok);
+int blsgpu_fr_from_bytes_wide_device(blsgpu_ctx* ctx, const void* d_bytes, size_t n, void* d_scalars);
 /* Radix-2 number-theoretic transform of 2^log_n scalars, in place, natural order in and out:
  *   forward  y_k = sum_j x_j w^(jk),   inverse  x_j = n^-1 sum_k y_k w^(-jk),   w = ROOT_OF_UNITY^(2^(32 - log_n))
  * with the reference's ROOT_OF_UNITY / S = 32 (scalar.rs:191-205, exported through ff::PrimeField :703-712).

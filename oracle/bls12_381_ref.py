@@ -1011,6 +1011,97 @@ def fr_from_bytes_wide(b):
     return int.from_bytes(bytes(b), "little") % R_ORDER
 
 
+# ---- `Scalar` <-> bytes on the reference's own limbs -----------------------------------------------
+# The three functions below follow scalar.rs limb by limb (mac / adc / sbb on 64-bit words) instead of using Python's big
+# integers, so that they pin the DEVICE conversions (scalar.hip.h) independently of fr_to_mont_limbs / fr_from_mont_limbs above.
+_M64 = 0xFFFFFFFFFFFFFFFF
+FR_MODULUS_LIMBS = [(R_ORDER >> (64 * i)) & _M64 for i in range(4)]                    # scalar.rs:76-81
+FR_INV = (-pow(R_ORDER, -1, 1 << 64)) % (1 << 64)                                       # scalar.rs:156 (asserted in tests against the literal)
+FR_R2_LIMBS = [((1 << 512) % R_ORDER >> (64 * i)) & _M64 for i in range(4)]             # scalar.rs:167-172
+FR_R3_LIMBS = [((1 << 768) % R_ORDER >> (64 * i)) & _M64 for i in range(4)]             # scalar.rs:174-180
+
+
+def _mac(a, b, c, carry):          # util.rs:14-20: a + b * c + carry -> (low, high)
+    t = a + b * c + carry
+    return t & _M64, t >> 64
+
+
+def _adc(a, b, carry):             # util.rs:1-6
+    t = a + b + carry
+    return t & _M64, t >> 64
+
+
+def _sbb(a, b, borrow):            # util.rs:8-12: a - (b + (borrow >> 63)) -> (low, borrow word)
+    t = a - (b + (borrow >> 63))
+    return t & _M64, (t >> 64) & _M64
+
+
+def scalar_limbs_sub(a, b):
+    """scalar.rs:420-432 `sub`: a - b, the modulus added back under the borrow mask."""
+    d, borrow = [0] * 4, 0
+    for i in range(4):
+        d[i], borrow = _sbb(a[i], b[i], borrow)
+    out, carry = [0] * 4, 0
+    for i in range(4):
+        out[i], carry = _adc(d[i], FR_MODULUS_LIMBS[i] & borrow, carry)
+    return out
+
+
+def scalar_limbs_add(a, b):
+    """scalar.rs:435-449 `add`: limb-wise sum, then `sub(&MODULUS)`."""
+    d, carry = [0] * 4, 0
+    for i in range(4):
+        d[i], carry = _adc(a[i], b[i], carry)
+    return scalar_limbs_sub(d, FR_MODULUS_LIMBS)
+
+
+def scalar_montgomery_reduce(r):
+    """scalar.rs:506-550: HAC 14.32 on eight limbs r[0..7], result = r / 2^256 mod q as four limbs."""
+    r = list(r)
+    carry2 = 0
+    for i in range(4):
+        k = (r[i] * FR_INV) & _M64
+        _, carry = _mac(r[i], k, FR_MODULUS_LIMBS[0], 0)
+        for j in range(1, 4):
+            r[i + j], carry = _mac(r[i + j], k, FR_MODULUS_LIMBS[j], carry)
+        r[i + 4], carry2 = _adc(r[i + 4], carry2, carry)
+    return scalar_limbs_sub(r[4:8], FR_MODULUS_LIMBS)
+
+
+def scalar_limbs_mul(a, b):
+    """scalar.rs:452-503 `mul`: schoolbook 4 x 4 into eight limbs, then montgomery_reduce."""
+    r = [0] * 8
+    for i in range(4):
+        carry = 0
+        for j in range(4):
+            r[i + j], carry = _mac(r[i + j], a[i], b[j], carry)
+        r[i + 4] = carry
+    return scalar_montgomery_reduce(r)
+
+
+def scalar_limbs_to_bytes(limbs):
+    """scalar.rs:284-296 `to_bytes`: montgomery_reduce(l0, l1, l2, l3, 0, 0, 0, 0), little-endian."""
+    t = scalar_montgomery_reduce(list(limbs) + [0, 0, 0, 0])
+    return b"".join(int(x).to_bytes(8, "little") for x in t)
+
+
+def scalar_limbs_from_bytes(b):
+    """scalar.rs:256-280 `from_bytes`: (limbs of tmp * R2, is_some) -- the value is computed either way, as in the reference."""
+    assert len(b) == 32
+    tmp = [int.from_bytes(bytes(b[8 * i:8 * i + 8]), "little") for i in range(4)]
+    borrow = 0
+    for i in range(4):
+        _, borrow = _sbb(tmp[i], FR_MODULUS_LIMBS[i], borrow)
+    return scalar_limbs_mul(tmp, FR_R2_LIMBS), bool(borrow & 1)
+
+
+def scalar_limbs_from_bytes_wide(b):
+    """scalar.rs:300-331 `from_bytes_wide` -> `from_u512`: d0 * R2 + d1 * R3."""
+    assert len(b) == 64
+    l = [int.from_bytes(bytes(b[8 * i:8 * i + 8]), "little") for i in range(8)]
+    return scalar_limbs_add(scalar_limbs_mul(l[0:4], FR_R2_LIMBS), scalar_limbs_mul(l[4:8], FR_R3_LIMBS))
+
+
 def fr_omega(log_n):
     """primitive 2^log_n-th root of unity: ROOT_OF_UNITY^(2^(S - log_n)) (how ff::PrimeField::ROOT_OF_UNITY is used)."""
     assert 0 <= log_n <= FR_S

@@ -72,6 +72,8 @@ fn with_ctx<R>(f: impl FnOnce(*mut ffi::BlsgpuCtx) -> Option<R>) -> Option<R> {
     if g.is_none() {
         let mut h = core::ptr::null_mut();
         if unsafe { ffi::blsgpu_create(0, &mut h) } != ffi::BLSGPU_OK { return None; }
+        // every scalar argument of this module is `&[Scalar]` memory (see scalar_bytes)
+        if unsafe { ffi::blsgpu_set_scalar_form(h, ffi::BLSGPU_SCALAR_MONT) } != ffi::BLSGPU_OK { unsafe { ffi::blsgpu_destroy(h) }; return None; }
         *g = Some(Ctx(h));
     }
     f(g.as_ref().unwrap().0)
@@ -98,10 +100,14 @@ fn g2_wire(points: &[G2Affine]) -> (Vec<u64>, Vec<u8>) {
     for p in points { put_fp2(&mut xy, &p.x); put_fp2(&mut xy, &p.y); inf.push(bool::from(p.is_identity()) as u8); }
     (xy, inf)
 }
-fn scalar_bytes(scalars: &[Scalar]) -> Vec<u8> {
-    let mut s = Vec::with_capacity(scalars.len() * 32);
-    for k in scalars { s.extend_from_slice(&k.to_bytes()); }
-    s
+/// The scalars exactly as the slice holds them: four u64 Montgomery limbs each (src/scalar.rs:23-27).  The library context is
+/// switched to BLSGPU_SCALAR_MONT when it is created (below), so `Scalar::to_bytes` -- one `montgomery_reduce` per scalar,
+/// src/scalar.rs:284-296 -- runs on the device inside the kernels that decompose the scalars; no per-element host work, no copy.
+/// Needs `#[repr(transparent)]` on `pub struct Scalar(pub(crate) [u64; 4])` (a one-line addition in the fork, src/scalar.rs:23);
+/// the assertions keep a layout surprise from going unnoticed.
+const _: () = assert!(core::mem::size_of::<Scalar>() == 32 && core::mem::align_of::<Scalar>() == 8);
+fn scalar_bytes(scalars: &[Scalar]) -> &[u8] {
+    unsafe { core::slice::from_raw_parts(scalars.as_ptr() as *const u8, scalars.len() * 32) }
 }
 
 // ---- MSM ----------------------------------------------------------------------------------------------------------------
@@ -284,7 +290,11 @@ impl Group {
     pub fn new(devices: &[c_int]) -> Option<Group> {
         let mut h = core::ptr::null_mut();
         ok(unsafe { ffi::blsgpu_group_create(devices.as_ptr(), devices.len() as c_int, &mut h) })?;
-        Some(Group(h))
+        let g = Group(h);                                        // (dropped -- and the group destroyed -- if a member refuses the setting)
+        for k in 0..devices.len() as c_int {                     // scalars travel as `&[Scalar]` memory on every member (see scalar_bytes)
+            ok(unsafe { ffi::blsgpu_set_scalar_form(ffi::blsgpu_group_ctx(h, k), ffi::BLSGPU_SCALAR_MONT) })?;
+        }
+        Some(g)
     }
     /// every device the HIP runtime shows
     pub fn all_devices() -> Option<Group> {

@@ -17,6 +17,9 @@ use core::ffi::{c_char, c_int, c_uint, c_void};
 #[repr(C)] pub struct BlsgpuGroupG2Prepared { _private: [u8; 0] }
 
 pub const BLSGPU_OK: c_int = 0;
+/// scalar arguments hold `Scalar::to_bytes()` output (default) / the Montgomery limbs of `Scalar([u64; 4])` (blsgpu_set_scalar_form)
+pub const BLSGPU_SCALAR_BYTES: c_int = 0;
+pub const BLSGPU_SCALAR_MONT: c_int = 1;
 
 #[link(name = "blsgpu")]
 extern "C" {
@@ -44,6 +47,11 @@ extern "C" {
     pub fn blsgpu_g2_msm(ctx: *mut BlsgpuCtx, bases: *const BlsgpuBases, first: usize, scalars: *const u8, n: usize, out_xyz: *mut u64) -> c_int;
     pub fn blsgpu_g1_msm_device(ctx: *mut BlsgpuCtx, bases: *const BlsgpuBases, first: usize, d_scalars: *const c_void, n: usize, d_out_xyz: *mut c_void) -> c_int;
     pub fn blsgpu_g2_msm_device(ctx: *mut BlsgpuCtx, bases: *const BlsgpuBases, first: usize, d_scalars: *const c_void, n: usize, d_out_xyz: *mut c_void) -> c_int;
+    pub fn blsgpu_set_scalar_form(ctx: *mut BlsgpuCtx, form: c_int) -> c_int;
+    pub fn blsgpu_g1_msm_mont(ctx: *mut BlsgpuCtx, bases: *const BlsgpuBases, first: usize, scalars: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_g2_msm_mont(ctx: *mut BlsgpuCtx, bases: *const BlsgpuBases, first: usize, scalars: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_g1_msm_mont_device(ctx: *mut BlsgpuCtx, bases: *const BlsgpuBases, first: usize, d_scalars: *const c_void, n: usize, d_out_xyz: *mut c_void) -> c_int;
+    pub fn blsgpu_g2_msm_mont_device(ctx: *mut BlsgpuCtx, bases: *const BlsgpuBases, first: usize, d_scalars: *const c_void, n: usize, d_out_xyz: *mut c_void) -> c_int;
     pub fn blsgpu_g1_msm_many(ctx: *mut BlsgpuCtx, bases: *const BlsgpuBases, first: usize, scalars: *const u8, n: usize, k: usize, out_xyz: *mut u64) -> c_int;
     pub fn blsgpu_g2_msm_many(ctx: *mut BlsgpuCtx, bases: *const BlsgpuBases, first: usize, scalars: *const u8, n: usize, k: usize, out_xyz: *mut u64) -> c_int;
     pub fn blsgpu_g1_msm_many_device(ctx: *mut BlsgpuCtx, bases: *const BlsgpuBases, first: usize, d_scalars: *const c_void, n: usize, k: usize, d_out_xyz: *mut c_void) -> c_int;
@@ -58,6 +66,10 @@ extern "C" {
     pub fn blsgpu_g2_mul_batch(ctx: *mut BlsgpuCtx, xy: *const u64, infinity: *const u8, scalars: *const u8, n: usize, out_xyz: *mut u64) -> c_int;
     pub fn blsgpu_g1_mul_batch_device(ctx: *mut BlsgpuCtx, d_xy: *const c_void, d_infinity: *const c_void, d_scalars: *const c_void, n: usize, d_out_xyz: *mut c_void) -> c_int;
     pub fn blsgpu_g2_mul_batch_device(ctx: *mut BlsgpuCtx, d_xy: *const c_void, d_infinity: *const c_void, d_scalars: *const c_void, n: usize, d_out_xyz: *mut c_void) -> c_int;
+    pub fn blsgpu_g1_mul_batch_mont(ctx: *mut BlsgpuCtx, xy: *const u64, infinity: *const u8, scalars: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_g2_mul_batch_mont(ctx: *mut BlsgpuCtx, xy: *const u64, infinity: *const u8, scalars: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_g1_mul_batch_mont_device(ctx: *mut BlsgpuCtx, d_xy: *const c_void, d_infinity: *const c_void, d_scalars: *const c_void, n: usize, d_out_xyz: *mut c_void) -> c_int;
+    pub fn blsgpu_g2_mul_batch_mont_device(ctx: *mut BlsgpuCtx, d_xy: *const c_void, d_infinity: *const c_void, d_scalars: *const c_void, n: usize, d_out_xyz: *mut c_void) -> c_int;
     pub fn blsgpu_g1_sum(ctx: *mut BlsgpuCtx, xyz: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
     pub fn blsgpu_g2_sum(ctx: *mut BlsgpuCtx, xyz: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
     pub fn blsgpu_g1_sum_device(ctx: *mut BlsgpuCtx, d_xyz: *const c_void, n: usize, d_out_xyz: *mut c_void) -> c_int;
@@ -131,8 +143,16 @@ extern "C" {
     pub fn blsgpu_last_msm_phase_ms(ctx: *mut BlsgpuCtx, phase: c_int, ms: *mut f32) -> c_int;
     pub fn blsgpu_set_profiling(ctx: *mut BlsgpuCtx, enabled: c_int) -> c_int;
     pub fn blsgpu_msm_accumulate_stats(ctx: *mut BlsgpuCtx, enable: c_int, avg_ms: *mut f64, launches: *mut c_uint) -> c_int;
+    pub fn blsgpu_kernel_timing(ctx: *mut BlsgpuCtx, enable: c_int) -> c_int;
+    pub fn blsgpu_kernel_timing_report(ctx: *mut BlsgpuCtx, buf: *mut c_char, cap: usize, needed: *mut usize) -> c_int;
     pub fn blsgpu_fr_op(ctx: *mut BlsgpuCtx, op: c_int, a: *const u64, b: *const u64, n: usize, out: *mut u64, nonzero_flags: *mut u8) -> c_int;
     pub fn blsgpu_fr_op_device(ctx: *mut BlsgpuCtx, op: c_int, d_a: *const c_void, d_b: *const c_void, n: usize, d_out: *mut c_void, d_nonzero_flags: *mut c_void) -> c_int;
+    pub fn blsgpu_fr_to_bytes(ctx: *mut BlsgpuCtx, scalars: *const u64, n: usize, bytes: *mut u8, ok: *mut u8) -> c_int;
+    pub fn blsgpu_fr_from_bytes(ctx: *mut BlsgpuCtx, bytes: *const u8, n: usize, scalars: *mut u64, ok: *mut u8) -> c_int;
+    pub fn blsgpu_fr_from_bytes_wide(ctx: *mut BlsgpuCtx, bytes: *const u8, n: usize, scalars: *mut u64) -> c_int;
+    pub fn blsgpu_fr_to_bytes_device(ctx: *mut BlsgpuCtx, d_scalars: *const c_void, n: usize, d_bytes: *mut c_void, d_ok: *mut c_void) -> c_int;
+    pub fn blsgpu_fr_from_bytes_device(ctx: *mut BlsgpuCtx, d_bytes: *const c_void, n: usize, d_scalars: *mut c_void, d_ok: *mut c_void) -> c_int;
+    pub fn blsgpu_fr_from_bytes_wide_device(ctx: *mut BlsgpuCtx, d_bytes: *const c_void, n: usize, d_scalars: *mut c_void) -> c_int;
     pub fn blsgpu_fr_ntt(ctx: *mut BlsgpuCtx, data: *mut u64, log_n: c_int, inverse: c_int) -> c_int;
     pub fn blsgpu_fr_ntt_device(ctx: *mut BlsgpuCtx, d_data: *mut c_void, log_n: c_int, inverse: c_int) -> c_int;
     pub fn blsgpu_g1_hash_to_curve_batch(ctx: *mut BlsgpuCtx, msgs: *const u8, offsets: *const u64, n: usize, dst: *const u8, dst_len: usize, encode_only: c_int, out_xyz: *mut u64) -> c_int;

@@ -635,6 +635,177 @@ def test_fr_ops(ctx, kats):
     assert np.array_equal(ctx.fr_op(4, root)[0], root_inv[0])
 
 
+# the reference's own byte vectors of scalar.rs:864-1040 (test_to_bytes / test_from_bytes / test_from_bytes_wide_*): data, cited
+SCALAR_R2_BYTES = bytes([254, 255, 255, 255, 1, 0, 0, 0, 2, 72, 3, 0, 250, 183, 132, 88, 245, 79, 188, 236, 239, 79, 140, 153, 111, 5, 197, 172, 89, 177, 36, 24])
+SCALAR_NEG1_BYTES = bytes([0, 0, 0, 0, 255, 255, 255, 255, 254, 91, 254, 255, 2, 164, 189, 83, 5, 216, 161, 9, 8, 216, 57, 51, 72, 125, 157, 41, 83, 167, 237, 115])
+
+
+def test_scalar_bytes_conversions_vs_oracle_and_reference_kats(ctx, kats):
+    """SURVEY.md 8 row a8 on the device: `Scalar::to_bytes` (scalar.rs:284-296), `from_bytes` (:256-280), `from_bytes_wide` (:300-331)
+    over vectors -- the reference's own known answers (scalar.rs:864-1040), the edge values 0, 1, r - 1, `from_bytes_wide(&[0xff; 64])`,
+    non-canonical inputs, and 4 000 random elements against the limb-level restatement in the oracle"""
+    c = kats["consts"]
+    u = lambda name: np.array(c[name], dtype=np.uint64)
+    # to_bytes: zero, one (= R limbs), R2, -1
+    neg1 = frw(o.R_ORDER - 1)
+    got, ok = ctx.fr_to_bytes(np.stack([np.zeros(4, dtype=np.uint64), u("scalar.R"), u("scalar.R2"), neg1]), return_flags=True)
+    assert bytes(got[0]) == bytes(32) and bytes(got[1]) == (1).to_bytes(32, "little")
+    assert bytes(got[2]) == SCALAR_R2_BYTES and bytes(got[3]) == SCALAR_NEG1_BYTES and list(ok) == [1, 1, 1, 1]
+    # from_bytes: the same four back, then the reference's rejections (modulus, modulus + 1, a higher byte bumped twice)
+    mod = bytearray(SCALAR_NEG1_BYTES); mod[0] = 1
+    bad2 = bytearray(mod); bad2[0] = 2
+    bad3 = bytearray(mod); bad3[22] = 58
+    bad4 = bytearray(mod); bad4[31] = 116
+    rows = [bytes(32), (1).to_bytes(32, "little"), SCALAR_R2_BYTES, SCALAR_NEG1_BYTES, bytes(mod), bytes(bad2), bytes(bad3), bytes(bad4)]
+    limbs, some = ctx.fr_from_bytes(np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(-1, 32))
+    assert list(some) == [1, 1, 1, 1, 0, 0, 0, 0]
+    assert not limbs[0].any() and np.array_equal(limbs[1], u("scalar.R")) and np.array_equal(limbs[2], u("scalar.R2")) and np.array_equal(limbs[3], neg1)
+    for i in range(4, 8):                        # the value is computed either way (tmp * R2), exactly as the reference computes it before CtOption masks it
+        assert [int(x) for x in limbs[i]] == o.scalar_limbs_from_bytes(rows[i])[0]
+    # from_bytes_wide: from_u512 KATs (modulus|0 -> 0, 1 -> R, 2^256 -> R2, max -> R3 - R), R2 / -1 padded, and the stored maximum
+    wide = [o.R_ORDER.to_bytes(32, "little") + bytes(32), (1).to_bytes(64, "little"), bytes(32) + (1).to_bytes(32, "little"), b"\xff" * 64,
+            SCALAR_R2_BYTES + bytes(32), SCALAR_NEG1_BYTES + bytes(32)]
+    w = ctx.fr_from_bytes_wide(np.frombuffer(b"".join(wide), dtype=np.uint8).reshape(-1, 64))
+    r3_minus_r = ctx.fr_op(2, u("scalar.R3")[None, :], u("scalar.R")[None, :])[0]
+    assert not w[0].any() and np.array_equal(w[1], u("scalar.R")) and np.array_equal(w[2], u("scalar.R2")) and np.array_equal(w[3], r3_minus_r)
+    assert np.array_equal(w[3], u("scalar.FROM_BYTES_WIDE_MAXIMUM")) and np.array_equal(w[4], u("scalar.R2")) and np.array_equal(w[5], neg1)
+    # random elements and raw 256- / 512-bit strings against the oracle's limb-level restatement
+    r = o.SplitMix64(0xA8)
+    vals = EDGE_FR + [r.scalar() for _ in range(4000)]
+    L = np.stack([frw(v) for v in vals])
+    B = ctx.fr_to_bytes(L)
+    assert [bytes(row) for row in B] == [o.scalar_limbs_to_bytes([int(x) for x in row]) for row in L] == [v.to_bytes(32, "little") for v in vals]
+    back, some = ctx.fr_from_bytes(B)
+    assert np.array_equal(back, L) and some.all()
+    raw = np.random.RandomState(8).randint(0, 256, size=(2000, 64), dtype=np.uint8)
+    raw[0] = 0; raw[1] = 255
+    W = ctx.fr_from_bytes_wide(raw)
+    assert [[int(x) for x in row] for row in W] == [o.scalar_limbs_from_bytes_wide(bytes(row)) for row in raw]
+    lim2, some2 = ctx.fr_from_bytes(raw[:, :32].copy())
+    want2 = [o.scalar_limbs_from_bytes(bytes(row[:32])) for row in raw]
+    assert [[int(x) for x in row] for row in lim2] == [w_[0] for w_ in want2] and [bool(x) for x in some2] == [w_[1] for w_ in want2]
+    # limbs that no `Scalar` holds (>= r): flagged by to_bytes
+    _, okb = ctx.fr_to_bytes(np.stack([np.array(o.FR_MODULUS_LIMBS, dtype=np.uint64), np.full(4, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64), neg1]), return_flags=True)
+    assert list(okb) == [0, 0, 1]
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_msm_and_mul_batch_take_scalar_limbs(ctx, group):
+    """`msm(&[G1Affine], &[Scalar])` with the scalars as `&[Scalar]` memory (Montgomery limbs, blsgpu_g{1,2}_msm_mont): the same point as the
+    byte-form call and as the oracle's discrete-log identity, on the endomorphism path, on plain windows (BLSGPU_NO_GLV) and through
+    mul_batch; scalars 0, 1, r - 1 included; limbs >= r are reported like non-canonical bytes"""
+    import ctypes
+    import bls12_381_amd as b
+    r = o.SplitMix64(0xA80 + group)
+    n = 777
+    ks = [r.scalar() for _ in range(n)]
+    ss = [0, 1, o.R_ORDER - 1, o.R_ORDER - 2] + [r.scalar() for _ in range(n - 4)]
+    L = np.stack([frw(v) for v in ss])
+    tot = sum(k * s for k, s in zip(ks, ss)) % o.R_ORDER
+    if group == 1:
+        want = o.g1_to_uncompressed(o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, tot))); Aff = b.G1Affine
+    else:
+        want = o.g2_to_uncompressed(o.g2_to_affine(o.g2_affine_mul(o.G2_GEN, tot))); Aff = b.G2Affine
+    made = [ctx]
+    os.environ["BLSGPU_NO_GLV"] = "1"
+    try:
+        made.append(b.Context(0))
+    finally:
+        os.environ.pop("BLSGPU_NO_GLV")
+    try:
+        for cx in made:
+            bases = cx.bases_from_scalars(group, ks)
+            for w in (0, 9, 16):
+                cx.set_msm_window(w)
+                xy, inf = cx.batch_normalize(group, cx.msm_mont(bases, L)[None, :])
+                assert Aff(xy[0], bool(inf[0])).to_uncompressed() == want, (cx is ctx, w)
+            cx.set_msm_window(0)
+            # the context-wide setting reaches the plain entry points (here: msm_many through the byte-typed signature)
+            cx.set_scalar_form(b.api.SCALAR_MONT)
+            try:
+                out = cx.msm_many(bases, L.view(np.uint8).reshape(1, n, 32))
+            finally:
+                cx.set_scalar_form(b.api.SCALAR_BYTES)
+            xy, inf = cx.batch_normalize(group, out)
+            assert Aff(xy[0], bool(inf[0])).to_uncompressed() == want
+            # limbs >= r: reported, and the flag does not stick
+            Lb = L.copy(); Lb[5] = np.array(o.FR_MODULUS_LIMBS, dtype=np.uint64)
+            with pytest.raises(b.BlsGpuError, match="canonical"):
+                cx.msm_mont(bases, Lb)
+            cx.msm_mont(bases, L)
+            bases.free()
+    finally:
+        made[1].close()
+    # mul_batch: n independent products, bytes vs limbs vs the oracle (first 24 through tier-1 multiply), also on the vouched fast path
+    m = 300
+    bases = ctx.bases_from_scalars(group, ks[:m])
+    xy, inf = bases.download()
+    via_bytes = ctx.batch_normalize(group, ctx.mul_batch(group, xy, inf, ss[:m]))
+    via_limbs = ctx.batch_normalize(group, ctx.mul_batch_mont(group, xy, inf, L[:m]))
+    assert np.array_equal(via_bytes[0], via_limbs[0]) and np.array_equal(via_bytes[1], via_limbs[1])
+    fast = b.Context(0)
+    try:
+        fast.set_assume_subgroup(True)
+        via_fast = fast.batch_normalize(group, fast.mul_batch_mont(group, xy, inf, L[:m]))
+    finally:
+        fast.close()
+    assert np.array_equal(via_bytes[0], via_fast[0]) and np.array_equal(via_bytes[1], via_fast[1])
+    gen, amul, toaff, enc = (o.G1_GEN, o.g1_affine_mul, o.g1_to_affine, o.g1_to_uncompressed) if group == 1 else (o.G2_GEN, o.g2_affine_mul, o.g2_to_affine, o.g2_to_uncompressed)
+    for i in range(24):
+        assert Aff(via_limbs[0][i], bool(via_limbs[1][i])).to_uncompressed() == enc(toaff(amul(gen, ks[i] * ss[i] % o.R_ORDER)))
+    bases.free()
+
+
+def test_transform_feeds_msm_on_the_device_without_a_host_copy(ctx):
+    """the chain row f3 exists for: blsgpu_fr_ntt_device -> blsgpu_g1_msm_mont_device on the same device buffer (no conversion kernel, no
+    host round trip), against the oracle: MSM(NTT(x), [k_i] G) = [sum_j NTT(x)_j k_j] G.  Also blsgpu_fr_to_bytes_device -> the byte-form MSM,
+    and `Gt * Scalar` with limbs"""
+    import torch
+    import bls12_381_amd as b
+    log_n = 10
+    n = 1 << log_n
+    r = o.SplitMix64(0xA8C)
+    x = [r.scalar() for _ in range(n)]
+    ks = [r.scalar() for _ in range(n)]
+    y = o.fr_ntt(x)
+    tot = sum(k * s for k, s in zip(ks, y)) % o.R_ORDER
+    want = o.g1_to_uncompressed(o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, tot)))
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        bases = ctx.bases_from_scalars(1, ks)
+        d_x = torch.from_numpy(np.stack([frw(v) for v in x]).view(np.int64)).to(dev)
+        d_out = torch.zeros(18, dtype=torch.int64, device=dev)
+        ctx.fr_ntt_device(d_x.data_ptr(), log_n)
+        ctx.msm_mont_device(bases, d_x.data_ptr(), n, d_out.data_ptr())
+        d_bytes = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+        d_out2 = torch.zeros(18, dtype=torch.int64, device=dev)
+        ctx.fr_to_bytes_device(d_x.data_ptr(), n, d_bytes.data_ptr())
+        ctx.msm_device(bases, d_bytes.data_ptr(), n, d_out2.data_ptr())
+        ctx.synchronize()
+        for d in (d_out, d_out2):
+            xy, inf = ctx.batch_normalize(1, d.cpu().numpy().view(np.uint64)[None, :])
+            assert b.G1Affine(xy[0], bool(inf[0])).to_uncompressed() == want
+        assert [bytes(row) for row in d_bytes.cpu().numpy()] == [v.to_bytes(32, "little") for v in y]
+        # Gt * Scalar with limbs: e(G1, G2)^s for s as bytes and as limbs
+        gt = b.pairing(b.G1Affine.generator(), b.G2Affine.generator()).f
+        svals = [1, 2, o.R_ORDER - 1, y[3]]
+        G = np.tile(gt, (len(svals), 1))
+        by_bytes = ctx.gt_mul_scalar_batch(G, svals)
+        d_g = torch.from_numpy(G.view(np.int64)).to(dev); d_s = torch.from_numpy(np.stack([frw(v) for v in svals]).view(np.int64)).to(dev)
+        d_o = torch.zeros((len(svals), 72), dtype=torch.int64, device=dev)
+        ctx.set_scalar_form(b.api.SCALAR_MONT)
+        try:
+            ctx.gt_mul_scalar_batch_device(d_g.data_ptr(), d_s.data_ptr(), len(svals), d_o.data_ptr())
+            ctx.synchronize()
+        finally:
+            ctx.set_scalar_form(b.api.SCALAR_BYTES)
+        assert np.array_equal(d_o.cpu().numpy().view(np.uint64), by_bytes)
+        bases.free()
+    finally:
+        ctx.set_stream(None)
+
+
 @pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 9, 10, 11, 12, 13])
 def test_fr_ntt_vs_oracle(ctx, log_n):
     n = 1 << log_n

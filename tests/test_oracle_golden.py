@@ -342,6 +342,51 @@ def test_scalar_field_kats(kats):
         t = o.fr_add(t, S(c["scalar.R2"]))
 
 
+def test_scalar_byte_conversions_limb_level(kats):
+    """The limb-level restatement of `Scalar::to_bytes` / `from_bytes` / `from_bytes_wide` (oracle: scalar_limbs_*; reference
+    scalar.rs:256-331 with montgomery_reduce :506-550, mul :452-503, add :435-449, sub :420-432) against the reference's own known
+    answers (scalar.rs:864-1040) and against the big-integer definitions above: it is what pins the device conversions (row a8)."""
+    c = kats["consts"]
+    r = o.R_ORDER
+    assert o.FR_INV == c["scalar.INV"] and o.FR_MODULUS_LIMBS == c["scalar.MODULUS"]
+    assert o.FR_R2_LIMBS == c["scalar.R2"] and o.FR_R3_LIMBS == c["scalar.R3"]
+    r2_bytes = bytes([254, 255, 255, 255, 1, 0, 0, 0, 2, 72, 3, 0, 250, 183, 132, 88, 245, 79, 188, 236, 239, 79, 140, 153, 111, 5, 197, 172, 89, 177, 36, 24])
+    neg1_bytes = bytes([0, 0, 0, 0, 255, 255, 255, 255, 254, 91, 254, 255, 2, 164, 189, 83, 5, 216, 161, 9, 8, 216, 57, 51, 72, 125, 157, 41, 83, 167, 237, 115])
+    neg1 = o.scalar_limbs_sub([0, 0, 0, 0], c["scalar.R"])                       # -&Scalar::one()
+    # test_to_bytes :864-896
+    assert o.scalar_limbs_to_bytes([0, 0, 0, 0]) == bytes(32)
+    assert o.scalar_limbs_to_bytes(c["scalar.R"]) == (1).to_bytes(32, "little")
+    assert o.scalar_limbs_to_bytes(c["scalar.R2"]) == r2_bytes
+    assert o.scalar_limbs_to_bytes(neg1) == neg1_bytes == (r - 1).to_bytes(32, "little")
+    # test_from_bytes :898-966
+    assert o.scalar_limbs_from_bytes(bytes(32)) == ([0, 0, 0, 0], True)
+    assert o.scalar_limbs_from_bytes((1).to_bytes(32, "little")) == (c["scalar.R"], True)
+    assert o.scalar_limbs_from_bytes(r2_bytes) == (c["scalar.R2"], True)
+    assert o.scalar_limbs_from_bytes(neg1_bytes) == (neg1, True)
+    mod = bytearray(neg1_bytes); mod[0] = 1
+    for idx, val in ((0, 1), (0, 2), (22, 58), (31, 116)):
+        bad = bytearray(mod); bad[idx] = val
+        assert o.scalar_limbs_from_bytes(bytes(bad))[1] is False
+    # test_from_u512_* :969-1003 and test_from_bytes_wide_* :1005-1040
+    assert o.scalar_limbs_from_bytes_wide(r.to_bytes(32, "little") + bytes(32)) == [0, 0, 0, 0]
+    assert o.scalar_limbs_from_bytes_wide((1).to_bytes(64, "little")) == c["scalar.R"]
+    assert o.scalar_limbs_from_bytes_wide(bytes(32) + (1).to_bytes(32, "little")) == c["scalar.R2"]
+    assert o.scalar_limbs_from_bytes_wide(b"\xff" * 64) == o.scalar_limbs_sub(c["scalar.R3"], c["scalar.R"]) == c["scalar.FROM_BYTES_WIDE_MAXIMUM"]
+    assert o.scalar_limbs_from_bytes_wide(r2_bytes + bytes(32)) == c["scalar.R2"]
+    assert o.scalar_limbs_from_bytes_wide(neg1_bytes + bytes(32)) == neg1
+    # against the big-integer definitions on seeded values
+    g = o.SplitMix64(0xA8)
+    for _ in range(300):
+        v = g.scalar()
+        l = o.fr_to_mont_limbs(v)
+        assert o.scalar_limbs_to_bytes(l) == v.to_bytes(32, "little") == o.scalar_to_bytes(v)
+        assert o.scalar_limbs_from_bytes(v.to_bytes(32, "little")) == (l, True)
+        w = (g.scalar() << 256) | (g.next() << 192) | g.scalar()
+        assert o.scalar_limbs_from_bytes_wide((w % (1 << 512)).to_bytes(64, "little")) == o.fr_to_mont_limbs(o.fr_from_bytes_wide((w % (1 << 512)).to_bytes(64, "little")))
+        a, b_ = o.fr_to_mont_limbs(g.scalar()), o.fr_to_mont_limbs(g.scalar())
+        assert o.scalar_limbs_mul(a, b_) == o.fr_to_mont_limbs(o.fr_mul(o.fr_from_mont_limbs(a), o.fr_from_mont_limbs(b_)))
+
+
 def test_fr_ntt_definition():
     """the recursive transform equals the defining sums; inverse undoes forward; omega has exact order n"""
     rng = o.SplitMix64(99)

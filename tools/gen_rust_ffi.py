@@ -20,7 +20,7 @@ C_TO_RUST = {
     "blsgpu_bases*": "*mut BlsgpuBases", "const blsgpu_bases*": "*const BlsgpuBases", "blsgpu_bases**": "*mut *mut BlsgpuBases",
     "const uint64_t*": "*const u64", "uint64_t*": "*mut u64", "const uint8_t*": "*const u8", "uint8_t*": "*mut u8",
     "const void*": "*const c_void", "void*": "*mut c_void", "double*": "*mut f64", "float*": "*mut f32", "unsigned*": "*mut c_uint",
-    "const char*": "*const c_char", "const int*": "*const c_int",
+    "const char*": "*const c_char", "char*": "*mut c_char", "size_t*": "*mut usize", "const int*": "*const c_int",
     "blsgpu_group*": "*mut BlsgpuGroup", "const blsgpu_group*": "*const BlsgpuGroup", "blsgpu_group**": "*mut *mut BlsgpuGroup",
     "blsgpu_g2_prepared*": "*mut BlsgpuG2Prepared", "const blsgpu_g2_prepared*": "*const BlsgpuG2Prepared", "blsgpu_g2_prepared**": "*mut *mut BlsgpuG2Prepared",
     "const uint32_t*": "*const u32", "uint32_t*": "*mut u32", "const void*const*": "*const *const c_void", "void*const*": "*const *mut c_void", "const size_t*": "*const usize",
@@ -79,6 +79,9 @@ def rust_source():
              "#[repr(C)] pub struct BlsgpuGroupG2Prepared { _private: [u8; 0] }",
              "",
              "pub const BLSGPU_OK: c_int = 0;",
+             "/// scalar arguments hold `Scalar::to_bytes()` output (default) / the Montgomery limbs of `Scalar([u64; 4])` (blsgpu_set_scalar_form)",
+             "pub const BLSGPU_SCALAR_BYTES: c_int = 0;",
+             "pub const BLSGPU_SCALAR_MONT: c_int = 1;",
              "",
              "#[link(name = \"blsgpu\")]",
              "extern \"C\" {"]
