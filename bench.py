@@ -84,8 +84,34 @@ def _num(x):
     return float("%.5g" % x)
 
 
+def _slim_timing(t):
+    return {"min": _num(t.get("min_ms")), "med": _num(t.get("median_ms")), "max": _num(t.get("max_ms")), "reps": t.get("reps"),
+            "kernel_ms": {k: (_num(v) if not isinstance(v, dict) else _num(v.get("total_ms"))) for k, v in (t.get("kernel_ms") or {}).items()}}
+
+
+def _compact_extra(v, depth=0):
+    """extras on the compact line: CPU-baseline samples cut to 60 characters, timing blocks only at the top level of a leg and of its `prepared` twin"""
+    if not isinstance(v, dict):
+        return v
+    out = {}
+    for k, x in v.items():
+        if k == "sample" and isinstance(x, str):
+            out[k] = x[:60]
+        elif k in ("timing", "unprepared_timing") and depth >= 2:
+            continue
+        elif k == "n65536" and isinstance(x, dict):
+            out[k] = {a: b for a, b in _compact_extra(x, 2).items() if a in ("ms", "equations_per_s", "frac", "speedup_over_unprepared", "unprepared_same_equations_ms", "roofline")}
+        elif k == "cpu_baseline" and isinstance(x, dict) and depth >= 1:
+            out[k] = {a: b for a, b in x.items() if a in ("value", "cores", "kind")}
+        else:
+            out[k] = _compact_extra(x, depth + 1)
+    return out
+
+
 def _slim(v, top=False):
     if isinstance(v, dict):
+        if "median_ms" in v and "kernel_ms" in v:
+            return _slim_timing(v)
         return {k: _slim(x) for k, x in v.items() if (top or k not in _DROP) and x is not None}
     if isinstance(v, (list, tuple)):
         return [_slim(x) for x in v]
@@ -112,7 +138,10 @@ def slim_line(line):
         out["cpu_baseline"] = {k: _slim(cpu.get(k)) for k in ("value", "unit", "cores", "kind", "sample", "gpu_result_matches") if cpu.get(k) is not None}
     if (line.get("latency") or {}).get("host_mirror_repeat_ms") is not None:
         out["host_mirror_repeat_ms"] = _num(line["latency"]["host_mirror_repeat_ms"])
-    for k in ("single_call_ms", "end_to_end_h2d_ms", "group_path"):
+    if (line.get("latency") or {}).get("end_to_end_from_scalar_limbs_ms") is not None:
+        out["end_to_end_from_scalar_limbs_ms"] = _num(line["latency"]["end_to_end_from_scalar_limbs_ms"])
+        out["host_to_bytes_one_thread_ms"] = _num(line["latency"].get("host_to_bytes_one_thread_ms"))
+    for k in ("single_call_ms", "end_to_end_h2d_ms", "group_path", "result_matches_identity", "ranks"):
         if line.get(k) is not None:
             out[k] = _slim(line[k])
     ex = line.get("extras")
@@ -124,14 +153,18 @@ def slim_line(line):
                 e2[k] = {kk: _num(v[kk]) for kk in _KEEP_SMALL if kk in v}
             elif k in ("pairing_batch", "cpu_baseline_pairing", "pairings_per_s"):
                 continue                                   # emitted LAST, below
+            elif k == "gpu_state":
+                keep = ("sclk", "mclk", "power_w", "power_cap_w", "temp_junction_c", "compute_partition", "memory_partition", "perf_level")
+                e2[k] = {"before": {a: b for a, b in (v.get("before_extras") or {}).items() if a in keep}, "after": {a: b for a, b in (v.get("after_extras") or {}).items() if a in ("sclk", "power_w", "temp_junction_c")},
+                         "env": {a: b for a, b in (v.get("runtime_env") or {}).items() if a.startswith(("HSA_", "GPU_", "BLSGPU_")) and a != "HSA_ENABLE_IPC_MODE_LEGACY"}}
             else:
-                e2[k] = _slim(v)
+                e2[k] = _compact_extra(_slim(v))
         out["extras"] = e2
         pb, mm, eq = ex.get("pairing_batch") or {}, ex.get("multi_miller_loop") or {}, ex.get("verification_equations") or {}
         if pb:
             # the second half of BASELINE's metric, with its roofline block and CPU baseline intact
             rf = pb.get("roofline") or {}
-            tail["pairing_batch"] = {"n": pb.get("n"), "ms": _num(pb.get("ms")),
+            tail["pairing_batch"] = {"n": pb.get("n"), "ms": _num(pb.get("ms")), "timing": _slim(pb.get("timing") or {}) or None, "clocks_under_load": _slim(pb.get("clocks_under_load") or {}) or None,
                                      "roofline": {k: _num(rf.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "mac32_per_unit")}}
             cp = ex.get("cpu_baseline_pairing")
             if cp:
@@ -271,6 +304,122 @@ def median_ms(fn, sync, warm=3, reps=11):
     return 1e3 * float(np.median(ts))
 
 
+def timed_leg(ctx, fn, sync, warm=2, reps=15):
+    """One measured leg of the pairing family: `warm` untimed calls (every reserve() growth, table build and wide-program load happens
+    there), `reps` timed calls reported as min / median / max, then ONE more call with the library's per-kernel HIP events switched
+    on (blsgpu_kernel_timing: events on the streams the kernels are launched on) -> kernel_ms.  Returns (median_ms, stats)."""
+    for _ in range(warm):
+        fn(); sync()
+    ts = []
+    for _ in range(reps):
+        t = time.perf_counter(); fn(); sync()
+        ts.append(1e3 * (time.perf_counter() - t))
+    ctx.kernel_timing(True)
+    try:
+        t = time.perf_counter(); fn(); sync()
+        timed_call = 1e3 * (time.perf_counter() - t)
+        rep_ = ctx.kernel_timing_report()
+    finally:
+        ctx.kernel_timing(False)
+    kern = {k.strip("()"): (round(v["total_ms"], 4) if v["launches"] == 1 else {"launches": v["launches"], "total_ms": round(v["total_ms"], 4), "max_ms": round(v["max_ms"], 4)}) for k, v in rep_.items()}
+    ksum = sum(v["total_ms"] for v in rep_.values())
+    med = float(np.median(ts))
+    return med, {"min_ms": float(np.min(ts)), "median_ms": med, "max_ms": float(np.max(ts)), "first_rep_ms": ts[0], "reps": reps, "warmups": warm,
+                 "kernel_ms": kern, "kernel_sum_ms": ksum, "call_with_events_ms": timed_call}
+
+
+def gpu_state(dev_index=0):
+    """clocks / power / partition modes of the device as the kernel driver reports them (sysfs first: no process start; rocm-smi --json for
+    what sysfs does not show).  Diagnostic context for the bench line: a box-to-box difference of a kernel time should be explainable from here."""
+    import glob
+    import subprocess
+    out = {}
+    try:
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        visible = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        idx = dev_index
+        if visible:
+            try:
+                idx = int(visible.split(",")[dev_index])
+            except Exception:
+                idx = dev_index
+        if cards:
+            base = os.path.dirname(cards[min(idx, len(cards) - 1)])
+
+            def cur(name):
+                try:
+                    lines = open(os.path.join(base, name)).read().strip().splitlines()
+                    star = [l for l in lines if l.rstrip().endswith("*")]
+                    return (star[0] if star else lines[-1]).split(":")[1].replace("*", "").strip()
+                except Exception:
+                    return None
+            out["sclk"], out["mclk"], out["fclk"] = cur("pp_dpm_sclk"), cur("pp_dpm_mclk"), cur("pp_dpm_fclk")
+            for name, key in (("current_compute_partition", "compute_partition"), ("current_memory_partition", "memory_partition"), ("power_dpm_force_performance_level", "perf_level"),
+                              ("gpu_busy_percent", "busy_percent"), ("mem_info_vram_used", "vram_used")):
+                try:
+                    out[key] = open(os.path.join(base, name)).read().strip()
+                except Exception:
+                    pass
+            for hw in glob.glob(os.path.join(base, "hwmon", "hwmon*")):
+                for name, key, scale in (("power1_average", "power_w", 1e-6), ("power1_input", "power_w", 1e-6), ("power1_cap", "power_cap_w", 1e-6), ("temp1_input", "temp_c", 1e-3),
+                                         ("temp2_input", "temp_junction_c", 1e-3), ("temp3_input", "temp_mem_c", 1e-3)):
+                    try:
+                        out.setdefault(key, round(float(open(os.path.join(hw, name)).read().strip()) * scale, 1))
+                    except Exception:
+                        pass
+    except Exception as ex:
+        out["sysfs_error"] = str(ex)[:120]
+    if not out.get("sclk"):
+        try:
+            js = json.loads(subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showmaxpower", "--showperflevel", "--showcomputepartition", "--showmemorypartition", "--json"],
+                                           capture_output=True, text=True, timeout=20).stdout)
+            card = js.get("card%d" % dev_index) or next(iter(js.values()))
+            out["rocm_smi"] = {k: v for k, v in card.items() if any(t in k.lower() for t in ("sclk", "mclk", "fclk", "power", "partition", "performance"))}
+        except Exception as ex:
+            out["rocm_smi_error"] = str(ex)[:120]
+    return out
+
+
+def clocks_under_load(fn, sync, launches=8, dev_index=0):
+    """sclk / power sampled from sysfs by a host thread WHILE `launches` back-to-back calls of fn run (one sample every ~20 ms; the driver's
+    readings lag the hardware by a few hundred ms, so the window is ~0.8 s and the LAST quarter of the samples is what counts)"""
+    import threading
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            st = gpu_state(dev_index)
+            samples.append((st.get("sclk"), st.get("power_w"), st.get("temp_junction_c", st.get("temp_c"))))
+            time.sleep(0.02)
+    th = threading.Thread(target=poll, daemon=True)
+    th.start()
+    t = time.perf_counter()
+    for _ in range(launches):
+        fn()
+    sync()
+    dt = time.perf_counter() - t
+    stop.set(); th.join(timeout=2)
+
+    def mhz(v):
+        try:
+            return float(str(v).lower().replace("mhz", ""))
+        except Exception:
+            return None
+    samples = samples[-max(1, len(samples) // 4):]
+    sc = [mhz(a) for a, _, _ in samples if mhz(a) is not None]
+    pw = [b for _, b, _ in samples if b is not None]
+    tj = [c for _, _, c in samples if c is not None]
+    return {"launches": launches, "ms_per_launch": 1e3 * dt / launches, "samples": len(samples),
+            "sclk_mhz": {"min": min(sc), "median": float(np.median(sc)), "max": max(sc)} if sc else None,
+            "power_w": {"median": float(np.median(pw)), "max": max(pw)} if pw else None, "temp_c_max": max(tj) if tj else None}
+
+
+def runtime_env():
+    """the HIP / ROCr switches that change how scratch-heavy kernels are dispatched, as this process sees them"""
+    keys = [k for k in os.environ if k.startswith(("HSA_", "HIP_", "ROCR_", "GPU_", "AMD_", "BLSGPU_"))]
+    return {k: os.environ[k][:60] for k in sorted(keys)}
+
+
 # =====================================================================================================================
 # workload "msm"
 # =====================================================================================================================
@@ -309,7 +458,7 @@ def run_msm(args, e):
     # two placements are equal -- 2.78 / 11.1 / 41.3 ms per step at 2^20 / 2^22 / 2^24 points against 2.77 / 11.0 / 41.0 on the context's
     # stream, BENCH_EXCHANGE_MAIN=1 -- the ~1 ms per step the RCCL branch used to cost came from the eagerly created communicator: setup().)
     main_stream = torch.cuda.current_stream()
-    xs = torch.cuda.Stream(device=dev) if (multi and e.xdev == dev) else None
+    xs = torch.cuda.Stream(device=dev) if multi else None
     ex_ev = [torch.cuda.Event() for _ in range(8)] if xs is not None else None
     ex_used = [False] * 8
     probe = os.environ.get("BENCH_EXCHANGE_PROBE", "")        # diagnostic: "join" / "gather" / "fold" run only that part of the exchange
@@ -319,8 +468,12 @@ def run_msm(args, e):
     def exchange(j, lag):
         """the path's single exchange step for MSM j: all-gather the per-rank partial sums, fold on every rank"""
         buf = d_out[j & 7]
-        if xs is None:                           # CPU collectives (gloo test path): on the context's stream as before
+        if xs is None:                           # diagnostic placement (BENCH_EXCHANGE_MAIN): on the context's stream
             ctx.join(lag)
+            if e.xdev != dev:
+                # torch's current stream is the NULL stream here, the context's stream (blsgpu_set_stream(NULL) = its own non-blocking stream) is
+                # not: a torch copy is not ordered behind the join -- round 6 found the gloo path gathering zeros this way -- so wait on the host
+                ctx.synchronize()
             all_gather_rows(gathered, buf.to(e.xdev), dist)
             g = gathered if gathered.device == dev else gathered.to(dev)
             ctx.point_sum_device(1, g.data_ptr(), world, d_fold.data_ptr())
@@ -330,10 +483,18 @@ def run_msm(args, e):
         try:
             ctx.join(lag)                        # the exchange stream waits for the tail of MSM j
             with torch.cuda.stream(xs):
-                if probe in ("", "gather"):
-                    all_gather_rows(gathered, buf, dist)
-                if probe in ("", "fold"):
-                    ctx.point_sum_device(1, gathered.data_ptr(), world, d_fold.data_ptr())     # asynchronous fold on this rank's GPU
+                if e.xdev != dev:
+                    # CPU collectives (gloo: the one-GPU plumbing tests): the partial sum goes through the host -- the copy is queued on the exchange
+                    # stream BEHIND the join and blocks the host until it is done -- and the gathered block comes back to the GPU for the fold
+                    all_gather_rows(gathered, buf.to(e.xdev), dist)
+                    g = gathered.to(dev)
+                    ctx.point_sum_device(1, g.data_ptr(), world, d_fold.data_ptr())
+                    state["g"] = g
+                else:
+                    if probe in ("", "gather"):
+                        all_gather_rows(gathered, buf, dist)
+                    if probe in ("", "fold"):
+                        ctx.point_sum_device(1, gathered.data_ptr(), world, d_fold.data_ptr())     # asynchronous fold on this rank's GPU
                 ex_ev[j & 7].record(xs)
             ex_used[j & 7] = True
         finally:
@@ -380,12 +541,25 @@ def run_msm(args, e):
     live_acc_ms, live_acc_n = ctx.msm_accumulate_stats(False)
     dt = max_over_ranks(e, dt)
     aff_rccl = None
+    identity_ok = None
     if multi:
         last = d_fold.cpu().numpy().view(np.uint64)
         aff = ctx.batch_normalize(1, last[None, :])[0][0]
         if not ranks_agree(e, aff):
             raise SystemExit("bench: ranks disagree on the folded MSM result")
         aff_rccl = aff.copy()
+        # ... and the folded point IS the MSM (agreement alone would also hold for a wrong fold): the discrete-log identity
+        # sum_i s_i [k_i]G = [sum_i s_i k_i mod r] G -- every rank contributes the share of its shard (eight u32 words), the shares are
+        # all-gathered like the partial sums, and [t]G comes from the library's fixed-base path (itself pinned to the golden multiples)
+        share = synthetic.dot_mod_r(sb, kb)
+        sh_t = torch.from_numpy(np.frombuffer(share.to_bytes(32, "little"), dtype="<u4").astype(np.int64)).to(e.xdev)
+        sh_all = torch.zeros((world, 8), dtype=torch.int64, device=e.xdev)
+        all_gather_rows(sh_all, sh_t, dist)
+        t_all = sum(int.from_bytes(np.ascontiguousarray(row.astype("<u4")).tobytes(), "little") for row in sh_all.cpu().numpy()) % synthetic.R_ORDER
+        want_aff = ctx.bases_from_scalars(1, np.frombuffer(t_all.to_bytes(32, "little"), dtype=np.uint8).reshape(1, 32)).download()[0][0]
+        identity_ok = bool(np.array_equal(aff, want_aff))
+        if not identity_ok:
+            raise SystemExit("bench: the folded multi-rank MSM is not [sum s_i k_i] G")
     ctx.set_pipelining(False)
     d_out0 = d_out[0]
     log_n = int(round(np.log2(n))) if n & (n - 1) == 0 else None
@@ -430,6 +604,29 @@ def run_msm(args, e):
         def e2e():
             bls._lib.check(ctx.lib.blsgpu_g1_msm(ctx.h, bases.handle, 0, ctypes.c_void_p(pinned.data_ptr()), n, ctypes.c_void_p(host_out.ctypes.data)), "g1_msm")
         e2e_ms = median_ms(e2e, lambda: None)
+        # the same two latencies with the scalars as `&[Scalar]` memory holds them (Montgomery limbs): `Scalar::to_bytes`
+        # runs inside k_glv_decompose, so a drop-in `msm(&[G1Affine], &[Scalar])` does no per-scalar host work at all
+        limbs_np, ok_np = ctx.fr_from_bytes(sb)
+        assert ok_np.all()
+        d_limbs = torch.from_numpy(limbs_np.view(np.int64)).to(dev)
+        d_out_m = torch.zeros(18, dtype=torch.int64, device=dev)
+        single_mont = median_ms(lambda: ctx.msm_mont_device(bases, d_limbs.data_ptr(), n, d_out_m.data_ptr()), sync)
+        mont_same = bool(np.array_equal(ctx.batch_normalize(1, d_out_m.cpu().numpy().view(np.uint64)[None, :])[0],
+                                        ctx.batch_normalize(1, d_out0.cpu().numpy().view(np.uint64)[None, :])[0]))
+        pinned_l = torch.from_numpy(limbs_np.view(np.int64)).pin_memory()
+        host_out_m = np.zeros(18, dtype=np.uint64)
+
+        def e2e_mont():
+            bls._lib.check(ctx.lib.blsgpu_g1_msm_mont(ctx.h, bases.handle, 0, ctypes.c_void_p(pinned_l.data_ptr()), n, ctypes.c_void_p(host_out_m.ctypes.data)), "g1_msm_mont")
+        e2e_mont_ms = median_ms(e2e_mont, lambda: None)
+        # what the host-side conversion costs that the limb form removes: 2^16 `Scalar::to_bytes` of the C port on ONE thread, scaled to n
+        to_bytes_host_ms = None
+        if not args.no_cpu_baseline:
+            from oracle import c_oracle
+            if hasattr(c_oracle, "scalar_to_bytes_batch"):
+                m_ = min(n, 1 << 16)
+                t1 = time.perf_counter(); c_oracle.scalar_to_bytes_batch(limbs_np[:m_]); to_bytes_host_ms = 1e3 * (time.perf_counter() - t1) * n / m_
+        del d_limbs, pinned_l
         # a drop-in caller that passes its base SLICE on every call (blsgpu_g1_msm_host, what the mirrored `msm_g1(&bases, &scalars)` does) with
         # the opt-in bases cache: first sight = one-shot upload, second = resident upload (subgroup test, images), then only the scalars move
         cctx = bls.Context(e.local_rank)
@@ -446,7 +643,8 @@ def run_msm(args, e):
         hm_same = bool(np.array_equal(cctx.batch_normalize(1, hm_out[None, :])[0], ctx.batch_normalize(1, d_out0.cpu().numpy().view(np.uint64)[None, :])[0]))
         cctx.close()
         del xy_all
-        latency = {"single_call_ms": single, "end_to_end_h2d_ms": e2e_ms, "host_mirror_first_ms": hm_t[0], "host_mirror_second_ms": hm_t[1],
+        latency = {"single_call_ms": single, "end_to_end_h2d_ms": e2e_ms, "single_call_scalar_limbs_ms": single_mont, "end_to_end_from_scalar_limbs_ms": e2e_mont_ms,
+                   "scalar_limbs_result_matches": mont_same, "host_to_bytes_one_thread_ms": to_bytes_host_ms, "host_mirror_first_ms": hm_t[0], "host_mirror_second_ms": hm_t[1],
                    "host_mirror_repeat_ms": float(np.median(hm_t[2:])), "host_mirror_matches": hm_same,
                    "single_call_scalar_muls_per_s": n / (single * 1e-3), "end_to_end_scalar_muls_per_s": n / (e2e_ms * 1e-3),
                    "note": "one MSM at a time, nothing else in flight: scalars in HBM -> projective result in HBM (single_call); scalars in pinned host "
@@ -486,7 +684,7 @@ def run_msm(args, e):
     if rank == 0:
         if strong:
             workload = ("ONE 2^%d-point G1 MSM sharded over %d MI355X (%d points per GPU), bases and scalars resident in HBM; one result per step: "
-                        "RCCL all-gather of the %d partial sums (144 B each) + fold on every rank" % (args.log_total, world, n, world))
+                        "%s all-gather of the %d partial sums (144 B each) + fold on every rank" % (args.log_total, world, n, "RCCL" if args.backend == "nccl" else args.backend, world))
         else:
             workload = ("2^%d-point G1 MSM per MI355X, bases resident in HBM, scalars in HBM; one result per step%s"
                         % (log_n, "" if not multi else " (RCCL all-gather of N partial sums + fold)"))
@@ -497,6 +695,9 @@ def run_msm(args, e):
             "dtype": "u32 (14x28-bit limbs, 64-bit accumulators)", "data": "synthetic",
             "config": {"workload": workload, "points_per_gpu": n, "total_points": total, "parallelism": "shard%d" % world,
                        "scalars": "SplitMix64(0xB1512381 + 2*rank), uniform in [0, r) by rejection (SURVEY.md 8d)"},
+            "result_matches_identity": identity_ok, "ranks": {"world": world, "backend": (dist.get_backend() if multi else None), "world_from_process_group": (dist.get_world_size() if multi else 1),
+                                                                  "communicator": (None if not multi or args.backend != "nccl" else ("eager (device_id bound at init)" if os.environ.get("BENCH_EAGER_PG") else "lazy (created by the first collective)")),
+                                                                  "same_device": bool(args.same_device), "devices_visible": torch.cuda.device_count()},
             "roofline": roof, "cpu_baseline": cpu, "latency": latency, "msm_phase_ms": phases, "extras": extras, "group_path": group_path,
         }
         if latency:
@@ -571,11 +772,14 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
     d_g1 = torch.from_numpy(g1xy.view(np.int64)).to(dev); d_g2 = torch.from_numpy(g2xy.view(np.int64)).to(dev)
     d_gt = torch.zeros((np_, 72), dtype=torch.int64, device=dev)
     sync = torch.cuda.synchronize
-    pms = median_ms(lambda: ctx.pairing_batch_device(d_g1.data_ptr(), d_g2.data_ptr(), np_, d_gt.data_ptr()), sync, warm=1, reps=5)
+    state_before = gpu_state(e.local_rank)
+    pfn = lambda: ctx.pairing_batch_device(d_g1.data_ptr(), d_g2.data_ptr(), np_, d_gt.data_ptr())
+    pms, pstat = timed_leg(ctx, pfn, sync)
+    load = clocks_under_load(pfn, sync, launches=40, dev_index=e.local_rank)
     pdt = pms * 1e-3
     extras["pairings_per_s"] = np_ / pdt
     ptraf, ptraf_src = static_traffic("pairing")
-    extras["pairing_batch"] = {"n": np_, "ms": pms, "note": "2^16 independent pairing(P_i, Q_i), inputs and outputs in HBM; quad layout (one pairing per four lanes, quad.hip.h)",
+    extras["pairing_batch"] = {"n": np_, "ms": pms, "timing": pstat, "clocks_under_load": load, "note": "2^16 independent pairing(P_i, Q_i), inputs and outputs in HBM; quad layout (one pairing per four lanes, quad.hip.h)",
                                "roofline": {"bound": "int-valu", "kernel": "k_pairing_quad", "mac32_per_unit": MAC32_PAIRING, "achieved": np_ * MAC32_PAIRING / pdt / 1e12,
                                             "peak": peak / 1e12, "unit": "TMAC32/s", "frac": np_ * MAC32_PAIRING / pdt / peak,
                                             "traffic": ptraf, "traffic_source": ptraf_src, "algorithmic_bytes": np_ * 864}}
@@ -624,13 +828,13 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
     # per four terms, partial products multiplied up; no final exponentiation in the timed region
     nm = 4 * np_
     d_g1m, d_g2m = d_g1.repeat(4, 1), d_g2.repeat(4, 1)
-    mms = median_ms(lambda: ctx.multi_miller_loop_device(d_g1m.data_ptr(), d_g2m.data_ptr(), nm, d_gt.data_ptr()), sync, warm=1, reps=5)
+    mms, mstat = timed_leg(ctx, lambda: ctx.multi_miller_loop_device(d_g1m.data_ptr(), d_g2m.data_ptr(), nm, d_gt.data_ptr()), sync, warm=2, reps=9)
     mdt = mms * 1e-3
     d_one = torch.zeros(72, dtype=torch.int64, device=dev)
     mfe = median_ms(lambda: (ctx.multi_miller_loop_device(d_g1m.data_ptr(), d_g2m.data_ptr(), nm, d_gt.data_ptr()),
                              bls._lib.check(ctx.lib.blsgpu_final_exponentiation_device(ctx.h, d_gt.data_ptr(), 1, d_one.data_ptr()), "final_exponentiation")), sync, warm=1, reps=3)
     extras["multi_miller_loop_terms_per_s"] = nm / mdt
-    extras["multi_miller_loop"] = {"n": nm, "ms": mms, "with_final_exponentiation_ms": mfe,
+    extras["multi_miller_loop"] = {"n": nm, "ms": mms, "timing": mstat, "with_final_exponentiation_ms": mfe,
                                    "note": "one product of 2^18 Miller values; `ms` and the roofline are the product alone, `with_final_exponentiation_ms` adds the ONE "
                                            "final exponentiation of BASELINE configs[4] (SURVEY.md 8d: one product + one final exp; wide path, ~0.8 ms)",
                                    "roofline": {"bound": "int-valu", "kernel": "k_multi_miller_shared", "mac32_per_unit": MAC32_MML_TERM, "achieved": nm * MAC32_MML_TERM / mdt / 1e12,
@@ -643,9 +847,9 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
     ne, ke = 1 << 14, 3
     d_off = torch.arange(0, (ne + 1) * ke, ke, dtype=torch.int64, device=dev)
     d_eq = torch.zeros((ne, 72), dtype=torch.int64, device=dev)
-    eqms = median_ms(lambda: ctx.multi_miller_loop_many_device(d_g1.data_ptr(), d_g2.data_ptr(), d_off.data_ptr(), ne, ne * ke, d_eq.data_ptr(), max_seg_terms=ke), sync, warm=1, reps=5)
+    eqms, eqstat = timed_leg(ctx, lambda: ctx.multi_miller_loop_many_device(d_g1.data_ptr(), d_g2.data_ptr(), d_off.data_ptr(), ne, ne * ke, d_eq.data_ptr(), max_seg_terms=ke), sync)
     mac_eq = (ke * 6900 + 9100) * 300
-    eq = {"n": ne, "terms_per_equation": ke, "ms": eqms, "equations_per_s": ne / (eqms * 1e-3),
+    eq = {"n": ne, "terms_per_equation": ke, "ms": eqms, "timing": eqstat, "equations_per_s": ne / (eqms * 1e-3),
           "note": "2^14 equations prod_{j<3} e(P_ij, Q_ij) in one blsgpu_multi_miller_loop_many_device call (Miller values of the 3 x 2^14 terms on the quad kernels, segmented "
                   "Fp12 product, batched final exponentiation), inputs and outputs in HBM",
           "roofline": {"bound": "int-valu", "kernel": "k_pairing_quad (Miller) + k_fp12_prod_seg_quad + k_final_exp_quad", "mac32_per_unit": mac_eq,
@@ -704,12 +908,12 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
         d_gp = (d_g1e if nn == ne2 else d_g1)[:nn * ke]
         kt = torch.from_numpy(key_xy.view(np.int64)).to(dev)
         d_gq[1::3] = kt[0]; d_gq[2::3] = kt[1]                  # the same equations for the unprepared path: the fixed points written out per term
-        tp = median_ms(lambda: ctx.multi_miller_loop_prepared_many_device(d_gp.data_ptr(), table, d_qi.data_ptr(), d_o.data_ptr(), nn, nn * ke, d_e.data_ptr(), max_seg_terms=ke,
-                                                                          d_g2=d_gq.data_ptr()), sync, warm=1, reps=5 if nn == ne else 3)
+        tp, tpstat = timed_leg(ctx, lambda: ctx.multi_miller_loop_prepared_many_device(d_gp.data_ptr(), table, d_qi.data_ptr(), d_o.data_ptr(), nn, nn * ke, d_e.data_ptr(), max_seg_terms=ke,
+                                                                                        d_g2=d_gq.data_ptr()), sync, warm=2, reps=15 if nn == ne else 5)
         got_p = d_e[:512].clone()
-        tu = median_ms(lambda: ctx.multi_miller_loop_many_device(d_gp.data_ptr(), d_gq.data_ptr(), d_o.data_ptr(), nn, nn * ke, d_e.data_ptr(), max_seg_terms=ke), sync, warm=1,
-                       reps=5 if nn == ne else 3)
-        rec = {"ms": tp, "equations_per_s": nn / (tp * 1e-3), "unprepared_same_equations_ms": tu, "speedup_over_unprepared": tu / tp,
+        tu, tustat = timed_leg(ctx, lambda: ctx.multi_miller_loop_many_device(d_gp.data_ptr(), d_gq.data_ptr(), d_o.data_ptr(), nn, nn * ke, d_e.data_ptr(), max_seg_terms=ke), sync, warm=2,
+                               reps=15 if nn == ne else 5)
+        rec = {"ms": tp, "timing": tpstat, "equations_per_s": nn / (tp * 1e-3), "unprepared_same_equations_ms": tu, "unprepared_timing": tustat, "speedup_over_unprepared": tu / tp,
                "paths_agree": bool(torch.equal(got_p, d_e[:512])),
                "roofline": {"bound": "int-valu", "kernel": "k_mml_prep_quad + k_final_exp_quad", "mac32_per_unit": mac_eq_prep, "achieved": nn * mac_eq_prep / (tp * 1e-3) / 1e12,
                             "peak": peak / 1e12, "unit": "TMAC32/s", "frac": nn * mac_eq_prep / (tp * 1e-3) / peak, "algorithmic_bytes": nn * (ke * 96 + 192 + 576), "traffic": None}}
@@ -763,10 +967,10 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
     d_vo = torch.arange(0, (nv + 1) * 32, 32, dtype=torch.int64, device=dev)
     d_vd = torch.from_numpy(np.frombuffer(vdst, dtype=np.uint8).copy()).to(dev)
     d_vv = torch.zeros(nv, dtype=torch.uint8, device=dev)
-    vms = median_ms(lambda: ctx.bls_verify_batch_device(0, d_pk.data_ptr(), d_sg.data_ptr(), d_vm.data_ptr(), d_vo.data_ptr(), nv, d_vd.data_ptr(), len(vdst), d_vv.data_ptr()), sync, warm=1, reps=5)
+    vms, vstat = timed_leg(ctx, lambda: ctx.bls_verify_batch_device(0, d_pk.data_ptr(), d_sg.data_ptr(), d_vm.data_ptr(), d_vo.data_ptr(), nv, d_vd.data_ptr(), len(vdst), d_vv.data_ptr()), sync)
     verd = d_vv.cpu().numpy()
     mac_ver = (2500 + 9000 + 8700 + 2 * 6900 + 9100) * 300
-    ver = {"n": nv, "ms": vms, "signatures_per_s": nv / (vms * 1e-3), "verdicts_as_expected": bool(verd[3] == 0 and verd.sum() == nv - 1),
+    ver = {"n": nv, "ms": vms, "timing": vstat, "signatures_per_s": nv / (vms * 1e-3), "verdicts_as_expected": bool(verd[3] == 0 and verd.sum() == nv - 1),
            "note": "compressed public keys (48 B) + signatures (96 B) + 32-byte messages in HBM -> verdict bytes in HBM: checked decoding, hash_to_curve, normalisation, "
                    "multi_miller_loop + final exponentiation per signature, identity test (blsgpu_bls_verify_batch_device)",
            "roofline": {"bound": "int-valu", "kernel": "k_point_decode x 2 + k_hash_to_curve<G2> + k_pairing_quad (Miller) + k_fp12_prod_seg_quad + k_final_exp_quad",
@@ -996,6 +1200,8 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
     extras["g1_msm_precomputed_tables"] = {"scalar_muls_per_s": n / pdt2, "ms": 1e3 * pdt2, "table_build_s": pre_s, "window_bits": 20,
                                            "resident_bytes": 13 * n * 128, "matches_plain_path": same,
                                            "note": "optional mode for reused bases (blsgpu_bases_precompute); NOT the headline value"}
+    extras["gpu_state"] = {"before_extras": state_before, "after_extras": gpu_state(e.local_rank), "runtime_env": runtime_env(),
+                           "note": "sysfs readings of the device the extras ran on (idle clocks before / after; clocks UNDER LOAD are in pairing_batch.clocks_under_load)"}
     return extras
 
 

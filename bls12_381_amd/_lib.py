@@ -44,6 +44,7 @@ SIGNATURES = {
     "blsgpu_g1_msm_device": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
     "blsgpu_g2_msm_device": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
     "blsgpu_set_bases_cache": (c_int, [c_vp, c_int]),
+    "blsgpu_set_bases_cache_verify": (c_int, [c_vp, c_int]),
     "blsgpu_set_scalar_form": (c_int, [c_vp, c_int]),
     "blsgpu_g1_msm_mont": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
     "blsgpu_g2_msm_mont": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),

@@ -349,6 +349,10 @@ class Context:
         """keep the base arrays of repeated one-shot MSMs (`msm_host`, the mirrored `msm_g1` / `msm_g2`) resident: see blsgpu_set_bases_cache"""
         check(self.lib.blsgpu_set_bases_cache(self.h, int(entries)), "set_bases_cache")
 
+    def set_bases_cache_verify(self, on):
+        """recognise cached base arrays by a hash of every word (safe for buffers that are reused with other contents): blsgpu_set_bases_cache_verify"""
+        check(self.lib.blsgpu_set_bases_cache_verify(self.h, 1 if on else 0), "set_bases_cache_verify")
+
     def msm_host(self, group, xy, infinity, scalars):
         w = 12 if group == 1 else 24
         xy = _u64(xy, (-1, w))

@@ -180,7 +180,10 @@ struct blsgpu_ctx {
   struct BasesCacheEntry { int group; size_t n; uint64_t fp; blsgpu_bases* b; unsigned long long last; };
   std::vector<BasesCacheEntry> bcache;  // blsgpu_set_bases_cache: base arrays of repeated one-shot MSMs kept resident
   int bcache_cap = 0; unsigned long long bcache_tick = 0;
+  bool bcache_verify = false;           // blsgpu_set_bases_cache_verify: recognise an array by a hash of ALL its words instead of the 65-point fingerprint
   DevBuf mmlp_work, mmlp_out;           // prepared Miller loops (prep.hip.h): per-quad work area, partial products of one long product
+  DevBuf fold_c, fold_d, fold_result;   // scratch of the sums / Fp12 products an asynchronous group fold runs on fold_stream: NOT io_c / io_d / result, which calls on `stream` own
+  bool on_fold_stream = false;          // set while partials_fold_device borrows the context: routes proj_sum_device / fp12_product_device to the fold scratch
   hipStream_t fold_stream = nullptr;    // the asynchronous group fold's copies and sums run here, NOT on `stream`: an MSM's front waits for whatever is queued on `stream`
   void* pin_stage = nullptr; hipEvent_t pin_ev[8] = {};      // pinned bounce buffers of staged_upload
   DevBuf gt_one; bool gt_one_ready = false; hipEvent_t ev_gt_one = nullptr;      // the wire form of Fp12::one() (blsgpu_gt_is_identity_device, bulk verification)
@@ -265,7 +268,12 @@ static int staged_upload(blsgpu_ctx* c, void* dst, const void* src, size_t bytes
   for (auto& x : th) x.join();
   // the bounce buffers are reused by the next upload: their last DMAs must have been issued -- and read -- before then
   for (int k = 0; k < 2 * T && !failed; k++) if (hipEventSynchronize(c->pin_ev[k]) != hipSuccess) failed = 1;
-  if (failed) { (void)hipGetLastError(); g_err = "staged upload failed"; return BLSGPU_ERR_HIP; }
+  if (failed) {
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(c->stream);          // DMAs already queued still read the bounce buffers: a retry must not overwrite them
+    (void)hipGetLastError();
+    g_err = "staged upload failed"; return BLSGPU_ERR_HIP;
+  }
   return BLSGPU_OK;
 }
 
@@ -627,7 +635,7 @@ extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
   hipDeviceSynchronize();
   if (c->d_status) hipFree(c->d_status);
   if (c->d_wide) hipFree(c->d_wide);
-  DevBuf* bufs[] = {&c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->io_f, &c->io_out, &c->flags_a, &c->flags_b, &c->fr_tw[0], &c->fr_tw[1], &c->fr_tmp, &c->fr_ninv, &c->fb_table[0], &c->fb_table[1], &c->fb_stage, &c->mmlp_work, &c->mmlp_out, &c->gt_one, &c->ver};
+  DevBuf* bufs[] = {&c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->io_f, &c->io_out, &c->flags_a, &c->flags_b, &c->fr_tw[0], &c->fr_tw[1], &c->fr_tmp, &c->fr_ninv, &c->fb_table[0], &c->fb_table[1], &c->fb_stage, &c->mmlp_work, &c->mmlp_out, &c->gt_one, &c->ver, &c->fold_c, &c->fold_d, &c->fold_result};
   for (auto b : bufs) b->release();
   for (auto& sl : c->slot) {
     DevBuf* sb[] = {&sl.ent, &sl.sorted, &sl.hist, &sl.offs, &sl.cursor, &sl.bsum, &sl.items, &sl.heavy, &sl.ctrl, &sl.glv,
@@ -1413,6 +1421,25 @@ extern "C" int blsgpu_g2_msm_many(blsgpu_ctx* c, const blsgpu_bases* b, size_t f
 // 64 evenly spaced points -- the caller promises not to change an array it passes again.  First sight: the one-shot path as always.
 // Second sight: the set is uploaded as RESIDENT bases (subgroup test, endomorphism images) and kept; from then on a call only moves its
 // scalars, i.e. it runs on the headline path (bases resident, 32 B per scalar over PCIe).
+// every word of the array, four host threads (blsgpu_set_bases_cache_verify): ~100 MB at memory speed for 2^20 G1 points
+static uint64_t bases_full_hash(const uint64_t* xy, const uint8_t* inf, size_t n, size_t words) {
+  constexpr int T = 4;
+  uint64_t part[T];
+  auto run = [&](int t) {
+    const size_t lo = n * (size_t)t / T, hi = n * (size_t)(t + 1) / T;
+    uint64_t a = 0x9e3779b97f4a7c15ull ^ (uint64_t)t, b = 0xc2b2ae3d27d4eb4full;
+    for (size_t i = lo * words; i < hi * words; i++) { a = (a ^ xy[i]) * 0xff51afd7ed558ccdull; a ^= a >> 29; b += a; }
+    if (inf) for (size_t i = lo; i < hi; i++) { b = (b ^ inf[i]) * 0x100000001b3ull; }
+    part[t] = a ^ (b * 0x9e3779b97f4a7c15ull);
+  };
+  std::vector<std::thread> th;
+  try { for (int t = 1; t < T; t++) th.emplace_back(run, t); } catch (...) { for (auto& x : th) x.join(); th.clear(); for (int t = 1; t < T; t++) run(t); }
+  run(0);
+  for (auto& x : th) x.join();
+  uint64_t h = 1469598103934665603ull ^ (uint64_t)n;
+  for (int t = 0; t < T; t++) { h ^= part[t]; h *= 1099511628211ull; }
+  return h;
+}
 static uint64_t bases_fingerprint(const uint64_t* xy, const uint8_t* inf, size_t n, size_t words) {
   uint64_t h = 1469598103934665603ull ^ (uint64_t)n;
   const size_t step = n > 64 ? n / 64 : 1;
@@ -1427,7 +1454,7 @@ template <class F>
 static int msm_oneshot(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, const uint8_t* s, size_t n, uint64_t* out) {
   if (c && c->bcache_cap > 0 && n >= 1024 && xy) {
     constexpr size_t W = 2 * Wire<F>::WORDS / 2;            // u64 per affine point
-    const uint64_t fp = bases_fingerprint(xy, inf, n, W);
+    const uint64_t fp = c->bcache_verify ? bases_full_hash(xy, inf, n, W) : bases_fingerprint(xy, inf, n, W);
     blsgpu_ctx::BasesCacheEntry* hit = nullptr;
     for (auto& e : c->bcache) if (e.group == GroupTag<F>::id && e.n == n && e.fp == fp) hit = &e;
     if (hit) {
@@ -1452,6 +1479,15 @@ static int msm_oneshot(blsgpu_ctx* c, const uint64_t* xy, const uint8_t* inf, co
   rc = msm_host<F>(c, b, 0, s, n, out);
   blsgpu_bases_free(b);
   return rc;
+}
+extern "C" int blsgpu_set_bases_cache_verify(blsgpu_ctx* c, int on) { CTX_CLAIM(c);
+  if (!c) return bad("ctx is NULL");
+  if ((on != 0) != c->bcache_verify) {                 // fingerprints of the two kinds do not compare: start over
+    for (auto& e : c->bcache) if (e.b) blsgpu_bases_free(e.b);
+    c->bcache.clear();
+  }
+  c->bcache_verify = on != 0;
+  return BLSGPU_OK;
 }
 extern "C" int blsgpu_set_bases_cache(blsgpu_ctx* c, int entries) { CTX_CLAIM(c);
   if (!c || entries < 0 || entries > 8) return bad("set_bases_cache: entries must be in [0, 8]");
@@ -1553,10 +1589,13 @@ static int proj_sum_device(blsgpu_ctx* c, const void* d_xyz, size_t n, void* d_o
   if (!c || !d_out || (n && !d_xyz)) return bad("sum_device: NULL argument");
   HIPCHK(hipSetDevice(c->device));
   constexpr int PW = Store<F>::PROJ_WORDS;
-  if (c->io_c.reserve((n ? n : 1) * PW * 4) || c->result.reserve(PW * 4)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
-  if (n) KLAUNCH(k_proj_import<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (const u32*)d_xyz, c->io_c.as<u32>(), n);
-  KLAUNCH(k_proj_sum_team<F>, dim3(1), dim3(TEAM), TEAM_LDS(TEAM), c->stream, c->io_c.as<u32>(), c->result.as<u32>(), n);
-  KLAUNCH(k_proj_export<F>, dim3(1), dim3(256), 0, c->stream, c->result.as<u32>(), (u32*)d_out, (size_t)1);
+  // (a fold queued on the fold stream must not share scratch with calls on the main stream: nothing orders the two)
+  DevBuf& recs = c->on_fold_stream ? c->fold_c : c->io_c;
+  DevBuf& res = c->on_fold_stream ? c->fold_result : c->result;
+  if (recs.reserve((n ? n : 1) * PW * 4) || res.reserve(PW * 4)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  if (n) KLAUNCH(k_proj_import<F>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (const u32*)d_xyz, recs.as<u32>(), n);
+  KLAUNCH(k_proj_sum_team<F>, dim3(1), dim3(TEAM), TEAM_LDS(TEAM), c->stream, recs.as<u32>(), res.as<u32>(), n);
+  KLAUNCH(k_proj_export<F>, dim3(1), dim3(256), 0, c->stream, res.as<u32>(), (u32*)d_out, (size_t)1);
   LAUNCHCHK();
   return BLSGPU_OK;
 }
@@ -2092,7 +2131,9 @@ extern "C" int blsgpu_final_exponentiation_device(blsgpu_ctx* c, const void* in,
 
 // product of n Fp12 wire values already in device memory (d_in) -> one wire value (d_out); tree of k_fp12_prod
 static int fp12_product_device(blsgpu_ctx* c, const u32* d_in, size_t n, u32* d_out) {
-  if (c->io_c.reserve((n / 2 + 1) * 576) || c->io_d.reserve((n / 4 + 1) * 576)) { g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP; }
+  DevBuf& lvl_a = c->on_fold_stream ? c->fold_c : c->io_c;        // (see proj_sum_device)
+  DevBuf& lvl_b = c->on_fold_stream ? c->fold_d : c->io_d;
+  if (lvl_a.reserve((n / 2 + 1) * 576) || lvl_b.reserve((n / 4 + 1) * 576)) { g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP; }
   if (n == 0) {
     KLAUNCH(k_fp12_one, dim3(1), dim3(64), 0, c->stream, d_out);
     LAUNCHCHK();
@@ -2106,7 +2147,7 @@ static int fp12_product_device(blsgpu_ctx* c, const u32* d_in, size_t n, u32* d_
     int fan = 2;
     while (fan < FP12_PROD_FAN && (n + fan - 1) / fan > 65536) fan *= 2;
     size_t m = (n + fan - 1) / fan;
-    u32* o = (m == 1) ? d_out : (flip ? c->io_d.as<u32>() : c->io_c.as<u32>());
+    u32* o = (m == 1) ? d_out : (flip ? lvl_b.as<u32>() : lvl_a.as<u32>());
     if (m <= 32768 && c->pairing_layout != 2)            // latency-bound level: a quad per product
       KLAUNCH(k_fp12_prod_quad, dim3(nblk(m * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, in, o, n, m, fan);
     else
@@ -2322,17 +2363,34 @@ static int mmlp_launch(blsgpu_ctx* c, const void* g1, const void* g1inf, const v
   if (p && p->device != c->device) return bad("multi_miller_loop_prepared: the table lives on another device than the context");
   if (kmax < 1) kmax = 1;
   if (kmax > MMLP_MAX_K) kmax = MMLP_MAX_K;
-  const unsigned blocks = nblk(nseg * QL, QUAD_BLOCK);
-  const size_t threads = (size_t)blocks * QUAD_BLOCK;
+  // The work area is kmax x 260 B per lane.  Segments given by offsets are independent, so a call whose work area would pass
+  // MMLP_WORK_MAX is cut into launches over consecutive runs of segments that share ONE bounded area (in stream order): 2^20
+  // eight-term segments take nine launches over 1 GiB instead of reserving 8.7 GB.  (The offset-less form -- runs of ONE long product --
+  // keeps a single launch: its callers size K themselves.)
+  constexpr size_t MMLP_WORK_MAX = (size_t)1 << 30;
+  const size_t per_seg = (size_t)kmax * QL * 260;
+  size_t seg_cap = nseg;
+  if (d_off && nseg * per_seg > MMLP_WORK_MAX) {
+    seg_cap = MMLP_WORK_MAX / per_seg;
+    seg_cap -= seg_cap % (QUAD_BLOCK / QL);                         // whole workgroups
+    if (seg_cap < (size_t)(QUAD_BLOCK / QL)) seg_cap = QUAD_BLOCK / QL;
+  }
+  const unsigned blocks_max = nblk((seg_cap < nseg ? seg_cap : nseg) * QL, QUAD_BLOCK);
+  const size_t threads = (size_t)blocks_max * QUAD_BLOCK;
   // [kmax][threads] u32 meta | [kmax][4][threads] uint4 P | [kmax][12][threads] uint4 running points
   const size_t meta_b = (size_t)kmax * threads * 4, pp_b = (size_t)kmax * 4 * threads * 16, rr_b = (size_t)kmax * 12 * threads * 16;
   if (c->mmlp_work.reserve(meta_b + pp_b + rr_b)) { g_err = "hipMalloc(prepared Miller work area) failed"; return BLSGPU_ERR_HIP; }
   uint8_t* w = c->mmlp_work.as<uint8_t>();
   if (p) HIPCHK(hipStreamWaitEvent(c->stream, p->ev_ready, 0));
-  KLAUNCH(k_mml_prep_quad, dim3(blocks), dim3(QUAD_BLOCK), 0, c->stream, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2, (const uint8_t*)g2inf,
-                     (const u32*)(p ? qidx : nullptr), p ? p->tab : (const u32*)nullptr, p ? p->inf : (const uint8_t*)nullptr, (u32)(p ? p->n : 0),
-                     (const unsigned long long*)d_off, nseg, total, kuni, kmax, (u32*)w, (uint4*)(w + meta_b), (uint4*)(w + meta_b + pp_b), (u32*)out, c->d_status);
-  LAUNCHCHK();
+  for (size_t s0 = 0; s0 < nseg; s0 += seg_cap) {
+    const size_t ns = nseg - s0 < seg_cap ? nseg - s0 : seg_cap;
+    // (the kernel strides its work area by ITS grid size: a shorter last launch uses a prefix of each plane)
+    KLAUNCH(k_mml_prep_quad, dim3(nblk(ns * QL, QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, c->stream, (const u32*)g1, (const uint8_t*)g1inf, (const u32*)g2, (const uint8_t*)g2inf,
+                       (const u32*)(p ? qidx : nullptr), p ? p->tab : (const u32*)nullptr, p ? p->inf : (const uint8_t*)nullptr, (u32)(p ? p->n : 0),
+                       d_off ? (const unsigned long long*)d_off + s0 : (const unsigned long long*)nullptr, ns, total, kuni, kmax, (u32*)w, (uint4*)(w + meta_b),
+                       (uint4*)(w + meta_b + pp_b), (u32*)out + s0 * 144, c->d_status);
+    LAUNCHCHK();
+  }
   return BLSGPU_OK;
 }
 extern "C" int blsgpu_multi_miller_loop_prepared_device(blsgpu_ctx* c, const void* g1, const void* g1inf, const void* g2, const void* g2inf, const void* qidx,
@@ -2395,7 +2453,13 @@ extern "C" int blsgpu_multi_miller_loop_prepared_many_device(blsgpu_ctx* c, cons
   HIPCHK(hipSetDevice(c->device));
   if (final_exp && c->io_d.reserve(nseg * 576)) { g_err = "hipMalloc failed"; return BLSGPU_ERR_HIP; }
   u32* prod = final_exp ? c->io_d.as<u32>() : (u32*)out;
-  const int kmax = (max_seg_terms == 0 || max_seg_terms > (size_t)MMLP_MAX_K) ? MMLP_MAX_K : (int)max_seg_terms;
+  // terms per pass: the caller's bound, or -- bound unknown -- the mean segment length (a longer segment simply takes more passes, see
+  // k_mml_prep_quad), so that the work area stays proportional to the input: 2^20 two-term segments no longer reserve eight slots each
+  int kmax = (max_seg_terms == 0 || max_seg_terms > (size_t)MMLP_MAX_K) ? MMLP_MAX_K : (int)max_seg_terms;
+  if (max_seg_terms == 0) {
+    const size_t mean = (total + nseg - 1) / nseg;
+    if (mean < (size_t)kmax) kmax = mean < 1 ? 1 : (int)mean;
+  }
   int rc = mmlp_launch(c, g1, g1inf, g2, g2inf, qidx, p, d_off, nseg, total, 0, kmax, prod);
   if (rc) return rc;
   return final_exp ? final_exp_launch(c, prod, nseg, out) : BLSGPU_OK;
@@ -2862,6 +2926,9 @@ extern "C" void blsgpu_group_destroy(blsgpu_group* g) {
     if (wk->th.joinable()) wk->th.join();
     delete wk;
   }
+  // peer copies into fold_in that members queued on their own fold streams may still be in flight: drain every member before any
+  // event or buffer of the fold goes away
+  for (auto c : g->ctx) if (c) { hipSetDevice(c->device); hipDeviceSynchronize(); }
   for (size_t i = 0; i < g->ev_copy.size(); i++) if (g->ev_copy[i]) { hipSetDevice(g->ctx[i]->device); hipEventDestroy(g->ev_copy[i]); }
   for (size_t i = 0; i < g->ev_main.size(); i++) if (g->ev_main[i]) { hipSetDevice(g->ctx[i]->device); hipEventDestroy(g->ev_main[i]); }
   for (size_t i = 0; i < g->fold_reads.size(); i++) for (auto& fr : g->fold_reads[i]) if (fr.ev) { hipSetDevice(g->ctx[i]->device); hipEventDestroy(fr.ev); }
@@ -3060,6 +3127,7 @@ static int partials_fold_device(blsgpu_group* g, const void* const* d_partials, 
   for (size_t k = 1; k < w; k++) HIPCHK(hipStreamWaitEvent(c0->fold_stream, g->ev_copy[k], 0));
   hipStream_t keep = c0->stream;
   c0->stream = c0->fold_stream;
+  c0->on_fold_stream = true;
   if (G == 12) {
     // `MillerLoopResult + MillerLoopResult` over the members' partial products (pairings.rs:179-186), then -- if asked -- the ONE final exponentiation
     rc = w == 1 ? BLSGPU_OK : blsgpu_fp12_product_device(c0, stage, w, d_out);
@@ -3068,6 +3136,7 @@ static int partials_fold_device(blsgpu_group* g, const void* const* d_partials, 
     rc = G == 1 ? blsgpu_g1_sum_device(c0, stage, w, d_out) : blsgpu_g2_sum_device(c0, stage, w, d_out);
   }
   c0->stream = keep;
+  c0->on_fold_stream = false;
   if (rc) return rc;
   HIPCHK(hipEventRecord(g->ev_sum[row], c0->fold_stream));
   g->ev_sum_used[row] = true;

@@ -160,6 +160,11 @@ int blsgpu_g2_msm_many_device(blsgpu_ctx* ctx, const blsgpu_bases* bases, size_t
  * passes again.  First sight: the one-shot path as always.  Second sight: the set is uploaded as resident bases (subgroup test,
  * endomorphism images) and kept; later calls only move their scalars and run on the path of blsgpu_g1_msm. */
 int blsgpu_set_bases_cache(blsgpu_ctx* ctx, int entries);
+/* HAZARD of the cache above: with the default fingerprint a caller that reuses a same-length buffer and changes only points that are
+ * not among the 65 sampled ones gets an MSM over the STALE resident bases, with no error.  blsgpu_set_bases_cache_verify(ctx, 1) makes the
+ * cache recognise an array by a hash of every word instead (four host threads, ~3 ms per 2^20 G1 points per call): use it unless the
+ * arrays are known to be immutable (an SRS loaded once).  Switching the mode drops what is cached. */
+int blsgpu_set_bases_cache_verify(blsgpu_ctx* ctx, int enabled);
 /* One-shot convenience: upload, multiply, free.  No subgroup test and no endomorphism split (plain windows: exact for every
  * curve point) unless blsgpu_set_assume_subgroup(ctx, 1) -- see the subgroup contract above.  For a set used more than once
  * upload it (blsgpu_g1_bases_upload) and call blsgpu_g1_msm. */

@@ -762,3 +762,31 @@ int ora_g2_mul_batch_affine(const u64* xy, const uint8_t* inf, const uint8_t* sc
   }
   return used;
 }
+
+/* ---- `Scalar::to_bytes` (scalar.rs:284-296): montgomery_reduce(l0..l3, 0, 0, 0, 0) (scalar.rs:506-550) then `sub(&MODULUS)` (:420-432).
+ * What a host caller does per scalar before it can hand bytes to an MSM; bench.py times it on one thread next to the device-side
+ * conversion. ------------------------------------------------------------------------------------------------- */
+static const u64 FR_MODULUS[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull};   /* scalar.rs:76-81 */
+static const u64 FR_INV = 0xfffffffeffffffffull;                                                                                  /* scalar.rs:156 */
+static void fr_montgomery_reduce(const u64* in8, u64* out4) {
+  u64 r[8]; memcpy(r, in8, 64);
+  u64 carry2 = 0;
+  for (int i = 0; i < 4; i++) {
+    u64 k = r[i] * FR_INV, carry = 0;
+    (void)mac(r[i], k, FR_MODULUS[0], &carry);
+    for (int j = 1; j < 4; j++) r[i + j] = mac(r[i + j], k, FR_MODULUS[j], &carry);
+    r[i + 4] = adc(r[i + 4], carry2, &carry);
+    carry2 = carry;
+  }
+  /* (&Scalar([r4, r5, r6, r7])).sub(&MODULUS) */
+  u64 d[4], bw = 0, c = 0;
+  for (int i = 0; i < 4; i++) d[i] = sbb(r[4 + i], FR_MODULUS[i], &bw);
+  for (int i = 0; i < 4; i++) out4[i] = adc(d[i], FR_MODULUS[i] & bw, &c);
+}
+void ora_scalar_to_bytes_batch(const u64* limbs, long n, uint8_t* out) {
+  for (long i = 0; i < n; i++) {
+    u64 in8[8] = {limbs[4 * i], limbs[4 * i + 1], limbs[4 * i + 2], limbs[4 * i + 3], 0, 0, 0, 0}, t[4];
+    fr_montgomery_reduce(in8, t);
+    memcpy(out + 32 * i, t, 32);            /* to_le_bytes of each limb (little-endian host) */
+  }
+}

@@ -57,6 +57,7 @@ extern "C" {
     pub fn blsgpu_g1_msm_many_device(ctx: *mut BlsgpuCtx, bases: *const BlsgpuBases, first: usize, d_scalars: *const c_void, n: usize, k: usize, d_out_xyz: *mut c_void) -> c_int;
     pub fn blsgpu_g2_msm_many_device(ctx: *mut BlsgpuCtx, bases: *const BlsgpuBases, first: usize, d_scalars: *const c_void, n: usize, k: usize, d_out_xyz: *mut c_void) -> c_int;
     pub fn blsgpu_set_bases_cache(ctx: *mut BlsgpuCtx, entries: c_int) -> c_int;
+    pub fn blsgpu_set_bases_cache_verify(ctx: *mut BlsgpuCtx, enabled: c_int) -> c_int;
     pub fn blsgpu_g1_msm_host(ctx: *mut BlsgpuCtx, xy: *const u64, infinity: *const u8, scalars: *const u8, n: usize, out_xyz: *mut u64) -> c_int;
     pub fn blsgpu_g2_msm_host(ctx: *mut BlsgpuCtx, xy: *const u64, infinity: *const u8, scalars: *const u8, n: usize, out_xyz: *mut u64) -> c_int;
     pub fn blsgpu_g1_msm_bytes(ctx: *mut BlsgpuCtx, bases_uncompressed: *const u8, scalars: *const u8, n: usize, out: *mut u8) -> c_int;

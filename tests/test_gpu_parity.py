@@ -2622,6 +2622,33 @@ def test_bases_cache_for_repeated_one_shot_msms(kats):
     c.close()
 
 
+def test_bases_cache_verify_mode_sees_a_mutated_buffer():
+    """blsgpu_set_bases_cache_verify: an array is recognised by a hash of EVERY word, so a caller that reuses a buffer and changes a point
+    the 65-point fingerprint does not sample gets the MSM over the NEW contents (the default mode would silently serve the stale resident set --
+    the documented hazard, shown here too so that the documentation stays honest)"""
+    import bls12_381_amd as b
+    n = 4096
+    kb, ks = _rand_scalars_np(n, 1301)
+    sb, ss = _rand_scalars_np(n, 1302)
+    want = lambda keys: g1aff_w(o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, sum(k * s for k, s in zip(keys, ss)) % o.R_ORDER)))[0]
+    for verify in (True, False):
+        c = b.Context(0)
+        c.set_bases_cache(2)
+        c.set_bases_cache_verify(verify)
+        xy, inf = c.bases_from_scalars(1, kb).download()
+        for _ in range(3):                                   # first sight, resident upload, cached
+            assert np.array_equal(c.batch_normalize(1, c.msm_host(1, xy, inf, sb)[None, :])[0][0], want(ks))
+        # position 5 lies between the sampled positions (step n / 64 = 64): replace it by another multiple of the generator
+        ks2 = list(ks); ks2[5] = 0xABCDEF
+        xy[5] = g1aff_w(o.g1_to_affine(o.g1_affine_mul(o.G1_GEN, ks2[5])))[0]
+        got = c.batch_normalize(1, c.msm_host(1, xy, inf, sb)[None, :])[0][0]
+        if verify:
+            assert np.array_equal(got, want(ks2))
+        else:
+            assert np.array_equal(got, want(ks))             # stale: the hazard include/bls12_381_hip.h warns about
+        c.close()
+
+
 def test_prepared_equations_full_size_2_16_bilinearity(ctx):
     """2^16 verification-shaped equations at the bench's size through the prepared path, checked by a size-independent property:
     e(a_i G1, [k1] G2) e(b_i G1, [k2] G2) e(-(a_i k1 + b_i k2) G1, G2) = 1 for every i (bilinearity), with [k1] G2 and [k2] G2 prepared and
@@ -2737,3 +2764,24 @@ def test_device_group_asynchronous_pairings_and_fp12_fold(ctx, members):
         grp.synchronize()
         assert np.array_equal(res.cpu().numpy().view(np.uint64), want), fe
     grp.close()
+
+
+def test_bench_two_ranks_on_one_gpu_runs_the_exchange_with_real_kernels():
+    """The multi-rank path of bench.py with REAL kernels on both ranks (the build box has one GPU): two processes, gloo
+    collectives, both on GPU 0, ONE 2^18-point MSM sharded two ways -- partial sums all-gathered, folded on every rank, ranks compared, and
+    the folded point checked against the discrete-log identity [sum s_i k_i] G (`result_matches_identity`)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", GLOO_SOCKET_IFNAME="lo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--log-total", "18", "--steps", "4", "--warmup", "2",
+           "--no-cpu-baseline", "--no-extras"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["total_points"] == 1 << 18
+    assert line["result_matches_identity"] is True
+    assert line["ranks"]["world"] == 2 and line["ranks"]["world_from_process_group"] == 2 and line["ranks"]["backend"] == "gloo" and line["ranks"]["same_device"] is True
+    assert line["value"] > 0

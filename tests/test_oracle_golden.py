@@ -385,6 +385,12 @@ def test_scalar_byte_conversions_limb_level(kats):
         assert o.scalar_limbs_from_bytes_wide((w % (1 << 512)).to_bytes(64, "little")) == o.fr_to_mont_limbs(o.fr_from_bytes_wide((w % (1 << 512)).to_bytes(64, "little")))
         a, b_ = o.fr_to_mont_limbs(g.scalar()), o.fr_to_mont_limbs(g.scalar())
         assert o.scalar_limbs_mul(a, b_) == o.fr_to_mont_limbs(o.fr_mul(o.fr_from_mont_limbs(a), o.fr_from_mont_limbs(b_)))
+    # the C port of `to_bytes` (bench.py's host-side conversion figure) against the same definitions
+    from oracle import c_oracle
+    import numpy as np
+    vals = [0, 1, r - 1, r - 2] + [g.scalar() for _ in range(500)]
+    L = np.array([o.fr_to_mont_limbs(v) for v in vals], dtype=np.uint64)
+    assert [bytes(row) for row in c_oracle.scalar_to_bytes_batch(L)] == [v.to_bytes(32, "little") for v in vals]
 
 
 def test_fr_ntt_definition():

@@ -8,6 +8,8 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 NG=$(python -c "import torch; print(torch.cuda.device_count())")
 for N in 1 2 4 8; do
   if [ "$N" -le "$NG" ]; then
+    # (the line carries "ranks": the process group's own world size, the backend, lazy / eager RCCL communicator, devices visible -- and
+    # "result_matches_identity": the folded point checked against [sum s_i k_i] G)
     python bench.py --gpus $N --no-cpu-baseline --no-extras "$@" | tail -1
     # the same sharded MSM from ONE process (the C library's device group; round 5)
     python bench.py --group $N --no-cpu-baseline --no-extras "$@" | tail -1
