@@ -118,4 +118,7 @@ DEV fe2 store2(const Fe2<A, V>& a) {
 DEV fe2 fe2_zero() { fe2 r; r.c0 = (Fe<1, VS2>)fe_zero(); r.c1 = (Fe<1, VS2>)fe_zero(); return r; }
 DEV fe2 fe2_one() { fe2 r; r.c0 = (Fe<1, VS2>)fe_one(); r.c1 = (Fe<1, VS2>)fe_zero(); return r; }
 
+// u (c0 + c1 u) = -c1 + c0 u
+template <int A, int V> DEV auto mul_by_u(const Fe2<A, V>& a) { Fe2<A + 1, V + 1> r; r.c0 = neg(a.c1); r.c1 = a.c0; return r; }
+
 }  // namespace bls

@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(256, FR_TILE_WAVES) k_fr_tile(const u32* __res
 // k_fr_tile), runs all d stages there with the radix-4 schedule of k_fr_tile (R stage + F stage per round trip, twiddles read from the
 // per-level tables at the element's GLOBAL offset), and writes the tile back where it came from with values in [0, 2r).  One pass over
 // the data instead of d / 2: the 2^20 transform is two such passes of five stages + k_fr_tile (ten stages) = three passes instead of
-// six, the 2^24 transform 2 x 7 stages + k_fr_tile instead of eight passes (the shape is the host's: api.hip::blsgpu_fr_ntt_device).
+// six, the 2^24 transform 2 x 7 stages + k_fr_tile instead of eight passes (the shape is the host's: api_aux.hip::blsgpu_fr_ntt_device).
 // Block b = (hi, chunk): hi = b >> (ls - lk) selects the aligned block of 2^(lh_top+1) elements, chunk the K columns inside a stride.
 constexpr int FR_COLS_LOG = 12;                    // largest tile the host may ask for: 4096 elements x 9 limbs = 144 KB of the CU's 160 KB
 constexpr int FR_COLS_BLOCK = 1024;

@@ -11,6 +11,7 @@
 // Only the XMD/SHA-256 expander (the BLS-signature suites) is provided.
 #pragma once
 #include "codec.hip.h"
+#include "pairlane.hip.h"
 
 namespace bls {
 
@@ -398,7 +399,7 @@ k_hash_to_curve(const uint8_t* __restrict__ msgs, const unsigned long long* __re
 // 2 x LANES lanes, group 0 maps u0 and group 1 maps u1 side by side, group 1 hands its image over with one DPP move per word
 // (LANES = 1: quad_perm:[1,0,3,2], LANES = 2: quad_perm:[2,3,0,1]) and retires; group 0 adds, clears the cofactor and stores.  Same
 // field elements in the same order as k_hash_to_curve, so the projective limbs are identical.  The host picks it for batches that leave
-// the chip under-filled (api.hip::h2c_launch); `BLSGPU_H2C_SPLIT=0|1` forces either form.
+// the chip under-filled (api_aux.hip::h2c_launch); `BLSGPU_H2C_SPLIT=0|1` forces either form.
 template <int CTRL> DEV u32 h2c_dpp(u32 x) { return (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xF, 0xF, true); }
 template <int CTRL, int A, int V> DEV Fe<A, V> h2c_partner(const Fe<A, V>& a) {
   Fe<A, V> r;

@@ -28,6 +28,7 @@
 #include <type_traits>
 #include "convert.hip.h"
 #include "scalar.hip.h"
+#include "limits.h"
 #include "team.hip.h"
 #include "pairlane.hip.h"
 
@@ -641,7 +642,6 @@ __global__ void __launch_bounds__(256) k_msm_scatter(const u32* __restrict__ ent
 // by many scalars -- or the narrow top window -- would otherwise serialise a whole bucket on one lane) and
 // sorting by length makes the 64 lanes of a wavefront finish together.  Buckets with one item write their
 // sum straight into the bucket array; the others ("heavy") write partial sums that k_msm_heavy folds.
-constexpr int ITEM_CAP_MAX = 4096;                // the cap is chosen per call: max(128, ~4 x mean bucket load)
 constexpr int ITEM_BINS = ITEM_CAP_MAX + 1;       // bin = cap - len  (bin 0 = longest)
 constexpr int HEAVY_SMALL = 16;                   // heavy buckets with <= this many partials are folded by one lane
 struct ItemDesc { u32 start, len, dest; };        // entries [start, start+len) of `sorted`; dest = record index

@@ -24,6 +24,7 @@
 #pragma once
 #include "convert.hip.h"
 #include "scalar.hip.h"
+#include "limits.h"
 #include "pairlane.hip.h"
 
 namespace bls {
@@ -65,7 +66,6 @@ template <int A1, int V1, int A2, int V2> DEV auto pmul(const FeP<A1, V1>& a, co
 template <int A, int V> DEV auto psqr(const Fe2<A, V>& a) { return sqr(a); }
 template <int A, int V> DEV auto psqr(const FeP<A, V>& a) { return sqr_ni(a); }
 // (a0 + a1 u) u = -a1 + a0 u
-template <int A, int V> DEV auto mul_by_u(const Fe2<A, V>& a) { Fe2<A + 1, V + 1> r; r.c0 = neg(a.c1); r.c1 = a.c0; return r; }
 
 #ifndef BLS_PAIRING_BLOCK
 #define BLS_PAIRING_BLOCK 256
@@ -391,7 +391,6 @@ template <class E> DEV void miller_loop(Fp12T<E>& fout, const fe1& px_, const fe
 // line(s) and the accumulator is squared once, instead of K accumulators each paying the 62 squarings.  Same element
 // as the product of the K separate Miller values (f <- f^2 * prod l_k = prod (f_k^2 l_k)).  Identity terms are skipped
 // (:566-569).  Per-term state (P, Q in internal form and the running point R) lives in per-lane scratch.
-constexpr int MML_MAX_K = 8;
 template <class E> struct MmlTerm { fe1 px, py; E qx, qy; G2JacT<E> r; bool skip; };
 template <class E> DEVNI void multi_miller_shared(Fp12T<E>& fout, MmlTerm<E>* t, int K) {
   Fp12T<E> f = fp12_one<E>();               // non-escaping, like miller_loop's

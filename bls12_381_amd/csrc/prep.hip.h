@@ -20,15 +20,14 @@
 // q_doubling_step / q_addition_step -- so raw Miller values stay limb-identical to both the unprepared kernels and the oracle.
 #pragma once
 #include "quad.hip.h"
+#include "limits.h"
 
 namespace bls {
 
 constexpr int PREP_STEPS = 68;                      // 63 doubling + 5 addition steps (pairings.rs:516-546)
 constexpr int PREP_LW = 16;                         // words per lane-coefficient (14 limbs + 2 of padding)
 constexpr size_t PREP_POINT_WORDS = (size_t)PREP_STEPS * 3 * 2 * PREP_LW;
-constexpr u32 PREP_NONE = 0xffffffffu;              // per-term index: not prepared, Q comes from the g2 array
 constexpr u32 PREP_SKIP = 0xfffffffeu;              // (internal) the term is skipped: identity on either side (pairings.rs:566-569)
-constexpr int MMLP_MAX_K = 8;                       // terms that share one pass of the loop; longer segments take several passes
 
 // which of the 68 steps are addition steps: walking the bits of BLS_X >> 1 below the leading one, a set bit appends an addition step
 // behind that iteration's doubling step (pairings.rs:671-687)

@@ -273,7 +273,7 @@ _RUST_TYPES = {"c_int": "int", "usize": "size_t", "c_uint": "unsigned", "*mut Bl
                "*mut BlsgpuBases": "blsgpu_bases*", "*const BlsgpuBases": "const blsgpu_bases*", "*mut *mut BlsgpuBases": "blsgpu_bases**",
                "*const u64": "const uint64_t*", "*mut u64": "uint64_t*", "*const u8": "const uint8_t*", "*mut u8": "uint8_t*",
                "*const c_void": "const void*", "*mut c_void": "void*", "*mut f64": "double*", "*mut f32": "float*", "*mut c_uint": "unsigned*",
-               "*const c_char": "const char*", "*const c_int": "const int*",
+               "*const c_char": "const char*", "*mut c_char": "char*", "*mut usize": "size_t*", "*const c_int": "const int*",
                "*mut BlsgpuGroup": "blsgpu_group*", "*const BlsgpuGroup": "const blsgpu_group*", "*mut *mut BlsgpuGroup": "blsgpu_group**",
                "*mut BlsgpuG2Prepared": "blsgpu_g2_prepared*", "*const BlsgpuG2Prepared": "const blsgpu_g2_prepared*", "*mut *mut BlsgpuG2Prepared": "blsgpu_g2_prepared**",
                "*const u32": "const uint32_t*", "*mut u32": "uint32_t*", "*const *const c_void": "const void*const*", "*const *mut c_void": "void*const*", "*const usize": "const size_t*",

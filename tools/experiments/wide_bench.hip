@@ -1,4 +1,4 @@
-// wide_bench.hip -- standalone timing / parity harness for k_pairing_wide (development tool; the product path is api.hip).
+// wide_bench.hip -- standalone timing / parity harness for k_pairing_wide (development tool; the product path is api_pairing.hip).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ibls12_381_amd/csrc tools/experiments/wide_bench.hip -o build/wide_bench
 //   build/wide_bench bls12_381_amd/wide_prog.bin build/wide_case.bin      (case file: tools/experiments/wide_case.py)
 #include <hip/hip_runtime.h>
