@@ -57,7 +57,7 @@ def static_traffic(tag):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc summary of the SAME workload (profiles/<round>_<tag>_pmc.json,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE).  Counters cannot be read inside a timed
     run, so this is a STATIC figure from a separate profiled run -- labelled as such in the bench line."""
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (rnd, tag))
         if os.path.exists(path):
             try:

@@ -69,6 +69,12 @@ SIGNATURES = {
     "blsgpu_g1_hash_to_curve_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp, c_sz, c_int, c_vp]),
     "blsgpu_g2_hash_to_curve_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp, c_sz, c_int, c_vp]),
     "blsgpu_hash_to_curve_device": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp, c_sz, c_int, c_vp]),
+    "blsgpu_hash_to_curve_expander_batch": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_sz, c_vp, c_sz, c_int, c_vp]),
+    "blsgpu_hash_to_curve_expander_device": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_sz, c_vp, c_sz, c_int, c_vp]),
+    "blsgpu_expand_message_batch": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp, c_sz, c_sz, c_vp]),
+    "blsgpu_expand_message_device": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp, c_sz, c_sz, c_vp]),
+    "blsgpu_hash_to_scalar_batch": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp, c_sz, c_sz, c_vp]),
+    "blsgpu_hash_to_scalar_device": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp, c_sz, c_sz, c_vp]),
     "blsgpu_gt_mul_scalar_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g1_msm_bytes": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
     "blsgpu_g2_msm_bytes": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),

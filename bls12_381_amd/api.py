@@ -63,6 +63,7 @@ def _flags(f, n):
 
 _R_WORDS = np.frombuffer(R_ORDER.to_bytes(32, "little"), dtype="<u8")
 SCALAR_BYTES, SCALAR_MONT = 0, 1          # include/bls12_381_hip.h: BLSGPU_SCALAR_BYTES / BLSGPU_SCALAR_MONT
+EXPAND_XMD_SHA256, EXPAND_XMD_SHA512, EXPAND_XOF_SHAKE128, EXPAND_XOF_SHAKE256 = 0, 1, 2, 3      # BLSGPU_EXPAND_*
 
 
 def scalars_are_canonical(sb):
@@ -473,6 +474,37 @@ class Context:
         out = np.zeros((n, 18 if group == 1 else 36), dtype=np.uint64)
         fn = self.lib.blsgpu_g1_hash_to_curve_batch if group == 1 else self.lib.blsgpu_g2_hash_to_curve_batch
         check(fn(self.h, _ptr(blob), _ptr(offs), n, _ptr(d), len(dst), 1 if encode_only else 0, _ptr(out)), "hash_to_curve")
+        return out
+
+    @staticmethod
+    def _msgs(msgs, dst):
+        msgs = [bytes(m) for m in msgs]
+        offs = np.zeros(len(msgs) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64) if msgs else 0
+        blob = np.frombuffer(b"".join(msgs) + b"\0", dtype=np.uint8).copy()
+        d = np.frombuffer(bytes(dst) + b"\0", dtype=np.uint8).copy()
+        return len(msgs), blob, offs, d
+
+    def hash_to_curve_expander(self, group, expander, msgs, dst, encode_only=False):
+        """`hash_to_curve::<X>` / `encode_to_curve::<X>` with X chosen by `expander` (EXPAND_XMD_SHA256 / _XMD_SHA512 / _XOF_SHAKE128 / _XOF_SHAKE256:
+        expand_msg.rs:167-328); returns (n, 18 | 36) u64 projective points"""
+        n, blob, offs, d = self._msgs(msgs, dst)
+        out = np.zeros((n, 18 if group == 1 else 36), dtype=np.uint64)
+        check(self.lib.blsgpu_hash_to_curve_expander_batch(self.h, group, int(expander), _ptr(blob), _ptr(offs), n, _ptr(d), len(dst), 1 if encode_only else 0, _ptr(out)), "hash_to_curve_expander")
+        return out
+
+    def expand_message(self, expander, msgs, dst, len_in_bytes):
+        """`ExpandMessage::init_expand` + reading all the bytes: (n, len_in_bytes) uint8"""
+        n, blob, offs, d = self._msgs(msgs, dst)
+        out = np.zeros((n, len_in_bytes), dtype=np.uint8)
+        check(self.lib.blsgpu_expand_message_batch(self.h, int(expander), _ptr(blob), _ptr(offs), n, _ptr(d), len(dst), len_in_bytes, _ptr(out)), "expand_message")
+        return out
+
+    def hash_to_scalar(self, expander, msgs, dst, count=1):
+        """`hash_to_field::<X, Scalar>` (mod.rs:32-49, map_scalar.rs:10-25): (n, count, 4) u64 Montgomery limbs"""
+        n, blob, offs, d = self._msgs(msgs, dst)
+        out = np.zeros((n, count, 4), dtype=np.uint64)
+        check(self.lib.blsgpu_hash_to_scalar_batch(self.h, int(expander), _ptr(blob), _ptr(offs), n, _ptr(d), len(dst), count, _ptr(out)), "hash_to_scalar")
         return out
 
     # ---- scalar field Fr (reference: src/scalar.rs) ----

@@ -3,6 +3,7 @@
 #include "host.h"
 #include "fr.hip.h"
 #include "h2c.hip.h"
+#include "expand_kernels.hip.h"
 #include "codec.hip.h"
 #include "generators.hip.h"
 
@@ -14,7 +15,22 @@ using namespace bls;
 // one launch of the batched hash: group 1 = one lane per message, group 2 = one lane pair; batches that leave the chip under-filled take
 // the split form (two lane groups per message, h2c.hip.h) -- up to 2^15 messages to G1 (<= 1 024 wavefronts of 64 lanes at one per SIMD),
 // up to 2^14 to G2 (4 lanes each: 1 024 wavefronts).  Measured on MI355X, 2^14 32-byte messages: see DESIGN.md 4.8.
-static void h2c_launch(blsgpu_ctx* c, int group, const uint8_t* msgs, const unsigned long long* offs, size_t n, const uint8_t* dst, u32 dlen, int encode_only, u32* out) {
+// uniform bytes of n messages into c->h2c_uniform (any expander; k_expand_message)
+static int expand_launch(blsgpu_ctx* c, int expander, const uint8_t* msgs, const unsigned long long* offs, size_t n, const uint8_t* dst, u32 dlen, u32 len_in_bytes, uint8_t* out) {
+  KLAUNCH(k_expand_message, dim3(nblk(n, 64)), dim3(64), 0, c->stream, expander, msgs, offs, n, dst, dlen, len_in_bytes, out);
+  LAUNCHCHK();
+  return BLSGPU_OK;
+}
+static int h2c_launch(blsgpu_ctx* c, int group, int expander, const uint8_t* msgs, const unsigned long long* offs, size_t n, const uint8_t* dst, u32 dlen, int encode_only, u32* out) {
+  if (expander != EXPAND_XMD_SHA256) {
+    // the reference's other expanders (expand_msg.rs:167-328 over SHA-512 / SHAKE128 / SHAKE256): expand, then map from the uniform bytes
+    const u32 len = (u32)((encode_only ? 1 : 2) * (group == 1 ? 1 : 2) * 64);
+    if (c->h2c_uniform.reserve(n * (size_t)len)) { g_err = "hipMalloc(uniform bytes) failed"; return BLSGPU_ERR_HIP; }
+    if (int rc = expand_launch(c, expander, msgs, offs, n, dst, dlen, len, c->h2c_uniform.as<uint8_t>())) return rc;
+    if (group == 1) KLAUNCH(k_hash_to_curve_uniform<FpPolicy>, dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->h2c_uniform.as<uint8_t>(), n, encode_only ? 1 : 0, out);
+    else KLAUNCH(k_hash_to_curve_uniform<Fp2PairPolicy>, dim3(nblk(n * 2, 256)), dim3(256), 0, c->stream, c->h2c_uniform.as<uint8_t>(), n, encode_only ? 1 : 0, out);
+    return BLSGPU_OK;
+  }
   const int forced = c->h2c_split;
   const bool split = !encode_only && (forced >= 0 ? forced == 1 : n <= (group == 1 ? (size_t)1 << 15 : (size_t)1 << 14));
   if (group == 1) {
@@ -24,37 +40,28 @@ static void h2c_launch(blsgpu_ctx* c, int group, const uint8_t* msgs, const unsi
     if (split) KLAUNCH(k_hash_to_curve_split<Fp2PairPolicy>, dim3(nblk(n * 4, 256)), dim3(256), 0, c->stream, msgs, offs, n, dst, dlen, out);
     else KLAUNCH(k_hash_to_curve<Fp2PairPolicy>, dim3(nblk(n * 2, 256)), dim3(256), 0, c->stream, msgs, offs, n, dst, dlen, encode_only ? 1 : 0, out);
   }
+  return BLSGPU_OK;
 }
 template <class F>
-static int h2c_host(blsgpu_ctx* c, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst, size_t dst_len, int encode_only,
+static int h2c_host(blsgpu_ctx* c, int expander, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst, size_t dst_len, int encode_only,
                     uint64_t* out) {
+  if (expander < EXPAND_XMD_SHA256 || expander > EXPAND_XOF_SHAKE256) return bad("hash_to_curve: unknown expander");
   if (!c || (n && (!offsets || !out)) || (dst_len && !dst)) return bad("hash_to_curve: NULL argument");
   if (!n) return BLSGPU_OK;
   const size_t total = (size_t)offsets[n];
   for (size_t i = 0; i < n; i++) if (offsets[i] > offsets[i + 1]) return bad("hash_to_curve: offsets must be non-decreasing");
   if (total && !msgs) return bad("hash_to_curve: NULL argument");
   HIPCHK(hipSetDevice(c->device));
-  // a DST longer than 255 bytes is replaced by H("H2C-OVERSIZE-DST-" || DST)  (expand_msg.rs:74-95)
-  uint8_t d[255]; u32 dlen;
-  if (dst_len > 255) {
-    Sha256 s; sha_init(s);
-    const char* salt = "H2C-OVERSIZE-DST-";
-    for (int i = 0; salt[i]; i++) sha_put(s, (uint8_t)salt[i]);
-    for (size_t i = 0; i < dst_len; i++) sha_put(s, dst[i]);
-    u32 hw[8]; sha_finish(s, hw);
-    for (int i = 0; i < 32; i++) d[i] = (uint8_t)(hw[i >> 2] >> (24 - 8 * (i & 3)));
-    dlen = 32;
-  } else {
-    for (size_t i = 0; i < dst_len; i++) d[i] = dst[i];
-    dlen = (u32)dst_len;
-  }
+  // a DST longer than 255 bytes is replaced by H("H2C-OVERSIZE-DST-" || DST)  (expand_msg.rs:47-95)
+  uint8_t d[255];
+  const u32 dlen = h2c_reduce_dst(expander, dst, dst_len, d);
   constexpr int WW = Wire<F>::WORDS;
   if (c->io_a.reserve(total + 16) || c->io_b.reserve((n + 1) * 8) || c->io_c.reserve(256) || c->io_out.reserve(n * 3 * WW * 4)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
   if (total) HIPCHK(hipMemcpyAsync(c->io_a.p, msgs, total, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->io_b.p, offsets, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
   if (dlen) HIPCHK(hipMemcpyAsync(c->io_c.p, d, dlen, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));                 // `d` lives on this stack frame
-  h2c_launch(c, GroupTag<F>::id, c->io_a.as<uint8_t>(), (const unsigned long long*)c->io_b.p, n, c->io_c.as<uint8_t>(), dlen, encode_only, c->io_out.as<u32>());
+  { int rl = h2c_launch(c, GroupTag<F>::id, expander, c->io_a.as<uint8_t>(), (const unsigned long long*)c->io_b.p, n, c->io_c.as<uint8_t>(), dlen, encode_only, c->io_out.as<u32>()); if (rl) return rl; }
   LAUNCHCHK();
   HIPCHK(hipMemcpyAsync(out, c->io_out.p, n * 3 * WW * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -62,22 +69,104 @@ static int h2c_host(blsgpu_ctx* c, const uint8_t* msgs, const uint64_t* offsets,
 }
 extern "C" int blsgpu_g1_hash_to_curve_batch(blsgpu_ctx* c, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst, size_t dst_len,
                                              int encode_only, uint64_t* out_xyz) { CTX_CLAIM(c);
-  return h2c_host<FpPolicy>(c, msgs, offsets, n, dst, dst_len, encode_only, out_xyz);
+  return h2c_host<FpPolicy>(c, EXPAND_XMD_SHA256, msgs, offsets, n, dst, dst_len, encode_only, out_xyz);
 }
 extern "C" int blsgpu_g2_hash_to_curve_batch(blsgpu_ctx* c, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst, size_t dst_len,
                                              int encode_only, uint64_t* out_xyz) { CTX_CLAIM(c);
-  return h2c_host<Fp2Policy>(c, msgs, offsets, n, dst, dst_len, encode_only, out_xyz);
+  return h2c_host<Fp2Policy>(c, EXPAND_XMD_SHA256, msgs, offsets, n, dst, dst_len, encode_only, out_xyz);
 }
 // device-resident variant: messages, offsets (n + 1 u64) and the DST (<= 255 bytes) already in device memory
-extern "C" int blsgpu_hash_to_curve_device(blsgpu_ctx* c, int group, const void* d_msgs, const void* d_offsets, size_t n, const void* d_dst, size_t dst_len,
-                                           int encode_only, void* d_out_xyz) { CTX_CLAIM(c);
+static int h2c_device(blsgpu_ctx* c, int group, int expander, const void* d_msgs, const void* d_offsets, size_t n, const void* d_dst, size_t dst_len, int encode_only, void* d_out_xyz) {
   if (!c || (n && (!d_offsets || !d_out_xyz)) || (dst_len && !d_dst)) return bad("hash_to_curve: NULL argument");
   if (dst_len > 255) return bad("hash_to_curve_device: reduce a DST longer than 255 bytes on the host first");
   if (group != 1 && group != 2) return bad("hash_to_curve: group must be 1 or 2");
+  if (expander < EXPAND_XMD_SHA256 || expander > EXPAND_XOF_SHAKE256) return bad("hash_to_curve: unknown expander");
   if (!n) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
-  h2c_launch(c, group, (const uint8_t*)d_msgs, (const unsigned long long*)d_offsets, n, (const uint8_t*)d_dst, (u32)dst_len, encode_only, (u32*)d_out_xyz);
+  if (int rc = h2c_launch(c, group, expander, (const uint8_t*)d_msgs, (const unsigned long long*)d_offsets, n, (const uint8_t*)d_dst, (u32)dst_len, encode_only, (u32*)d_out_xyz)) return rc;
   LAUNCHCHK();
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_hash_to_curve_device(blsgpu_ctx* c, int group, const void* d_msgs, const void* d_offsets, size_t n, const void* d_dst, size_t dst_len,
+                                           int encode_only, void* d_out_xyz) { CTX_CLAIM(c);
+  return h2c_device(c, group, EXPAND_XMD_SHA256, d_msgs, d_offsets, n, d_dst, dst_len, encode_only, d_out_xyz);
+}
+// ---- the reference's other expanders, uniform bytes, and `HashToField for Scalar` (expand.hip.h) ---------------------------------------
+// `G1Projective::hash_to_curve::<X>` / `encode_to_curve::<X>` (hash_to_curve/mod.rs:86-108) for X = ExpandMsgXmd<Sha256 | Sha512> or
+// ExpandMsgXof<Shake128 | Shake256> (expand_msg.rs:167-328)
+extern "C" int blsgpu_hash_to_curve_expander_batch(blsgpu_ctx* c, int group, int expander, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst, size_t dst_len,
+                                                   int encode_only, uint64_t* out_xyz) { CTX_CLAIM(c);
+  if (group != 1 && group != 2) return bad("hash_to_curve: group must be 1 or 2");
+  return group == 1 ? h2c_host<FpPolicy>(c, expander, msgs, offsets, n, dst, dst_len, encode_only, out_xyz) : h2c_host<Fp2Policy>(c, expander, msgs, offsets, n, dst, dst_len, encode_only, out_xyz);
+}
+extern "C" int blsgpu_hash_to_curve_expander_device(blsgpu_ctx* c, int group, int expander, const void* d_msgs, const void* d_offsets, size_t n, const void* d_dst, size_t dst_len,
+                                                    int encode_only, void* d_out_xyz) { CTX_CLAIM(c);
+  return h2c_device(c, group, expander, d_msgs, d_offsets, n, d_dst, dst_len, encode_only, d_out_xyz);
+}
+// `ExpandMessage::init_expand` + reading all `len_in_bytes` bytes, per message (out: n x len_in_bytes)
+extern "C" int blsgpu_expand_message_device(blsgpu_ctx* c, int expander, const void* d_msgs, const void* d_offsets, size_t n, const void* d_dst, size_t dst_len, size_t len_in_bytes,
+                                            void* d_out) { CTX_CLAIM(c);
+  if (!c || (n && (!d_offsets || !d_out)) || (dst_len && !d_dst)) return bad("expand_message: NULL argument");
+  if (expander < EXPAND_XMD_SHA256 || expander > EXPAND_XOF_SHAKE256) return bad("expand_message: unknown expander");
+  if (dst_len > 255) return bad("expand_message_device: reduce a DST longer than 255 bytes on the host first");
+  // expand_msg.rs:181-183, :263-268: the reference panics beyond these
+  if (len_in_bytes > 65535) return bad("expand_message: len_in_bytes must not exceed 65535");
+  if (expander <= EXPAND_XMD_SHA512 && (len_in_bytes + (expander == EXPAND_XMD_SHA256 ? 31 : 63)) / (expander == EXPAND_XMD_SHA256 ? 32 : 64) > 255) return bad("expand_message: more than 255 digest blocks");
+  if (!n || !len_in_bytes) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  return expand_launch(c, expander, (const uint8_t*)d_msgs, (const unsigned long long*)d_offsets, n, (const uint8_t*)d_dst, (u32)dst_len, (u32)len_in_bytes, (uint8_t*)d_out);
+}
+// messages / offsets / DST from the host into io_a / io_b / io_c (the DST reduced if it is longer than 255 bytes); returns the DST length through *dlen
+static int h2c_stage(blsgpu_ctx* c, int expander, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst, size_t dst_len, u32* dlen) {
+  if (expander < EXPAND_XMD_SHA256 || expander > EXPAND_XOF_SHAKE256) return bad("unknown expander");
+  const size_t total = (size_t)offsets[n];
+  for (size_t i = 0; i < n; i++) if (offsets[i] > offsets[i + 1]) return bad("offsets must be non-decreasing");
+  if (total && !msgs) return bad("NULL messages");
+  HIPCHK(hipSetDevice(c->device));
+  uint8_t d[255];
+  *dlen = h2c_reduce_dst(expander, dst, dst_len, d);
+  if (c->io_a.reserve(total + 16) || c->io_b.reserve((n + 1) * 8) || c->io_c.reserve(256)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  if (total) HIPCHK(hipMemcpyAsync(c->io_a.p, msgs, total, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->io_b.p, offsets, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  if (*dlen) HIPCHK(hipMemcpyAsync(c->io_c.p, d, *dlen, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));                 // `d` lives on this stack frame
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_expand_message_batch(blsgpu_ctx* c, int expander, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst, size_t dst_len, size_t len_in_bytes,
+                                           uint8_t* out) { CTX_CLAIM(c);
+  if (!c || (n && (!offsets || !out)) || (dst_len && !dst)) return bad("expand_message: NULL argument");
+  if (!n || !len_in_bytes) return BLSGPU_OK;
+  u32 dlen = 0;
+  if (int rc = h2c_stage(c, expander, msgs, offsets, n, dst, dst_len, &dlen)) return rc;
+  if (c->io_out.reserve(n * len_in_bytes)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  if (int rc = blsgpu_expand_message_device(c, expander, c->io_a.p, c->io_b.p, n, c->io_c.p, dlen, len_in_bytes, c->io_out.p)) return rc;
+  HIPCHK(hipMemcpyAsync(out, c->io_out.p, n * len_in_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
+// `hash_to_field::<X, Scalar>` (mod.rs:32-49 with map_scalar.rs:10-25): `count` scalars per message as Montgomery limbs (out: n x count x 4 u64)
+extern "C" int blsgpu_hash_to_scalar_device(blsgpu_ctx* c, int expander, const void* d_msgs, const void* d_offsets, size_t n, const void* d_dst, size_t dst_len, size_t count,
+                                            void* d_out) { CTX_CLAIM(c);
+  if (!c || (n && count && (!d_offsets || !d_out)) || (dst_len && !d_dst)) return bad("hash_to_scalar: NULL argument");
+  if (count * 48 > 65535) return bad("hash_to_scalar: count * 48 must not exceed 65535 (expand_msg.rs:181-183)");
+  if (!n || !count) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  if (c->h2c_uniform.reserve(n * count * 48)) { g_err = "hipMalloc(uniform bytes) failed"; return BLSGPU_ERR_HIP; }
+  if (int rc = blsgpu_expand_message_device(c, expander, d_msgs, d_offsets, n, d_dst, dst_len, count * 48, c->h2c_uniform.p)) return rc;
+  KLAUNCH(k_hash_to_scalar, dim3(nblk(n * count, 256)), dim3(256), 0, c->stream, c->h2c_uniform.as<uint8_t>(), n * count, (u32*)d_out);
+  LAUNCHCHK();
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_hash_to_scalar_batch(blsgpu_ctx* c, int expander, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst, size_t dst_len, size_t count,
+                                           uint64_t* out) { CTX_CLAIM(c);
+  if (!c || (n && count && (!offsets || !out)) || (dst_len && !dst)) return bad("hash_to_scalar: NULL argument");
+  if (!n || !count) return BLSGPU_OK;
+  u32 dlen = 0;
+  if (int rc = h2c_stage(c, expander, msgs, offsets, n, dst, dst_len, &dlen)) return rc;
+  if (c->io_out.reserve(n * count * 32)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  if (int rc = blsgpu_hash_to_scalar_device(c, expander, c->io_a.p, c->io_b.p, n, c->io_c.p, dlen, count, c->io_out.p)) return rc;
+  HIPCHK(hipMemcpyAsync(out, c->io_out.p, n * count * 32, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
   return BLSGPU_OK;
 }
 
@@ -188,7 +277,8 @@ extern "C" int blsgpu_fr_ntt_device(blsgpu_ctx* c, void* d_data, int log_n, int 
   // passes stay.  BLSGPU_NTT_COLS="tile log2,stages per pass,lanes" overrides the shape for experiments.
   if (c->fr_cols_ok && lh >= tl && (log_n >= 20 || c->fr_cols_want == 2)) {
     int tlog = 11, dmax = 7, block = 512;
-    if (const char* v = getenv("BLSGPU_NTT_COLS")) { int a = 0, b = 0, cc = 0; if (sscanf(v, "%d,%d,%d", &a, &b, &cc) == 3 && a >= 6 && a <= FR_COLS_LOG && b >= 1 && b <= a && cc >= 64 && cc <= 1024) { tlog = a; dmax = b; block = cc; } }
+    static_assert(FR_COLS_LOG == FR_COLS_LOG_MAX, "limits.h and fr.hip.h disagree on the largest column tile");
+    if (c->diag.ntt_cols[0]) { tlog = c->diag.ntt_cols[0]; dmax = c->diag.ntt_cols[1]; block = c->diag.ntt_cols[2]; }
     const int m = lh + 1 - tl, passes = (m + dmax - 1) / dmax;
     for (int ps = 0; ps < passes; ps++) {
       const int d = (lh + 1 - tl + (passes - ps) - 1) / (passes - ps);      // the remaining stages split evenly over the remaining passes
@@ -417,7 +507,7 @@ extern "C" int blsgpu_bls_verify_batch_device(blsgpu_ctx* c, int mode, const voi
     // has nothing else to do -- here the decoders run beside it; measured 2^14 signatures: 15.5 ms plain, 18.7-18.9 ms split (16.6 / 21.7 ms with the
     // slower G2 decoder of before); BLSGPU_VERIFY_H2C_SPLIT=1 lets the batch-size rule apply here too, for re-measuring)
     const int keep_split = c->h2c_split;
-    c->h2c_split = getenv("BLSGPU_VERIFY_H2C_SPLIT") ? keep_split : 0;
+    c->h2c_split = c->diag.verify_h2c_split ? keep_split : 0;
     if (e == hipSuccess) rc = blsgpu_hash_to_curve_device(c, mode == 0 ? 2 : 1, d_msgs, d_offsets, n, d_dst, dst_len, 0, base + o_hp);
     c->h2c_split = keep_split;
     if (e == hipSuccess && !rc)
@@ -462,19 +552,8 @@ extern "C" int blsgpu_bls_verify_batch(blsgpu_ctx* c, int mode, const uint8_t* p
   const size_t total = (size_t)offsets[n];
   if (total && !msgs) return bad("bls_verify_batch: NULL argument");
   HIPCHK(hipSetDevice(c->device));
-  uint8_t d[255]; u32 dlen;
-  if (dst_len > 255) {                    // a DST longer than 255 bytes is replaced by H("H2C-OVERSIZE-DST-" || DST)  (expand_msg.rs:74-95)
-    Sha256 sh; sha_init(sh);
-    const char* salt = "H2C-OVERSIZE-DST-";
-    for (int i = 0; salt[i]; i++) sha_put(sh, (uint8_t)salt[i]);
-    for (size_t i = 0; i < dst_len; i++) sha_put(sh, dst[i]);
-    u32 hw[8]; sha_finish(sh, hw);
-    for (int i = 0; i < 32; i++) d[i] = (uint8_t)(hw[i >> 2] >> (24 - 8 * (i & 3)));
-    dlen = 32;
-  } else {
-    for (size_t i = 0; i < dst_len; i++) d[i] = dst[i];
-    dlen = (u32)dst_len;
-  }
+  uint8_t d[255];
+  const u32 dlen = h2c_reduce_dst(EXPAND_XMD_SHA256, dst, dst_len, d);        // expand_msg.rs:74-95
   const size_t pkb = n * (mode == 0 ? 48 : 96), sgb = n * (mode == 0 ? 96 : 48);
   // ONE staging block: pk | sig | msgs | offsets | dst | verdict
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };

@@ -152,9 +152,8 @@ static int ctx_init(blsgpu_ctx* c) {
   HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
   // A/B hooks for the stream priorities: BLSGPU_PRIO = three characters for accumulation / tail / front, each h, n or l
   // (default "nhl": accumulation normal, tail high, front low)
-  int pr[3] = {(prio_lo + prio_hi) / 2, prio_hi, prio_lo};
-  if (const char* v = getenv("BLSGPU_PRIO"))
-    for (int i = 0; i < 3 && v[i]; i++) pr[i] = v[i] == 'h' ? prio_hi : v[i] == 'l' ? prio_lo : (prio_lo + prio_hi) / 2;
+  int pr[3];
+  for (int i = 0; i < 3; i++) pr[i] = c->diag.prio[i] == 'h' ? prio_hi : c->diag.prio[i] == 'l' ? prio_lo : (prio_lo + prio_hi) / 2;
   HIPCHK(hipStreamCreateWithPriority(&c->acc_stream, hipStreamNonBlocking, pr[0]));
   HIPCHK(hipMalloc((void**)&c->d_status, 16));
   HIPCHK(hipMemset(c->d_status, 0, 16));
@@ -184,22 +183,11 @@ extern "C" int blsgpu_create(int device, blsgpu_ctx** out) {
   HIPCHK(hipSetDevice(device));
   blsgpu_ctx* c = new blsgpu_ctx();
   c->device = device;
-  c->force_slow_sort = getenv("BLSGPU_FORCE_SLOW_SORT") != nullptr;
-  c->no_glv = getenv("BLSGPU_NO_GLV") != nullptr;
-  if (const char* v = getenv("BLSGPU_PAIRING_LAYOUT")) {
-    // exact names only: a typo must not silently select the slowest kernels
-    const std::string s(v);
-    if (s == "auto" || s == "0" || s.empty()) c->pairing_layout = 0;
-    else if (s == "pair" || s == "2") c->pairing_layout = 2;
-    else if (s == "quad" || s == "4") c->pairing_layout = 4;
-    else if (s == "wide" || s == "256") c->pairing_layout = 256;
-    else { delete c; return bad("blsgpu_create: BLSGPU_PAIRING_LAYOUT must be one of auto, pair, quad, wide"); }
-  }
-  if (const char* v = getenv("BLSGPU_MMLP_K")) { long k = atol(v); if (k >= 1 && k <= MMLP_MAX_K) c->mmlp_k = (int)k; }
-  if (const char* v = getenv("BLSGPU_MML_IMPL")) { long k = atol(v); if (k == 1 || k == 4) c->mml_impl = (int)k; }
-  if (const char* v = getenv("BLSGPU_H2C_SPLIT")) c->h2c_split = atoi(v) ? 1 : 0;
-  if (const char* v = getenv("BLSGPU_NTT_IMPL")) c->fr_cols_want = !strcmp(v, "cols") ? 2 : !strcmp(v, "stage") ? 0 : 1;      // cols: at every size (tests)
-  if (const char* v = getenv("BLSGPU_ITEM_CAP")) { long k = atol(v); if (k >= 8 && k <= ITEM_CAP_MAX) c->item_cap = (u32)k; }
+  // the A/B and test switches of the environment, read here and nowhere else (diag.h)
+  c->diag = diag_read(MMLP_MAX_K, ITEM_CAP_MAX, FR_COLS_LOG_MAX);
+  if (c->diag.pairing_layout < 0) { delete c; return bad("blsgpu_create: BLSGPU_PAIRING_LAYOUT must be one of auto, pair, quad, wide"); }
+  c->force_slow_sort = c->diag.force_slow_sort; c->no_glv = c->diag.no_glv; c->pairing_layout = c->diag.pairing_layout;
+  c->mmlp_k = c->diag.mmlp_k; c->mml_impl = c->diag.mml_impl; c->h2c_split = c->diag.h2c_split; c->fr_cols_want = c->diag.fr_cols_want; c->item_cap = c->diag.item_cap;
   int rc = ctx_init(c);
   if (rc != BLSGPU_OK) { blsgpu_destroy(c); return rc; }       // destroy tolerates the half-built context (null handles are skipped)
   *out = c;
@@ -211,7 +199,7 @@ extern "C" void blsgpu_destroy(blsgpu_ctx* c) {
   hipDeviceSynchronize();
   if (c->d_status) hipFree(c->d_status);
   if (c->d_wide) hipFree(c->d_wide);
-  DevBuf* bufs[] = {&c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->io_f, &c->io_out, &c->flags_a, &c->flags_b, &c->fr_tw[0], &c->fr_tw[1], &c->fr_tmp, &c->fr_ninv, &c->fb_table[0], &c->fb_table[1], &c->fb_stage, &c->mmlp_work, &c->mmlp_out, &c->gt_one, &c->ver, &c->fold_c, &c->fold_d, &c->fold_result};
+  DevBuf* bufs[] = {&c->result, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->io_f, &c->io_out, &c->flags_a, &c->flags_b, &c->fr_tw[0], &c->fr_tw[1], &c->fr_tmp, &c->fr_ninv, &c->fb_table[0], &c->fb_table[1], &c->fb_stage, &c->mmlp_work, &c->mmlp_out, &c->gt_one, &c->ver, &c->fold_c, &c->fold_d, &c->fold_result, &c->h2c_uniform};
   for (auto b : bufs) b->release();
   for (auto& sl : c->slot) {
     DevBuf* sb[] = {&sl.ent, &sl.sorted, &sl.hist, &sl.offs, &sl.cursor, &sl.bsum, &sl.items, &sl.heavy, &sl.ctrl, &sl.glv,

@@ -28,7 +28,7 @@ static int wide_load(blsgpu_ctx* c) {
   if (c->wide_state) return c->wide_state;
   c->wide_state = -1;
   std::string path;
-  if (const char* e = getenv("BLSGPU_WIDE_PROG")) path = e;
+  if (!c->diag.wide_prog.empty()) path = c->diag.wide_prog;
   else {
     Dl_info info;
     if (!dladdr((const void*)&blsgpu_create, &info) || !info.dli_fname) return wide_unavailable(c, "the library's own path is unknown (static link?): set BLSGPU_WIDE_PROG to wide_prog.bin");

@@ -8,73 +8,14 @@
 // src/g1.rs:800-802 and src/g2.rs:847-947 (psi, psi2, clear_cofactor).  The formulas are the reference's, step for
 // step, so even the projective coordinates of the result are the reference's (tests compare X, Y and Z); its
 // fixed addition chains (chain.rs) are replaced by windowed exponentiation with the same exponents.
-// Only the XMD/SHA-256 expander (the BLS-signature suites) is provided.
+// XMD:SHA-256 (the BLS-signature suites) is fused into the kernels here; the other expanders of the reference (XMD:SHA-512, XOF:SHAKE128 /
+// SHAKE256) go through expand.hip.h::k_expand_message and k_hash_to_curve_uniform below.
 #pragma once
 #include "codec.hip.h"
 #include "pairlane.hip.h"
+#include "expand.hip.h"        // SHA-256 / SHA-512 / SHAKE and the expanders other than XMD:SHA-256
 
 namespace bls {
-
-#define HD __host__ __device__ inline
-
-// ---- SHA-256 (FIPS 180-4), byte-oriented streaming; also used on the host to shorten an oversize DST ---------
-struct Sha256 {
-  u32 h[8];
-  u32 w[16];
-  u32 fill;            // bytes in w
-  u64 total;           // bytes absorbed
-};
-HD u32 sha_rotr(u32 x, int n) { return (x >> n) | (x << (32 - n)); }
-HD void sha256_compress(u32* h, const u32* blk) {
-  constexpr u32 K[64] = {
-      0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u, 0xd807aa98u, 0x12835b01u, 0x243185beu,
-      0x550c7dc3u, 0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u, 0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu, 0x4a7484aau,
-      0x5cb0a9dcu, 0x76f988dau, 0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u, 0x27b70a85u,
-      0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u, 0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u, 0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u,
-      0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u, 0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu,
-      0x682e6ff3u, 0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
-  u32 w[16];
-  for (int i = 0; i < 16; i++) w[i] = blk[i];
-  u32 a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
-#pragma unroll
-  for (int i = 0; i < 64; i++) {
-    if (i >= 16) {
-      u32 w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
-      u32 s0 = sha_rotr(w15, 7) ^ sha_rotr(w15, 18) ^ (w15 >> 3);
-      u32 s1 = sha_rotr(w2, 17) ^ sha_rotr(w2, 19) ^ (w2 >> 10);
-      w[i & 15] = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
-    }
-    u32 S1 = sha_rotr(e, 6) ^ sha_rotr(e, 11) ^ sha_rotr(e, 25);
-    u32 ch = (e & f) ^ (~e & g);
-    u32 t1 = hh + S1 + ch + K[i] + w[i & 15];
-    u32 S0 = sha_rotr(a, 2) ^ sha_rotr(a, 13) ^ sha_rotr(a, 22);
-    u32 mj = (a & b) ^ (a & c) ^ (b & c);
-    u32 t2 = S0 + mj;
-    hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
-  }
-  h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
-}
-HD void sha_init(Sha256& s) {
-  const u32 iv[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
-  for (int i = 0; i < 8; i++) s.h[i] = iv[i];
-  for (int i = 0; i < 16; i++) s.w[i] = 0;
-  s.fill = 0; s.total = 0;
-}
-HD void sha_put(Sha256& s, uint8_t b) {
-  s.w[s.fill >> 2] |= (u32)b << (24 - 8 * (s.fill & 3));
-  s.fill++; s.total++;
-  if (s.fill == 64) { sha256_compress(s.h, s.w); for (int i = 0; i < 16; i++) s.w[i] = 0; s.fill = 0; }
-}
-HD void sha_put_words(Sha256& s, const u32* words, int n) {          // n big-endian words
-  for (int i = 0; i < n; i++) for (int k = 0; k < 4; k++) sha_put(s, (uint8_t)(words[i] >> (24 - 8 * k)));
-}
-HD void sha_finish(Sha256& s, u32* out) {                             // 8 big-endian words
-  const u64 bits = s.total * 8;
-  sha_put(s, 0x80);
-  while (s.fill != 56) sha_put(s, 0);
-  for (int k = 7; k >= 0; k--) sha_put(s, (uint8_t)(bits >> (8 * k)));
-  for (int i = 0; i < 8; i++) out[i] = s.h[i];
-}
 
 // expand_message_xmd (expand_msg.rs:247-328): ell blocks of 8 big-endian words into `out` (dst already <= 255 bytes)
 DEVNI void h2c_expand_xmd(const uint8_t* __restrict__ msg, size_t mlen, const uint8_t* __restrict__ dst, u32 dlen, u32 len_in_bytes,
@@ -361,6 +302,25 @@ template <> struct H2cField<Fp2PairPolicy> {
   template <class T> static DEV void save(const T& a, u32* w) { H2c2<Fp2PairPolicy>::save(a, w); }
 };
 
+// mod.rs:86-108 behind the expander: the uniform bytes `ub` (big-endian words) -> field elements -> SSWU -> isogeny -> (sum) -> cofactor clearing -> o
+template <class F> DEV void h2c_map_and_store(const u32* ub, int encode_only, u32* o) {
+  constexpr int M = H2cField<F>::M, WW = M * 12;
+  Proj<F> q, t;
+  H2cField<F>::sswu(t, H2cField<F>::from_okm(ub));
+  h2c_iso_map<F>(q, t);
+  if (!encode_only) {
+    Proj<F> q1;
+    H2cField<F>::sswu(t, H2cField<F>::from_okm(ub + 16 * M));
+    h2c_iso_map<F>(q1, t);
+    q = pt_add<F>(q, q1);
+  }
+  Proj<F> r;
+  H2cField<F>::clear(r, q);
+  H2cField<F>::save(r.x, o);
+  H2cField<F>::save(r.y, o + WW);
+  H2cField<F>::save(r.z, o + 2 * WW);
+}
+
 // mod.rs:86-108.  msgs = the messages back to back, offs[i] .. offs[i+1] the bytes of message i; dst <= 255 bytes.
 // out[i] = projective (X : Y : Z) in wire limbs.  encode_only: one field element (the *_NU_ suites).
 // F = FpPolicy: one message per lane; F = Fp2PairPolicy: one message per lane PAIR (both lanes hash the message, each keeps
@@ -376,20 +336,21 @@ k_hash_to_curve(const uint8_t* __restrict__ msgs, const unsigned long long* __re
   const int ell = count * M * 2;
   u32 ub[64];
   h2c_expand_xmd(msgs + offs[i], (size_t)(offs[i + 1] - offs[i]), dst, dlen, (u32)(ell * 32), ell, ub);
-  Proj<F> q, t;
-  H2cField<F>::sswu(t, H2cField<F>::from_okm(ub));
-  h2c_iso_map<F>(q, t);
-  if (!encode_only) {
-    Proj<F> q1;
-    H2cField<F>::sswu(t, H2cField<F>::from_okm(ub + 16 * M));
-    h2c_iso_map<F>(q1, t);
-    q = pt_add<F>(q, q1);
-  }
-  Proj<F> r;
-  H2cField<F>::clear(r, q);
-  H2cField<F>::save(r.x, out + i * 3 * WW);
-  H2cField<F>::save(r.y, out + i * 3 * WW + WW);
-  H2cField<F>::save(r.z, out + i * 3 * WW + 2 * WW);
+  h2c_map_and_store<F>(ub, encode_only, out + i * 3 * WW);
+}
+// the same from uniform bytes that another expander produced (expand.hip.h::k_expand_message: XMD:SHA-512, XOF:SHAKE128 / SHAKE256 -- or XMD:SHA-256,
+// which then gives the very limbs of the fused kernel): message i owns count * M * 64 bytes at uniform + i * that, count = encode_only ? 1 : 2
+template <class F>
+__global__ void __launch_bounds__(H2cField<F>::LANES == 2 ? 256 : 64, H2cField<F>::LANES == 2 ? 2 : 1)
+k_hash_to_curve_uniform(const uint8_t* __restrict__ uniform, size_t n, int encode_only, u32* __restrict__ out) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / H2cField<F>::LANES;
+  if (i >= n) return;
+  constexpr int M = H2cField<F>::M, WW = M * 12;
+  const int words = (encode_only ? 1 : 2) * M * 16;
+  const uint8_t* u = uniform + i * (size_t)words * 4;
+  u32 ub[64];
+  for (int k = 0; k < words; k++) ub[k] = ((u32)u[4 * k] << 24) | ((u32)u[4 * k + 1] << 16) | ((u32)u[4 * k + 2] << 8) | (u32)u[4 * k + 3];      // big-endian words, as h2c_expand_xmd leaves them
+  h2c_map_and_store<F>(ub, encode_only, out + i * 3 * WW);
 }
 
 // ---- small batches (round 5): the two maps of one message on two lane groups ---------------------------------------------------------

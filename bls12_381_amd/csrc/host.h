@@ -28,6 +28,7 @@
 #include "convert.hip.h"
 #include "scalar.hip.h"
 #include "limits.h"
+#include "diag.h"
 
 using namespace bls;
 
@@ -194,6 +195,7 @@ struct blsgpu_ctx {
   blsgpu_g2_prepared* ver_table = nullptr;   // ... and the resident `G2Prepared` of -G2 for mode 1
   bool ver_consts_ready = false; hipEvent_t ev_ver = nullptr;
   hipStream_t ver_stream[2] = {nullptr, nullptr}; hipEvent_t ev_ver_side[3] = {};     // the independent stages of the chain run side by side
+  DevBuf h2c_uniform;                   // uniform bytes between k_expand_message and the kernels that consume them (expand.hip.h)
   DevBuf fb_stage;                      // staging of the one-byte scalars the tables are built from
   DevBuf fb_table[2];                   // fixed-base comb tables of the generators (k_fixed_base): 32 x 256 affine records each, built at first use
   hipEvent_t ev_fb[2] = {};             // recorded where a table was built; awaited by every user (the caller may switch streams)
@@ -201,6 +203,7 @@ struct blsgpu_ctx {
   DevBuf fr_tw[2], fr_tmp, fr_ninv;     // Fr transform: twiddle tables (forward / inverse), permutation target, n^-1
   int fr_tw_log[2] = {-1, -1};
   int fr_ninv_log = -1;
+  BlsDiag diag;                         // the environment switches as they were when the context was created (diag.h)
   KTimer ktimer;                        // blsgpu_kernel_timing
   int h2c_split = -1;                   // -1 by batch size / 0 never / 1 always: BLSGPU_H2C_SPLIT, read when the context is created
   int fr_cols_want = 1;                 // 0 never / 1 from 2^20 elements / 2 always: BLSGPU_NTT_IMPL=stage|cols, read when the context is created

@@ -53,12 +53,13 @@ template <int A, int V> DEV auto select(bool c, const FeP<A, V>& a, const FeP<A,
 
 // (a0 + a1 u)(1 + u) = (a0 - a1) + (a0 + a1) u
 template <int A, int V> DEV auto mul_by_nonresidue(const FeP<A, V>& a) {
-  auto o = partner(a.v);
+  // c0 lane: a_me - a_other, c1 lane: a_me + a_other -- ONE exchange: the c1 lane sends its negation, the c0 lane itself (round 6: a
+  // negation, a select and an addition that can take the DPP operand, 3 instructions per limb; the form that built both a_me - a_other
+  // and a_me + a_other and selected took 6)
+  typedef Fe<A + 1, V + 1> ST;
+  const ST send = select(lane_is_c1(), neg(a.v), (ST)a.v);
   FeP<2 * A + 1, 2 * V + 1> r;
-  // c0 lane: a_me - a_other ; c1 lane: a_other + a_me
-  auto m = add(a.v, partner(neg(a.v)));
-  auto p = add(a.v, o);
-  r.v = select(lane_is_c1(), (Fe<2 * A + 1, 2 * V + 1>)p, m);
+  r.v = add(a.v, partner(send));
   return r;
 }
 
@@ -85,8 +86,14 @@ DEV auto sqr_inl(const FeP<A, V>& a) {
   auto ao = partner(a.v);
   typedef Fe<2 * A, 2 * V> XT;
   typedef Fe<2 * A + 1, 2 * V + 1> YT;
+  typedef Fe<A + 1, V + 1> NT;
   XT x = add(ao, select(c1, ao, a.v));               // c1 lane: 2 a0 ; c0 lane: a0 + a1
-  YT y = select(c1, (YT)a.v, add(a.v, partner(neg(a.v))));
+  // y: c0 lane a0 - a1, c1 lane a1 -- the c1 lane sends its negation, the c0 lane sends zero, and both ADD what they receive (one select
+  // on the sender's side instead of a subtraction and a select on the receiver's)
+  NT zero;
+#pragma unroll
+  for (int i = 0; i < NL; i++) zero.l[i] = 0;
+  YT y = add(a.v, partner(select(c1, neg(a.v), zero)));
   FeP<1, mul_v(2 * V, 2 * V + 1)> r;
   r.v = mul_inl(x, y);
   return r;
@@ -137,8 +144,12 @@ DEV auto sqr_ni(const FeP<A, V>& a) {
   auto ao = partner(a.v);
   typedef Fe<2 * A, 2 * V> XT;
   typedef Fe<2 * A + 1, 2 * V + 1> YT;
+  typedef Fe<A + 1, V + 1> NT;
   XT x = add(ao, select(c1, ao, a.v));               // c1 lane: 2 a0 ; c0 lane: a0 + a1
-  YT y = select(c1, (YT)a.v, add(a.v, partner(neg(a.v))));
+  NT zero;
+#pragma unroll
+  for (int i = 0; i < NL; i++) zero.l[i] = 0;
+  YT y = add(a.v, partner(select(c1, neg(a.v), zero)));     // c0 lane: a0 - a1, c1 lane: a1 (see sqr_inl)
   auto p = mulx(x, y);
   FeP<1, decltype(p)::kV> r; r.v = p;
   return r;
@@ -158,8 +169,9 @@ template <int A, int V> DEV auto conj(const FeP<A, V>& a) {
 }
 // (a0 + a1 u) u = -a1 + a0 u
 template <int A, int V> DEV auto mul_by_u(const FeP<A, V>& a) {
-  auto o = partner(a.v);
-  FeP<A + 1, V + 1> r; r.v = select(lane_is_c1(), (Fe<A + 1, V + 1>)o, partner(neg(a.v))); return r;
+  // c0 lane: -a1 (the c1 lane sends its negation), c1 lane: a0 (the c0 lane sends itself): one exchange
+  typedef Fe<A + 1, V + 1> ST;
+  FeP<A + 1, V + 1> r; r.v = partner(select(lane_is_c1(), neg(a.v), (ST)a.v)); return r;
 }
 // Fp2 x Fp (k identical in both lanes)
 template <int A1, int V1, int A2, int V2> DEV auto mul_fp(const FeP<A1, V1>& a, const Fe<A2, V2>& k) {

@@ -488,9 +488,10 @@ DEV void q_cyc_sqr_compressed(QZ& a, QZ& b) {
   // what the other pair needs: A wants (xi t3, t2) = (xi u1, u0) of B; B wants (t0, t1) = (u0, u1) of A
   auto r0 = xpair(norm(selB(B, mul_by_nonresidue(u1), u0)));
   auto r1 = xpair(norm(selB(B, u0, u1)));
-  // A: nz2 = 2 (r0 + z2) + r0, nz3 = 2 (r1 - z3) + r1        B: nz4 = 2 (r0 - z4) + r0, nz5 = 2 (r1 + z5) + r1
-  QZ na = fit<VQ>(add(dbl(selB(B, sub(r0, a), add(r0, a))), r0));
-  QZ nb = fit<VQ>(add(dbl(selB(B, add(r1, b), sub(r1, b))), r1));
+  // A: nz2 = 3 r0 + 2 z2, nz3 = 3 r1 - 2 z3        B: nz4 = 3 r0 - 2 z4, nz5 = 3 r1 + 2 z5      (the sign is chosen on the SMALL operand: one negation
+  // and one select, then two shift-and-add instructions per limb; round 6 -- the sum and the difference were both formed and selected before)
+  QZ na = fit<VQ>(add(mul_small<3>(r0), dbl(selB(B, neg(a), a))));
+  QZ nb = fit<VQ>(add(mul_small<3>(r1), dbl(selB(B, b, neg(b)))));
   a = na; b = nb;
 }
 // f^|x| conjugated (pairings.rs:114-132), |x| = 2^63 + 2^62 + 2^60 + 2^57 + 2^48 + 2^16: 57 compressed squarings with the

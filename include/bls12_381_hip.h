@@ -490,6 +490,34 @@ int blsgpu_g2_hash_to_curve_batch(blsgpu_ctx* ctx, const uint8_t* msgs, const ui
 /* Same with messages, offsets and DST (<= 255 bytes) already in device memory; group = 1 | 2. */
 int blsgpu_hash_to_curve_device(blsgpu_ctx* ctx, int group, const void* d_msgs, const void* d_offsets, size_t n, const void* d_dst, size_t dst_len,
                                 int encode_only, void* d_out_xyz);
+/* The reference's hash-to-curve is generic in the expander: `hash_to_curve::<X>` with X = ExpandMsgXmd<H> for a fixed-output digest H
+ * (src/hash_to_curve/expand_msg.rs:230-328) or ExpandMsgXof<H> for an extendable-output function (:167-228); its tests run Sha256, Sha512,
+ * Shake128 and Shake256 (tests/expand_msg.rs).  The entry points above are X = ExpandMsgXmd<Sha256>, fused into the hashing kernels (the
+ * BLS-signature suites); the `_expander` forms take the choice as an argument, expand into uniform bytes and map from those -- for
+ * BLSGPU_EXPAND_XMD_SHA256 with results limb-identical to the fused kernels.  A DST longer than 255 bytes is reduced as
+ * expand_msg.rs:47-95 does (XMD: the digest of the salted tag; XOF: its first 32 output bytes) by the host-pointer forms; the
+ * device-pointer forms take a DST of at most 255 bytes.  group = 1 | 2. */
+#define BLSGPU_EXPAND_XMD_SHA256 0
+#define BLSGPU_EXPAND_XMD_SHA512 1
+#define BLSGPU_EXPAND_XOF_SHAKE128 2
+#define BLSGPU_EXPAND_XOF_SHAKE256 3
+int blsgpu_hash_to_curve_expander_batch(blsgpu_ctx* ctx, int group, int expander, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst,
+                                        size_t dst_len, int encode_only, uint64_t* out_xyz);
+int blsgpu_hash_to_curve_expander_device(blsgpu_ctx* ctx, int group, int expander, const void* d_msgs, const void* d_offsets, size_t n, const void* d_dst,
+                                         size_t dst_len, int encode_only, void* d_out_xyz);
+/* `ExpandMessage::init_expand(msg, dst, len_in_bytes)` followed by reading all `len_in_bytes` bytes, for n messages: out = n x len_in_bytes
+ * uniform bytes.  len_in_bytes <= 65535, and at most 255 digest blocks for the XMD expanders (the reference panics beyond, :181-183, :263-268). */
+int blsgpu_expand_message_batch(blsgpu_ctx* ctx, int expander, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst, size_t dst_len,
+                                size_t len_in_bytes, uint8_t* out);
+int blsgpu_expand_message_device(blsgpu_ctx* ctx, int expander, const void* d_msgs, const void* d_offsets, size_t n, const void* d_dst, size_t dst_len,
+                                 size_t len_in_bytes, void* d_out);
+/* `hash_to_field::<X, Scalar>` (src/hash_to_curve/mod.rs:32-49 with `HashToField for Scalar`, map_scalar.rs:10-25: 48 uniform bytes per
+ * element, zero-extended to 64 and read as `Scalar::from_bytes_wide`): `count` scalars per message, as the reference's `Scalar` (four u64
+ * Montgomery limbs): out = n x count x 4 u64 -- ready for blsgpu_g{1,2}_msm_mont* / blsgpu_fr_*. */
+int blsgpu_hash_to_scalar_batch(blsgpu_ctx* ctx, int expander, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst, size_t dst_len,
+                                size_t count, uint64_t* out);
+int blsgpu_hash_to_scalar_device(blsgpu_ctx* ctx, int expander, const void* d_msgs, const void* d_offsets, size_t n, const void* d_dst, size_t dst_len,
+                                 size_t count, void* d_out);
 
 
 /* ---- the widened rows with inputs and outputs in device memory: a chain that stays on the GPU ---------------- */

@@ -4,7 +4,8 @@ Follows /root/reference/src/hash_to_curve/: expand_msg.rs (ExpandMsgXmd :230-328
 mod.rs (hash_to_field :32-49, hash_to_curve / encode_to_curve :86-108), map_g1.rs (from_okm :513-531, sgn0
 :535-543, map_to_curve_simple_swu :550-586, iso_map :589-630), map_g2.rs (from_okm :374-378, sgn0 :382-388,
 map_to_curve_simple_swu :391-454, iso_map :457-492), g1.rs clear_cofactor :800-802, g2.rs psi2 :890-912 and
-clear_cofactor :938-947.  Only XMD with SHA-256 (the BLS-signature suites).
+clear_cofactor :938-947.  Expanders: XMD over SHA-256 / SHA-512 and XOF over SHAKE128 / SHAKE256 (expand_msg.rs:167-328; hashlib
+provides the digests), and `HashToField for Scalar` (map_scalar.rs:10-25).
 
 Pinned by tests/test_oracle_golden.py against the RFC 9380 (draft-16) vectors the reference's integration tests
 hold (tests/golden/h2c_vectors.json) and its SSWU exceptional-case answers.  The isogeny / SSWU constants are the
@@ -41,21 +42,53 @@ def _consts():
     return _K
 
 
-# ---- expand_message_xmd (expand_msg.rs:230-328) ---------------------------------------------------------------
-def expand_message_xmd(msg, dst, len_in_bytes):
+# ---- message expansion (expand_msg.rs): the four expanders the reference's tests exercise ---------------------------------
+# expander ids as in include/bls12_381_hip.h: 0 XMD:SHA-256, 1 XMD:SHA-512, 2 XOF:SHAKE128, 3 XOF:SHAKE256
+XMD_SHA256, XMD_SHA512, XOF_SHAKE128, XOF_SHAKE256 = 0, 1, 2, 3
+_XMD = {XMD_SHA256: (hashlib.sha256, 32, 64), XMD_SHA512: (hashlib.sha512, 64, 128)}          # digest, output bytes, block bytes
+_XOF = {XOF_SHAKE128: hashlib.shake_128, XOF_SHAKE256: hashlib.shake_256}
+XOF_DST_LEN = 32            # `L` = ceil(2 k / 8) with k = 128: `XofOutputLength = U32` of Fp / Fp2 / Scalar (map_g1.rs, map_g2.rs, map_scalar.rs:15-16)
+
+
+def expand_message(expander, msg, dst, len_in_bytes):
+    """ExpandMessage::init_expand + reading everything (expand_msg.rs): XMD :230-328 (generic in the digest), XOF :167-228;
+    DST reduction :47-95."""
     msg, dst = bytes(msg), bytes(dst)
-    if len(dst) > 255:                                     # expand_msg.rs:74-95
-        dst = hashlib.sha256(b"H2C-OVERSIZE-DST-" + dst).digest()
-    ell = (len_in_bytes + 31) // 32
-    assert ell <= 255 and len_in_bytes <= 0xFFFF
-    dst_prime = dst + bytes([len(dst)])
-    b0 = hashlib.sha256(bytes(64) + msg + len_in_bytes.to_bytes(2, "big") + b"\x00" + dst_prime).digest()
-    bi = hashlib.sha256(b0 + b"\x01" + dst_prime).digest()
-    out = bi
-    for i in range(2, ell + 1):
-        bi = hashlib.sha256(bytes(x ^ y for x, y in zip(b0, bi)) + bytes([i]) + dst_prime).digest()
-        out += bi
-    return out[:len_in_bytes]
+    assert len_in_bytes <= 0xFFFF
+    if expander in _XMD:
+        H, hs, bs = _XMD[expander]
+        if len(dst) > 255:                                 # expand_msg.rs:74-95
+            dst = H(b"H2C-OVERSIZE-DST-" + dst).digest()
+        ell = (len_in_bytes + hs - 1) // hs
+        assert ell <= 255
+        dst_prime = dst + bytes([len(dst)])
+        b0 = H(bytes(bs) + msg + len_in_bytes.to_bytes(2, "big") + b"\x00" + dst_prime).digest()
+        bi = H(b0 + b"\x01" + dst_prime).digest()
+        out = bi
+        for i in range(2, ell + 1):
+            bi = H(bytes(x ^ y for x, y in zip(b0, bi)) + bytes([i]) + dst_prime).digest()
+            out += bi
+        return out[:len_in_bytes]
+    X = _XOF[expander]
+    if len(dst) > 255:                                     # expand_msg.rs:47-70
+        dst = X(b"H2C-OVERSIZE-DST-" + dst).digest(XOF_DST_LEN)
+    return X(msg + len_in_bytes.to_bytes(2, "big") + dst + bytes([len(dst)])).digest(len_in_bytes)
+
+
+def expand_message_xmd(msg, dst, len_in_bytes):
+    return expand_message(XMD_SHA256, msg, dst, len_in_bytes)
+
+
+def scalar_from_okm(okm):
+    """`HashToField for Scalar` (map_scalar.rs:10-25): 48 big-endian bytes, zero-extended to 64 and reversed -> from_bytes_wide."""
+    assert len(okm) == 48
+    return o.fr_from_bytes_wide((bytes(16) + bytes(okm))[::-1])
+
+
+def hash_to_field_scalar(msg, dst, count, expander=XMD_SHA256):
+    """mod.rs:32-49 with T = Scalar (InputLength = 48)"""
+    u = expand_message(expander, msg, dst, 48 * count)
+    return [scalar_from_okm(u[48 * i:48 * i + 48]) for i in range(count)]
 
 
 def fp_from_okm(okm):
@@ -64,13 +97,13 @@ def fp_from_okm(okm):
     return (int.from_bytes(okm[:32], "big") * _consts()["F_2_256"] + int.from_bytes(okm[32:], "big")) % P
 
 
-def hash_to_field_fp(msg, dst, count):
-    u = expand_message_xmd(msg, dst, 64 * count)
+def hash_to_field_fp(msg, dst, count, expander=XMD_SHA256):
+    u = expand_message(expander, msg, dst, 64 * count)
     return [fp_from_okm(u[64 * i:64 * i + 64]) for i in range(count)]
 
 
-def hash_to_field_fp2(msg, dst, count):
-    u = expand_message_xmd(msg, dst, 128 * count)
+def hash_to_field_fp2(msg, dst, count, expander=XMD_SHA256):
+    u = expand_message(expander, msg, dst, 128 * count)
     return [(fp_from_okm(u[128 * i:128 * i + 64]), fp_from_okm(u[128 * i + 64:128 * i + 128])) for i in range(count)]
 
 
@@ -137,13 +170,13 @@ def g1_clear_cofactor(p):
     return o.g1_add(p, o.g1_neg(o.g1_mul_by_x(p)))
 
 
-def g1_hash_to_curve(msg, dst):
-    u = hash_to_field_fp(msg, dst, 2)
+def g1_hash_to_curve(msg, dst, expander=XMD_SHA256):
+    u = hash_to_field_fp(msg, dst, 2, expander)
     return g1_clear_cofactor(o.g1_add(g1_map_to_curve(u[0]), g1_map_to_curve(u[1])))     # mod.rs:86-92
 
 
-def g1_encode_to_curve(msg, dst):
-    return g1_clear_cofactor(g1_map_to_curve(hash_to_field_fp(msg, dst, 1)[0]))           # mod.rs:103-108
+def g1_encode_to_curve(msg, dst, expander=XMD_SHA256):
+    return g1_clear_cofactor(g1_map_to_curve(hash_to_field_fp(msg, dst, 1, expander)[0]))           # mod.rs:103-108
 
 
 # ---- G2 (map_g2.rs) --------------------------------------------------------------------------------------------
@@ -216,10 +249,10 @@ def g2_clear_cofactor(p):
     return o.g2_add(r, o.g2_neg(p))
 
 
-def g2_hash_to_curve(msg, dst):
-    u = hash_to_field_fp2(msg, dst, 2)
+def g2_hash_to_curve(msg, dst, expander=XMD_SHA256):
+    u = hash_to_field_fp2(msg, dst, 2, expander)
     return g2_clear_cofactor(o.g2_add(g2_map_to_curve(u[0]), g2_map_to_curve(u[1])))
 
 
-def g2_encode_to_curve(msg, dst):
-    return g2_clear_cofactor(g2_map_to_curve(hash_to_field_fp2(msg, dst, 1)[0]))
+def g2_encode_to_curve(msg, dst, expander=XMD_SHA256):
+    return g2_clear_cofactor(g2_map_to_curve(hash_to_field_fp2(msg, dst, 1, expander)[0]))

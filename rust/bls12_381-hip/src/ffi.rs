@@ -159,6 +159,12 @@ extern "C" {
     pub fn blsgpu_g1_hash_to_curve_batch(ctx: *mut BlsgpuCtx, msgs: *const u8, offsets: *const u64, n: usize, dst: *const u8, dst_len: usize, encode_only: c_int, out_xyz: *mut u64) -> c_int;
     pub fn blsgpu_g2_hash_to_curve_batch(ctx: *mut BlsgpuCtx, msgs: *const u8, offsets: *const u64, n: usize, dst: *const u8, dst_len: usize, encode_only: c_int, out_xyz: *mut u64) -> c_int;
     pub fn blsgpu_hash_to_curve_device(ctx: *mut BlsgpuCtx, group: c_int, d_msgs: *const c_void, d_offsets: *const c_void, n: usize, d_dst: *const c_void, dst_len: usize, encode_only: c_int, d_out_xyz: *mut c_void) -> c_int;
+    pub fn blsgpu_hash_to_curve_expander_batch(ctx: *mut BlsgpuCtx, group: c_int, expander: c_int, msgs: *const u8, offsets: *const u64, n: usize, dst: *const u8, dst_len: usize, encode_only: c_int, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_hash_to_curve_expander_device(ctx: *mut BlsgpuCtx, group: c_int, expander: c_int, d_msgs: *const c_void, d_offsets: *const c_void, n: usize, d_dst: *const c_void, dst_len: usize, encode_only: c_int, d_out_xyz: *mut c_void) -> c_int;
+    pub fn blsgpu_expand_message_batch(ctx: *mut BlsgpuCtx, expander: c_int, msgs: *const u8, offsets: *const u64, n: usize, dst: *const u8, dst_len: usize, len_in_bytes: usize, out: *mut u8) -> c_int;
+    pub fn blsgpu_expand_message_device(ctx: *mut BlsgpuCtx, expander: c_int, d_msgs: *const c_void, d_offsets: *const c_void, n: usize, d_dst: *const c_void, dst_len: usize, len_in_bytes: usize, d_out: *mut c_void) -> c_int;
+    pub fn blsgpu_hash_to_scalar_batch(ctx: *mut BlsgpuCtx, expander: c_int, msgs: *const u8, offsets: *const u64, n: usize, dst: *const u8, dst_len: usize, count: usize, out: *mut u64) -> c_int;
+    pub fn blsgpu_hash_to_scalar_device(ctx: *mut BlsgpuCtx, expander: c_int, d_msgs: *const c_void, d_offsets: *const c_void, n: usize, d_dst: *const c_void, dst_len: usize, count: usize, d_out: *mut c_void) -> c_int;
     pub fn blsgpu_g1_batch_normalize_device(ctx: *mut BlsgpuCtx, d_xyz: *const c_void, n: usize, d_xy: *mut c_void, d_infinity: *mut c_void) -> c_int;
     pub fn blsgpu_g2_batch_normalize_device(ctx: *mut BlsgpuCtx, d_xyz: *const c_void, n: usize, d_xy: *mut c_void, d_infinity: *mut c_void) -> c_int;
     pub fn blsgpu_g1_from_bytes_batch_device(ctx: *mut BlsgpuCtx, d_bytes: *const c_void, n: usize, compressed: c_int, checked: c_int, d_xy: *mut c_void, d_infinity: *mut c_void, d_ok: *mut c_void) -> c_int;

@@ -139,8 +139,14 @@ def vector_file(path, out_key):
 
 T = "/root/reference/tests"
 h2c = {"g1": vector_file(f"{T}/hash_to_curve_g1.rs", "g1"), "g2": vector_file(f"{T}/hash_to_curve_g2.rs", "g2"),
-       "expand_msg": [v for v in vector_file(f"{T}/expand_msg.rs", "x") if "sha256" in v["test"] and "xmd" in v["test"]]}
-assert len(h2c["g1"]) == 10 and len(h2c["g2"]) == 10 and len(h2c["expand_msg"]) >= 10, {k: len(v) for k, v in h2c.items()}
+       # every expander the reference tests: XMD over SHA-256 (+ long DST) and SHA-512, XOF over SHAKE128 (+ long DST) and SHAKE256
+       "expand_msg": vector_file(f"{T}/expand_msg.rs", "x")}
+# `HashToField for Scalar` (hash_to_curve/map_scalar.rs:24-45): 48 input bytes -> the Debug form of the Scalar (big-endian hex of the canonical integer)
+ms = open(f"{H2C}/map_scalar.rs").read()
+h2c["hash_to_scalar"] = [{"okm": (bytes(48) if m.group(1) else rust_bytes(m.group(2))).hex(), "out": m.group(3)}
+                         for m in re.finditer(r'(?:(&\[0u8; 48\])|b"([^"]*)"),\s*"0x([0-9a-f]{64})"', ms)]
+assert len(h2c["hash_to_scalar"]) == 3, h2c["hash_to_scalar"]
+assert len(h2c["g1"]) == 10 and len(h2c["g2"]) == 10 and len(h2c["expand_msg"]) == 60, {k: len(v) for k, v in h2c.items()}
 with open(os.path.join(OUT, "h2c_vectors.json"), "w") as fh:
     json.dump(h2c, fh, indent=0, separators=(",", ":"))
 

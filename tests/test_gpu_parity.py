@@ -846,12 +846,16 @@ def test_fr_ntt_column_tiles_equal_stage_passes(log_n):
         assert np.array_equal(new.fr_ntt(Y, inverse=True), X)
         assert np.array_equal(new.fr_ntt(X, inverse=True), old.fr_ntt(X, inverse=True))
         if log_n == 20:
-            for shape in ("12,10,1024", "10,3,256"):
-                os.environ["BLSGPU_NTT_COLS"] = shape
+            for shape in ("12,10,1024", "10,3,256"):           # (the switches are read when a context is created: csrc/diag.h)
+                os.environ["BLSGPU_NTT_COLS"] = shape; os.environ["BLSGPU_NTT_IMPL"] = "cols"
                 try:
-                    assert np.array_equal(new.fr_ntt(X), Yo), shape
+                    shaped = bls.Context(0)
                 finally:
-                    os.environ.pop("BLSGPU_NTT_COLS")
+                    os.environ.pop("BLSGPU_NTT_COLS"); os.environ.pop("BLSGPU_NTT_IMPL")
+                try:
+                    assert np.array_equal(shaped.fr_ntt(X), Yo), shape
+                finally:
+                    shaped.close()
     finally:
         new.close(); old.close()
     if log_n <= 13:
@@ -923,6 +927,77 @@ def test_hash_to_curve_rfc_vectors(ctx, golden_dir, group):
         for k, t in enumerate(sel):
             pt = (b.G1Affine if group == 1 else b.G2Affine)(xy[k], bool(inf[k]))
             assert pt.to_uncompressed().hex() == t["out"], (group, encode, k)
+
+
+def test_expanders_reference_vectors_and_oracle(ctx, golden_dir):
+    """the reference's expander vectors (tests/expand_msg.rs: XMD over SHA-256 with short and long DST and over SHA-512, XOF over SHAKE128 with
+    short and long DST and over SHAKE256 -- 60 cases) through blsgpu_expand_message_batch, then random messages / lengths / DSTs against the
+    oracle (hashlib digests); `HashToField for Scalar` on the reference's stored answers (map_scalar.rs:27-45) and against the oracle"""
+    import bls12_381_amd as b
+    from oracle import h2c_ref as h
+    A = b.api
+    vecs = _h2c_vectors(golden_dir)["expand_msg"]
+    assert len(vecs) == 60
+    ex_of = lambda name: A.EXPAND_XMD_SHA512 if "sha512" in name else A.EXPAND_XMD_SHA256 if "sha256" in name else A.EXPAND_XOF_SHAKE128 if "shake128" in name else A.EXPAND_XOF_SHAKE256
+    by_call = {}
+    for t in vecs:
+        by_call.setdefault((ex_of(t["test"]), t["dst"], t["len_in_bytes"]), []).append(t)
+    for (ex, dst, ln), ts in by_call.items():
+        got = ctx.expand_message(ex, [bytes.fromhex(t["msg"]) for t in ts], bytes.fromhex(dst), ln)
+        for k, t in enumerate(ts):
+            assert bytes(got[k]).hex() == t["out"], (t["test"], k)
+    assert {k[0] for k in by_call} == {0, 1, 2, 3}
+    r = o.SplitMix64(0xE7)
+    msgs = [b"", b"a", bytes(111), bytes(112), bytes(127), bytes(128), bytes(135), bytes(136), bytes(137), bytes(167), bytes(168), bytes(169), bytes(range(256)) * 3] + \
+           [bytes((r.next() >> 8) & 0xFF for _ in range(int(r.next() % 400))) for _ in range(20)]
+    for ex in (A.EXPAND_XMD_SHA256, A.EXPAND_XMD_SHA512, A.EXPAND_XOF_SHAKE128, A.EXPAND_XOF_SHAKE256):
+        for dst in (b"QUUX-V01-CS02", b"", b"x" * 255, b"long-dst-" * 40):
+            for ln in (1, 31, 32, 33, 48, 64, 96, 128, 135, 136, 137, 168, 169, 256, 500):
+                got = ctx.expand_message(ex, msgs if ln in (48, 128, 500) else msgs[:4], dst, ln)
+                for k in range(got.shape[0]):
+                    assert bytes(got[k]) == h.expand_message(ex, msgs[k], dst, ln), (ex, len(dst), ln, k)
+    # limits the reference enforces by panicking
+    with pytest.raises(b.BlsGpuError):
+        ctx.expand_message(A.EXPAND_XMD_SHA256, [b"m"], b"d", 255 * 32 + 1)
+    with pytest.raises(b.BlsGpuError):
+        ctx.expand_message(4, [b"m"], b"d", 32)
+    assert bytes(ctx.expand_message(A.EXPAND_XMD_SHA256, [b"m"], b"d", 255 * 32)[0]) == h.expand_message(0, b"m", b"d", 255 * 32)
+    assert bytes(ctx.expand_message(A.EXPAND_XOF_SHAKE256, [b"m"], b"d", 65535)[0]) == h.expand_message(3, b"m", b"d", 65535)
+    # Scalar::from_okm on the stored answers: hash_to_scalar's second stage (k_hash_to_scalar) is fed directly through expand -> identity check below
+    for ex in (0, 1, 2, 3):
+        for dst in (b"BLS12381-scalar-suite", b"y" * 300):
+            for count in (1, 2, 5):
+                got = ctx.hash_to_scalar(ex, msgs[:12], dst, count)
+                for k in range(12):
+                    want = h.hash_to_field_scalar(msgs[k], dst, count, ex)
+                    assert [o.fr_from_mont_limbs(row) for row in got[k]] == want, (ex, count, k)
+    for t in _h2c_vectors(golden_dir)["hash_to_scalar"]:
+        assert "%064x" % h.scalar_from_okm(bytes.fromhex(t["okm"])) == t["out"]
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_hash_to_curve_with_every_expander(ctx, group):
+    """`hash_to_curve::<X>` / `encode_to_curve::<X>` for the four expanders the reference tests: XMD:SHA-256 through the uniform-bytes path must give
+    the very limbs of the fused kernel (and so the RFC vectors); the others are compared with the oracle on the projective coordinates"""
+    import bls12_381_amd as b
+    from oracle import h2c_ref as h
+    A = b.api
+    r = o.SplitMix64(0xE8 + group)
+    msgs = [b"", b"abc", bytes(200)] + [bytes((r.next() >> 8) & 0xFF for _ in range(int(r.next() % 150))) for _ in range(9)]
+    for dst in (b"QUUX-V01-CS02-with-BLS12381G%d_XOF:SHAKE-256_SSWU_RO_" % group, b"z" * 300):
+        for encode in (False, True):
+            fused = ctx.hash_to_curve(group, msgs, dst, encode_only=encode)
+            assert np.array_equal(ctx.hash_to_curve_expander(group, A.EXPAND_XMD_SHA256, msgs, dst, encode_only=encode), fused)
+            for ex in (A.EXPAND_XMD_SHA512, A.EXPAND_XOF_SHAKE128, A.EXPAND_XOF_SHAKE256):
+                out = ctx.hash_to_curve_expander(group, ex, msgs, dst, encode_only=encode)
+                for k, m in enumerate(msgs[:6] if len(dst) > 255 else msgs):
+                    if group == 1:
+                        want = np.concatenate([fpw(c) for c in (h.g1_encode_to_curve if encode else h.g1_hash_to_curve)(m, dst, ex)])
+                    else:
+                        want = np.concatenate([fp2w(c) for c in (h.g2_encode_to_curve if encode else h.g2_hash_to_curve)(m, dst, ex)])
+                    assert np.array_equal(out[k], want), (group, ex, encode, k)
+    with pytest.raises(b.BlsGpuError):
+        ctx.hash_to_curve_expander(group, 7, msgs, b"d")
 
 
 @pytest.mark.parametrize("group", [1, 2])

@@ -416,8 +416,13 @@ def test_hash_to_curve_vectors(kats, golden_dir):
     import json
     from oracle import h2c_ref as h
     v = json.load(open(os.path.join(golden_dir, "h2c_vectors.json")))
-    for t in v["expand_msg"]:
-        assert h.expand_message_xmd(bytes.fromhex(t["msg"]), bytes.fromhex(t["dst"]), t["len_in_bytes"]).hex() == t["out"]
+    assert len(v["expand_msg"]) == 60
+    for t in v["expand_msg"]:                      # every expander the reference tests (tests/expand_msg.rs), long DSTs included
+        ex = h.XMD_SHA512 if "sha512" in t["test"] else h.XMD_SHA256 if "sha256" in t["test"] else h.XOF_SHAKE128 if "shake128" in t["test"] else h.XOF_SHAKE256
+        assert "shake256" in t["test"] or ex != h.XOF_SHAKE256
+        assert h.expand_message(ex, bytes.fromhex(t["msg"]), bytes.fromhex(t["dst"]), t["len_in_bytes"]).hex() == t["out"], t["test"]
+    for t in v["hash_to_scalar"]:                  # `HashToField for Scalar`, map_scalar.rs:27-45
+        assert "%064x" % h.scalar_from_okm(bytes.fromhex(t["okm"])) == t["out"]
     for t in v["g1"]:
         fn = h.g1_hash_to_curve if t["test"].endswith("_ro") else h.g1_encode_to_curve
         p = fn(bytes.fromhex(t["msg"]), bytes.fromhex(t["dst"]))

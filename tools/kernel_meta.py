@@ -25,7 +25,8 @@ def kernel_meta(lib=None):
         objs = [os.path.join(tmp, f) for f in os.listdir(tmp) if "amdgcn" in f]
         if not objs:
             return {}
-        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", objs[0]], capture_output=True, text=True).stdout
+        # one code object per translation unit of the library (bls12_381_amd/csrc/host.h)
+        notes = "\n".join(subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", o], capture_output=True, text=True).stdout for o in sorted(objs))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     out, cur = {}, None

@@ -53,11 +53,14 @@ for log_n in sizes:
     to = med(lambda: old.fr_ntt_device(b.data_ptr(), log_n))
     row = {"log_n": log_n, "column_tiles_ms": round(tn, 4), "stage_passes_ms": round(to, 4), "identical": same}
     for shape in os.environ.get("NTT_TIME_SHAPES", "").split():          # "tile log2,max depth per pass,block" variants of the column pass
-        os.environ["BLSGPU_NTT_COLS"] = shape
-        a.copy_(x); sync(); new.fr_ntt_device(a.data_ptr(), log_n); sync()
+        os.environ["BLSGPU_NTT_COLS"] = shape; os.environ["BLSGPU_NTT_IMPL"] = "cols"      # read when the context is created (csrc/diag.h)
+        shaped = bls.Context(0)
+        shaped.set_stream(torch.cuda.current_stream().cuda_stream)
+        os.environ.pop("BLSGPU_NTT_COLS"); os.environ.pop("BLSGPU_NTT_IMPL")
+        a.copy_(x); sync(); shaped.fr_ntt_device(a.data_ptr(), log_n); sync()
         ok = bool(torch.equal(a, b0))
-        row["cols " + shape] = (round(med(lambda: new.fr_ntt_device(a.data_ptr(), log_n)), 4), ok)
-        os.environ.pop("BLSGPU_NTT_COLS")
+        row["cols " + shape] = (round(med(lambda: shaped.fr_ntt_device(a.data_ptr(), log_n)), 4), ok)
+        shaped.close()
     rows.append(row)
     print(rows[-1], flush=True)
 print(json.dumps({"fr_ntt": rows}))
