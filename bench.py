@@ -975,7 +975,7 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
                    "multi_miller_loop + final exponentiation per signature, identity test (blsgpu_bls_verify_batch_device)",
            "roofline": {"bound": "int-valu", "kernel": "k_point_decode x 2 + k_hash_to_curve<G2> + k_pairing_quad (Miller) + k_fp12_prod_seg_quad + k_final_exp_quad",
                         "mac32_per_unit": mac_ver, "mac32_per_unit_is": "estimate for the decoding and hashing stages", "achieved": nv * mac_ver / (vms * 1e-3) / 1e12, "peak": peak / 1e12,
-                        "unit": "TMAC32/s", "frac": nv * mac_ver / (vms * 1e-3) / peak, "algorithmic_bytes": nv * (48 + 96 + 32 + 1), "traffic": None}}
+                        "unit": "TMAC32/s", "frac": nv * mac_ver / (vms * 1e-3) / peak, "algorithmic_bytes": nv * (48 + 96 + 32 + 1), "traffic": static_traffic("bls_verify")[0], "traffic_source": static_traffic("bls_verify")[1]}}
     if not ver["verdicts_as_expected"]:
         raise SystemExit("bench: bulk verification verdicts are wrong")
     if not args.no_cpu_baseline:
@@ -1010,6 +1010,10 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
                             "roofline": {"bound": "int-valu", "kernel": "k_fr_stage2 x 5 + k_fr_tile", "mac32_per_unit": (log_n * 136) // 2,
                                          "achieved": ntt_mac / (nms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s", "frac": ntt_mac / (nms * 1e-3) / peak,
                                          "algorithmic_bytes": ntt_bytes, "hbm_frac_of_8TBs": ntt_bytes / (nms * 1e-3) / 8e12,
+                                         # what the butterflies EXECUTE: one 9 x 29-bit lazy Montgomery product = 171 v_mad_u64_u32 and ~375 VALU instructions in all (fr.hip.h;
+                                         # instruction mix from the ISA, tools/isa_stats.py); against the issue rate of ALL VALU instructions (= the v_mad peak: they issue alike)
+                                         "executed_mac_per_unit": (log_n * 171) // 2, "executed_valu_instructions_per_unit": (log_n * 375) // 2,
+                                         "executed_valu_frac_of_issue_peak": (n // 2) * log_n * 375 / (nms * 1e-3) / peak,
                                          "traffic": static_traffic("ntt")[0], "traffic_source": static_traffic("ntt")[1]}}
         del d_fr
     # hash-to-curve in front of the pairings: 2^16 32-byte messages -> G2
@@ -1032,7 +1036,7 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
     extras["hash_to_g2"] = {"n": np_, "ms": hms, "hashes_per_s": np_ / (hms * 1e-3), "note": "hash_to_curve (XMD:SHA-256, SSWU, RO) of 32-byte messages to G2",
                             "roofline": {"bound": "int-valu", "kernel": "k_hash_to_curve<G2, lane pair>", "mac32_per_unit": mac_h2c, "mac32_per_unit_is": "estimate (see bench.py)",
                                          "achieved": np_ * mac_h2c / (hms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s", "frac": np_ * mac_h2c / (hms * 1e-3) / peak,
-                                         "algorithmic_bytes": np_ * (32 + 288), "traffic": None}}
+                                         "algorithmic_bytes": np_ * (32 + 288), "traffic": static_traffic("hash_to_g2")[0], "traffic_source": static_traffic("hash_to_g2")[1]}}
     # ... and to G1 (the min-sig placement), same messages
     hout1 = torch.zeros((np_, 18), dtype=torch.int64, device=dev)
     hdst1 = b"BLS_SIG_BLS12381G1_XMD:SHA-256_SSWU_RO_NUL_"
@@ -1043,7 +1047,7 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
     extras["hash_to_g1"] = {"n": np_, "ms": h1ms, "hashes_per_s": np_ / (h1ms * 1e-3),
                             "roofline": {"bound": "int-valu", "kernel": "k_hash_to_curve<G1>", "mac32_per_unit": mac_h2c1, "mac32_per_unit_is": "estimate (see bench.py)",
                                          "achieved": np_ * mac_h2c1 / (h1ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s", "frac": np_ * mac_h2c1 / (h1ms * 1e-3) / peak,
-                                         "algorithmic_bytes": np_ * (32 + 144), "traffic": None}}
+                                         "algorithmic_bytes": np_ * (32 + 144), "traffic": static_traffic("hash_to_g1")[0], "traffic_source": static_traffic("hash_to_g1")[1]}}
     del hm, ho, hout, hout1
     # point codecs with device pointers: checked decoding of 2^16 compressed points (square root + subgroup test) and encoding
     cod = {}
@@ -1062,7 +1066,7 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
         cod["g%d" % grp] = {"n": np_, "decode_checked_ms": dms, "decoded_per_s": np_ / (dms * 1e-3), "encode_ms": ems, "roundtrip_ok": ok_all and bool(torch.equal(d_eo, d_enc)),
                             "roofline": {"bound": "int-valu", "kernel": "k_point_decode<G%d>" % grp, "mac32_per_unit": mac_dec, "mac32_per_unit_is": "estimate (see bench.py)",
                                          "achieved": np_ * mac_dec / (dms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s", "frac": np_ * mac_dec / (dms * 1e-3) / peak,
-                                         "algorithmic_bytes": np_ * (cb + 2 * cb + 2), "traffic": None}}
+                                         "algorithmic_bytes": np_ * (cb + 2 * cb + 2), "traffic": static_traffic("decode_g%d" % grp)[0], "traffic_source": static_traffic("decode_g%d" % grp)[1]}}
         if not cod["g%d" % grp]["roundtrip_ok"]:
             raise SystemExit("bench: codec round trip failed")
         del d_enc, d_cx, d_eo
@@ -1105,7 +1109,8 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
     extras["g2_msm_scalar_muls_per_s"] = n2 / g2dt
     extras["g2_msm"] = {"n": n2, "ms": 1e3 * g2dt, "single_call_ms": g2single,
                         "roofline": {"bound": "int-valu", "kernel": "whole G2 MSM (k_msm_accumulate_g2pair dominant)", "mac32_per_unit": MAC32_G2_MSM_2_20,
-                                     "achieved": n2 * MAC32_G2_MSM_2_20 / g2dt / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s", "frac": n2 * MAC32_G2_MSM_2_20 / g2dt / peak}}
+                                     "achieved": n2 * MAC32_G2_MSM_2_20 / g2dt / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s", "frac": n2 * MAC32_G2_MSM_2_20 / g2dt / peak,
+                                     "algorithmic_bytes": n2 * (192 + 32) + 288, "traffic": static_traffic("g2_msm")[0], "traffic_source": static_traffic("g2_msm")[1]}}
     # batched variable-base scalar multiplication, N in -> N out (the reference's unit operation `&G1Affine * &Scalar`)
     xy1, _ = bases.download(0, n)
     d_xy1 = torch.from_numpy(xy1.view(np.int64)).to(dev)
@@ -1117,7 +1122,8 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
           "roofline": {"bound": "int-valu", "kernel": "k_mul_batch<G1>", "mac32_per_unit": MAC32_G1_MUL, "achieved": n * MAC32_G1_MUL / (mbms * 1e-3) / 1e12,
                        "peak": peak / 1e12, "unit": "TMAC32/s", "frac": n * MAC32_G1_MUL / (mbms * 1e-3) / peak,
                        "executed_mac_per_unit": 2852 * 406, "executed_frac_of_peak": n * 2852 * 406 / (mbms * 1e-3) / peak,
-                       "reference_algorithm_mac32_per_unit": MAC32_G1_MUL_REF}}
+                       "reference_algorithm_mac32_per_unit": MAC32_G1_MUL_REF, "algorithmic_bytes": n * (96 + 32 + 144), "traffic": static_traffic("g1_mul_batch")[0],
+                       "traffic_source": static_traffic("g1_mul_batch")[1]}}
     if not args.no_cpu_baseline:
         from oracle import c_oracle
         mm = 1 << 12
@@ -1153,7 +1159,8 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
     extras["g2_mul_batch"] = {"n": n2m, "ms": mb2ms, "scalar_muls_per_s": n2m / (mb2ms * 1e-3),
                               "roofline": {"bound": "int-valu", "kernel": "k_mul_batch<G2, lane pair>", "mac32_per_unit": MAC32_G2_MUL, "achieved": n2m * MAC32_G2_MUL / (mb2ms * 1e-3) / 1e12,
                                            "peak": peak / 1e12, "unit": "TMAC32/s", "frac": n2m * MAC32_G2_MUL / (mb2ms * 1e-3) / peak,
-                                           "reference_algorithm_mac32_per_unit": MAC32_G2_MUL_REF}}
+                                           "reference_algorithm_mac32_per_unit": MAC32_G2_MUL_REF, "algorithmic_bytes": n2m * (192 + 32 + 288),
+                                           "traffic": static_traffic("g2_mul_batch")[0], "traffic_source": static_traffic("g2_mul_batch")[1]}}
     if not args.no_cpu_baseline:
         from oracle import c_oracle
         mm2 = 1 << 10
