@@ -2860,3 +2860,62 @@ def test_bench_two_ranks_on_one_gpu_runs_the_exchange_with_real_kernels():
     assert line["result_matches_identity"] is True
     assert line["ranks"]["world"] == 2 and line["ranks"]["world_from_process_group"] == 2 and line["ranks"]["backend"] == "gloo" and line["ranks"]["same_device"] is True
     assert line["value"] > 0
+
+
+def test_round6_entry_points_edge_cases_and_argument_errors(ctx):
+    """round-6 entry points: empty inputs are values (the identity, nothing written), NULL / out-of-range arguments are status codes with a
+    message, the scalar form of a context is restored by the *_mont entry points, and the kernel-timing facility reports what was launched"""
+    import ctypes
+    import bls12_381_amd as b
+    from bls12_381_amd import synthetic as sy
+    lib = ctx.lib
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    ERR_ARG = -2
+    A = b.api
+    # scalar form: bad value, n = 0 MSM over limbs = identity, form unchanged after a *_mont call
+    assert lib.blsgpu_set_scalar_form(ctx.h, 2) == ERR_ARG and lib.blsgpu_set_scalar_form(None, 0) == ERR_ARG
+    kb = sy.scalars(4, 960)
+    bases = ctx.bases_from_scalars(1, kb)
+    ident = ctx.msm_mont(bases, np.zeros((0, 4), dtype=np.uint64))
+    assert ctx.batch_normalize(1, ident[None, :])[1][0] == 1
+    sb = sy.scalars(4, 961)
+    limbs, ok = ctx.fr_from_bytes(sb)
+    assert ok.all()
+    nrm = lambda x: ctx.batch_normalize(1, x[None, :])[0][0]
+    assert np.array_equal(nrm(ctx.msm_mont(bases, limbs)), nrm(ctx.msm(bases, sb)))
+    assert np.array_equal(nrm(ctx.msm(bases, sb)), nrm(ctx.msm_mont(bases, limbs)))          # bytes again right after limbs: the form was restored
+    o18 = np.zeros(18, dtype=np.uint64)
+    assert lib.blsgpu_g1_msm_mont(ctx.h, bases.handle, 0, None, 4, P(o18)) == ERR_ARG
+    assert lib.blsgpu_g2_msm_mont(ctx.h, bases.handle, 0, P(limbs), 4, P(o18)) == ERR_ARG and b"other group" in lib.blsgpu_last_error()
+    # Fr conversions: n = 0, NULLs
+    assert ctx.fr_to_bytes(np.zeros((0, 4), dtype=np.uint64)).shape == (0, 32)
+    assert lib.blsgpu_fr_to_bytes(ctx.h, None, 3, P(o18), None) == ERR_ARG
+    assert lib.blsgpu_fr_from_bytes_wide(ctx.h, None, 0, None) == 0
+    # expanders: empty batch, empty message, len 0, unknown expander, too many blocks, NULL
+    assert ctx.expand_message(A.EXPAND_XOF_SHAKE128, [], b"d", 32).shape == (0, 32)
+    assert ctx.expand_message(A.EXPAND_XMD_SHA512, [b""], b"", 0).shape == (1, 0)
+    assert ctx.hash_to_scalar(A.EXPAND_XMD_SHA256, [], b"d", 3).shape == (0, 3, 4)
+    assert ctx.hash_to_scalar(A.EXPAND_XMD_SHA256, [b"m"], b"d", 0).shape == (1, 0, 4)
+    off = np.array([0, 1], dtype=np.uint64); m = np.zeros(8, dtype=np.uint8); out = np.zeros(64, dtype=np.uint8)
+    assert lib.blsgpu_expand_message_batch(ctx.h, -1, P(m), P(off), 1, P(m), 1, 32, P(out)) == ERR_ARG and b"expander" in lib.blsgpu_last_error()
+    assert lib.blsgpu_expand_message_batch(ctx.h, A.EXPAND_XMD_SHA512, P(m), P(off), 1, P(m), 1, 255 * 64 + 1, P(out)) == ERR_ARG
+    assert lib.blsgpu_expand_message_batch(ctx.h, 0, P(m), None, 1, P(m), 1, 32, P(out)) == ERR_ARG
+    assert lib.blsgpu_expand_message_batch(ctx.h, 0, P(m), P(np.array([1, 0], dtype=np.uint64)), 1, P(m), 1, 32, P(out)) == ERR_ARG and b"offsets" in lib.blsgpu_last_error()
+    assert lib.blsgpu_hash_to_scalar_batch(ctx.h, 0, P(m), P(off), 1, P(m), 1, 2000, P(out)) == ERR_ARG                 # 2000 * 48 > 65535
+    assert lib.blsgpu_hash_to_curve_expander_batch(ctx.h, 3, 1, P(m), P(off), 1, P(m), 1, 0, P(out)) == ERR_ARG        # group 3
+    # kernel timing: off by default (empty report), on: one line per kernel of the calls made, cleared by the report
+    assert ctx.kernel_timing_report() == {}
+    ctx.kernel_timing(True)
+    ctx.msm(bases, sb)
+    rep = ctx.kernel_timing_report()
+    ctx.kernel_timing(False)
+    assert any("k_msm_accumulate" in k for k in rep) and all(v["launches"] >= 1 and v["total_ms"] > 0 and v["min_ms"] <= v["max_ms"] for v in rep.values())
+    assert ctx.kernel_timing_report() == {}
+    ctx.msm(bases, sb)
+    assert ctx.kernel_timing_report() == {}
+    need = ctypes.c_size_t(0)
+    assert lib.blsgpu_kernel_timing_report(ctx.h, None, 16, ctypes.byref(need)) == ERR_ARG
+    assert lib.blsgpu_kernel_timing_report(ctx.h, None, 0, ctypes.byref(need)) == 0 and need.value == 0
+    # bases cache verify: NULL context
+    assert lib.blsgpu_set_bases_cache_verify(None, 1) == ERR_ARG
+    bases.free()
