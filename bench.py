@@ -56,12 +56,22 @@ MAC32_G2_MUL = 9554 * 300                  # the same over Fp2 (2852 x 17085 / 5
 def static_traffic(tag):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc summary of the SAME workload (profiles/<round>_<tag>_pmc.json,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE).  Counters cannot be read inside a timed
-    run, so this is a STATIC figure from a separate profiled run -- labelled as such in the bench line."""
+    run, so this is a STATIC figure from a separate profiled run -- labelled as such in the bench line, and marked STALE when the kernel sources
+    of the leg have changed since the counters were collected (tools/srcdigest.py: the digest stored in the file against the sources being timed)."""
     for rnd in ("r06", "r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (rnd, tag))
         if os.path.exists(path):
             try:
-                return json.load(open(path))["hbm_bytes_per_launch_corrected"], "profiles/%s_%s_pmc.json (static: separate rocprofv3 --pmc passes of this workload, not measured in this run)" % (rnd, tag)
+                j = json.load(open(path))
+                src = "profiles/%s_%s_pmc.json (static: separate rocprofv3 --pmc passes of this workload, not measured in this run)" % (rnd, tag)
+                try:
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    from srcdigest import source_digest
+                    if j.get("source_digest") != source_digest(tag):
+                        src += " -- STALE: the kernel sources of this leg changed since the counters were collected"
+                except Exception:
+                    pass
+                return j["hbm_bytes_per_launch_corrected"], src
             except Exception:
                 pass
     return None, None

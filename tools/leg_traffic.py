@@ -85,6 +85,9 @@ def summarise(rnd):
         fh.write("| leg (bench key) | calls in run | fetch raw | write | fetch x 2 + write | algorithmic | ratio |\n|---|---:|---:|---:|---:|---:|---:|\n")
         for leg, tag, calls, fetch, write, hbm, alg in rows:
             fh.write("| %s (`%s`) | %d | %.3e | %.3e | %.3e | %.3e | %.1fx |\n" % (leg, tag, calls, fetch, write, hbm, alg, hbm / alg))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from srcdigest import stamp
+    stamp(rnd)
     print("wrote", len(rows), "legs")
 
 

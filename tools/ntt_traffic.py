@@ -63,6 +63,9 @@ def summarise(rnd):
         fh.write("| FETCH_SIZE (raw, KiB units -> bytes) | %.3e |\n| WRITE_SIZE | %.3e |\n| fetch x 2 (gfx950 correction) + write | %.3e |\n| algorithmic (32 B in + 32 B out per element) | %.3e |\n| ratio | %.2f |\n\n"
                  % (fetch, write, 2 * fetch + write, n * 64, res["ratio_to_algorithmic"]))
         fh.write("Kernels of one transform (kernel trace, average per launch): " + ", ".join("%s %.1f us x %.1f" % (k, res["kernel_avg_us"][k], res["launches_per_transform"][k]) for k in res["kernel_avg_us"]) + "\n")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from srcdigest import stamp
+    stamp(rnd)
     print(json.dumps(res, indent=1))
 
 

@@ -191,4 +191,6 @@ for mode, what in ((0, "keys in G1, signatures in G2"), (1, "keys in G2, signatu
     if f:
         stats_table(f, f"{RND}: rocprofv3 --kernel-trace --stats -- python tools/run_verify.py 14 {mode} 3  (bulk verification of 2^14 signatures from bytes, {what}; "
                        "three calls + the construction of the synthetic signatures)", os.path.join(OUT, f"{RND}_verify_chain_mode{mode}_kernel_stats.md"))
+from srcdigest import stamp
+stamp(RND)                     # the counters were collected from this checkout's sources (bench.py marks a figure stale when they differ)
 print("profiles written for", RND)
