@@ -2850,7 +2850,9 @@ def test_bench_two_ranks_on_one_gpu_runs_the_exchange_with_real_kernels():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", GLOO_SOCKET_IFNAME="lo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()          # a free port, not a fixed one
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--log-total", "18", "--steps", "4", "--warmup", "2",
            "--no-cpu-baseline", "--no-extras"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
