@@ -105,6 +105,11 @@ int staged_upload(blsgpu_ctx* c, void* dst, const void* src, size_t bytes) {
   const size_t nchunks = (bytes + STAGE_CHUNK - 1) / STAGE_CHUNK;
   const int T = (int)(nchunks < (size_t)STAGE_THREADS ? nchunks : (size_t)STAGE_THREADS);
   std::atomic<int> failed{0};
+  // the bounce buffers may still be read by the DMAs of the PREVIOUS staged upload: waited for here, where the buffers are needed again,
+  // not at the end of that upload -- so the host is not held until everything queued before that upload has drained, and the upload of
+  // call i + 1 overlaps the kernels of call i (the source is copied out by the time this function returns either way)
+  for (int k = 0; k < 2 * STAGE_THREADS; k++)
+    if (c->pin_busy[k]) { if (hipEventSynchronize(c->pin_ev[k]) != hipSuccess) failed = 1; c->pin_busy[k] = false; }
   auto work = [&](int t) {
     if (hipSetDevice(c->device) != hipSuccess) { failed = 1; return; }
     const size_t lo = nchunks * (size_t)t / (size_t)T, hi = nchunks * (size_t)(t + 1) / (size_t)T;
@@ -122,12 +127,12 @@ int staged_upload(blsgpu_ctx* c, void* dst, const void* src, size_t bytes) {
   try { for (int t = 1; t < T; t++) th.emplace_back(work, t); } catch (...) { failed = 1; }
   if (!failed) work(0);
   for (auto& x : th) x.join();
-  // the bounce buffers are reused by the next upload: their last DMAs must have been issued -- and read -- before then
-  for (int k = 0; k < 2 * T && !failed; k++) if (hipEventSynchronize(c->pin_ev[k]) != hipSuccess) failed = 1;
+  for (int k = 0; k < 2 * T; k++) c->pin_busy[k] = true;            // (waited for by the next staged upload, blsgpu_synchronize or blsgpu_destroy)
   if (failed) {
     (void)hipGetLastError();
     (void)hipStreamSynchronize(c->stream);          // DMAs already queued still read the bounce buffers: a retry must not overwrite them
     (void)hipGetLastError();
+    for (auto& b : c->pin_busy) b = false;
     g_err = "staged upload failed"; return BLSGPU_ERR_HIP;
   }
   return BLSGPU_OK;

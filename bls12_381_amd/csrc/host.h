@@ -190,6 +190,7 @@ struct blsgpu_ctx {
   bool on_fold_stream = false;          // set while partials_fold_device borrows the context: routes proj_sum_device / fp12_product_device to the fold scratch
   hipStream_t fold_stream = nullptr;    // the asynchronous group fold's copies and sums run here, NOT on `stream`: an MSM's front waits for whatever is queued on `stream`
   void* pin_stage = nullptr; hipEvent_t pin_ev[8] = {};      // pinned bounce buffers of staged_upload
+  bool pin_busy[8] = {};                // ... whose last DMA may still be in flight (waited for where the buffer is needed again)
   DevBuf gt_one; bool gt_one_ready = false; hipEvent_t ev_gt_one = nullptr;      // the wire form of Fp12::one() (blsgpu_gt_is_identity_device, bulk verification)
   DevBuf ver;                           // bulk verification (blsgpu_bls_verify_batch): every intermediate of the chain
   blsgpu_g2_prepared* ver_table = nullptr;   // ... and the resident `G2Prepared` of -G2 for mode 1
