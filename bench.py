@@ -77,6 +77,24 @@ def static_traffic(tag):
     return None, None
 
 
+def valu_issue(tag, seconds, peak):
+    """MEASURED counterpart of the canonical fractions: VALU wave-instructions the leg executes (rocprofv3 SQ_INSTS_VALU of a committed counter run of
+    the same workload: profiles/<round>_<tag>_pmc.json, static like `traffic`) x 64 lanes / the time measured here / the v_mad_u64_u32 issue rate measured
+    here.  Cheap VOP2 instructions can issue faster than multiply-adds, so this is a utilisation of the multiply-add issue rate by ALL instructions, not a
+    share of a hard ceiling; it says how much of a leg's time is instruction issue and how much is waiting."""
+    for rnd in ("r06",):
+        path = os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (rnd, tag))
+        if os.path.exists(path):
+            try:
+                j = json.load(open(path))
+                w = j.get("valu_wave_instructions_per_call") or (j.get("counters") or {}).get("SQ_INSTS_VALU")
+                if w and seconds:
+                    return {"valu_wave_instructions": w, "valu_issue_frac": w * 64 / seconds / peak, "valu_source": "profiles/%s_%s_pmc.json" % (rnd, tag)}
+            except Exception:
+                pass
+    return {}
+
+
 # ---- the ONE JSON line ----------------------------------------------------------------------------------------------------------
 # The driver keeps the last ~8 000 characters of stdout.  The full record (every note, per-op table and latency probe) goes to stderr
 # and, when the directory exists, to gpurun_out/bench_detail.json; stdout carries a compact line (< 6 000 characters) whose LAST keys
@@ -84,7 +102,7 @@ def static_traffic(tag):
 _DROP = {"note", "traffic_source", "launch_sampling", "sample_detail", "per_op_ns", "host", "mac32_per_launch", "reference_algorithm_mac32_per_unit",
          "executed_mac_per_unit", "executed_frac_of_peak", "mac32_per_unit_is", "launch_ms_isolated", "hbm_frac_of_8TBs", "table_build_s", "resident_bytes",
          "single_thread_value", "parallel_speedup", "algorithmic_bytes", "scalars", "single_call_scalar_muls_per_s", "end_to_end_scalar_muls_per_s",
-         "with_final_exponentiation_ms", "window_bits", "per_term_path_ms", "launches_timed", "peak", "unit", "bound", "kernel", "mac32_per_unit", "achieved"}
+         "with_final_exponentiation_ms", "window_bits", "per_term_path_ms", "launches_timed", "peak", "unit", "bound", "kernel", "mac32_per_unit", "achieved", "valu_wave_instructions", "valu_source"}
 _KEEP_SMALL = ("pairing_n1_ms", "pairing_n1024_ms", "final_exponentiation_n1_ms", "multi_miller_loop_n3_plus_final_exponentiation_ms")
 
 
@@ -96,7 +114,8 @@ def _num(x):
 
 def _slim_timing(t):
     return {"min": _num(t.get("min_ms")), "med": _num(t.get("median_ms")), "max": _num(t.get("max_ms")), "reps": t.get("reps"),
-            "kernel_ms": {k: (_num(v) if not isinstance(v, dict) else _num(v.get("total_ms"))) for k, v in (t.get("kernel_ms") or {}).items()}}
+            # (the five longest kernels of the call: the verification chain launches ten)
+            "kernel_ms": dict(sorted(((k, (_num(v) if not isinstance(v, dict) else _num(v.get("total_ms")))) for k, v in (t.get("kernel_ms") or {}).items()), key=lambda kv: -kv[1])[:5])}
 
 
 def _compact_extra(v, depth=0):
@@ -107,7 +126,7 @@ def _compact_extra(v, depth=0):
     for k, x in v.items():
         if k == "sample" and isinstance(x, str):
             out[k] = x[:60]
-        elif k in ("timing", "unprepared_timing") and depth >= 2:
+        elif k == "unprepared_timing" or (k == "timing" and depth >= 2):
             continue
         elif k == "n65536" and isinstance(x, dict):
             out[k] = {a: b for a, b in _compact_extra(x, 2).items() if a in ("ms", "equations_per_s", "frac", "speedup_over_unprepared", "unprepared_same_equations_ms", "roofline")}
@@ -141,17 +160,21 @@ def slim_line(line):
     roof = line.get("roofline")
     if roof:
         r = {k: _num(roof.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_isolated", "launch_ms", "launch_ms_isolated", "whole_msm_frac_pipelined",
-                                                "whole_msm_frac_single_call")}
+                                                "whole_msm_frac_single_call", "valu_issue_frac")}
         out["roofline"] = r
     cpu = line.get("cpu_baseline")
     if cpu:
         out["cpu_baseline"] = {k: _slim(cpu.get(k)) for k in ("value", "unit", "cores", "kind", "sample", "gpu_result_matches") if cpu.get(k) is not None}
+        if isinstance(out["cpu_baseline"].get("sample"), str):
+            out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"][:140]
     if (line.get("latency") or {}).get("host_mirror_repeat_ms") is not None:
         out["host_mirror_repeat_ms"] = _num(line["latency"]["host_mirror_repeat_ms"])
     if (line.get("latency") or {}).get("end_to_end_from_scalar_limbs_ms") is not None:
         out["end_to_end_from_scalar_limbs_ms"] = _num(line["latency"]["end_to_end_from_scalar_limbs_ms"])
         out["host_to_bytes_one_thread_ms"] = _num(line["latency"].get("host_to_bytes_one_thread_ms"))
     for k in ("single_call_ms", "end_to_end_h2d_ms", "group_path", "result_matches_identity", "ranks"):
+        if k == "ranks" and (line.get(k) or {}).get("world", 1) == 1:
+            continue                                       # one rank: nothing to say
         if line.get(k) is not None:
             out[k] = _slim(line[k])
     ex = line.get("extras")
@@ -164,7 +187,7 @@ def slim_line(line):
             elif k in ("pairing_batch", "cpu_baseline_pairing", "pairings_per_s"):
                 continue                                   # emitted LAST, below
             elif k == "gpu_state":
-                keep = ("sclk", "mclk", "power_w", "power_cap_w", "temp_junction_c", "compute_partition", "memory_partition", "perf_level")
+                keep = ("pci", "sclk", "mclk", "power_w", "power_cap_w", "temp_junction_c", "compute_partition", "memory_partition", "perf_level")
                 e2[k] = {"before": {a: b for a, b in (v.get("before_extras") or {}).items() if a in keep}, "after": {a: b for a, b in (v.get("after_extras") or {}).items() if a in ("sclk", "power_w", "temp_junction_c")},
                          "env": {a: b for a, b in (v.get("runtime_env") or {}).items() if a.startswith(("HSA_", "GPU_", "BLSGPU_")) and a != "HSA_ENABLE_IPC_MODE_LEGACY"}}
             else:
@@ -175,10 +198,12 @@ def slim_line(line):
             # the second half of BASELINE's metric, with its roofline block and CPU baseline intact
             rf = pb.get("roofline") or {}
             tail["pairing_batch"] = {"n": pb.get("n"), "ms": _num(pb.get("ms")), "timing": _slim(pb.get("timing") or {}) or None, "clocks_under_load": _slim(pb.get("clocks_under_load") or {}) or None,
-                                     "roofline": {k: _num(rf.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "mac32_per_unit")}}
+                                     "roofline": {k: _num(rf.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "mac32_per_unit", "valu_issue_frac")}}
             cp = ex.get("cpu_baseline_pairing")
             if cp:
                 tail["cpu_baseline_pairing"] = {k: _slim(cp.get(k)) for k in ("value", "unit", "cores", "kind", "sample", "gpu_result_matches") if cp.get(k) is not None}
+                if isinstance(tail["cpu_baseline_pairing"].get("sample"), str):
+                    tail["cpu_baseline_pairing"]["sample"] = tail["cpu_baseline_pairing"]["sample"][:110]
             tail["pairings_per_s"] = _num(ex.get("pairings_per_s"))
             tail["pairing_ms"] = _num(pb.get("ms"))
             tail["pairing_frac"] = _num(rf.get("frac"))
@@ -346,15 +371,22 @@ def gpu_state(dev_index=0):
     out = {}
     try:
         cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
-        visible = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
-        idx = dev_index
-        if visible:
-            try:
-                idx = int(visible.split(",")[dev_index])
-            except Exception:
-                idx = dev_index
-        if cards:
-            base = os.path.dirname(cards[min(idx, len(cards) - 1)])
+        base = None
+        # the card whose PCI address is the HIP device's (a container can see every card of the host in sysfs while HIP sees one GPU: reading
+        # "card0" there gives the idle clocks of somebody else's GPU)
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(dev_index)
+            want = "%04x:%02x:%02x." % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            for c_ in cards:
+                if os.path.basename(os.path.realpath(os.path.dirname(c_))).startswith(want):
+                    base = os.path.dirname(c_); out["pci"] = want + "0"
+        except Exception:
+            pass
+        out["cards_in_sysfs"] = len(cards)
+        if base is None and cards:
+            base = os.path.dirname(cards[0]); out["pci"] = "unmatched (first card in sysfs)"
+        if base is not None:
 
             def cur(name):
                 try:
@@ -600,6 +632,7 @@ def run_msm(args, e):
             "launch_ms": dur * 1e3, "launches_timed": int(live_acc_n), "launch_sampling": "HIP events around every 3rd launch of the timed region", "launch_ms_isolated": float(np.mean(acc_ms)), "mac32_per_launch": mac32_per_launch,
             "whole_msm_frac_pipelined": (float(n) * MAC32_G1_MSM_2_20) / (dt / steps) / peak,
             "whole_msm_frac_single_call": (float(n) * MAC32_G1_MSM_2_20) / (float(np.mean(tot_ms)) * 1e-3) / peak,
+            **valu_issue("msm", dur, peak),
             "note": "integer-VALU bound (no MFMA, HBM traffic ~13% of peak, see traffic): canonical 300 MAC32 per Fp mul, 11 Fp mul per mixed add, "
                     "16 windows (SURVEY.md 8d); peak = v_mad_u64_u32 issue rate measured in this run",
         }
@@ -1217,6 +1250,18 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
     extras["g1_msm_precomputed_tables"] = {"scalar_muls_per_s": n / pdt2, "ms": 1e3 * pdt2, "table_build_s": pre_s, "window_bits": 20,
                                            "resident_bytes": 13 * n * 128, "matches_plain_path": same,
                                            "note": "optional mode for reused bases (blsgpu_bases_precompute); NOT the headline value"}
+    # measured instruction-issue utilisation next to every canonical fraction (valu_issue)
+    def _kms(block, name):
+        v = ((block.get("timing") or {}).get("kernel_ms") or {}).get(name)
+        return (v.get("total_ms") if isinstance(v, dict) else v)
+    for blk, tag, ms in ((extras["pairing_batch"], "pairing", pms), (extras["multi_miller_loop"], "mml", _kms(extras["multi_miller_loop"], "k_multi_miller_shared") or mms),
+                         (extras["verification_equations"], "equations", _kms(extras["verification_equations"], "k_pairing_quad")),
+                         (extras["bls_verify_from_bytes"], "bls_verify", vms), (extras.get("fr_ntt") or {}, "ntt_leg", (extras.get("fr_ntt") or {}).get("ms")),
+                         (extras["hash_to_g2"], "hash_to_g2", hms), (extras["hash_to_g1"], "hash_to_g1", h1ms),
+                         (extras["codec"]["g1"], "decode_g1", extras["codec"]["g1"]["decode_checked_ms"]), (extras["codec"]["g2"], "decode_g2", extras["codec"]["g2"]["decode_checked_ms"]),
+                         (extras["g2_msm"], "g2_msm", 1e3 * g2dt), (extras["g1_mul_batch"], "g1_mul_batch", mbms), (extras["g2_mul_batch"], "g2_mul_batch", mb2ms)):
+        if blk and ms and "roofline" in blk:
+            blk["roofline"].update(valu_issue(tag, ms * 1e-3, peak))
     extras["gpu_state"] = {"before_extras": state_before, "after_extras": gpu_state(e.local_rank), "runtime_env": runtime_env(),
                            "note": "sysfs readings of the device the extras ran on (idle clocks before / after; clocks UNDER LOAD are in pairing_batch.clocks_under_load)"}
     return extras

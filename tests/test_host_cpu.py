@@ -405,4 +405,14 @@ def test_bench_line_is_compact_and_ends_with_the_pairing_half_of_the_metric():
         assert needle in tail, needle
     assert back["pairing_ms"] == pytest.approx(full["extras"]["pairing_batch"]["ms"], rel=1e-4)
     assert back["pairing_batch"]["roofline"]["frac"] == pytest.approx(full["extras"]["pairing_batch"]["roofline"]["frac"], rel=1e-4)
+    # round 6: the record as bench.py now writes it (per-leg timing blocks with kernel_ms, clocks, counter traffic and VALU issue fractions on every leg)
+    full6 = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_default_n1_detail.json")))
+    s6 = json.dumps(bench.slim_line(full6))
+    assert len(s6) < 7700, len(s6)
+    back6 = json.loads(s6)
+    tail6 = s6[-2000:]
+    for needle in ('"pairing_frac"', '"pairing_ms"', '"pairings_per_s"', '"cpu_baseline_pairing"', '"mml_frac"', '"prepared_equations_speedup"', '"kernel_ms"'):
+        assert needle in tail6, needle
+    assert "timing" in back6["pairing_batch"] and set(("min", "med", "max", "kernel_ms")) <= set(back6["pairing_batch"]["timing"])
+    assert back6["roofline"]["traffic"] and all("roofline" not in v or v["roofline"].get("traffic") for v in back6["extras"].values() if isinstance(v, dict) and "roofline" in v)
     assert list(back)[-1] in ("prepared_equations_speedup", "equations_frac")

@@ -7,7 +7,8 @@
 
 A leg may launch several kernels per call (the G2 MSM launches ~40): the figure is the sum over every kernel the leg's calls launched, divided by
 the number of calls; kernels that only build the inputs are excluded by name.  FETCH_SIZE / WRITE_SIZE are KiB; gfx950 counts 64-byte fetches
-as 32-byte ones, so FETCH_SIZE is doubled (the same correction as tools/summarise_profiles.py).  The bulk-verification chain is covered the
+as 32-byte ones, so FETCH_SIZE is doubled (the same correction as tools/summarise_profiles.py).  A third pass counts SQ_INSTS_VALU: the VALU wave-instructions a call EXECUTES -- bench.py turns it into
+`valu_issue_frac`, the measured counterpart of the canonical (and, for the decoding / hashing legs, estimated) MAC32 fractions.  The bulk-verification chain is covered the
 same way through tools/run_verify.py."""
 import collections
 import csv
@@ -29,6 +30,7 @@ LEGS = {
     "g2_msm": ("g2_msm", ["tools/run_leg.py", "g2_msm", "3"], (1 << 20) * (192 + 32) + 288, ("k_fixed_base", "k_bases_from_scalars", "k_bases_endo", "k_bases_subgroup")),
     "mul_g1": ("g1_mul_batch", ["tools/run_leg.py", "mul_g1", "3"], (1 << 20) * (96 + 32 + 144), ("k_fixed_base", "k_bases_from_scalars", "k_bases_export", "k_bases_endo", "k_bases_subgroup")),
     "mul_g2": ("g2_mul_batch", ["tools/run_leg.py", "mul_g2", "3"], (1 << 18) * (192 + 32 + 288), ("k_fixed_base", "k_bases_from_scalars", "k_bases_export", "k_bases_endo", "k_bases_subgroup")),
+    "ntt": ("ntt_leg", ["tools/run_leg.py", "ntt", "3"], (1 << 20) * 64, ()),
     "verify": ("bls_verify", ["tools/run_verify.py", "14", "0", "3"], (1 << 14) * (48 + 96 + 32 + 1),
                ("k_fixed_base", "k_bases_from_scalars", "k_bases_export", "k_bases_endo", "k_bases_subgroup", "k_mul_batch", "k_point_encode")),
 }
@@ -40,7 +42,7 @@ def collect(legs):
         tag, cmd, _, _ = LEGS[leg]
         out = os.path.join(G, "prof_leg_" + leg)
         subprocess.run(["rm", "-rf", out]); os.makedirs(out, exist_ok=True)
-        for i, c in enumerate(("FETCH_SIZE", "WRITE_SIZE")):
+        for i, c in enumerate(("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU")):
             log = open(os.path.join(out, "pmc_%d.log" % i), "w")
             subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", os.path.join(out, "pmc_%d" % i), "--", sys.executable] + cmd,
                            cwd=ROOT, stdout=log, stderr=subprocess.STDOUT, env=dict(os.environ, TMPDIR="/tmp"))
@@ -73,6 +75,7 @@ def summarise(rnd):
         fetch, write = tot["FETCH_SIZE"] * 1024 / calls, tot["WRITE_SIZE"] * 1024 / calls
         hbm = 2 * fetch + write
         j = {"leg": leg, "calls_in_run": calls, "FETCH_SIZE_bytes_raw_per_call": fetch, "WRITE_SIZE_bytes_per_call": write, "hbm_bytes_per_launch_corrected": hbm,
+             "valu_wave_instructions_per_call": (tot["SQ_INSTS_VALU"] / calls) if tot["SQ_INSTS_VALU"] else None,
              "algorithmic_bytes_per_launch": alg, "ratio": hbm / alg,
              "correction": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64-byte fetches as 32-byte ones); WRITE_SIZE as reported; sum over every kernel of a call",
              "kernels": {k: {"fetch_bytes_raw_per_call": v["FETCH_SIZE"] * 1024 / calls, "write_bytes_per_call": v["WRITE_SIZE"] * 1024 / calls} for k, v in per_kernel.items()}}
