@@ -1255,7 +1255,7 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
         v = ((block.get("timing") or {}).get("kernel_ms") or {}).get(name)
         return (v.get("total_ms") if isinstance(v, dict) else v)
     for blk, tag, ms in ((extras["pairing_batch"], "pairing", pms), (extras["multi_miller_loop"], "mml", _kms(extras["multi_miller_loop"], "k_multi_miller_shared") or mms),
-                         (extras["verification_equations"], "equations", _kms(extras["verification_equations"], "k_pairing_quad")),
+                         (extras["verification_equations"], "equations", eqms),
                          (extras["bls_verify_from_bytes"], "bls_verify", vms), (extras.get("fr_ntt") or {}, "ntt_leg", (extras.get("fr_ntt") or {}).get("ms")),
                          (extras["hash_to_g2"], "hash_to_g2", hms), (extras["hash_to_g1"], "hash_to_g1", h1ms),
                          (extras["codec"]["g1"], "decode_g1", extras["codec"]["g1"]["decode_checked_ms"]), (extras["codec"]["g2"], "decode_g2", extras["codec"]["g2"]["decode_checked_ms"]),
