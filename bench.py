@@ -1245,9 +1245,11 @@ def run_extras(args, e, ctx, bases, d_scalars, sb, n, peak, d_out):
     ctx.join(0); torch.cuda.synchronize()
     pdt2 = (time.perf_counter() - t1) / 60
     ctx.set_pipelining(False)
+    tab_single = median_ms(lambda: ctx.msm_device(bases, d_scalars.data_ptr(), n, d_o1[0].data_ptr()), sync)      # ONE call alone on the tables (SURVEY.md 8d protocol)
     same = bool(np.array_equal(ctx.batch_normalize(1, d_o1[3].cpu().numpy().view(np.uint64)[None, :])[0],
                                ctx.batch_normalize(1, d_out.cpu().numpy().view(np.uint64)[None, :])[0]))
-    extras["g1_msm_precomputed_tables"] = {"scalar_muls_per_s": n / pdt2, "ms": 1e3 * pdt2, "table_build_s": pre_s, "window_bits": 20,
+    extras["g1_msm_precomputed_tables"] = {"scalar_muls_per_s": n / pdt2, "ms": 1e3 * pdt2, "single_call_ms": tab_single,
+                                           "whole_msm_frac_single_call": n * MAC32_G1_MSM_2_20 / (tab_single * 1e-3) / peak, "table_build_s": pre_s, "window_bits": 20,
                                            "resident_bytes": 13 * n * 128, "matches_plain_path": same,
                                            "note": "optional mode for reused bases (blsgpu_bases_precompute); NOT the headline value"}
     # measured instruction-issue utilisation next to every canonical fraction (valu_issue)
