@@ -478,7 +478,8 @@ DEVNI void qc_cyc_sqr(QC12& r, const QC12& f) {
 // (z4, z5); each pair squares ITS Fp4 element (three slots, all lanes busy) and sends the result across:
 //   A: (nz2, nz3) = (3 xi t3 + 2 z2, 3 t2 - 2 z3) with (t2, t3) from B      B: (nz4, nz5) = (3 t0 - 2 z4, 3 t1 + 2 z5) with (t0, t1) from A
 typedef FeP<1, VQ> QZ;
-DEV void q_cyc_sqr_compressed(QZ& a, QZ& b) {
+// the new (a, b) with limbs normalised and the value bounds the arithmetic produced: the caller decides where a value reduction goes
+template <int VA, int VB> DEV auto q_cyc_sqr_compressed_raw(const FeP<1, VA>& a, const FeP<1, VB>& b) {
   const bool B = lane_is_B();
   auto t0 = qsqr(a);
   auto t1 = qsqr(b);
@@ -490,9 +491,22 @@ DEV void q_cyc_sqr_compressed(QZ& a, QZ& b) {
   auto r1 = xpair(norm(selB(B, u0, u1)));
   // A: nz2 = 3 r0 + 2 z2, nz3 = 3 r1 - 2 z3        B: nz4 = 3 r0 - 2 z4, nz5 = 3 r1 + 2 z5      (the sign is chosen on the SMALL operand: one negation
   // and one select, then two shift-and-add instructions per limb; round 6 -- the sum and the difference were both formed and selected before)
-  QZ na = fit<VQ>(add(mul_small<3>(r0), dbl(selB(B, neg(a), a))));
-  QZ nb = fit<VQ>(add(mul_small<3>(r1), dbl(selB(B, b, neg(b)))));
-  a = na; b = nb;
+  auto na = norm(add(mul_small<3>(r0), dbl(selB(B, neg(a), a))));
+  auto nb = norm(add(mul_small<3>(r1), dbl(selB(B, b, neg(b)))));
+  struct R { decltype(na) a; decltype(nb) b; };
+  return R{na, nb};
+}
+DEV void q_cyc_sqr_compressed(QZ& a, QZ& b) {
+  auto r = q_cyc_sqr_compressed_raw(a, b);
+  a = fit<VQ>(r.a); b = fit<VQ>(r.b);
+}
+// TWO squarings with ONE value reduction per coordinate: the first leaves its results unreduced (value bounds 57 p / 30 p from inputs below 2 p),
+// the second squares those (the static bounds of the products still hold: they are checked at compile time) and reduces.  Saves two of the
+// four reduce_v of a pair of squarings (~64 instructions each, all 64-bit VOP3 work).
+DEV void q_cyc_sqr_compressed_x2(QZ& a, QZ& b) {
+  auto r1 = q_cyc_sqr_compressed_raw(a, b);
+  auto r2 = q_cyc_sqr_compressed_raw(r1.a, r1.b);
+  a = fit<VQ>(r2.a); b = fit<VQ>(r2.b);
 }
 // f^|x| conjugated (pairings.rs:114-132), |x| = 2^63 + 2^62 + 2^60 + 2^57 + 2^48 + 2^16: 57 compressed squarings with the
 // states after 16 and 48 of them parked in LDS, the three powers decompressed with ONE shared inversion, the powers 2^60,
@@ -505,11 +519,12 @@ DEVNI bool q_cyc_exp_compressed(QC12& r, const QC12& f, u32* park) {
   const bool B = lane_is_B();
   // pair A takes (z2, z3) = (c1.c0, c0.c2), pair B (z4, z5) = (c0.c1, c1.c2)
   QZ a = fit<VQ>(xpair(selB(B, f.h.c0, f.h.c1))), b = fit<VQ>(f.h.c2);
-  for (int i = 1; i <= 57; i++) {
-    q_cyc_sqr_compressed(a, b);
+  for (int i = 2; i <= 56; i += 2) {          // 28 double steps (the snapshots fall on even counts), then the 57th squaring
+    q_cyc_sqr_compressed_x2(a, b);
     if (i == 16) qsnap_put(park, 0, a, b);
     if (i == 48) qsnap_put(park, 1, a, b);
   }
+  q_cyc_sqr_compressed(a, b);
   // decompression (both pairs, replicated): z1 = (xi z5^2 + 3 z4^2 - 2 z3) / (4 z2)  [z2 = 0: 2 z4 z5 / z3],
   // z0 = (2 z1^2 + z2 z5 - 3 z3 z4) xi + 1
   QR z2[3], z3[3], z4[3], z5[3], den[3], pre[3];
