@@ -883,3 +883,10 @@ static int msm_bytes(blsgpu_ctx* c, const uint8_t* bases, const uint8_t* scalars
 extern "C" int blsgpu_g1_msm_bytes(blsgpu_ctx* c, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]) { CTX_CLAIM(c); return msm_bytes<1>(c, bases, scalars, n, out); }
 extern "C" int blsgpu_g2_msm_bytes(blsgpu_ctx* c, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[192]) { CTX_CLAIM(c); return msm_bytes<2>(c, bases, scalars, n, out); }
 
+#ifdef BLS_ACC_TRACE
+// diagnostic build only: where the accumulation kernel writes its per-wavefront trace (4 words per wavefront; nullptr = off)
+extern "C" int blsgpu_diag_set_acc_trace(void* device_words) {
+  unsigned long long* p = (unsigned long long*)device_words;
+  return hipMemcpyToSymbol(HIP_SYMBOL(bls::g_acc_trace), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -85,6 +85,21 @@ template <class F> DEV void load_aff(const u32* rec, Aff<F>& q, bool& inf) {
   Store<F>::ld(w + EL, q.y);
   inf = w[2 * EL] != 0;
 }
+// the same with the identity flag left as the stored word: a prefetching loop must not test it before the record is needed
+// (the comparison is a use of the load: `bool` made the accumulation loop wait for the record it had just requested)
+template <class F> DEV void load_aff_word(const u32* rec, Aff<F>& q, u32& flag) {
+  constexpr int EL = Store<F>::EL;
+  u32 w[2 * EL + 4];
+  const uint4* v = reinterpret_cast<const uint4*>(rec);
+#pragma unroll
+  for (int i = 0; i < (2 * EL + 4) / 4; i++) {
+    uint4 t = v[i];
+    w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w;
+  }
+  Store<F>::ld(w, q.x);
+  Store<F>::ld(w + EL, q.y);
+  flag = w[2 * EL];
+}
 template <class F> DEV void load_proj(const u32* rec, Proj<F>& p) {
   constexpr int EL = Store<F>::EL;
   Store<F>::ldw(rec, p.x); Store<F>::ldw(rec + EL, p.y); Store<F>::ldw(rec + 2 * EL, p.z);
@@ -738,12 +753,21 @@ __global__ void __launch_bounds__(256) k_item_fill(const u32* __restrict__ offs,
 #ifndef BLS_ACC_PRIO
 #define BLS_ACC_PRIO 1
 #endif
+// diagnostic build only (-DBLS_ACC_TRACE, tools/acc_trace.py): every wavefront of the accumulation records its start and end on the
+// constant-rate clock, its hardware id and its item length, so that the occupancy of the chip over the launch can be drawn
+#ifdef BLS_ACC_TRACE
+__device__ unsigned long long* g_acc_trace = nullptr;
+#endif
 template <class F>
 __global__ void __launch_bounds__(BLS_ACC_BLOCK) k_msm_accumulate(const u32* __restrict__ bases, const u32* __restrict__ bases2, u32 nsplit,
                                                         const u32* __restrict__ sorted,
                                                         const ItemDesc* __restrict__ items, const u32* __restrict__ ctrl,
                                                         u32* __restrict__ records) {
   if (BLS_ACC_PRIO) __builtin_amdgcn_s_setprio(BLS_ACC_PRIO);
+#ifdef BLS_ACC_TRACE
+  unsigned long long* const trace = g_acc_trace;
+  const unsigned long long trace_t0 = wall_clock64(), trace_c0 = clock64();
+#endif
   u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ctrl[2]) return;
   ItemDesc d = items[t];
@@ -755,27 +779,43 @@ __global__ void __launch_bounds__(BLS_ACC_BLOCK) k_msm_accumulate(const u32* __r
   acc.x = F::zero(); acc.y = F::zero(); acc.zz = F::zero(); acc.zzz = F::zero();
   bool acc_inf = true;
   // software pipeline: while addition j runs, the record of entry j+1 and the index of entry j+2 are in flight
-  // (two dependent loads per entry; with two wavefronts per SIMD nothing else hides their latency)
+  // (two dependent loads per entry; with two wavefronts per SIMD nothing else hides their latency).  The prefetches are
+  // UNCONDITIONAL (indices clamped to the item's last entry, whose record is then fetched once more and dropped): behind a
+  // branch the backend cannot count the loads in flight and waits for all of them where the current record is first used --
+  // i.e. right after issuing them (round 6: that wait stood in the loop since round 2).  The identity flag stays a word for
+  // the same reason: a `bool` is a comparison, a use of the load.
   const u32 end = d.start + d.len;
-  u32 e = d.len ? sorted[d.start] : 0;
-  u32 e_next = d.len > 1 ? sorted[d.start + 1] : 0;
-  Aff<F> q; bool inf;
-  load_aff<F>(rec_of(e), q, inf);
-  for (u32 j = d.start; j < end; j++) {
-    Aff<F> qn = q; bool infn = true;
-    u32 e_next2 = 0;
-    if (j + 1 < end) load_aff<F>(rec_of(e_next), qn, infn);
-    if (j + 2 < end) e_next2 = sorted[j + 2];
-    if (!inf) {                                             // identity base: contributes nothing
-      auto qy = cond_neg(q.y, (e >> 31) != 0);
-      // G1: the ten field products are inlined (one ~35 KB straight-line body; measured 8% faster than calls even
-      // at 2 waves/SIMD).  G2 keeps the out-of-line Fp2 products (its body would not fit the instruction cache).
-      if constexpr (std::is_same<F, FpPolicy>::value) acc = xyzz_add_mixed_inl(acc, acc_inf, q.x, qy);
-      else acc = xyzz_add_mixed<F>(acc, acc_inf, q.x, qy);
+  if (d.len) {
+    const u32 last = end - 1;
+    u32 e = sorted[d.start];
+    u32 e_next = sorted[d.start + 1 < end ? d.start + 1 : last];
+    Aff<F> q; u32 inf;
+    load_aff_word<F>(rec_of(e), q, inf);
+    for (u32 j = d.start; j < end; j++) {
+#ifdef BLS_ACC_TRACE
+      if (trace && (threadIdx.x & 63) == 0 && ((t >> 6) & 255) == 0 && j - d.start < 250) trace[6 * 16384 + (size_t)(t >> 14) * 256 + (j - d.start)] = wall_clock64();
+#endif
+      Aff<F> qn; u32 infn;
+      load_aff_word<F>(rec_of(e_next), qn, infn);
+      const u32 e_next2 = sorted[j + 2 < end ? j + 2 : last];
+      if (inf == 0) {                                       // identity base: contributes nothing
+        auto qy = cond_neg(q.y, (e >> 31) != 0);
+        // G1: the ten field products are inlined (one ~35 KB straight-line body; measured 8% faster than calls even
+        // at 2 waves/SIMD).  G2 keeps the out-of-line Fp2 products (its body would not fit the instruction cache).
+        if constexpr (std::is_same<F, FpPolicy>::value) acc = xyzz_add_mixed_inl(acc, acc_inf, q.x, qy);
+        else acc = xyzz_add_mixed<F>(acc, acc_inf, q.x, qy);
+      }
+      q = qn; inf = infn; e = e_next; e_next = e_next2;
     }
-    q = qn; inf = infn; e = e_next; e_next = e_next2;
   }
   store_proj<F>(records + (size_t)d.dest * Store<F>::PROJ_WORDS, xyzz_to_proj<F>(acc, acc_inf));
+#ifdef BLS_ACC_TRACE
+  if (trace && (threadIdx.x & 63) == 0) {
+    unsigned long long* o = trace + 6 * (size_t)(t >> 6);
+    o[4] = trace_c0; o[5] = clock64();
+    o[0] = trace_t0; o[1] = wall_clock64(); o[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32); o[3] = d.len;
+  }
+#endif
 }
 // G2 accumulation with every Fp2 value spread over a lane pair (pairlane.hip.h): lane 2k works on the c0 coefficients
 // and lane 2k+1 on the c1 coefficients of chain k.  Same items, same records, same formula.
