@@ -95,6 +95,20 @@ def valu_issue(tag, seconds, peak):
     return {}
 
 
+def kernel_trace_facts():
+    """static, like `traffic`: what a per-wavefront trace of the accumulation kernel showed (tools/acc_trace.py, profiles/r06_acc_trace.md) -- the
+    shader clock UNDER the kernel (s_memtime against the 100 MHz clock; the peak above is measured by a short multiply-add probe at a higher clock) and
+    the share of SIMD-time with two / one / no resident wavefront.  With two resident the SIMD issues one VALU instruction per 4.0 cycles (its limit)."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "r06_acc_trace_default.json")))
+        mhz = j["shader_mhz_by_start_order"]
+        return {"kernel_trace": {"shader_mhz_under_kernel": round(float(np.mean(mhz)), 0),
+                                 "simd_time_two_one_no_wavefront": [j["frac_simd_time_two_waves"], j["frac_simd_time_one_wave"], j["frac_simd_time_idle"]],
+                                 "source": "profiles/r06_acc_trace.md"}}
+    except Exception:
+        return {}
+
+
 # ---- the ONE JSON line ----------------------------------------------------------------------------------------------------------
 # The driver keeps the last ~8 000 characters of stdout.  The full record (every note, per-op table and latency probe) goes to stderr
 # and, when the directory exists, to gpurun_out/bench_detail.json; stdout carries a compact line (< 6 000 characters) whose LAST keys
@@ -161,6 +175,9 @@ def slim_line(line):
     if roof:
         r = {k: _num(roof.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_isolated", "launch_ms", "launch_ms_isolated", "whole_msm_frac_pipelined",
                                                 "whole_msm_frac_single_call", "valu_issue_frac")}
+        kt = roof.get("kernel_trace")
+        if kt:
+            r["kernel_trace"] = {"shader_mhz_under_kernel": kt.get("shader_mhz_under_kernel"), "simd_time_two_one_no_wavefront": kt.get("simd_time_two_one_no_wavefront")}
         out["roofline"] = r
     cpu = line.get("cpu_baseline")
     if cpu:
@@ -633,6 +650,7 @@ def run_msm(args, e):
             "whole_msm_frac_pipelined": (float(n) * MAC32_G1_MSM_2_20) / (dt / steps) / peak,
             "whole_msm_frac_single_call": (float(n) * MAC32_G1_MSM_2_20) / (float(np.mean(tot_ms)) * 1e-3) / peak,
             **valu_issue("msm", dur, peak),
+            **kernel_trace_facts(),
             "note": "integer-VALU bound (no MFMA, HBM traffic ~13% of peak, see traffic): canonical 300 MAC32 per Fp mul, 11 Fp mul per mixed add, "
                     "16 windows (SURVEY.md 8d); peak = v_mad_u64_u32 issue rate measured in this run",
         }
