@@ -65,7 +65,13 @@ def summarise(rnd):
         if not calls:
             print("no call count for", leg); continue
         tot = collections.Counter(); per_kernel = collections.defaultdict(collections.Counter)
-        for f in glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        # gpurun MERGES every run's files into gpurun_out/ (the file names carry the process id): per pass directory only the newest file counts
+        newest = []
+        for pd in sorted(glob.glob(os.path.join(d, "pmc_*"))):
+            fs = glob.glob(os.path.join(pd, "**", "*counter_collection.csv"), recursive=True)
+            if fs:
+                newest.append(max(fs, key=os.path.getmtime))
+        for f in newest:
             for r in csv.DictReader(open(f)):
                 name = r["Kernel_Name"]
                 if any(s in name for s in setup) or name.startswith("__amd_rocclr") or "at::native" in name or "k_fr_tw" in name:
@@ -90,7 +96,7 @@ def summarise(rnd):
             fh.write("| %s (`%s`) | %d | %.3e | %.3e | %.3e | %.3e | %.1fx |\n" % (leg, tag, calls, fetch, write, hbm, alg, hbm / alg))
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from srcdigest import stamp
-    stamp(rnd)
+    stamp(rnd, [tag for _, tag, *_ in rows])
     print("wrote", len(rows), "legs")
 
 

@@ -65,7 +65,7 @@ def summarise(rnd):
         fh.write("Kernels of one transform (kernel trace, average per launch): " + ", ".join("%s %.1f us x %.1f" % (k, res["kernel_avg_us"][k], res["launches_per_transform"][k]) for k in res["kernel_avg_us"]) + "\n")
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from srcdigest import stamp
-    stamp(rnd)
+    stamp(rnd, ["ntt"])
     print(json.dumps(res, indent=1))
 
 

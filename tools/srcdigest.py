@@ -27,14 +27,16 @@ def source_digest(tag):
     return h.hexdigest()[:16]
 
 
-def stamp(rnd):
-    """write "source_digest" into every profiles/<rnd>_*_pmc.json (called by the summarising tools right after they wrote the files: the counters
-    in them were collected from the sources of this checkout)"""
+def stamp(rnd, tags=None):
+    """write "source_digest" into profiles/<rnd>_<tag>_pmc.json for the tags the CALLER has just written (a summarising tool stamps only the files whose
+    counters it took from this checkout's run; stamping every file of the round would vouch for counters that were not re-collected)"""
     import glob
     import json
     alias = {"pairing_lanepair": "pairing", "mml_quad_explicit": "mml"}
     for f in glob.glob(os.path.join(ROOT, "profiles", "%s_*_pmc.json" % rnd)):
         tag = os.path.basename(f)[len(rnd) + 1:-len("_pmc.json")]
+        if tags is not None and tag not in tags:
+            continue
         j = json.load(open(f))
         j["source_digest"] = source_digest(alias.get(tag, tag))
         json.dump(j, open(f, "w"), indent=1)

@@ -17,6 +17,7 @@ META = kernel_meta()
 G = os.path.join(ROOT, "gpurun_out")
 OUT = os.path.join(ROOT, "profiles")
 RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+WRITTEN = []                    # tags of the *_pmc.json files this run writes (only those get a source digest)
 
 
 def one(pattern):
@@ -86,6 +87,7 @@ def msm():
          "mad_wave_insts_expected": mads / 64, "vgpr": meta_find(META, "k_msm_accumulate FpPolicy").get("vgpr_count"),
          "scratch": meta_find(META, "k_msm_accumulate FpPolicy").get("private_segment_fixed_size")}
     json.dump(j, open(os.path.join(OUT, f"{RND}_msm_pmc.json"), "w"), indent=1)
+    WRITTEN.append("msm")
     ghz = c.get("GRBM_GUI_ACTIVE", 0) / 8 / (dur * 1e-9) / 1e9 if dur else 0
     wc = c.get("SQ_WAVE_CYCLES", 1)
     with open(os.path.join(OUT, f"{RND}_msm_pmc.md"), "w") as fh:
@@ -128,6 +130,7 @@ def pairing(d, K, units, unit_name, mac32, tag, what, layout, alg_bytes_per_unit
          "vgpr": m.get("vgpr_count"), "scratch_frame_bytes": m.get("private_segment_fixed_size"), "lds_bytes_per_block": m.get("group_segment_fixed_size"),
          "counters": {k: v for k, v in c.items() if not k.startswith("_")}}
     json.dump(j, open(os.path.join(OUT, f"{RND}_{tag}_pmc.json"), "w"), indent=1)
+    WRITTEN.append(tag)
     with open(os.path.join(OUT, f"{RND}_{tag}_pmc.md"), "w") as fh:
         fh.write(f"""# {RND}: PMC counters of {K} ({units} {unit_name} per launch, {layout})
 
@@ -171,9 +174,14 @@ if one("prof_eq/stats/**/*kernel_trace.csv"):
             "quad layout, one Miller loop per term (per-term path of blsgpu_multi_miller_loop_many)", 288)
     try:
         import csv as _csv
-        tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+        tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "SQ_INSTS_VALU": 0.0}
         names = ("k_pairing_quad", "k_multi_miller_seg", "k_fp12_prod_seg_quad", "k_final_exp_quad", "k_mml_prep_quad")
-        for f in glob.glob(os.path.join(G, "prof_eq", "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        newest = []
+        for pd in sorted(glob.glob(os.path.join(G, "prof_eq", "pmc_*"))):
+            fs = glob.glob(os.path.join(pd, "**", "*counter_collection.csv"), recursive=True)
+            if fs:
+                newest.append(max(fs, key=os.path.getmtime))          # gpurun merges every run into gpurun_out/: the newest file of each pass
+        for f in newest:
             for r in _csv.DictReader(open(f)):
                 if r["Counter_Name"] in tot and any(k in r["Kernel_Name"] for k in names):
                     tot[r["Counter_Name"]] += float(r["Counter_Value"])
@@ -181,6 +189,7 @@ if one("prof_eq/stats/**/*kernel_trace.csv"):
         jp = os.path.join(OUT, f"{RND}_equations_pmc.json")
         j = json.load(open(jp)); j["hbm_bytes_per_launch_miller_kernel"] = j["hbm_bytes_per_launch_corrected"]
         j["hbm_bytes_per_launch_corrected"] = (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / calls
+        j["valu_wave_instructions_per_call"] = tot["SQ_INSTS_VALU"] / calls          # every kernel of the call (bench.py::valu_issue reads this first)
         j["algorithmic_bytes_per_call"] = 16384 * (3 * 288 + 576)
         j["note"] = "hbm_bytes_per_launch_corrected = every kernel of ONE blsgpu_multi_miller_loop_many call (2^14 three-term equations) together"
         json.dump(j, open(jp, "w"), indent=1)
@@ -192,5 +201,5 @@ for mode, what in ((0, "keys in G1, signatures in G2"), (1, "keys in G2, signatu
         stats_table(f, f"{RND}: rocprofv3 --kernel-trace --stats -- python tools/run_verify.py 14 {mode} 3  (bulk verification of 2^14 signatures from bytes, {what}; "
                        "three calls + the construction of the synthetic signatures)", os.path.join(OUT, f"{RND}_verify_chain_mode{mode}_kernel_stats.md"))
 from srcdigest import stamp
-stamp(RND)                     # the counters were collected from this checkout's sources (bench.py marks a figure stale when they differ)
+stamp(RND, WRITTEN)            # the counters were collected from this checkout's sources (bench.py marks a figure stale when they differ)
 print("profiles written for", RND)
