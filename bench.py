@@ -97,12 +97,14 @@ def valu_issue(tag, seconds, peak):
 
 def kernel_trace_facts():
     """static, like `traffic`: what a per-wavefront trace of the accumulation kernel showed (tools/acc_trace.py, profiles/r06_acc_trace.md) -- the
-    shader clock UNDER the kernel (s_memtime against the 100 MHz clock; the peak above is measured by a short multiply-add probe at a higher clock) and
-    the share of SIMD-time with two / one / no resident wavefront.  With two resident the SIMD issues one VALU instruction per 4.0 cycles (its limit)."""
+    shader clock of a LONE call (s_memtime against the 100 MHz clock: after every idle moment the clock restarts near 2.0 GHz and climbs to ~2.29 GHz over
+    ~35 ms of load, so `launch_ms_isolated` / `single_call_ms` sit at the bottom of that ramp while `peak` is probed near its top, and a 20-step timed region
+    spends its first half climbing) and the share of SIMD-time with two / one / no resident wavefront.  With two resident the SIMD issues one VALU
+    instruction per 4.0 cycles (its limit)."""
     try:
         j = json.load(open(os.path.join(ROOT, "profiles", "r06_acc_trace_default.json")))
         mhz = j["shader_mhz_by_start_order"]
-        return {"kernel_trace": {"shader_mhz_under_kernel": round(float(np.mean(mhz)), 0),
+        return {"kernel_trace": {"shader_mhz_lone_call": round(float(np.mean(mhz)), 0),
                                  "simd_time_two_one_no_wavefront": [j["frac_simd_time_two_waves"], j["frac_simd_time_one_wave"], j["frac_simd_time_idle"]],
                                  "source": "profiles/r06_acc_trace.md"}}
     except Exception:
@@ -177,7 +179,7 @@ def slim_line(line):
                                                 "whole_msm_frac_single_call", "valu_issue_frac")}
         kt = roof.get("kernel_trace")
         if kt:
-            r["kernel_trace"] = {"shader_mhz_under_kernel": kt.get("shader_mhz_under_kernel"), "simd_time_two_one_no_wavefront": kt.get("simd_time_two_one_no_wavefront")}
+            r["kernel_trace"] = {"shader_mhz_lone_call": kt.get("shader_mhz_lone_call"), "simd_time_two_one_no_wavefront": kt.get("simd_time_two_one_no_wavefront")}
         out["roofline"] = r
     cpu = line.get("cpu_baseline")
     if cpu:

@@ -889,4 +889,8 @@ extern "C" int blsgpu_diag_set_acc_trace(void* device_words) {
   unsigned long long* p = (unsigned long long*)device_words;
   return hipMemcpyToSymbol(HIP_SYMBOL(bls::g_acc_trace), &p, sizeof(p)) == hipSuccess ? 0 : 1;
 }
+// sequence mode: 1 = every wavefront of every following launch appends its record (up to 2^18); 0 = back to one record per wavefront index
+extern "C" int blsgpu_diag_set_acc_trace_seq(unsigned int on) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(bls::g_acc_seq), &on, sizeof(on)) == hipSuccess ? 0 : 1;
+}
 #endif

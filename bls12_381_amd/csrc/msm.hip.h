@@ -757,6 +757,8 @@ __global__ void __launch_bounds__(256) k_item_fill(const u32* __restrict__ offs,
 // constant-rate clock, its hardware id and its item length, so that the occupancy of the chip over the launch can be drawn
 #ifdef BLS_ACC_TRACE
 __device__ unsigned long long* g_acc_trace = nullptr;
+__device__ unsigned int g_acc_seq = 0;             // != 0: sequence mode (records appended across launches, BLS_ACC_TRACE_SEQ_CAP of them)
+constexpr unsigned int BLS_ACC_TRACE_SEQ_CAP = 1u << 18;
 #endif
 template <class F>
 __global__ void __launch_bounds__(BLS_ACC_BLOCK) k_msm_accumulate(const u32* __restrict__ bases, const u32* __restrict__ bases2, u32 nsplit,
@@ -793,7 +795,7 @@ __global__ void __launch_bounds__(BLS_ACC_BLOCK) k_msm_accumulate(const u32* __r
     load_aff_word<F>(rec_of(e), q, inf);
     for (u32 j = d.start; j < end; j++) {
 #ifdef BLS_ACC_TRACE
-      if (trace && (threadIdx.x & 63) == 0 && ((t >> 6) & 255) == 0 && j - d.start < 250) trace[6 * 16384 + (size_t)(t >> 14) * 256 + (j - d.start)] = wall_clock64();
+      if (trace && !g_acc_seq && (threadIdx.x & 63) == 0 && ((t >> 6) & 255) == 0 && j - d.start < 250) trace[6 * 16384 + (size_t)(t >> 14) * 256 + (j - d.start)] = wall_clock64();
 #endif
       Aff<F> qn; u32 infn;
       load_aff_word<F>(rec_of(e_next), qn, infn);
@@ -811,9 +813,11 @@ __global__ void __launch_bounds__(BLS_ACC_BLOCK) k_msm_accumulate(const u32* __r
   store_proj<F>(records + (size_t)d.dest * Store<F>::PROJ_WORDS, xyzz_to_proj<F>(acc, acc_inf));
 #ifdef BLS_ACC_TRACE
   if (trace && (threadIdx.x & 63) == 0) {
-    unsigned long long* o = trace + 6 * (size_t)(t >> 6);
+    size_t slot = (size_t)(t >> 6);
+    if (g_acc_seq) { unsigned int q = atomicAdd(&g_acc_seq, 1u); if (q >= BLS_ACC_TRACE_SEQ_CAP) return; slot = q; }
+    unsigned long long* o = trace + 6 * slot;
     o[4] = trace_c0; o[5] = clock64();
-    o[0] = trace_t0; o[1] = wall_clock64(); o[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32); o[3] = d.len;
+    o[0] = trace_t0; o[1] = wall_clock64(); o[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32); o[3] = d.len | ((unsigned long long)((size_t)ctrl >> 8) << 32);
   }
 #endif
 }

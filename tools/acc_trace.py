@@ -59,7 +59,7 @@ def run():
     samples = full[nw * 6:].reshape(64, 256)
     np.save(os.path.join(ROOT, "gpurun_out", "acc_trace_samples.npy"), samples)
     t = t[t[:, 1] != 0]
-    t0, t1, hw, ln = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64), t[:, 2].astype(np.uint64), t[:, 3].astype(np.int64)
+    t0, t1, hw, ln = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64), t[:, 2].astype(np.uint64), (t[:, 3] & 0xffffffff).astype(np.int64)
     base = t0.min()
     tick_ns = 10.0                                           # the constant-rate clock of wall_clock64: 100 MHz
     s = (t0 - base) * tick_ns * 1e-3                         # us
@@ -114,5 +114,77 @@ def run():
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "acc_trace.json"), "w"), indent=1)
 
 
+def ramp():
+    """the timed region of bench.py as the driver runs it (5 warm-up steps, sync, K pipelined steps, join, sync) with every accumulation launch's start,
+    end and shader clock recorded: where do the ~4 ms go that a 20-step region costs beyond 20 steady-state steps?"""
+    os.environ["BLSGPU_LIB_PATH"] = TRACE_LIB
+    import time
+    import numpy as np
+    import torch
+    import bls12_381_amd as bls
+    from bls12_381_amd import synthetic
+    n = 1 << 20
+    K = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+    ctx = bls.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    bases = ctx.bases_from_scalars(1, synthetic.scalars(n, synthetic.SEED + 1))
+    d_s = torch.from_numpy(synthetic.scalars(n, synthetic.SEED)).cuda()
+    d_o = torch.zeros((8, 18), dtype=torch.int64, device="cuda")
+    call = lambda i: ctx.msm_device(bases, d_s.data_ptr(), n, d_o[i % 8].data_ptr())
+    lib = ctypes.CDLL(TRACE_LIB)
+    lib.blsgpu_diag_set_acc_trace.argtypes = [ctypes.c_void_p]
+    lib.blsgpu_diag_set_acc_trace_seq.argtypes = [ctypes.c_uint]
+    cap = 1 << 18
+    tr = torch.zeros(cap * 6, dtype=torch.int64, device="cuda")
+    ctx.set_pipelining(True)
+    W = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    assert lib.blsgpu_diag_set_acc_trace(tr.data_ptr()) == 0 and lib.blsgpu_diag_set_acc_trace_seq(1) == 0
+    lib.blsgpu_diag_set_acc_trace_seq(0)              # symbols set before the warm-up: hipMemcpyToSymbol afterwards would be a longer idle gap than the driver's fence
+    for i in range(W):
+        call(i)
+    ctx.join(); torch.cuda.synchronize()
+    lib.blsgpu_diag_set_acc_trace_seq(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        call(i)
+    ctx.join(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lib.blsgpu_diag_set_acc_trace_seq(0); lib.blsgpu_diag_set_acc_trace(None)
+    t = tr.cpu().numpy().reshape(cap, 6)
+    t = t[t[:, 1] != 0]
+    order = np.argsort(t[:, 0])
+    t = t[order]
+    s = (t[:, 0] - t[0, 0]) * 0.01
+    e = (t[:, 1] - t[0, 0]) * 0.01
+    mhz = (t[:, 5] - t[:, 4]) / np.maximum(e - s, 1e-3)
+    # launches: consecutive calls use different pipeline slots (the kernel records its slot's control-block address); within a slot, launches are
+    # separated by more than 5 ms
+    slot = (t[:, 3] >> 32)
+    rows = []
+    for sid in np.unique(slot):
+        m = np.where(slot == sid)[0]
+        m = m[np.argsort(s[m])]
+        cut = [0] + [k + 1 for k in range(len(m) - 1) if s[m[k + 1]] - s[m[k]] > 5000] + [len(m)]
+        for a, b in zip(cut[:-1], cut[1:]):
+            idx = m[a:b]
+            if len(idx) < 1000:
+                continue
+            ll = idx[(e - s)[idx] > 100]
+            rows.append({"waves": int(len(idx)), "start_us": round(float(s[idx].min()), 1), "end_us": round(float(e[idx].max()), 1),
+                         "dur_us": round(float(e[idx].max() - s[idx].min()), 1), "mhz": round(float(np.median(mhz[ll])), 0)})
+    rows.sort(key=lambda r: r["start_us"])
+    for k, r in enumerate(rows):
+        r["since_prev_start_us"] = round(r["start_us"] - rows[k - 1]["start_us"], 1) if k else 0.0
+    bins = {}
+    long_lived = (e - s) > 100
+    for x, m in zip(s[long_lived], mhz[long_lived]):
+        bins.setdefault(int(x // 3000), []).append(m)
+    clock_by_3ms = [round(float(np.median(bins[k])), 0) for k in sorted(bins)]
+    out = {"steps": K, "warmup": W, "timed_region_ms": round(1e3 * dt, 3), "ms_per_step": round(1e3 * dt / K, 4), "shader_mhz_by_3ms_of_the_region": clock_by_3ms, "launches": rows}
+    print(json.dumps(out))
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "acc_ramp.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
-    {"build": build, "run": run}[sys.argv[1]]()
+    {"build": build, "run": run, "ramp": ramp}[sys.argv[1]]()
