@@ -148,7 +148,7 @@ extern "C" int blsgpu_expand_message_batch(blsgpu_ctx* c, int expander, const ui
 extern "C" int blsgpu_hash_to_scalar_device(blsgpu_ctx* c, int expander, const void* d_msgs, const void* d_offsets, size_t n, const void* d_dst, size_t dst_len, size_t count,
                                             void* d_out) { CTX_CLAIM(c);
   if (!c || (n && count && (!d_offsets || !d_out)) || (dst_len && !d_dst)) return bad("hash_to_scalar: NULL argument");
-  if (count * 48 > 65535) return bad("hash_to_scalar: count * 48 must not exceed 65535 (expand_msg.rs:181-183)");
+  if (count > 65535 / 48) return bad("hash_to_scalar: count * 48 must not exceed 65535 (expand_msg.rs:181-183)");
   if (!n || !count) return BLSGPU_OK;
   HIPCHK(hipSetDevice(c->device));
   if (c->h2c_uniform.reserve(n * count * 48)) { g_err = "hipMalloc(uniform bytes) failed"; return BLSGPU_ERR_HIP; }

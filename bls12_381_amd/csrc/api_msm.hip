@@ -297,7 +297,7 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   {
     blsgpu_ctx::Slot* g = &sl;
     bad_alloc |= g->items.reserve(max_items * sizeof(ItemDesc));
-    bad_alloc |= g->heavy.reserve(nb * sizeof(uint4));
+    bad_alloc |= g->heavy.reserve(2 * nb * sizeof(uint4));            // the heavy list, then the indices of its block-folded entries
     bad_alloc |= g->ctrl.reserve((4 + 2 * ITEM_BINS) * 4);
     // (re)allocation frees memory: make sure nothing of this slot is in flight
     size_t lvl = (nb / 2 + 1) * PW * 4;
@@ -422,7 +422,8 @@ static int msm_device(blsgpu_ctx* c, const blsgpu_bases* bases, size_t first, co
   // the fold of cut buckets (almost always a no-op) stays on the accumulation stream: as the first kernel of the tail it made
   // the next accumulation start ~90 us earlier, inside the previous call's bottom reduction level, and the pipelined rate FELL
   // by 2.6 % (A/B on one box, twice: 3.57 vs 3.66*10^8 scalar-muls/s)
-  KLAUNCH(k_msm_heavy<F>, dim3(HEAVY_SMALL_BLOCKS + 512), dim3(256), 0, gas, gs.heavy.as<uint4>(), ctrl, records);
+  const u32 heavy_small_blocks = (u32)nblk(gnb, 256);
+  KLAUNCH(k_msm_heavy<F>, dim3(heavy_small_blocks + HEAVY_BIG_BLOCKS), dim3(256), 0, gas, gs.heavy.as<uint4>(), ctrl, records, (u32)gnb, heavy_small_blocks);
   LAUNCHCHK();
   if (prof) hipEventRecord(c->ev[5], gas);
   // ---- tail ------------------------------------------------------------------------------------------------------

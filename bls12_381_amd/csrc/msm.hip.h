@@ -660,7 +660,8 @@ __global__ void __launch_bounds__(256) k_msm_scatter(const u32* __restrict__ ent
 constexpr int ITEM_BINS = ITEM_CAP_MAX + 1;       // bin = cap - len  (bin 0 = longest)
 constexpr int HEAVY_SMALL = 16;                   // heavy buckets with <= this many partials are folded by one lane
 struct ItemDesc { u32 start, len, dest; };        // entries [start, start+len) of `sorted`; dest = record index
-// ctrl[0] = #partial records handed out, ctrl[1] = #heavy buckets, ctrl[2] = #items
+// ctrl[0] = #partial records handed out, ctrl[1] = #heavy buckets, ctrl[2] = #items, ctrl[3] = #heavy buckets folded by a whole block
+// heavy[0 .. ctrl[1]) = (bucket, first partial record, #partials); heavy[nb .. nb + ctrl[3]).x = indices of the block-folded ones
 // Each block handles ITEM_BLOCK_BUCKETS buckets: the per-block LDS histograms are flushed with one global atomic per
 // non-empty bin, and all blocks hit the same few dozen bins (lengths cluster around the mean load), so fewer, fatter blocks
 // mean proportionally fewer contended atomics (256 buckets per block: 55 + 48 us for 2^18 buckets; 2048: see DESIGN.md).
@@ -728,6 +729,7 @@ __global__ void __launch_bounds__(256) k_item_fill(const u32* __restrict__ offs,
         dest0 = (u32)nb + atomicAdd(&ctrl[0], nitems);
         u32 h = atomicAdd(&ctrl[1], 1u);
         heavy[h] = make_uint4((u32)b, dest0, nitems, 0);
+        if (nitems > (u32)HEAVY_SMALL) heavy[(u32)nb + atomicAdd(&ctrl[3], 1u)].x = h;      // the few block-folded buckets, listed apart
       }
       for (u32 j = 0; j < full[k]; j++) {
         ItemDesc d; d.start = beg[k] + j * ITEM_CAP; d.len = ITEM_CAP; d.dest = dest0 + j;
@@ -905,13 +907,14 @@ __global__ void __launch_bounds__(BLS_G2ACC_BLOCK, 2) k_msm_accumulate_g2pair(co
   for (int i = 0; i < NL; i++) { o[i] = pr.x.v.l[i]; o[2 * NL + i] = pr.y.v.l[i]; o[4 * NL + i] = pr.z.v.l[i]; }
 }
 
-// fold the partial sums of the heavy buckets: one lane per bucket when it has few partials ...
-constexpr int HEAVY_SMALL_BLOCKS = 256;      // blocks [0, 256) of k_msm_heavy run the per-lane path, the rest the per-block path
+// fold the partial sums of the heavy buckets: one lane per bucket when it has few partials (blocks [0, small_blocks): the host sizes them
+// to one lane per bucket of the call -- with an item cap below the mean load MOST buckets are cut in two or three) ...
+constexpr int HEAVY_BIG_BLOCKS = 512;
 template <class F>
-DEV void msm_heavy_small(const uint4* __restrict__ heavy, const u32* __restrict__ ctrl, u32* __restrict__ records) {
+DEV void msm_heavy_small(const uint4* __restrict__ heavy, const u32* __restrict__ ctrl, u32* __restrict__ records, u32 small_blocks) {
   constexpr int PW = Store<F>::PROJ_WORDS;
   u32 nh = ctrl[1];
-  for (u32 h = blockIdx.x * blockDim.x + threadIdx.x; h < nh; h += HEAVY_SMALL_BLOCKS * blockDim.x) {
+  for (u32 h = blockIdx.x * blockDim.x + threadIdx.x; h < nh; h += small_blocks * blockDim.x) {
     uint4 d = heavy[h];
     if (d.z > HEAVY_SMALL) continue;
     const u32* part = records + (size_t)d.y * PW;
@@ -920,14 +923,14 @@ DEV void msm_heavy_small(const uint4* __restrict__ heavy, const u32* __restrict_
     store_proj<F>(records + (size_t)d.x * PW, acc);
   }
 }
-// ... and one block per bucket (in-place tree, fan 8) when it has many
+// ... and one block per bucket (in-place tree, fan 8) when it has many.  These buckets are listed apart (heavy[nb + i].x): walking the whole
+// heavy list for them cost 0.3 ms when every bucket of a 2^18-bucket call was on it (512 dependent loads per block).
 template <class F>
-DEV void msm_heavy_big(const uint4* __restrict__ heavy, const u32* __restrict__ ctrl, u32* __restrict__ records) {
+DEV void msm_heavy_big(const uint4* __restrict__ heavy, const u32* __restrict__ ctrl, u32* __restrict__ records, u32 nb, u32 small_blocks) {
   constexpr int PW = Store<F>::PROJ_WORDS;
-  u32 nh = ctrl[1];
-  for (u32 h = blockIdx.x - HEAVY_SMALL_BLOCKS; h < nh; h += gridDim.x - HEAVY_SMALL_BLOCKS) {
-    uint4 d = heavy[h];
-    if (d.z <= HEAVY_SMALL) continue;                      // uniform across the block
+  const u32 nbig = ctrl[3];
+  for (u32 i = blockIdx.x - small_blocks; i < nbig; i += gridDim.x - small_blocks) {
+    uint4 d = heavy[heavy[nb + i].x];
     u32* part = records + (size_t)d.y * PW;
     u32 n = d.z;
     for (u32 stride = 1; stride < n; stride *= 8) {
@@ -936,8 +939,8 @@ DEV void msm_heavy_big(const uint4* __restrict__ heavy, const u32* __restrict__ 
         size_t i0 = (size_t)g * stride * 8;
         Proj<F> acc; load_proj<F>(part + i0 * PW, acc);
         for (int k = 1; k < 8; k++) {
-          size_t i = i0 + (size_t)k * stride;
-          if (i < n) { Proj<F> e; load_proj<F>(part + i * PW, e); acc = pt_add<F>(acc, e); }
+          size_t j = i0 + (size_t)k * stride;
+          if (j < n) { Proj<F> e; load_proj<F>(part + j * PW, e); acc = pt_add<F>(acc, e); }
         }
         store_proj<F>(part + i0 * PW, acc);
       }
@@ -953,10 +956,10 @@ DEV void msm_heavy_big(const uint4* __restrict__ heavy, const u32* __restrict__ 
 }
 
 template <class F>
-__global__ void __launch_bounds__(256) k_msm_heavy(const uint4* __restrict__ heavy, const u32* __restrict__ ctrl, u32* __restrict__ records) {
-  if (ctrl[1] == 0) return;                                  // no bucket was cut (the common case)
-  if (blockIdx.x < HEAVY_SMALL_BLOCKS) msm_heavy_small<F>(heavy, ctrl, records);
-  else msm_heavy_big<F>(heavy, ctrl, records);
+__global__ void __launch_bounds__(256) k_msm_heavy(const uint4* __restrict__ heavy, const u32* __restrict__ ctrl, u32* __restrict__ records, u32 nb, u32 small_blocks) {
+  if (ctrl[1] == 0) return;                                  // no bucket was cut
+  if (blockIdx.x < small_blocks) msm_heavy_small<F>(heavy, ctrl, records, small_blocks);
+  else msm_heavy_big<F>(heavy, ctrl, records, nb, small_blocks);
 }
 
 // ---- 6. weighted bucket reduction -----------------------------------------------------------------------
