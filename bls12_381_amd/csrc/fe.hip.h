@@ -39,6 +39,35 @@ typedef u32 v16 __attribute__((ext_vector_type(16)));   // ABI carrier: passes i
 #define DEVNI __device__ __noinline__
 #endif
 
+// Issue arbitration between the wavefronts of a SIMD is strict oldest-first (profiles/r06_acc_trace.md): of two resident wavefronts with equal
+// work the older one runs at its own pace (84 % of the issue slots), the younger gets the rest and then runs ALONE at 84 % for most of its
+// life.  fair_tick() alternates the user priority of a wavefront with a time slice of the shader-cycle counter and the parity of its hardware
+// slot, so that the two wavefronts of a SIMD advance at the same average rate and retire together.  It acts only on launches that put an EVEN
+// number (2 .. 8) of equal-work wavefronts on every SIMD of the chip -- with an odd number the last wavefront is alone either way and the plain
+// order is slightly better (2^14 three-term equations = 3 per SIMD: +1.8 % with the tick) -- and is called at the step boundaries of the long
+// loops (a starved wavefront must reach a tick to raise itself, so slices are long: 2^21 .. 2^23 cycles, ~1/16 of the launch).  Measured
+// (profiles/r06_fair_tick.md): 2^18-term multi_miller_loop 31.0 -> 28.9 ms, 2^16 pairings 19.8 -> 19.5 ms.  Results do not depend on it.
+#ifndef BLS_FAIR
+#define BLS_FAIR 1
+#endif
+#ifndef BLS_FAIR_SLICE_LOG
+#define BLS_FAIR_SLICE_LOG 21
+#endif
+constexpr unsigned BLS_CHIP_SIMDS = 1024;          // MI355X: 256 CUs x 4 SIMDs (the only target of this library)
+__device__ __forceinline__ void fair_tick(int longer = 0) {
+#if BLS_FAIR
+  const unsigned q = (gridDim.x * (blockDim.x >> 6)) / (BLS_CHIP_SIMDS / 4);      // wavefronts per SIMD, in quarters
+  const unsigned k = (q + 2) >> 2;
+  const int d = (int)q - (int)(4 * k);
+  if (k < 2 || k > 8 || (k & 1) || d < -1 || d > 1) return;
+  const int slice_log = BLS_FAIR_SLICE_LOG + longer + (k >= 4 ? 1 : 0) + (k >= 8 ? 1 : 0);
+  const unsigned t = (unsigned)(__builtin_readcyclecounter() >> slice_log);
+  const unsigned w = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11));      // HW_ID.wave_id: the wavefront's slot on its SIMD
+  if ((t ^ w) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#else
+  (void)longer;
+#endif
+}
 constexpr int NL = 14;
 constexpr int LW = 28;
 constexpr u32 LMASK = (1u << LW) - 1;

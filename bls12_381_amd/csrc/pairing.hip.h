@@ -396,11 +396,13 @@ template <class E> DEVNI void multi_miller_shared(Fp12T<E>& fout, MmlTerm<E>* t,
   Fp12T<E> f = fp12_one<E>();               // non-escaping, like miller_loop's
   for (int b = 61; b >= -1; b--) {          // b = -1: the final doubling step
     for (int k = 0; k < K; k++) {
+      fair_tick(1);
       if (t[k].skip) continue;
       G2JacT<E> r = t[k].r;
       const fe1 px = t[k].px, py = t[k].py;
       LineT<E> l;
       doubling_step(r, l);
+      fair_tick(1);
       ell(f, l, px, py);
       t[k].r = r;
       if (b >= 0 && ((X_HALF >> b) & 1)) {
@@ -410,6 +412,7 @@ template <class E> DEVNI void multi_miller_shared(Fp12T<E>& fout, MmlTerm<E>* t,
       }
     }
     if (b < 0) break;
+    fair_tick(1);
     fp12_sqr_hot(f, f);
   }
   f.c1 = fp6_neg(f.c1);

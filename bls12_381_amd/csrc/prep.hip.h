@@ -166,6 +166,7 @@ DEV QC12 mmlp_pass(const u32* __restrict__ g1, const uint8_t* __restrict__ g1inf
     if (!is_add && s > 0) g = q12_widen(q12_sqr(g));
     for (int k = 0; k < K; k++) {
       const u32 meta = w.meta[(size_t)k * w.stride + gt];
+      fair_tick(1);
       if (meta == PREP_SKIP) continue;
       fe1 pp; work_get(w.pp + (size_t)k * 4 * w.stride + gt, w.stride, pp);
       QLin l;

@@ -339,6 +339,7 @@ DEV void q_miller_loop(Q12<VQM>& fout, const fe1& px, const fe1& py, const u32* 
   Q12<VQM> g;
   for (int b = 61; b >= -1; b--) {            // bit 62 is the leading one; b = -1: the final doubling step (pairings.rs:686-687)
     QLin l;
+    fair_tick();
     // while R is in registers its three LDS slots hold f (g in the addition step): the accumulator is out of the register allocator's
     // hands exactly where it is not used (round 4: 561 -> 276 scratch instructions in the kernel, 84 more LDS instructions per iteration)
     {
@@ -348,6 +349,7 @@ DEV void q_miller_loop(Q12<VQM>& fout, const fe1& px, const fe1& py, const u32* 
       qpark_get(park, 0, f.h.c0.v); qpark_get(park, 1, f.h.c1.v); qpark_get(park, 2, f.h.c2.v);
       qpark_put_r(park, r);
     }
+    fair_tick();
     { fe1 pp; qpark_get(park, 3, pp); g = q_ell(f, l, pp); }
     if (b < 0) break;
     if ((X_HALF >> b) & 1) {
@@ -360,6 +362,7 @@ DEV void q_miller_loop(Q12<VQM>& fout, const fe1& px, const fe1& py, const u32* 
       fe1 pp; qpark_get(park, 3, pp);
       g = q_ell(g, l, pp);
     }
+    fair_tick();
     f = q12_sqr(g);
   }
   // conjugate (BLS_X_IS_NEGATIVE): c1 -> -c1 on pair B
@@ -520,6 +523,7 @@ DEVNI bool q_cyc_exp_compressed(QC12& r, const QC12& f, u32* park) {
   // pair A takes (z2, z3) = (c1.c0, c0.c2), pair B (z4, z5) = (c0.c1, c1.c2)
   QZ a = fit<VQ>(xpair(selB(B, f.h.c0, f.h.c1))), b = fit<VQ>(f.h.c2);
   for (int i = 2; i <= 56; i += 2) {          // 28 double steps (the snapshots fall on even counts), then the 57th squaring
+    fair_tick();
     q_cyc_sqr_compressed_x2(a, b);
     if (i == 16) qsnap_put(park, 0, a, b);
     if (i == 48) qsnap_put(park, 1, a, b);
