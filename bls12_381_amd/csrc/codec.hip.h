@@ -29,6 +29,7 @@ DEVNI v16 fe_pow_raw(v16 xin, int which) {
   bool started = false;
 #pragma nounroll
   for (int w = 95; w >= 0; w--) {
+    fair_tick();
     u64 word = which == 0 ? e_inv[w >> 4] : which == 1 ? e_sqrt[w >> 4] : e_pm3[w >> 4];
     u32 d = (u32)(word >> ((w & 15) * 4)) & 15u;
     if (started) { acc = (fe)sqr(acc); acc = (fe)sqr(acc); acc = (fe)sqr(acc); acc = (fe)sqr(acc); }
@@ -171,6 +172,7 @@ DEVNI void pt_mul_by_x(Proj<F>& out, const Proj<F>& p) {
   constexpr u64 XH = 0xd201000000010000ull >> 1;
   Proj<F> xself = pt_identity<F>(), tmp = p;
   for (int i = 0; i < 63; i++) {
+    fair_tick();
     tmp = pt_double<F>(tmp);
     if ((XH >> i) & 1) xself = pt_add<F>(xself, tmp);
   }

@@ -121,6 +121,7 @@ template <class F2> DEVNI void h2c_pow_p2m9div16(typename F2::elem& r, const typ
   bool started = false;
 #pragma nounroll
   for (int w = 191; w >= 0; w--) {
+    fair_tick();
     u32 d = (u32)(e[w >> 4] >> ((w & 15) * 4)) & 15u;
     if (started) { acc = F2::st(sqr(acc)); acc = F2::st(sqr(acc)); acc = F2::st(sqr(acc)); acc = F2::st(sqr(acc)); }
     if (d) { acc = started ? F2::st(mul(acc, tab[d - 1])) : tab[d - 1]; started = true; }
