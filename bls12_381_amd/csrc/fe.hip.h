@@ -41,12 +41,18 @@ typedef u32 v16 __attribute__((ext_vector_type(16)));   // ABI carrier: passes i
 
 // Issue arbitration between the wavefronts of a SIMD is strict oldest-first (profiles/r06_acc_trace.md): of two resident wavefronts with equal
 // work the older one runs at its own pace (84 % of the issue slots), the younger gets the rest and then runs ALONE at 84 % for most of its
-// life.  fair_tick() alternates the user priority of a wavefront with a time slice of the shader-cycle counter and the parity of its hardware
-// slot, so that the two wavefronts of a SIMD advance at the same average rate and retire together.  It acts only on launches that put an EVEN
-// number (2 .. 8) of equal-work wavefronts on every SIMD of the chip -- with an odd number the last wavefront is alone either way and the plain
-// order is slightly better (2^14 three-term equations = 3 per SIMD: +1.8 % with the tick) -- and is called at the step boundaries of the long
-// loops (a starved wavefront must reach a tick to raise itself, so slices are long: 2^21 .. 2^23 cycles, ~1/16 of the launch).  Measured
-// (profiles/r06_fair_tick.md): 2^18-term multi_miller_loop 31.0 -> 28.9 ms, 2^16 pairings 19.8 -> 19.5 ms.  Results do not depend on it.
+// life.  The pair fair_init() / fair_tick() makes the LAST TWO wavefronts a SIMD will see share it evenly -- they alternate their user priority
+// (1 / 2) with a time slice of the shader-cycle counter and the parity of their hardware slot, so that they retire together and nothing runs
+// alone -- while the wavefronts before them keep a constant higher priority (3), i.e. the plain order.  "Layer" l of a launch = wavefronts
+// [1024 l, 1024 (l + 1)): with equal work the dispatcher gives every SIMD one wavefront of each layer, in order.  For n layers the launch then
+// takes about n W instead of (n + 0.16) W (W = one wavefront's work; n = 3: 3.04 W against 3.13 W).
+//   fair_init()  at kernel entry: decides from the launch shape (2 .. 8 layers; one layer has nothing to share with, beyond eight the end
+//                effect is below 2 %) and parks the decision in the wavefront's own priority: 0 = untouched, 3 = early layer, 1 = alternating.
+//   fair_tick()  at the step boundaries of the long loops: scalar code only (the priority is read back from the STATUS register), nothing
+//                unless the wavefront alternates.  A starved wavefront must reach a tick to raise itself, so slices are long (2^21 cycles;
+//                2^22 where a wavefront lives ~15 ms).  Kernels that never call fair_init() stay at priority 0 and their ticks do nothing.
+// Measured, same box (profiles/r06_fair_tick.md): 2^18-term multi_miller_loop 31.0 -> 28.8 ms, 2^16 pairings 19.8 -> 19.4 ms, hash-to-G2 of
+// 2^16 messages 9.5 -> 8.7 ms.  Results do not depend on priorities.
 #ifndef BLS_FAIR
 #define BLS_FAIR 1
 #endif
@@ -54,16 +60,22 @@ typedef u32 v16 __attribute__((ext_vector_type(16)));   // ABI carrier: passes i
 #define BLS_FAIR_SLICE_LOG 21
 #endif
 constexpr unsigned BLS_CHIP_SIMDS = 1024;          // MI355X: 256 CUs x 4 SIMDs (the only target of this library)
+__device__ __forceinline__ void fair_init() {
+#if BLS_FAIR
+  const unsigned wpb = blockDim.x >> 6;                                           // wavefronts per block (1024 is a multiple of it)
+  const unsigned layers = (gridDim.x * wpb + BLS_CHIP_SIMDS - 1) / BLS_CHIP_SIMDS;
+  if (layers < 2 || layers > 8) return;
+  const unsigned mine = (blockIdx.x * wpb) / BLS_CHIP_SIMDS;
+  if (mine + 2 < layers) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
+#endif
+}
 __device__ __forceinline__ void fair_tick(int longer = 0) {
 #if BLS_FAIR
-  const unsigned q = (gridDim.x * (blockDim.x >> 6)) / (BLS_CHIP_SIMDS / 4);      // wavefronts per SIMD, in quarters
-  const unsigned k = (q + 2) >> 2;
-  const int d = (int)q - (int)(4 * k);
-  if (k < 2 || k > 8 || (k & 1) || d < -1 || d > 1) return;
-  const int slice_log = BLS_FAIR_SLICE_LOG + longer + (k >= 4 ? 1 : 0) + (k >= 8 ? 1 : 0);
-  const unsigned t = (unsigned)(__builtin_readcyclecounter() >> slice_log);
+  const unsigned p = __builtin_amdgcn_s_getreg((2 << 0) | (3 << 6) | (1 << 11));       // STATUS.USER_PRIO (bits 4:3)
+  if (p - 1u > 1u) return;                                                             // only the alternating wavefronts (1 or 2)
+  const unsigned t = (unsigned)(__builtin_readcyclecounter() >> (BLS_FAIR_SLICE_LOG + longer));
   const unsigned w = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11));      // HW_ID.wave_id: the wavefront's slot on its SIMD
-  if ((t ^ w) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+  if ((t ^ w) & 1u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
 #else
   (void)longer;
 #endif

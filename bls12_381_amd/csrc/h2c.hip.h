@@ -330,6 +330,7 @@ template <class F>
 __global__ void __launch_bounds__(H2cField<F>::LANES == 2 ? 256 : 64, H2cField<F>::LANES == 2 ? 2 : 1)
 k_hash_to_curve(const uint8_t* __restrict__ msgs, const unsigned long long* __restrict__ offs, size_t n, const uint8_t* __restrict__ dst, u32 dlen,
                 int encode_only, u32* __restrict__ out) {
+  fair_init();
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / H2cField<F>::LANES;
   if (i >= n) return;
   constexpr int M = H2cField<F>::M, WW = M * 12;
@@ -344,6 +345,7 @@ k_hash_to_curve(const uint8_t* __restrict__ msgs, const unsigned long long* __re
 template <class F>
 __global__ void __launch_bounds__(H2cField<F>::LANES == 2 ? 256 : 64, H2cField<F>::LANES == 2 ? 2 : 1)
 k_hash_to_curve_uniform(const uint8_t* __restrict__ uniform, size_t n, int encode_only, u32* __restrict__ out) {
+  fair_init();
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / H2cField<F>::LANES;
   if (i >= n) return;
   constexpr int M = H2cField<F>::M, WW = M * 12;
@@ -374,6 +376,7 @@ template <class F>
 __global__ void __launch_bounds__(H2cField<F>::LANES == 2 ? 256 : 64, H2cField<F>::LANES == 2 ? 2 : 1)
 k_hash_to_curve_split(const uint8_t* __restrict__ msgs, const unsigned long long* __restrict__ offs, size_t n, const uint8_t* __restrict__ dst, u32 dlen,
                       u32* __restrict__ out) {
+  fair_init();
   constexpr int L = H2cField<F>::LANES, CTRL = L == 2 ? 0x4E : 0xB1;
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / (2 * L);
   if (i >= n) return;

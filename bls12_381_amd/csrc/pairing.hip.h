@@ -587,6 +587,7 @@ PAIR_KERNEL k_pairing(int mode, const u32* __restrict__ g1, const uint8_t* __res
 // out[j] = Miller value of terms [j*K, (j+1)*K) with shared squarings (the partial products are then multiplied up)
 PAIR_KERNEL k_multi_miller_shared(const u32* __restrict__ g1, const uint8_t* __restrict__ g1inf, const u32* __restrict__ g2,
                                   const uint8_t* __restrict__ g2inf, u32* __restrict__ out, size_t n, int K) {
+  fair_init();
   size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / PL;
   const size_t groups = (n + K - 1) / K;
   if (j >= groups) return;
@@ -609,6 +610,7 @@ PAIR_KERNEL k_multi_miller_shared(const u32* __restrict__ g1, const uint8_t* __r
 // MANY short segments, where a lane pair per segment fills the chip and (k - 1) / k of the 62 squarings per term disappear.
 PAIR_KERNEL k_multi_miller_seg(const u32* __restrict__ g1, const uint8_t* __restrict__ g1inf, const u32* __restrict__ g2, const uint8_t* __restrict__ g2inf,
                                const unsigned long long* __restrict__ off, size_t nseg, size_t total, u32* __restrict__ out, u32* __restrict__ status) {
+  fair_init();
   size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / PL;
   if (j >= nseg) return;
   size_t beg = (size_t)off[j], end = (size_t)off[j + 1];

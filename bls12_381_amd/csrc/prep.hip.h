@@ -205,6 +205,7 @@ QUAD_KERNEL k_mml_prep_quad(const u32* __restrict__ g1, const uint8_t* __restric
                             const u32* __restrict__ qidx, const u32* __restrict__ tab, const uint8_t* __restrict__ tab_inf, u32 tab_n,
                             const unsigned long long* __restrict__ off, size_t nseg, size_t total, int kuni, int kmax,
                             u32* __restrict__ wmeta, uint4* __restrict__ wpp, uint4* __restrict__ wrr, u32* __restrict__ out, u32* __restrict__ status) {
+  fair_init();
   __shared__ u32 park_lds[QPARK_WORDS * QUAD_BLOCK];
   const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t q = gt / QL;

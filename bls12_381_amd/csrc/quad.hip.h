@@ -637,6 +637,7 @@ DEV QC12 qc_load(const u32* w) {
 // Identity on either side -> Fp12::one() (pairings.rs:636-651; multi_miller_loop skips such terms :566-569).
 QUAD_KERNEL k_pairing_quad(int mode, const u32* __restrict__ g1, const uint8_t* __restrict__ g1inf, const u32* __restrict__ g2,
                            const uint8_t* __restrict__ g2inf, u32* __restrict__ out, size_t n) {
+  fair_init();
   __shared__ u32 park_lds[QPARK_WORDS * QUAD_BLOCK];
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / QL;
   if (i >= n) return;
@@ -654,6 +655,7 @@ QUAD_KERNEL k_pairing_quad(int mode, const u32* __restrict__ g1, const uint8_t* 
   qc_save(f, out + i * 144);
 }
 QUAD_KERNEL k_final_exp_quad(const u32* __restrict__ in, u32* __restrict__ out, size_t n) {
+  fair_init();
   __shared__ u32 park_lds[QPARK_WORDS * QUAD_BLOCK];
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / QL;
   if (i >= n) return;

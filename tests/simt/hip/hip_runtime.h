@@ -88,5 +88,6 @@ static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 static inline void __syncthreads() { g_emu_group.barrier(); }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_getreg(x) 0u
+#define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_readcyclecounter() 0ull
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)

@@ -26,6 +26,8 @@ def med(fn, warm=2, reps=9):
     return float(np.median(ts)), float(min(ts))
 print("pairing 2^16        median %.3f ms  min %.3f" % med(lambda: ctx.pairing_batch_device(P(d_g1), P(d_g2), n, P(d_gt))))
 d4g1 = d_g1.repeat(4, 1); d4g2 = d_g2.repeat(4, 1); d_one = torch.zeros(72, dtype=torch.int64, device=dev)
+for m in (49152, 40000, 32768, 24576):
+    print("pairing %6d      median %.3f ms  min %.3f" % ((m,) + med(lambda: ctx.pairing_batch_device(P(d_g1), P(d_g2), m, P(d_gt)))))
 print("mml 2^18            median %.3f ms  min %.3f" % med(lambda: ctx.multi_miller_loop_device(P(d4g1), P(d4g2), 4 * n, P(d_one))))
 ne = 1 << 14
 off = torch.arange(0, 3 * ne + 1, 3, dtype=torch.int64, device=dev)
