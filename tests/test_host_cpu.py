@@ -416,3 +416,21 @@ def test_bench_line_is_compact_and_ends_with_the_pairing_half_of_the_metric():
     assert "timing" in back6["pairing_batch"] and set(("min", "med", "max", "kernel_ms")) <= set(back6["pairing_batch"]["timing"])
     assert back6["roofline"]["traffic"] and all("roofline" not in v or v["roofline"].get("traffic") for v in back6["extras"].values() if isinstance(v, dict) and "roofline" in v)
     assert list(back)[-1] in ("prepared_equations_speedup", "equations_frac")
+
+
+def test_profile_digests_are_stamped_only_on_the_files_a_tool_wrote(tmp_path, monkeypatch):
+    """bench.py marks a leg's committed counter traffic STALE when the kernel sources changed since collection (tools/srcdigest.py).  A summarising
+    tool must therefore stamp only the files whose counters it has just taken from a run of this checkout: stamping every file of the round would
+    vouch for counters that were not re-collected (round 6: it did)."""
+    import importlib, json, sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sd = importlib.import_module("srcdigest")
+    prof = tmp_path / "profiles"; prof.mkdir()
+    for tag in ("msm", "pairing", "hash_to_g2"):
+        (prof / ("r99_%s_pmc.json" % tag)).write_text(json.dumps({"source_digest": "old", "counters": {}}))
+    monkeypatch.setattr(sd, "ROOT", str(tmp_path))
+    sd.stamp("r99", ["msm"])
+    got = {tag: json.loads((prof / ("r99_%s_pmc.json" % tag)).read_text())["source_digest"] for tag in ("msm", "pairing", "hash_to_g2")}
+    assert got["msm"] == sd.source_digest("msm") != "old" and got["pairing"] == "old" and got["hash_to_g2"] == "old"
+    # the digest covers the field arithmetic every kernel shares and the family's own sources
+    assert sd.source_digest("msm") != sd.source_digest("pairing")
