@@ -41,3 +41,11 @@ try:
     print("mml prepared 2^18   median %.3f ms  min %.3f" % med(lambda: ctx.multi_miller_loop_prepared_device(P(d4g1), tab, P(qidx), 4 * n, P(d_one))))
 except Exception as ex:
     print("prepared legs skipped:", ex)
+# single-layer launches (one wavefront per SIMD): 2^14 pairings, 2^14 three-term equations with two prepared terms
+try:
+    print("pairing 2^14        median %.3f ms  min %.3f" % med(lambda: ctx.pairing_batch_device(P(d_g1), P(d_g2), 1 << 14, P(d_gt))))
+    qi = np.full(3 * ne, bls.UNPREPARED, dtype=np.uint32); qi[1::3] = 0; qi[2::3] = 1
+    d_qi3 = torch.from_numpy(qi.view(np.int32)).to(dev)
+    print("prepared eq 2^14    median %.3f ms  min %.3f" % med(lambda: ctx.multi_miller_loop_prepared_many_device(P(d_g1), tab, P(d_qi3), P(off), ne, 3 * ne, P(d_eq), max_seg_terms=3, d_g2=P(d_g2))))
+except Exception as ex:
+    print("single-layer legs skipped:", ex)
