@@ -199,6 +199,99 @@ template <class F2> DEVNI void h2c_sswu_g2(Proj<F2>& out, const typename F2::ele
   out.x = x_num; out.y = F2::st(mul(y, x_den)); out.z = x_den;
 }
 
+// ---- the two maps of a message at once, on a lane pair (round 6) ---------------------------------------------------------------
+// hash_to_curve maps TWO field elements per message (mod.rs:86-96).  The reference finds the square root of g(x) = U/V by raising u v^15 to
+// (p^2 - 9)/16 in Fp2 (192 windows of four Fp2 squarings and a multiplication) and trying eight roots of unity; what it RETURNS does not depend
+// on the method: x = x0 when U/V is a square in Fp2, else x1 = xi u^2 x0; y = the root of g(x) whose sgn0 equals sgn0(u) (a field element has
+// two roots, the sign rule picks one); and y = 0, x = x1 whenever gx1_num = 0 (u = 0 or U = 0: every candidate of the reference's second loop is
+// zero and "matches").  Any exact square root serves, and one built from BASE-FIELD exponentiations lets the two lanes of a pair work on the
+// two maps at the same time -- lane 0 on the first field element, lane 1 on the second -- instead of sharing every product of one Fp2 chain:
+//   n = norm(U V), e = n^((p+1)/4):  e^2 = n  <=>  U/V is a square;  otherwise e^2 = -n and norm(gx1_num V) = n norm(xi)^3 norm(u)^6 has the
+//   root e sqrt(-125) norm(u)^3  (xi = -(2 + u), norm 5; -125 is a residue mod p);
+//   sqrt(a), a = U V or gx1_num V, from the root s of its norm as codec.hip.h fe2_sqrt does: X = 2 (a0 + s) (a0 when a1 = 0),
+//   g = X^((p-3)/4), f = g X, f g = +-1 the quadratic character of X (so 1/f = +-g):  f^2 = X: (f/2, a1/f),  f^2 = -X: (a1/f, f/2);
+//   y = sqrt(a) / V, with 1/V = conj(V) / norm(V) and the base-field inverse taken in the same per-lane phase.
+// The Fp2 arithmetic before and after stays pair-cooperative.  A single map built this way is SLOWER than the reference's chain on lane pairs
+// (both lanes would run the same base-field chain: 8.7 -> 9.9 ms); two maps side by side: hash-to-G2 of 2^16 messages 8.7 -> see
+// profiles/r06_fair_tick.md.  Checked against the oracle's restatement of the reference on random and degenerate u and by every vector.
+struct SswuMid { FeP<1, VS2> u, xi_usq, x_den, x0_num, gx_den, a0v, a1v; fe N, NV; bool g1zero; };
+DEV fe h2c_pnorm(const FeP<1, VS2>& z) { const fe own = store(z.v); auto q = sqr(own); return store(add(q, partner(q))); }      // norm, in both lanes
+DEV void h2c_sswu_g2_pre(SswuMid& m, const FeP<1, VS2>& u) {
+  typedef Fp2PairPolicy F2;
+  typedef F2::elem E;
+  typedef H2c2<F2> H;
+  const E A = H::row2(H2C_G2_T, 0), B = H::row2(H2C_G2_T, 1), XI = H::row2(H2C_G2_T, 2);
+  E usq = F2::st(sqr(u));
+  E xi_usq = F2::st(mul(XI, usq));
+  E xisq_u4 = F2::st(sqr(xi_usq));
+  E nd_common = F2::st(add(xisq_u4, xi_usq));
+  E x_den = F2::st(mul(A, select(is_zero(nd_common), XI, F2::st(neg(nd_common)))));
+  E x0_num = F2::st(mul(B, F2::st(add(F2::one(), nd_common))));
+  E x_densq = F2::st(sqr(x_den));
+  E gx_den = F2::st(mul(x_densq, x_den));
+  E gx0_num = F2::st(add(mul(F2::st(add(sqr(x0_num), mul(A, x_densq))), x0_num), mul(B, gx_den)));
+  E gx1_num = F2::st(mul(F2::st(mul(gx0_num, xi_usq)), xisq_u4));
+  m.u = u; m.xi_usq = xi_usq; m.x_den = x_den; m.x0_num = x0_num; m.gx_den = gx_den;
+  m.g1zero = is_zero(gx1_num);
+  m.a0v = F2::st(mul(gx0_num, gx_den)); m.a1v = F2::st(mul(gx1_num, gx_den));
+  m.N = h2c_pnorm(u); m.NV = h2c_pnorm(gx_den);
+}
+struct SswuRoot { fe lo, hi, vinv; bool qr, sq0; };
+// base field only: a = (A00, A01) = U V, a' = (A10, A11) = gx1_num V, N = norm(u), NV = norm(V)
+DEV void h2c_sswu_g2_root(SswuRoot& r, const fe& A00, const fe& A01, const fe& A10, const fe& A11, const fe& N, const fe& NV) {
+  constexpr PLimbs csq = {BLS_SQRT_M125_MONT}, half = {BLS_TWO_INV_MONT};
+  const fe n = store(add(sqr(A00), sqr(A01)));
+  bool sq0;
+  const fe e = (fe)fe_sqrt(n, sq0);
+  const fe N3 = store(mul(store(sqr(N)), N));
+  const fe s1 = store(mul(store(mul(e, fe1_const(csq))), N3));
+  const fe s = select(sq0, e, s1);
+  const fe a0 = select(sq0, A00, A10), a1 = select(sq0, A01, A11);
+  const bool real = is_zero(a1);
+  const fe X = select(real, a0, store(dbl(add(a0, s))));
+  const fe g = h2c_pow_pm3div4(X);
+  const fe f = store(mul(g, X));
+  const bool qr = fe_eq(store(mul(f, g)), fe_one()) || is_zero(X);
+  const fe h = store(mul(f, fe1_const(half)));
+  const fe w = store(mul(a1, select(qr, g, store(neg(g)))));
+  r.lo = select(real, f, h); r.hi = select(real, fe_zero(), w);
+  r.vinv = (fe)inv(NV);
+  r.qr = qr; r.sq0 = sq0;
+}
+DEV void h2c_sswu_g2_post(Proj<Fp2PairPolicy>& out, const SswuMid& m, const fe& lo, const fe& hi, const fe& vinv, bool qr, bool sq0) {
+  typedef Fp2PairPolicy F2;
+  typedef F2::elem E;
+  const bool c1 = lane_is_c1();
+  E r; r.v = (Fe<1, VS2>)select(qr != c1, lo, hi);                         // lane c0: qr ? lo : hi;  lane c1: qr ? hi : lo
+  E vi; vi.v = (Fe<1, VS2>)store(mul(select(c1, store(neg(m.gx_den.v)), store(m.gx_den.v)), vinv));      // 1/V = conj(V) / norm(V)
+  E y = F2::st(mul(r, vi));
+  if (m.g1zero) y = F2::zero();
+  const bool eta_found = !sq0 || m.g1zero;
+  E x_num = eta_found ? F2::st(mul(m.x0_num, m.xi_usq)) : m.x0_num;
+  if (h2c_sgn0(m.u) != h2c_sgn0(y)) y = F2::st(neg(y));
+  out.x = x_num; out.y = F2::st(mul(y, m.x_den)); out.z = m.x_den;
+}
+DEVNI void h2c_sswu_g2_dual(Proj<Fp2PairPolicy>& o0, Proj<Fp2PairPolicy>& o1, const FeP<1, VS2>& u0, const FeP<1, VS2>& u1) {
+  SswuMid m0, m1;
+  h2c_sswu_g2_pre(m0, u0);
+  h2c_sswu_g2_pre(m1, u1);
+  const bool c1 = lane_is_c1();
+  // lane L works on map L: its own coefficient of map L's value, and the other coefficient from the partner (which sends what THIS lane's map needs)
+  const fe a0_own = select(c1, store(m1.a0v.v), store(m0.a0v.v));
+  const fe a0_oth = partner(select(c1, store(m0.a0v.v), store(m1.a0v.v)));
+  const fe a1_own = select(c1, store(m1.a1v.v), store(m0.a1v.v));
+  const fe a1_oth = partner(select(c1, store(m0.a1v.v), store(m1.a1v.v)));
+  // lane 0 owns the c0 coefficient, lane 1 the c1 coefficient
+  SswuRoot rt;
+  h2c_sswu_g2_root(rt, select(c1, a0_oth, a0_own), select(c1, a0_own, a0_oth), select(c1, a1_oth, a1_own), select(c1, a1_own, a1_oth),
+                   select(c1, m1.N, m0.N), select(c1, m1.NV, m0.NV));
+  // map 0's root was computed by lane 0, map 1's by lane 1: each lane receives the other map's
+  const fe lo_x = partner(rt.lo), hi_x = partner(rt.hi), vinv_x = partner(rt.vinv);
+  const bool qr_x = partner_flag(rt.qr), sq_x = partner_flag(rt.sq0);
+  h2c_sswu_g2_post(o0, m0, select(c1, lo_x, rt.lo), select(c1, hi_x, rt.hi), select(c1, vinv_x, rt.vinv), c1 ? qr_x : rt.qr, c1 ? sq_x : rt.sq0);
+  h2c_sswu_g2_post(o1, m1, select(c1, rt.lo, lo_x), select(c1, rt.hi, hi_x), select(c1, rt.vinv, vinv_x), c1 ? rt.qr : qr_x, c1 ? rt.sq0 : sq_x);
+}
+
 // ---- isogenies (map_g1.rs:589-630, map_g2.rs:457-492): Horner in x with powers of z --------------------------------
 template <class F> struct H2cIso;
 template <> struct H2cIso<FpPolicy> {
@@ -307,6 +400,19 @@ template <> struct H2cField<Fp2PairPolicy> {
 template <class F> DEV void h2c_map_and_store(const u32* ub, int encode_only, u32* o) {
   constexpr int M = H2cField<F>::M, WW = M * 12;
   Proj<F> q, t;
+  if constexpr (std::is_same<F, Fp2PairPolicy>::value) {
+    if (!encode_only) {
+      // both field elements at once: the base-field chains of the two maps run on the two lanes (h2c_sswu_g2_dual)
+      Proj<F> t1, q1;
+      h2c_sswu_g2_dual(t, t1, H2cField<F>::from_okm(ub), H2cField<F>::from_okm(ub + 16 * M));
+      h2c_iso_map<F>(q, t);
+      h2c_iso_map<F>(q1, t1);
+      q = pt_add<F>(q, q1);
+    } else {
+      H2cField<F>::sswu(t, H2cField<F>::from_okm(ub));
+      h2c_iso_map<F>(q, t);
+    }
+  } else {
   H2cField<F>::sswu(t, H2cField<F>::from_okm(ub));
   h2c_iso_map<F>(q, t);
   if (!encode_only) {
@@ -314,6 +420,7 @@ template <class F> DEV void h2c_map_and_store(const u32* ub, int encode_only, u3
     H2cField<F>::sswu(t, H2cField<F>::from_okm(ub + 16 * M));
     h2c_iso_map<F>(q1, t);
     q = pt_add<F>(q, q1);
+  }
   }
   Proj<F> r;
   H2cField<F>::clear(r, q);

@@ -14,7 +14,7 @@ _FAMILY = {
 }
 _TAG = {"msm": "msm", "g2_msm": "msm", "g1_mul_batch": "mul", "g2_mul_batch": "mul", "pairing": "pairing", "mml": "pairing", "equations": "pairing",
         "equations_prepared": "pairing", "mml_prepared": "pairing", "pairing_wide": "pairing", "ntt": "aux", "hash_to_g1": "aux", "hash_to_g2": "aux",
-        "decode_g1": "aux", "decode_g2": "aux", "bls_verify": None}          # the verification chain spans the pairing and the aux families
+        "decode_g1": "aux", "decode_g2": "aux", "ntt_leg": "aux", "bls_verify": None}          # the verification chain spans the pairing and the aux families
 
 
 def source_digest(tag):
