@@ -71,6 +71,8 @@ SIGNATURES = {
     "blsgpu_hash_to_curve_device": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp, c_sz, c_int, c_vp]),
     "blsgpu_hash_to_curve_expander_batch": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_sz, c_vp, c_sz, c_int, c_vp]),
     "blsgpu_hash_to_curve_expander_device": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_sz, c_vp, c_sz, c_int, c_vp]),
+    "blsgpu_hash_to_curve_from_uniform_batch": (c_int, [c_vp, c_int, c_vp, c_sz, c_int, c_vp]),
+    "blsgpu_hash_to_curve_from_uniform_device": (c_int, [c_vp, c_int, c_vp, c_sz, c_int, c_vp]),
     "blsgpu_expand_message_batch": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp, c_sz, c_sz, c_vp]),
     "blsgpu_expand_message_device": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp, c_sz, c_sz, c_vp]),
     "blsgpu_hash_to_scalar_batch": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp, c_sz, c_sz, c_vp]),

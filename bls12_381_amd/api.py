@@ -493,6 +493,15 @@ class Context:
         check(self.lib.blsgpu_hash_to_curve_expander_batch(self.h, group, int(expander), _ptr(blob), _ptr(offs), n, _ptr(d), len(dst), 1 if encode_only else 0, _ptr(out)), "hash_to_curve_expander")
         return out
 
+    def hash_to_curve_from_uniform(self, group, uniform, encode_only=False):
+        """the part of hash_to_curve behind the expander (mod.rs:86-108): `uniform` = (n, count * M * 64) bytes per message (count = 1 | 2, M = 1 for G1,
+        2 for G2) -> from_okm -> map_to_curve -> sum -> clear_h; returns (n, 18 | 36) u64 projective points"""
+        per = (1 if encode_only else 2) * (1 if group == 1 else 2) * 64
+        u = np.ascontiguousarray(np.asarray(uniform, dtype=np.uint8)).reshape(-1, per)
+        out = np.zeros((u.shape[0], 18 if group == 1 else 36), dtype=np.uint64)
+        check(self.lib.blsgpu_hash_to_curve_from_uniform_batch(self.h, group, _ptr(u), u.shape[0], 1 if encode_only else 0, _ptr(out)), "hash_to_curve_from_uniform")
+        return out
+
     def expand_message(self, expander, msgs, dst, len_in_bytes):
         """`ExpandMessage::init_expand` + reading all the bytes: (n, len_in_bytes) uint8"""
         n, blob, offs, d = self._msgs(msgs, dst)

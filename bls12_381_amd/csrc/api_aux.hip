@@ -103,6 +103,30 @@ extern "C" int blsgpu_hash_to_curve_expander_device(blsgpu_ctx* c, int group, in
                                                     int encode_only, void* d_out_xyz) { CTX_CLAIM(c);
   return h2c_device(c, group, expander, d_msgs, d_offsets, n, d_dst, dst_len, encode_only, d_out_xyz);
 }
+// the part behind the expander: caller-supplied uniform bytes -> from_okm -> map_to_curve -> (sum) -> clear_h
+extern "C" int blsgpu_hash_to_curve_from_uniform_device(blsgpu_ctx* c, int group, const void* d_uniform, size_t n, int encode_only, void* d_out_xyz) { CTX_CLAIM(c);
+  if (!c || (n && (!d_uniform || !d_out_xyz))) return bad("hash_to_curve_from_uniform: NULL argument");
+  if (group != 1 && group != 2) return bad("hash_to_curve: group must be 1 or 2");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  if (group == 1) KLAUNCH(k_hash_to_curve_uniform<FpPolicy>, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (const uint8_t*)d_uniform, n, encode_only ? 1 : 0, (u32*)d_out_xyz);
+  else KLAUNCH(k_hash_to_curve_uniform<Fp2PairPolicy>, dim3(nblk(n * 2, 256)), dim3(256), 0, c->stream, (const uint8_t*)d_uniform, n, encode_only ? 1 : 0, (u32*)d_out_xyz);
+  LAUNCHCHK();
+  return BLSGPU_OK;
+}
+extern "C" int blsgpu_hash_to_curve_from_uniform_batch(blsgpu_ctx* c, int group, const uint8_t* uniform, size_t n, int encode_only, uint64_t* out_xyz) { CTX_CLAIM(c);
+  if (!c || (n && (!uniform || !out_xyz))) return bad("hash_to_curve_from_uniform: NULL argument");
+  if (group != 1 && group != 2) return bad("hash_to_curve: group must be 1 or 2");
+  if (!n) return BLSGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  const size_t per = (size_t)(encode_only ? 1 : 2) * (group == 1 ? 1 : 2) * 64, ob = n * 3 * (group == 1 ? 12 : 24) * 4;
+  if (c->io_a.reserve(n * per) || c->io_out.reserve(ob)) { g_err = "hipMalloc(io) failed"; return BLSGPU_ERR_HIP; }
+  HIPCHK(hipMemcpyAsync(c->io_a.p, uniform, n * per, hipMemcpyHostToDevice, c->stream));
+  if (int rc = blsgpu_hash_to_curve_from_uniform_device(c, group, c->io_a.p, n, encode_only, c->io_out.p)) return rc;
+  HIPCHK(hipMemcpyAsync(out_xyz, c->io_out.p, ob, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLSGPU_OK;
+}
 // `ExpandMessage::init_expand` + reading all `len_in_bytes` bytes, per message (out: n x len_in_bytes)
 extern "C" int blsgpu_expand_message_device(blsgpu_ctx* c, int expander, const void* d_msgs, const void* d_offsets, size_t n, const void* d_dst, size_t dst_len, size_t len_in_bytes,
                                             void* d_out) { CTX_CLAIM(c);

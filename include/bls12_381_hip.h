@@ -505,6 +505,15 @@ int blsgpu_hash_to_curve_expander_batch(blsgpu_ctx* ctx, int group, int expander
                                         size_t dst_len, int encode_only, uint64_t* out_xyz);
 int blsgpu_hash_to_curve_expander_device(blsgpu_ctx* ctx, int group, int expander, const void* d_msgs, const void* d_offsets, size_t n, const void* d_dst,
                                          size_t dst_len, int encode_only, void* d_out_xyz);
+/* The part of `hash_to_curve` / `encode_to_curve` BEHIND the expander (hash_to_curve/mod.rs:86-108 after `hash_to_field`'s
+ * `expand_message` call): per message count x M x 64 uniform bytes (count = 1 for encode_only, else 2; M = 1 for G1, 2 for G2) are reduced
+ * as `from_okm` does (map_g1.rs:512-531, map_g2.rs:362-380), mapped (`map_to_curve`: simplified SWU + isogeny), added and cleared of the
+ * cofactor.  For callers with an expander of their own; with the bytes of blsgpu_expand_message_* it gives the limbs of
+ * blsgpu_hash_to_curve_expander_*.  uniform = n x count x M x 64 bytes, out_xyz = n projective points in wire limbs -- the reference's own
+ * coordinates, except that an identity result (the two field elements of a message negatives of each other) is (0 : Y : 0) with a Y of the
+ * formulas' making where the reference's `double` substitutes the literal (0 : 1 : 0) (g1.rs:666, g2.rs:737). */
+int blsgpu_hash_to_curve_from_uniform_batch(blsgpu_ctx* ctx, int group, const uint8_t* uniform, size_t n, int encode_only, uint64_t* out_xyz);
+int blsgpu_hash_to_curve_from_uniform_device(blsgpu_ctx* ctx, int group, const void* d_uniform, size_t n, int encode_only, void* d_out_xyz);
 /* `ExpandMessage::init_expand(msg, dst, len_in_bytes)` followed by reading all `len_in_bytes` bytes, for n messages: out = n x len_in_bytes
  * uniform bytes.  len_in_bytes <= 65535, and at most 255 digest blocks for the XMD expanders (the reference panics beyond, :181-183, :263-268). */
 int blsgpu_expand_message_batch(blsgpu_ctx* ctx, int expander, const uint8_t* msgs, const uint64_t* offsets, size_t n, const uint8_t* dst, size_t dst_len,

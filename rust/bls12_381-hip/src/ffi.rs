@@ -161,6 +161,8 @@ extern "C" {
     pub fn blsgpu_hash_to_curve_device(ctx: *mut BlsgpuCtx, group: c_int, d_msgs: *const c_void, d_offsets: *const c_void, n: usize, d_dst: *const c_void, dst_len: usize, encode_only: c_int, d_out_xyz: *mut c_void) -> c_int;
     pub fn blsgpu_hash_to_curve_expander_batch(ctx: *mut BlsgpuCtx, group: c_int, expander: c_int, msgs: *const u8, offsets: *const u64, n: usize, dst: *const u8, dst_len: usize, encode_only: c_int, out_xyz: *mut u64) -> c_int;
     pub fn blsgpu_hash_to_curve_expander_device(ctx: *mut BlsgpuCtx, group: c_int, expander: c_int, d_msgs: *const c_void, d_offsets: *const c_void, n: usize, d_dst: *const c_void, dst_len: usize, encode_only: c_int, d_out_xyz: *mut c_void) -> c_int;
+    pub fn blsgpu_hash_to_curve_from_uniform_batch(ctx: *mut BlsgpuCtx, group: c_int, uniform: *const u8, n: usize, encode_only: c_int, out_xyz: *mut u64) -> c_int;
+    pub fn blsgpu_hash_to_curve_from_uniform_device(ctx: *mut BlsgpuCtx, group: c_int, d_uniform: *const c_void, n: usize, encode_only: c_int, d_out_xyz: *mut c_void) -> c_int;
     pub fn blsgpu_expand_message_batch(ctx: *mut BlsgpuCtx, expander: c_int, msgs: *const u8, offsets: *const u64, n: usize, dst: *const u8, dst_len: usize, len_in_bytes: usize, out: *mut u8) -> c_int;
     pub fn blsgpu_expand_message_device(ctx: *mut BlsgpuCtx, expander: c_int, d_msgs: *const c_void, d_offsets: *const c_void, n: usize, d_dst: *const c_void, dst_len: usize, len_in_bytes: usize, d_out: *mut c_void) -> c_int;
     pub fn blsgpu_hash_to_scalar_batch(ctx: *mut BlsgpuCtx, expander: c_int, msgs: *const u8, offsets: *const u64, n: usize, dst: *const u8, dst_len: usize, count: usize, out: *mut u64) -> c_int;

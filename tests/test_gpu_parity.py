@@ -1001,6 +1001,65 @@ def test_hash_to_curve_with_every_expander(ctx, group):
 
 
 @pytest.mark.parametrize("group", [1, 2])
+def test_hash_to_curve_from_uniform_bytes_and_degenerate_field_elements(ctx, group):
+    """the part of hash_to_curve behind the expander (mod.rs:86-108: from_okm, map_to_curve twice, sum, clear_h) on caller-supplied uniform bytes:
+    (a) with the bytes of expand_message it gives the limbs of hash_to_curve itself; (b) field elements no hash will ever produce -- 0, 1, u, -1,
+    equal pairs -- against the oracle's restatement of the reference's formulas on the projective coordinates.  The bulk G2 form finds the square
+    root of the map by another method than the reference (h2c_sswu_g2_dual): (b) is where its degenerate branches (u = 0: gx1_num = 0, y = 0,
+    x = x1) are exercised."""
+    import bls12_381_amd as b
+    from oracle import h2c_ref as h
+    A = b.api
+    M = 1 if group == 1 else 2
+    msgs = [b"", b"abc", bytes(77), b"q" * 130]
+    dst = b"QUUX-V01-CS02-with-BLS12381G%d_XMD:SHA-256_SSWU_RO_" % group
+    for encode in (False, True):
+        per = (1 if encode else 2) * M * 64
+        uni = ctx.expand_message(A.EXPAND_XMD_SHA256, msgs, dst, per)
+        assert np.array_equal(ctx.hash_to_curve_from_uniform(group, uni, encode_only=encode), ctx.hash_to_curve(group, msgs, dst, encode_only=encode))
+    # (b) chosen field elements: okm = db * 2^256 + da (map_g1.rs:513-531), so a value v < p is the 64 bytes of v itself
+    okm = lambda v: int(v).to_bytes(64, "big")
+
+    def same(got, want_limbs, want_pt):
+        """exact projective limbs -- except for the identity (u1 = -u0 maps to P and -P): the reference's `double` returns the literal (0 : 1 : 0) for an
+        identity input (g1.rs:666, g2.rs:737) where the kernels let the formula run, so the Y of an identity result differs; the point does not"""
+        z = want_pt[2]
+        if z == 0 or z == (0, 0):
+            n = len(got) // 3
+            return (not got[:n].any()) and got[n:2 * n].any() and (not got[2 * n:].any())
+        return np.array_equal(got, want_limbs)
+    r = o.SplitMix64(0x51 + group)
+    big = lambda: r.scalar() * r.scalar() % o.P
+    if group == 1:
+        vals = [0, 1, o.P - 1, 2, 5, big(), big()]
+        pairs = [(0, 0), (0, 1), (1, 0), (1, 1), (o.P - 1, 1), (2, 5), (vals[5], vals[5]), (vals[5], vals[6]), (0, vals[6])]
+        uni = np.frombuffer(b"".join(okm(a) + okm(c) for a, c in pairs), dtype=np.uint8).reshape(len(pairs), 128)
+        out = ctx.hash_to_curve_from_uniform(1, uni)
+        for k, (a, c) in enumerate(pairs):
+            want = h.g1_clear_cofactor(o.g1_add(h.g1_map_to_curve(a), h.g1_map_to_curve(c)))
+            assert same(out[k], np.concatenate([fpw(x) for x in want]), want), (k, a, c)
+        enc = ctx.hash_to_curve_from_uniform(1, np.frombuffer(b"".join(okm(v) for v in vals), dtype=np.uint8).reshape(len(vals), 64), encode_only=True)
+        for k, v in enumerate(vals):
+            assert np.array_equal(enc[k], np.concatenate([fpw(x) for x in h.g1_clear_cofactor(h.g1_map_to_curve(v))])), (k, v)
+    else:
+        vals = [(0, 0), (1, 0), (0, 1), (o.P - 1, 0), (0, o.P - 1), (1, 1), (2, 0), (big(), big()), (big(), 0), (0, big()), (big(), big())]
+        pairs = [(vals[0], vals[0]), (vals[0], vals[1]), (vals[1], vals[0]), (vals[2], vals[3]), (vals[4], vals[5]), (vals[7], vals[7]), (vals[7], vals[10]),
+                 (vals[8], vals[9]), (vals[6], vals[0]), (vals[10], vals[1])]
+        enc2 = lambda u: okm(u[0]) + okm(u[1])
+        uni = np.frombuffer(b"".join(enc2(a) + enc2(c) for a, c in pairs), dtype=np.uint8).reshape(len(pairs), 256)
+        out = ctx.hash_to_curve_from_uniform(2, uni)
+        for k, (a, c) in enumerate(pairs):
+            want = h.g2_clear_cofactor(o.g2_add(h.g2_map_to_curve(a), h.g2_map_to_curve(c)))
+            assert same(out[k], np.concatenate([fp2w(x) for x in want]), want), (k, a, c)
+        enc = ctx.hash_to_curve_from_uniform(2, np.frombuffer(b"".join(enc2(v) for v in vals), dtype=np.uint8).reshape(len(vals), 128), encode_only=True)
+        for k, v in enumerate(vals):
+            assert np.array_equal(enc[k], np.concatenate([fp2w(x) for x in h.g2_clear_cofactor(h.g2_map_to_curve(v))])), (k, v)
+    assert ctx.hash_to_curve_from_uniform(group, np.zeros((0, 128 * M), dtype=np.uint8)).shape[0] == 0
+    with pytest.raises(b.BlsGpuError):
+        b._lib.check(ctx.lib.blsgpu_hash_to_curve_from_uniform_batch(ctx.h, 3, None, 1, 0, None), "group")
+
+
+@pytest.mark.parametrize("group", [1, 2])
 def test_hash_to_curve_vs_oracle(ctx, group):
     """random and edge-case messages / DSTs against the oracle, on the PROJECTIVE coordinates (the kernels follow the
     reference's formulas step for step), plus subgroup membership of the results"""
