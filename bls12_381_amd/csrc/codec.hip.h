@@ -222,10 +222,7 @@ template <class F> DEV void emit_identity_wire(u32* xy) {
 // ---- kernels ---------------------------------------------------------------------------------------------------
 // mode bit 0: compressed input; bit 1: checked variant (from_compressed / from_uncompressed), else *_unchecked
 template <class F>
-__global__ void __launch_bounds__(128) k_point_decode(const uint8_t* __restrict__ in, size_t n, int mode, u32* __restrict__ xy,
-                                                      uint8_t* __restrict__ inf_out, uint8_t* __restrict__ ok_out) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+DEV void point_decode_one(size_t i, const uint8_t* __restrict__ in, int mode, u32* __restrict__ xy, uint8_t* __restrict__ inf_out, uint8_t* __restrict__ ok_out) {
   constexpr int CB = Codec<F>::COORD_BYTES, WW = Wire<F>::WORDS;
   const bool compressed = mode & 1, checked = (mode & 2) != 0;
   const uint8_t* b = in + i * (compressed ? CB : 2 * CB);
@@ -260,7 +257,13 @@ __global__ void __launch_bounds__(128) k_point_decode(const uint8_t* __restrict_
   inf_out[i] = (inf || !ok) ? 1 : 0;
   ok_out[i] = ok ? 1 : 0;
 }
-
+template <class F>
+__global__ void __launch_bounds__(128) k_point_decode(const uint8_t* __restrict__ in, size_t n, int mode, u32* __restrict__ xy,
+                                                      uint8_t* __restrict__ inf_out, uint8_t* __restrict__ ok_out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  point_decode_one<F>(i, in, mode, xy, inf_out, ok_out);
+}
 template <class F>
 __global__ void __launch_bounds__(128) k_point_encode(const u32* __restrict__ xy, const uint8_t* __restrict__ inf_in, size_t n, int compressed,
                                                       uint8_t* __restrict__ out) {
