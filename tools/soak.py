@@ -39,6 +39,23 @@ while time.time() - t0 < budget:
     except AssertionError:
         print("MISMATCH group", group, "n", n, "window", w, "kinds", kk, sk); np.save("/tmp/soak_fail.npy", np.array([ks, ss], dtype=object)); sys.exit(1)
     cases += 1
+    if cases % 200 == 0:
+        # the part of hash_to_curve behind the expander on random uniform bytes, both groups, against the oracle's restatement of the reference
+        from oracle import h2c_ref as h
+        for g in (1, 2):
+            M = 1 if g == 1 else 2
+            uni = np.frombuffer(bytes(rnd.getrandbits(8) for _ in range(3 * 2 * M * 64)), dtype=np.uint8).reshape(3, 2 * M * 64)
+            out = ctx.hash_to_curve_from_uniform(g, uni)
+            for k in range(3):
+                raw = uni[k].tobytes()
+                if g == 1:
+                    u = [h.fp_from_okm(raw[64 * i:64 * i + 64]) for i in range(2)]
+                    want = np.concatenate([T.fpw(c) for c in h.g1_clear_cofactor(o.g1_add(h.g1_map_to_curve(u[0]), h.g1_map_to_curve(u[1])))])
+                else:
+                    u = [(h.fp_from_okm(raw[128 * i:128 * i + 64]), h.fp_from_okm(raw[128 * i + 64:128 * i + 128])) for i in range(2)]
+                    want = np.concatenate([T.fp2w(c) for c in h.g2_clear_cofactor(o.g2_add(h.g2_map_to_curve(u[0]), h.g2_map_to_curve(u[1])))])
+                assert np.array_equal(out[k], want), ("hash_to_curve_from_uniform", g, k)
+        h2c_checked = globals().get("h2c_checked", 0) + 6
     if cases % 25 == 0:
         # pairing bilinearity on a fresh random pair: e(aP, bQ) == e(P, Q)^(ab)
         a, bb = rnd.randrange(1, R), rnd.randrange(1, R)
@@ -46,4 +63,4 @@ while time.time() - t0 < budget:
         gt = ctx.pairing_batch(g1, f1, g2, f2)
         want = ctx.gt_mul_scalar_batch(gt[1:2], [a * bb % R])[0]
         assert np.array_equal(gt[0], want), "bilinearity"
-print("soak ok:", cases, "MSM cases in", round(time.time() - t0), "s")
+print("soak ok:", cases, "MSM cases,", globals().get("h2c_checked", 0), "maps from uniform bytes in", round(time.time() - t0), "s")
